@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` via gpurun)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`-m gpu` tests must fail (not skip) on a box without the HIP path, but plain `pytest tests`
+    on a CPU-only container should not try them."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    markexpr = config.getoption("-m") or ""
+    if "gpu" in markexpr and "not gpu" not in markexpr:
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
