@@ -1,0 +1,86 @@
+"""ctypes binding of libelg_hip.so (include/elg_hip.h).  No CPU fallback: if the library is
+missing the import fails loudly -- build it with `python -m elg_amd.build`."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libelg_hip.so")
+
+ELG_OK, ELG_EINVAL, ELG_ELAUNCH, ELG_ENOTIMPL = 0, -1, -2, -3
+PROBLEM_CVRP, PROBLEM_TSP = 0, 1
+MODE_GREEDY, MODE_SAMPLE, MODE_FORCED = 0, 1, 2
+
+LOC_ROWS = 64
+LOC_LA, LOC_LT, LOC_LAV, LOC_LCV, LOC_LWC, LOC_LBC, LOC_LWE, LOC_LPE, LOC_SIZE = \
+    0, 16, 272, 368, 2416, 3440, 3472, 3568, 5616
+
+_vp = C.c_void_p
+
+
+class RolloutArgs(C.Structure):
+    _fields_ = [
+        ("problem", C.c_int32), ("B", C.c_int32), ("M", C.c_int32), ("N1", C.c_int32), ("K", C.c_int32),
+        ("Tmax", C.c_int32), ("mode", C.c_int32), ("Tforced", C.c_int32), ("has_local", C.c_int32),
+        ("has_penalty", C.c_int32), ("max_steps", C.c_int32), ("do_decode", C.c_int32), ("do_update", C.c_int32),
+        ("use_state", C.c_int32), ("waves", C.c_int32), ("tiles", C.c_int32), ("lds_stage", C.c_int32),
+        ("dump_T", C.c_int32),
+        ("xi", C.c_float), ("clip", C.c_float), ("inv_ens", C.c_float), ("pad0", C.c_float),
+        ("seed", C.c_uint64),
+        ("Kmat", _vp), ("Vmat", _vp), ("PK", _vp), ("pb", _vp), ("Q1", _vp), ("Q2", _vp), ("wl", _vp),
+        ("xy", _vp), ("demand", _vp), ("nbr_idx", _vp), ("nbr_dist", _vp), ("nbr_theta", _vp), ("loc", _vp),
+        ("starts", _vp), ("forced", _vp), ("uniforms", _vp),
+        ("st_cur", _vp), ("st_cnt", _vp), ("st_fin", _vp), ("st_first", _vp), ("st_load", _vp), ("st_len", _vp),
+        ("st_vis", _vp),
+        ("actions", _vp), ("probs", _vp), ("reward", _vp), ("tlen", _vp), ("full_probs", _vp),
+    ]
+
+
+class BwdArgs(C.Structure):
+    _fields_ = [
+        ("fwd", RolloutArgs), ("T", C.c_int32), ("pad1", C.c_int32),
+        ("gprob", _vp), ("rowA", _vp), ("rowDS", _vp), ("rowDL", _vp), ("rowQ", _vp), ("rowO", _vp),
+        ("rowDO", _vp), ("rowDQ", _vp), ("gloc", _vp),
+    ]
+
+
+EXPORTS = ["elg_version", "elg_last_error", "elg_aug8", "elg_dist_matrix", "elg_nbr_tables", "elg_route_length",
+           "elg_rollout_fwd", "elg_rollout_bwd"]
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: the HIP extension is mandatory (no CPU fallback). "
+                              "Build it with `python -m elg_amd.build`.")
+        L = C.CDLL(LIB_PATH)
+        L.elg_version.restype = C.c_char_p
+        L.elg_last_error.restype = C.c_char_p
+        i, f = C.c_int, C.c_void_p
+        L.elg_aug8.argtypes = [f, f, i, i, f]
+        L.elg_dist_matrix.argtypes = [f, f, i, i, f]
+        L.elg_nbr_tables.argtypes = [f, f, f, f, i, i, f]
+        L.elg_route_length.argtypes = [f, f, f, i, i, i, i, i, f]
+        L.elg_rollout_fwd.argtypes = [C.POINTER(RolloutArgs), f]
+        L.elg_rollout_bwd.argtypes = [C.POINTER(BwdArgs), f]
+        for n in ("elg_aug8", "elg_dist_matrix", "elg_nbr_tables", "elg_route_length", "elg_rollout_fwd",
+                  "elg_rollout_bwd"):
+            getattr(L, n).restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def check(code: int, what: str):
+    """Map ELG_E* codes to the Python exceptions the reference's protocol raises."""
+    if code == ELG_OK:
+        return
+    msg = f"{what}: {lib().elg_last_error().decode()}"
+    if code == ELG_EINVAL:
+        raise ValueError(msg)
+    if code == ELG_ENOTIMPL:
+        raise NotImplementedError(msg)
+    raise RuntimeError(msg)

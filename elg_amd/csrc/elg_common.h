@@ -1,0 +1,100 @@
+// ELG-POMO rollout engine for MI355X (gfx950 / CDNA4): shared device helpers.
+// Wave = 64 lanes everywhere; no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ELG_WAVE 64
+#define ELG_E 128          // embedding dim            (CVRP/config.yml:41)
+#define ELG_H 8            // decoder heads            (:43)
+#define ELG_DK 16          // decoder qkv dim          (:44)
+#define ELG_LE 32          // local_att_hidden_dim     (:47)
+#define ELG_LH 4           // local_att_head_num       (:48)
+#define ELG_LDK 8          // local_att_qkv_dim        (:49)
+
+#define ELG_NEG_INF (-__builtin_huge_valf())
+
+namespace elg {
+
+__device__ __forceinline__ int f2i(float v) { return __builtin_bit_cast(int, v); }
+__device__ __forceinline__ float i2f(int v) { return __builtin_bit_cast(float, v); }
+
+// ---- DPP quad permutes (no LDS traffic) ------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+    return i2f(__builtin_amdgcn_mov_dpp(f2i(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_xor1(float v) { return dpp<0xB1>(v); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ float quad_xor2(float v) { return dpp<0x4E>(v); }   // quad_perm [2,3,0,1]
+template <int J>
+__device__ __forceinline__ float quad_bcast(float v) { return dpp<J * 0x55>(v); }   // quad_perm [J,J,J,J]
+
+__device__ __forceinline__ float shfl_xor(float v, int m) { return __shfl_xor(v, m, ELG_WAVE); }
+__device__ __forceinline__ int shfl_xor(int v, int m) { return __shfl_xor(v, m, ELG_WAVE); }
+
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, quad_xor1(v));
+    v = fmaxf(v, quad_xor2(v));
+#pragma unroll
+    for (int m = 4; m < 64; m <<= 1) v = fmaxf(v, shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v += quad_xor1(v);
+    v += quad_xor2(v);
+#pragma unroll
+    for (int m = 4; m < 64; m <<= 1) v += shfl_xor(v, m);
+    return v;
+}
+// inclusive prefix sum over the 64 lanes (Hillis-Steele)
+__device__ __forceinline__ float wave_scan_incl(float v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        float o = __shfl_up(v, d, ELG_WAVE);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ float readlane(float v, int l) { return i2f(__builtin_amdgcn_readlane(f2i(v), l)); }
+__device__ __forceinline__ int readlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ int lanes_below(unsigned long long bal) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+}
+// wave-local LDS hand-off: DS ops of one wave execute in issue order; stop the compiler reordering.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float dot4(const float4 a, const float4 b, float acc) {
+    acc = fmaf(a.x, b.x, acc);
+    acc = fmaf(a.y, b.y, acc);
+    acc = fmaf(a.z, b.z, acc);
+    acc = fmaf(a.w, b.w, acc);
+    return acc;
+}
+
+// Euclidean distance exactly as a plain fp32 evaluation: sqrt(dx*dx + dy*dy), every op rounded once
+// (no fma contraction) -- CVRPEnv.py:148 / :261.
+__device__ __forceinline__ float dist2d(float ax, float ay, float bx, float by) {
+    float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by);
+    return __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+}
+
+// Philox-4x32-10 counter RNG: one uniform in [0,1) per (seed, trajectory, step).
+__device__ __forceinline__ float philox_uniform(unsigned long long seed, unsigned traj, unsigned step) {
+    unsigned c0 = traj, c1 = step, c2 = 0x243F6A88u, c3 = 0x85A308D3u;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+        unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return (float)(c0 >> 8) * (1.0f / 16777216.0f);
+}
+
+}  // namespace elg

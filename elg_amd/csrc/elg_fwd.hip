@@ -1,0 +1,497 @@
+// Forward POMO construction kernel (persistent: one launch runs every trajectory of the batch to
+// completion) + the small per-batch kernels (neighbour tables, distance matrix, aug8, route length).
+//
+// Replaces, for gaocrr/ELG: CVRP/utils.py:7-29 (rollout loop), CVRPEnv.py:152-318 (reset / step /
+// get_cur_feature / _get_reward), CVRPModel.py:36-75 (one_step_rollout), models.py:51-175,322-423
+// (local policy + decoder); and the TSP counterparts (TSP/utils.py:7-26, TSPEnv.py, TSPModel.py,
+// TSP/models.py:48-110,244-303).
+#include "elg_rollout.h"
+#include <string>
+
+namespace elg {
+
+static thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+const char* last_error() { return g_err.c_str(); }
+
+// =============================================================================================
+// small kernels
+// =============================================================================================
+__global__ void aug8_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int N) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // over B*N points
+    if (i >= B * N) return;
+    const float x = in[2 * i], y = in[2 * i + 1];
+    const float mx = __fsub_rn(1.f, x), my = __fsub_rn(1.f, y);
+    const size_t s = (size_t)B * N * 2;
+    float* o = out + 2 * (size_t)i;
+    o[0] = x;          o[1] = y;
+    o[s] = mx;         o[s + 1] = y;
+    o[2 * s] = x;      o[2 * s + 1] = my;
+    o[3 * s] = mx;     o[3 * s + 1] = my;
+    o[4 * s] = y;      o[4 * s + 1] = x;
+    o[5 * s] = my;     o[5 * s + 1] = x;
+    o[6 * s] = y;      o[6 * s + 1] = mx;
+    o[7 * s] = my;     o[7 * s + 1] = mx;
+}
+
+__global__ void dist_matrix_kernel(const float* __restrict__ xy, float* __restrict__ dist, int N) {
+    const int b = blockIdx.y, i = blockIdx.x;
+    const float* p = xy + (size_t)b * N * 2;
+    const float ax = p[2 * i], ay = p[2 * i + 1];
+    float* row = dist + ((size_t)b * N + i) * N;
+    for (int j = threadIdx.x; j < N; j += blockDim.x) row[j] = dist2d(ax, ay, p[2 * j], p[2 * j + 1]);
+}
+
+// one workgroup per (instance, centre node): bitonic sort of (dist bits << 32 | index) in LDS
+__global__ void nbr_tables_kernel(const float* __restrict__ xy, int* __restrict__ idx, float* __restrict__ dist,
+                                  float* __restrict__ theta, int N, int NP) {
+    extern __shared__ unsigned long long keys[];
+    const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const float* p = xy + (size_t)b * N * 2;
+    const float cx = p[2 * c], cy = p[2 * c + 1];
+    for (int i = tid; i < NP; i += nt) {
+        unsigned long long k = ~0ull;
+        if (i < N) {
+            const float d = dist2d(p[2 * i], p[2 * i + 1], cx, cy);
+            k = ((unsigned long long)(unsigned)f2i(d) << 32) | (unsigned)i;
+        }
+        keys[i] = k;
+    }
+    __syncthreads();
+    for (int k = 2; k <= NP; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < NP; i += nt) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = keys[i], bb = keys[ixj];
+                    const bool asc = (i & k) == 0;
+                    if ((a > bb) == asc) { keys[i] = bb; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const size_t row = ((size_t)b * N + c) * N;
+    for (int i = tid; i < N; i += nt) {
+        const unsigned long long k = keys[i];
+        const int n = (int)(k & 0xffffffffull);
+        idx[row + i] = n;
+        dist[row + i] = i2f((int)(k >> 32));
+        theta[row + i] = atan2f(__fsub_rn(p[2 * n + 1], cy), __fsub_rn(p[2 * n], cx));   // CVRPEnv.py:302-311
+    }
+}
+
+__global__ void route_length_kernel(const float* __restrict__ xy, const long long* __restrict__ tour,
+                                    float* __restrict__ out, int B, int M, int T, int N, int rounding) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // over B*M
+    if (i >= B * M) return;
+    const int b = i / M;
+    const float* p = xy + (size_t)b * N * 2;
+    const long long* t = tour + (size_t)i * T;
+    float len = 0.f;
+    int prev = (int)t[0];
+    const int first = prev;
+    for (int s = 1; s <= T; ++s) {
+        const int nx = (s < T) ? (int)t[s] : first;                 // roll(-1): last -> first
+        float d = dist2d(p[2 * prev], p[2 * prev + 1], p[2 * nx], p[2 * nx + 1]);
+        if (rounding) d = rintf(d);                                 // torch.round = half to even
+        len += d;
+        prev = nx;
+    }
+    out[i] = len;
+}
+
+// =============================================================================================
+// the rollout kernel
+// =============================================================================================
+struct FwdOut {
+    int sel;
+    float p;
+};
+
+// One decode step for the trajectory held by this wave.  Returns the chosen node and its probability.
+template <int NCH, bool TSP, bool LDSK>
+__device__ __forceinline__ FwdOut decode_step(const elg_rollout_args& A, const Inst& I, const Traj<NCH>& st,
+                                              int lane, float* sb, int forced_sel, float uni,
+                                              float* full_row /* (N1) or null */) {
+    const int N1 = A.N1;
+    unsigned long long mk[NCH];
+    build_mask<NCH, TSP>(st, I, N1, lane, mk);
+
+    // ---- glimpse query (prefetch early): q = Wq_last [enc[cur]; load]   (models.py:330-333)
+    const int cb = (lane & 31) * 4;
+    float4 q4 = *reinterpret_cast<const float4*>(I.Q1 + (size_t)st.cur * ELG_E + cb);
+    if (TSP) {
+        const float4 qf = *reinterpret_cast<const float4*>(I.Q2 + (size_t)st.first * ELG_E + cb);
+        q4.x += qf.x; q4.y += qf.y; q4.z += qf.z; q4.w += qf.w;          // TSP/models.py:252-255
+    } else {
+        const float4 w = *reinterpret_cast<const float4*>(I.wl + cb);
+        q4.x = fmaf(st.load, w.x, q4.x); q4.y = fmaf(st.load, w.y, q4.y);
+        q4.z = fmaf(st.load, w.z, q4.z); q4.w = fmaf(st.load, w.w, q4.w);
+    }
+
+    // ---- k-NN slots + distance penalty + local policy (slot layout)
+    constexpr int S0 = TSP ? 0 : 1;
+    float addval = 0.f;          // per-slot additive term (penalty + local score)
+    int snid = -1;               // node of this lane's slot
+    if (A.has_penalty || A.has_local) {
+        const int k = knn_slots<NCH, TSP>(I, N1, A.K, st.cur, lane, mk, sb);
+        wave_lds_fence();
+        const int j = lane;
+        const bool cust = (j >= S0) && (j < S0 + k);                 // a real neighbour slot
+        float sd = 0.f, sth = 0.f;
+        if (cust) {
+            sd = sb[j];
+            sth = sb[ELG_SLOT_STRIDE + j];
+            snid = f2i(sb[2 * ELG_SLOT_STRIDE + j]);
+        }
+        const float dmax = (k > 0) ? sb[S0 + k - 1] : 0.f;            // distance of the k-th neighbour
+        wave_lds_fence();
+        if (!TSP && j == 0) snid = 0;                                 // depot slot
+        float pen = 0.f;
+        if (A.has_penalty && cust) {
+            if (TSP) pen = -(sd / (dmax + 1e-6f));                    // TSP/models.py:290
+            else pen = (dmax != 0.f) ? -(sd / dmax) : -sd;            // models.py:379-405 (no epsilon)
+        }
+        float u = 0.f;
+        if (A.has_local) {
+            const float nf = dmax + 1e-6f;                            // models.py:79 / TSP :72
+            float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+            if (cust) {
+                f0 = sd / nf;
+                f1 = sth;
+                if (!TSP) f2 = I.dem[snid] / st.load;                 // CVRPEnv.py:315-316
+            }
+            bool smask = !cust;
+            if (!TSP && j == 0) smask = mk[0] & 1ull;                 // depot slot carries the depot's mask
+            u = local_policy<TSP>(I.loc, lane, f0, f1, f2, smask, nullptr);
+        }
+        addval = pen + u * A.inv_ens;
+    }
+
+    // ---- glimpse + pointer
+    const float4 o4 = glimpse<NCH, LDSK>(I, N1, lane, q4, mk, nullptr);
+    float s[NCH];
+    pointer_scores<NCH, LDSK>(I, N1, lane, o4, sb, s);
+
+    // ---- scatter the slot terms to node order (xi everywhere else)   models.py:405-413
+    const float dflt = A.has_penalty ? A.xi : 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int n = lane + 64 * ch;
+        if (n < N1) sb[n] = dflt;
+    }
+    wave_lds_fence();
+    if (snid >= 0) sb[snid] = addval;
+    wave_lds_fence();
+
+    // ---- clip, mask, softmax (node layout)   models.py:416-420
+    float lg[NCH];
+    float mx = ELG_NEG_INF;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int n = lane + 64 * ch;
+        const bool masked = (mk[ch] >> lane) & 1ull;
+        float x = ELG_NEG_INF;
+        if (n < N1 && !masked) x = A.clip * tanhf(s[ch] + sb[n]);
+        lg[ch] = x;
+        mx = fmaxf(mx, x);
+    }
+    wave_lds_fence();
+    mx = wave_max(mx);
+    float e[NCH];
+    float part = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        e[ch] = (lg[ch] > ELG_NEG_INF) ? __expf(lg[ch] - mx) : 0.f;
+        part += e[ch];
+    }
+    const float tot = wave_sum(part);
+    const float inv = 1.0f / tot;
+    if (full_row) {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int n = lane + 64 * ch;
+            if (n < N1) full_row[n] = e[ch] * inv;
+        }
+    }
+
+    // ---- choose
+    int sel = 0;
+    if (A.mode == ELG_MODE_FORCED) {
+        sel = forced_sel;
+    } else if (A.mode == ELG_MODE_GREEDY) {
+        // argmax over probabilities, ties -> lowest node index (torch.argmax)
+        float bv = -1.f;
+        int bn = 0x7fffffff;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int n = lane + 64 * ch;
+            const float pv = e[ch] * inv;
+            if (n < N1 && pv > bv) { bv = pv; bn = n; }
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const float ov = shfl_xor(bv, m);
+            const int on = shfl_xor(bn, m);
+            if (ov > bv || (ov == bv && on < bn)) { bv = ov; bn = on; }
+        }
+        sel = bn;
+    } else {
+        // inverse-CDF sample in node order
+        float cs[NCH];
+        float run = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            cs[ch] = wave_scan_incl(e[ch], lane) + run;
+            run = readlane(cs[ch], 63);
+        }
+        const float target = uni * run;
+        int found = -1, lastpos = 0;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const unsigned long long pos = __ballot(e[ch] > 0.f);
+            const unsigned long long hit = __ballot(e[ch] > 0.f && cs[ch] > target);
+            if (found < 0 && hit) found = 64 * ch + (int)__builtin_ctzll(hit);
+            if (pos) lastpos = 64 * ch + 63 - (int)__builtin_clzll(pos);
+        }
+        sel = found >= 0 ? found : lastpos;
+    }
+    // probability of the chosen node
+    sel = __builtin_amdgcn_readfirstlane(sel);
+    float ps = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+        if ((sel >> 6) == ch) ps = readlane(e[ch], sel & 63) * inv;
+    FwdOut o;
+    o.sel = sel;
+    o.p = ps;
+    return o;
+}
+
+template <int NCH, bool TSP, bool LDSK, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void rollout_fwd_kernel(const elg_rollout_args A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int N1 = A.N1;
+    // XCD-aware unit mapping: the `tiles` workgroups of one instance share an XCD (L2 locality of the
+    // instance's Q1 / neighbour tables); placement only affects speed.
+    const int G = gridDim.x;
+    int u = blockIdx.x;
+    if ((G & 7) == 0) u = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int b = u / A.tiles, tile = u % A.tiles;
+    const int tile_m = (A.M + A.tiles - 1) / A.tiles;
+    const int m_lo = tile * tile_m, m_hi = min(A.M, m_lo + tile_m);
+
+    // ---- LDS carve: [K | V | PK(swizzled)] | dem | counter | per-wave scratch
+    const int NE = N1 * ELG_E;
+    float* p = lds;
+    float *sK = nullptr, *sV = nullptr, *sPK = nullptr;
+    if (LDSK) { sK = p; sV = p + NE; sPK = p + 2 * NE; p += 3 * NE; }
+    float* sdem = p; p += (N1 + 3) & ~3;
+    int* sctr = reinterpret_cast<int*>(p); p += 4;
+    float* sb = p + wave * ELG_SB_FLOATS;
+
+    const float* gK = A.Kmat + (size_t)b * NE;
+    const float* gV = A.Vmat + (size_t)b * NE;
+    const float* gPK = A.PK + (size_t)b * NE;
+    if (LDSK) {
+        const int nt = WAVES * 64;
+        for (int i = threadIdx.x; i < NE / 4; i += nt) {
+            reinterpret_cast<float4*>(sK)[i] = reinterpret_cast<const float4*>(gK)[i];
+            reinterpret_cast<float4*>(sV)[i] = reinterpret_cast<const float4*>(gV)[i];
+            const int n = i >> 5, c4 = i & 31;
+            reinterpret_cast<float4*>(sPK)[n * 32 + (c4 ^ (n & 31))] = reinterpret_cast<const float4*>(gPK)[i];
+        }
+    }
+    if (!TSP)
+        for (int i = threadIdx.x; i < N1; i += WAVES * 64) sdem[i] = A.demand[(size_t)b * N1 + i];
+    __syncthreads();
+
+    Inst I;
+    I.K = LDSK ? sK : gK;
+    I.V = LDSK ? sV : gV;
+    I.PK = LDSK ? sPK : gPK;
+    I.pb = A.pb + (size_t)b * N1;
+    I.Q1 = A.Q1 + (size_t)b * NE;
+    I.Q2 = TSP ? A.Q2 + (size_t)b * NE : nullptr;
+    I.wl = A.wl;
+    I.xy = A.xy + (size_t)b * N1 * 2;
+    I.dem = sdem;
+    I.nidx = A.nbr_idx + (size_t)b * N1 * N1;
+    I.ndist = A.nbr_dist + (size_t)b * N1 * N1;
+    I.ntheta = A.nbr_theta + (size_t)b * N1 * N1;
+    I.loc = A.loc;
+
+    constexpr int NW = NCH;
+    // static round-robin of the tile's trajectories over the waves (all control flow below is
+    // wave-uniform: every trajectory-state value is forced into SGPRs with readfirstlane)
+    for (int m = m_lo + wave; m < m_hi; m += WAVES) {
+        const size_t bm = (size_t)b * A.M + m;
+
+        Traj<NCH> st;
+        if (A.use_state) {
+            st.cur = __builtin_amdgcn_readfirstlane(A.st_cur[bm]);
+            st.cnt = __builtin_amdgcn_readfirstlane(A.st_cnt[bm]);
+            st.fin = __builtin_amdgcn_readfirstlane(A.st_fin[bm]);
+            st.first = TSP ? __builtin_amdgcn_readfirstlane(A.st_first[bm]) : 0;
+            st.load = i2f(__builtin_amdgcn_readfirstlane(f2i(A.st_load[bm])));
+            st.len = i2f(__builtin_amdgcn_readfirstlane(f2i(A.st_len[bm])));
+#pragma unroll
+            for (int c = 0; c < NW; ++c) {
+                const unsigned long long v = A.st_vis[bm * NW + c];
+                const unsigned lo = __builtin_amdgcn_readfirstlane((int)(unsigned)v);
+                const unsigned hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+                st.vis[c] = ((unsigned long long)hi << 32) | lo;
+            }
+        } else {
+            st.cur = 0; st.first = 0; st.cnt = 0; st.fin = 0; st.load = 1.0f; st.len = 0.f;
+#pragma unroll
+            for (int c = 0; c < NW; ++c) st.vis[c] = 0ull;
+        }
+
+        const int step_cap = A.max_steps > 0 ? A.max_steps : 2 * N1 + 2;      // hard bound: never spin
+        for (int steps = 0; steps < step_cap; ++steps) {
+            if (A.max_steps <= 0 && st.fin != 0) break;
+            const int t = st.cnt;
+            if (!A.use_state && t >= A.Tmax) break;
+            int sel = 0;
+            float pr = 1.0f;
+            int fsel = 0;
+            if (A.forced && t < A.Tforced) fsel = __builtin_amdgcn_readfirstlane(A.forced[bm * A.Tforced + t]);
+            const bool first_move = (!TSP && t <= 1) || (TSP && t == 0);
+            if (!A.do_decode) {
+                sel = fsel;                                          // CVRPEnv.step with a given action
+            } else if (st.fin) {
+                sel = 0;                                             // finished: stay at the depot, prob 1
+            } else if (first_move) {
+                // CVRPModel.py:42-51 (depot, then POMO start) / TSPModel.py:30-34 (POMO start)
+                if (A.mode == ELG_MODE_FORCED) sel = fsel;
+                else sel = (!TSP && t == 0) ? 0 : __builtin_amdgcn_readfirstlane(A.starts[m]);
+            } else {
+                float uni = 0.f;
+                if (A.mode == ELG_MODE_SAMPLE)
+                    uni = A.uniforms ? A.uniforms[bm * A.Tmax + t] : philox_uniform(A.seed, (unsigned)bm, (unsigned)t);
+                float* frow = (A.full_probs && t < A.dump_T) ? A.full_probs + (bm * A.dump_T + t) * N1 : nullptr;
+                const FwdOut o = decode_step<NCH, TSP, LDSK>(A, I, st, lane, sb, fsel, uni, frow);
+                sel = __builtin_amdgcn_readfirstlane(o.sel);
+                pr = i2f(__builtin_amdgcn_readfirstlane(f2i(o.p)));
+            }
+            // time index of the outputs: absolute step, or call-relative in the step-wise protocol
+            const int tout = A.use_state ? steps : t;
+            if (lane == 0 && tout < A.Tmax) {
+                if (A.actions) A.actions[bm * A.Tmax + tout] = sel;
+                if (A.probs) A.probs[((size_t)b * A.Tmax + tout) * A.M + m] = pr;
+            }
+            if (A.do_update) env_update<NCH, TSP>(st, I, N1, sel);
+            else break;
+        }
+
+        if (lane == 0) {
+            if (A.reward) A.reward[bm] = -st.len;
+            if (A.tlen) A.tlen[bm] = st.cnt;
+            if (A.use_state && A.do_update) {
+                A.st_cur[bm] = st.cur; A.st_cnt[bm] = st.cnt; A.st_fin[bm] = st.fin;
+                if (TSP) A.st_first[bm] = st.first;
+                A.st_load[bm] = st.load; A.st_len[bm] = st.len;
+#pragma unroll
+                for (int c = 0; c < NW; ++c) A.st_vis[bm * NW + c] = st.vis[c];
+            }
+        }
+    }
+}
+
+template <int NCH, bool TSP, bool LDSK, int WAVES>
+static int launch_fwd(const elg_rollout_args& A, hipStream_t stream) {
+    size_t lds = 0;
+    if (LDSK) lds += (size_t)3 * A.N1 * ELG_E * 4;
+    lds += (size_t)((A.N1 + 3) & ~3) * 4 + 16 + (size_t)WAVES * ELG_SB_FLOATS * 4;
+    if (lds > 163840) return fail(ELG_EINVAL, "rollout: LDS budget exceeded");
+    auto kern = rollout_fwd_kernel<NCH, TSP, LDSK, WAVES>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                163840) != hipSuccess)
+            return fail(ELG_ELAUNCH, "hipFuncSetAttribute failed");
+        attr_done = true;
+    }
+    dim3 grid(A.B * A.tiles), block(WAVES * 64);
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, A);
+    if (hipGetLastError() != hipSuccess) return fail(ELG_ELAUNCH, "rollout_fwd launch failed");
+    return ELG_OK;
+}
+
+template <bool TSP>
+static int dispatch_fwd(const elg_rollout_args& A, hipStream_t stream) {
+    const int nch = (A.N1 + 63) / 64;
+    const bool lds = A.lds_stage != 0;
+    if (lds && A.N1 > 104) return fail(ELG_EINVAL, "lds_stage needs N1 <= 104");
+    if (A.waves != 8 && A.waves != 13) return fail(ELG_EINVAL, "waves must be 8 or 13");
+#define ELG_GO(NCHV, L, W) return launch_fwd<NCHV, TSP, L, W>(A, stream)
+    if (nch == 1) { if (lds) { if (A.waves == 8) ELG_GO(1, true, 8); else ELG_GO(1, true, 13); }
+                    else { if (A.waves == 8) ELG_GO(1, false, 8); else ELG_GO(1, false, 13); } }
+    if (nch == 2) { if (lds) { if (A.waves == 8) ELG_GO(2, true, 8); else ELG_GO(2, true, 13); }
+                    else { if (A.waves == 8) ELG_GO(2, false, 8); else ELG_GO(2, false, 13); } }
+    if (lds) return fail(ELG_EINVAL, "lds_stage needs N1 <= 104");
+    if (nch <= 4) { ELG_GO(4, false, 8); }
+    if (nch <= 8) { ELG_GO(8, false, 8); }
+    if (nch <= 16) { ELG_GO(16, false, 8); }
+#undef ELG_GO
+    return fail(ELG_ENOTIMPL, "N1 > 1024 not built");
+}
+
+}  // namespace elg
+
+using namespace elg;
+
+extern "C" {
+
+const char* elg_version(void) { return "elg-hip 0.1 (gfx950)"; }
+const char* elg_last_error(void) { return elg::last_error(); }
+
+int elg_aug8(const float* xy_in, float* xy_out, int B, int N, void* stream) {
+    if (B <= 0 || N <= 0) return fail(ELG_EINVAL, "aug8: empty input");
+    const int n = B * N;
+    hipLaunchKernelGGL(aug8_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, xy_in, xy_out, B, N);
+    return hipGetLastError() == hipSuccess ? ELG_OK : fail(ELG_ELAUNCH, "aug8 launch failed");
+}
+
+int elg_dist_matrix(const float* xy, float* dist, int B, int N, void* stream) {
+    if (B <= 0 || N <= 0) return fail(ELG_EINVAL, "dist_matrix: empty input");
+    hipLaunchKernelGGL(dist_matrix_kernel, dim3(N, B), dim3(128), 0, (hipStream_t)stream, xy, dist, N);
+    return hipGetLastError() == hipSuccess ? ELG_OK : fail(ELG_ELAUNCH, "dist_matrix launch failed");
+}
+
+int elg_nbr_tables(const float* xy, int32_t* nbr_idx, float* nbr_dist, float* nbr_theta, int B, int N, void* stream) {
+    if (B <= 0 || N <= 0) return fail(ELG_EINVAL, "nbr_tables: empty input");
+    if (N > 8192) return fail(ELG_ENOTIMPL, "nbr_tables: N > 8192");
+    int NP = 64;
+    while (NP < N) NP <<= 1;
+    const int threads = NP >= 512 ? 256 : 64;
+    hipLaunchKernelGGL(nbr_tables_kernel, dim3(N, B), dim3(threads), (size_t)NP * 8, (hipStream_t)stream, xy, nbr_idx,
+                       nbr_dist, nbr_theta, N, NP);
+    return hipGetLastError() == hipSuccess ? ELG_OK : fail(ELG_ELAUNCH, "nbr_tables launch failed");
+}
+
+int elg_route_length(const float* xy, const int64_t* tour, float* out, int B, int M, int T, int N, int rounding,
+                     void* stream) {
+    if (B <= 0 || M <= 0 || T <= 0) return fail(ELG_EINVAL, "route_length: empty input");
+    const int n = B * M;
+    hipLaunchKernelGGL(route_length_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, xy,
+                       reinterpret_cast<const long long*>(tour), out, B, M, T, N, rounding);
+    return hipGetLastError() == hipSuccess ? ELG_OK : fail(ELG_ELAUNCH, "route_length launch failed");
+}
+
+int elg_rollout_fwd(const elg_rollout_args* a, void* stream) {
+    if (!a) return fail(ELG_EINVAL, "null args");
+    const elg_rollout_args& A = *a;
+    if (A.B <= 0 || A.M <= 0 || A.N1 <= 1 || A.tiles <= 0) return fail(ELG_EINVAL, "rollout: bad sizes");
+    if (A.K < 0 || A.K + 1 > ELG_SLOT_STRIDE) return fail(ELG_EINVAL, "rollout: local_size must be <= 47");
+    if (A.has_local && !A.loc) return fail(ELG_EINVAL, "rollout: has_local without tables");
+    if (A.mode == ELG_MODE_FORCED && !A.forced) return fail(ELG_EINVAL, "rollout: forced mode without actions");
+    if (A.problem == ELG_PROBLEM_CVRP) return dispatch_fwd<false>(A, (hipStream_t)stream);
+    if (A.problem == ELG_PROBLEM_TSP) return dispatch_fwd<true>(A, (hipStream_t)stream);
+    return fail(ELG_EINVAL, "rollout: unknown problem");
+}
+
+}  // extern "C"

@@ -1,0 +1,438 @@
+// Device-side pieces of one ELG construction step, shared by the forward (elg_fwd.hip) and the
+// backward replay (elg_bwd.hip).  One wavefront owns one trajectory; all per-trajectory state is
+// wave-uniform (cur, load, visited words) and lives in SGPRs.
+//
+// Lane layouts used inside a step:
+//   node layout   : lane l owns nodes n = l + 64*ch, ch < NCH           (masks, pointer scores, softmax)
+//   quad layout   : lane l = (half = l>>5, hq = l&31): channels cb = 4*hq .. +3 (head hq>>2),
+//                   rows 2c+half of read c; K/V rows are consumed 1 KiB per wave-instruction,
+//                   i.e. two whole 128-float rows, perfectly linear in LDS (glimpse attention)
+//   slot layout   : lane j owns k-NN slot j (CVRP: slot 0 = depot)        (local policy)
+//   sorted layout : lane l owns position l + 64*ch of the current node's neighbour list
+#pragma once
+#include "elg_common.h"
+#include "../../include/elg_hip.h"
+
+#define ELG_SLOT_STRIDE 48      // max slots (K + 1 <= 48)
+#define ELG_SB_FLOATS 144       // per-wave LDS scratch (>= 3*ELG_SLOT_STRIDE, >= 128)
+
+namespace elg {
+
+struct Inst {                 // per-instance table pointers (global or LDS)
+    const float* K;           // [N1][128]
+    const float* V;           // [N1][128]
+    const float* PK;          // [N1][128]  (LDS copy is XOR-swizzled per 16-B chunk: chunk ^ (n & 31))
+    const float* pb;          // [N1] global
+    const float* Q1;          // [N1][128] global
+    const float* Q2;          // [N1][128] global (TSP) or null
+    const float* wl;          // [128] global (CVRP)
+    const float* xy;          // [N1][2]   global (two uniform reads per step)
+    const float* dem;         // [N1]      LDS (CVRP)
+    const int* nidx;          // [N1][N1] global
+    const float* ndist;
+    const float* ntheta;
+    const float* loc;         // folded local tables (global)
+};
+
+template <int NCH>
+struct Traj {                 // wave-uniform trajectory state
+    int cur;
+    int first;                // TSP: first node
+    int cnt;                  // steps taken so far
+    int fin;
+    float load;
+    float len;                // running tour length (closed at the end for TSP)
+    unsigned long long vis[NCH];
+};
+
+template <int NCH>
+__device__ __forceinline__ bool test_bit(const unsigned long long (&w)[NCH], int n) {
+    // n is per-lane; NCH is small in the LDS-staged configuration, so a select chain is fine
+    unsigned long long x = w[0];
+#pragma unroll
+    for (int c = 1; c < NCH; ++c) x = ((n >> 6) == c) ? w[c] : x;
+    return (x >> (n & 63)) & 1ull;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Feasibility mask of the current state, as ballot words in node layout.
+// CVRPEnv.py:214-232: visited | (load + 1e-6 < demand); depot re-opened once finished.
+// TSPEnv.py:120: visited only.
+// ---------------------------------------------------------------------------------------------
+template <int NCH, bool TSP>
+__device__ __forceinline__ void build_mask(const Traj<NCH>& st, const Inst& I, int N1, int lane,
+                                           unsigned long long (&mk)[NCH]) {
+    const float lim = __fadd_rn(st.load, 1e-6f);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int n = lane + 64 * ch;
+        bool m = true;
+        if (n < N1) {
+            m = (st.vis[ch] >> lane) & 1ull;
+            if (!TSP) {
+                m = m || (lim < I.dem[n]);
+                if (n == 0 && st.fin) m = false;
+            }
+        }
+        mk[ch] = __ballot(m);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Environment transition for the chosen node (CVRPEnv.py:195-232, TSPEnv.py:108-124).
+// load is updated with exactly one rounded fp32 subtraction, as the reference does.
+// ---------------------------------------------------------------------------------------------
+template <int NCH, bool TSP>
+__device__ __forceinline__ void env_update(Traj<NCH>& st, const Inst& I, int N1, int sel) {
+    const float sx = I.xy[2 * sel], sy = I.xy[2 * sel + 1];
+    if (st.cnt > 0) {
+        const float px = I.xy[2 * st.cur], py = I.xy[2 * st.cur + 1];
+        st.len += dist2d(px, py, sx, sy);
+    }
+    if (TSP) {
+        if (st.cnt == 0) st.first = sel;
+    } else {
+        st.load = (sel == 0) ? 1.0f : __fsub_rn(st.load, I.dem[sel]);
+    }
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+        if ((sel >> 6) == ch) st.vis[ch] |= 1ull << (sel & 63);
+    if (!TSP) {
+        // depot counts as visited exactly while the trajectory stands on it (CVRPEnv.py:214-216)
+        if (sel == 0) st.vis[0] |= 1ull; else st.vis[0] &= ~1ull;
+    }
+    st.cur = sel;
+    st.cnt += 1;
+    bool all = true;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int rem = N1 - 64 * ch;
+        if (rem > 0) {
+            const unsigned long long full = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+            all = all && ((st.vis[ch] & full) == full);
+        }
+    }
+    if (TSP) {
+        if (st.cnt == N1) {                    // close the tour (TSPEnv.py:166 roll(-1))
+            const float fx = I.xy[2 * st.first], fy = I.xy[2 * st.first + 1];
+            st.len += dist2d(sx, sy, fx, fy);
+            st.fin = 1;
+        }
+    } else {
+        if (all) st.fin = 1;                   // CVRPEnv.py:226-228
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k-NN slots of the current node: walk its sorted neighbour list, keep the first K unmasked
+// customers (total order (dist, index) is baked into the list).  Selected entries are compacted
+// to slot order through the per-wave LDS scratch `sb` (3*ELG_SLOT_STRIDE floats): d | theta | node id.
+// Returns k (number of valid slots, without the depot slot).        models.py:55-90,355-391
+// ---------------------------------------------------------------------------------------------
+template <int NCH, bool TSP>
+__device__ __forceinline__ int knn_slots(const Inst& I, int N1, int K, int cur, int lane,
+                                         const unsigned long long (&mk)[NCH], float* sb) {
+    constexpr int S0 = TSP ? 0 : 1;
+    int found = 0;
+    const size_t row = (size_t)cur * N1;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        if (64 * ch < N1 && found < K) {                 // wave-uniform early exit
+            const int i = lane + 64 * ch;
+            const bool valid = i < N1;
+            const int nid = valid ? I.nidx[row + i] : 0;
+            bool cand = valid && !test_bit<NCH>(mk, nid);
+            if (!TSP) cand = cand && (nid != 0);
+            const unsigned long long bal = __ballot(cand);
+            const int rank = found + lanes_below(bal);
+            if (cand && rank < K) {
+                sb[S0 + rank] = I.ndist[row + i];
+                sb[ELG_SLOT_STRIDE + S0 + rank] = I.ntheta[row + i];
+                sb[2 * ELG_SLOT_STRIDE + S0 + rank] = i2f(nid);
+            }
+            found += __popcll(bal);
+        }
+    }
+    return found < K ? found : K;
+}
+
+// 32 per-lane values -> lane l ends with the wave-wide sum of element (l & 31)
+__device__ __forceinline__ float reduce_scatter32(float (&c)[32], int lane) {
+    const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float keep = b4 ? c[i + 16] : c[i], send = b4 ? c[i] : c[i + 16];
+        c[i] = keep + shfl_xor(send, 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float keep = b3 ? c[i + 8] : c[i], send = b3 ? c[i] : c[i + 8];
+        c[i] = keep + shfl_xor(send, 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float keep = b2 ? c[i + 4] : c[i], send = b2 ? c[i] : c[i + 4];
+        c[i] = keep + shfl_xor(send, 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float keep = b1 ? c[i + 2] : c[i], send = b1 ? c[i] : c[i + 2];
+        c[i] = keep + quad_xor2(send);
+    }
+    {
+        const float keep = b0 ? c[1] : c[0], send = b0 ? c[0] : c[1];
+        c[0] = keep + quad_xor1(send);
+    }
+    return c[0] + shfl_xor(c[0], 32);
+}
+
+// Saved intermediates of the local policy for the backward pass.
+struct LocalSave {
+    float f0, f1, f2;        // slot features
+    float al[ELG_LH];        // attention weights alpha_h of this slot
+    float op;                // o'[lane & 31]
+    float g;                 // g'[lane & 31]
+    bool smask;              // slot masked / absent
+};
+
+// ---------------------------------------------------------------------------------------------
+// Local policy on the k-NN slots (slot layout).  Returns u_j of this lane's slot.
+// models.py:133-166 with the projections folded:  k_j = Wk(We f_j + be + PE[j]) etc.
+//   sc_h   = la[h].f_j + lt[j][h]                      (q is the same learned vector for all)
+//   alpha  = softmax_j(sc_h + mask)
+//   o'[d]  = sum_j alpha_{h(d),j} (lAv[d].f_j + lcv[j][d])
+//   g'     = lWc o' + lbc
+//   u_j    = g'.(lWe f_j + lpe[j])                      (1/sqrt(32) folded into lWe, lpe)
+// ---------------------------------------------------------------------------------------------
+template <bool TSP>
+__device__ __forceinline__ float local_policy(const float* __restrict__ loc, int lane, float f0, float f1,
+                                              float f2, bool smask, LocalSave* save) {
+    const int j = lane;
+    const float* la = loc + ELG_LOC_LA;
+    const float4 lt = *reinterpret_cast<const float4*>(loc + ELG_LOC_LT + 4 * j);
+    float sc[ELG_LH] = {lt.x, lt.y, lt.z, lt.w};
+    float al[ELG_LH];
+#pragma unroll
+    for (int h = 0; h < ELG_LH; ++h) {
+        float s = sc[h];
+        s = fmaf(la[3 * h + 0], f0, s);
+        s = fmaf(la[3 * h + 1], f1, s);
+        if (!TSP) s = fmaf(la[3 * h + 2], f2, s);
+        s = smask ? ELG_NEG_INF : s;
+        const float mx = wave_max(s);
+        const float e = smask ? 0.f : __expf(s - mx);
+        const float den = wave_sum(e);
+        al[h] = den > 0.f ? e / den : 0.f;
+    }
+    // o' contributions of this slot
+    float c[32];
+    const float* lAv = loc + ELG_LOC_LAV;
+    const float* lcv = loc + ELG_LOC_LCV + 32 * j;
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4) {
+        const float4 cv = *reinterpret_cast<const float4*>(lcv + 4 * d4);
+        const float cvv[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int d = 4 * d4 + e;
+            float v = cvv[e];
+            v = fmaf(lAv[3 * d + 0], f0, v);
+            v = fmaf(lAv[3 * d + 1], f1, v);
+            if (!TSP) v = fmaf(lAv[3 * d + 2], f2, v);
+            c[d] = al[d >> 3] * v;
+        }
+    }
+    const float op = reduce_scatter32(c, lane);          // o'[lane & 31]
+    // g' = lWc o' + lbc  (lane d' computes g'[d'])
+    const int dd = lane & 31;
+    const float* wrow = loc + ELG_LOC_LWC + 32 * dd;
+    float g = loc[ELG_LOC_LBC + dd];
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4) {
+        const float4 w = *reinterpret_cast<const float4*>(wrow + 4 * d4);
+        g = fmaf(w.x, readlane(op, 4 * d4 + 0), g);
+        g = fmaf(w.y, readlane(op, 4 * d4 + 1), g);
+        g = fmaf(w.z, readlane(op, 4 * d4 + 2), g);
+        g = fmaf(w.w, readlane(op, 4 * d4 + 3), g);
+    }
+    // u_j = sum_d g'[d] (lpe[j][d] + lWe[d].f_j)
+    const float* lWe = loc + ELG_LOC_LWE;
+    const float* lpe = loc + ELG_LOC_LPE + 32 * j;
+    float u = 0.f;
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4) {
+        const float4 pe = *reinterpret_cast<const float4*>(lpe + 4 * d4);
+        const float pev[4] = {pe.x, pe.y, pe.z, pe.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int d = 4 * d4 + e;
+            float ev = pev[e];
+            ev = fmaf(lWe[3 * d + 0], f0, ev);
+            ev = fmaf(lWe[3 * d + 1], f1, ev);
+            if (!TSP) ev = fmaf(lWe[3 * d + 2], f2, ev);
+            u = fmaf(readlane(g, d), ev, u);
+        }
+    }
+    if (save) {
+        save->f0 = f0; save->f1 = f1; save->f2 = f2;
+#pragma unroll
+        for (int h = 0; h < ELG_LH; ++h) save->al[h] = al[h];
+        save->op = op; save->g = g; save->smask = smask;
+    }
+    return u;
+}
+
+// Saved intermediates of the glimpse for the backward pass (quad layout).
+template <int NG>
+struct GlimpseSave {
+    float e[NG];             // normalised attention weights a_h[row] of this lane's rows
+    float4 q4;               // q[cb..cb+3]
+};
+
+// ---------------------------------------------------------------------------------------------
+// Glimpse: 8-head attention of the trajectory's query over all nodes (models.py:330-341,455-503).
+// K and V are consumed two whole rows (1 KiB) per wave-instruction; the per-head 16-wide dot
+// products are finished with a quad reduce-scatter so that every lane ends up with the scores of
+// its own rows (row = 8k + 2*(lane&3) + (lane>>5), k = 0..NG-1) for head (lane&31)>>2.
+// Returns o[cb..cb+3] (cb = 4*(lane&31)), identical in both half-waves.
+// NG = number of row groups (8 rows each) = ceil(N1/8) rounded up to the template bound.
+// ---------------------------------------------------------------------------------------------
+template <int NCH, bool LDSK>
+__device__ __forceinline__ float4 glimpse(const Inst& I, int N1, int lane, const float4 q4,
+                                          const unsigned long long (&mk)[NCH],
+                                          GlimpseSave<8 * NCH>* save) {
+    constexpr int NG = 8 * NCH;                    // groups of 8 rows
+    const int half = lane >> 5, hq = lane & 31, ql = lane & 3, cb = hq * 4;
+    const bool b0 = ql & 1, b1 = ql & 2;
+    const int r = 2 * ql + half;                   // row offset of this lane inside a group
+    const float* Kp = I.K + cb;
+    const float* Vp = I.V + cb;
+    float m_run = ELG_NEG_INF, l_run = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int GB = NG < 16 ? NG : 16;          // groups per online-softmax block
+#pragma unroll
+    for (int g0 = 0; g0 < NG; g0 += GB) {
+        if (8 * g0 < N1) {
+            float sc[GB];
+#pragma unroll
+            for (int k = 0; k < GB; ++k) {
+                const int g = g0 + k;
+                sc[k] = ELG_NEG_INF;
+                if (8 * g < N1) {                  // wave-uniform
+                    float p[4];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        int row = 8 * g + 2 * jj + half;
+                        if (!LDSK) row = row < N1 ? row : N1 - 1;
+                        const float4 kv = *reinterpret_cast<const float4*>(Kp + (size_t)row * ELG_E);
+                        p[jj] = dot4(kv, q4, 0.f);
+                    }
+                    const float s0 = b0 ? p[1] : p[0], t0 = b0 ? p[0] : p[1];
+                    const float s1 = b0 ? p[3] : p[2], t1 = b0 ? p[2] : p[3];
+                    const float a0 = s0 + quad_xor1(t0), a1 = s1 + quad_xor1(t1);
+                    const float keep = b1 ? a1 : a0, send = b1 ? a0 : a1;
+                    const float dotv = keep + quad_xor2(send);
+                    const int myrow = 8 * g + r;
+                    const unsigned byte = (unsigned)(mk[g >> 3] >> (8 * (g & 7))) & 0xffu;   // uniform
+                    const bool masked = (myrow >= N1) || ((byte >> r) & 1u);
+                    sc[k] = masked ? ELG_NEG_INF : dotv * 0.25f;          // / sqrt(qkv_dim)
+                }
+            }
+            float mb = sc[0];
+#pragma unroll
+            for (int k = 1; k < GB; ++k) mb = fmaxf(mb, sc[k]);
+            mb = fmaxf(mb, quad_xor1(mb));
+            mb = fmaxf(mb, quad_xor2(mb));
+            mb = fmaxf(mb, shfl_xor(mb, 32));
+            const float m_new = fmaxf(m_run, mb);
+            if (m_new > ELG_NEG_INF) {             // same for every lane (mask is head-independent)
+                const float scale = (m_run > ELG_NEG_INF) ? __expf(m_run - m_new) : 0.f;
+                l_run *= scale;
+                acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
+                if (save) {
+#pragma unroll
+                    for (int k = 0; k < NG; ++k) if (k < g0) save->e[k] *= scale;
+                }
+                m_run = m_new;
+#pragma unroll
+                for (int k = 0; k < GB; ++k) {
+                    const int g = g0 + k;
+                    const float e = (sc[k] > ELG_NEG_INF) ? __expf(sc[k] - m_new) : 0.f;
+                    l_run += e;
+                    if (save) save->e[g] = e;
+                    if (8 * g < N1) {
+#define ELG_VACC(JJ)                                                                             \
+    {                                                                                            \
+        int row = 8 * g + 2 * JJ + half;                                                         \
+        const bool ok = row < N1;                                                                \
+        if (!LDSK) row = ok ? row : N1 - 1;                                                      \
+        float4 vv = *reinterpret_cast<const float4*>(Vp + (size_t)row * ELG_E);                  \
+        float a = quad_bcast<JJ>(e);                                                             \
+        a = ok ? a : 0.f;                                                                        \
+        if (!ok) vv = make_float4(0.f, 0.f, 0.f, 0.f);                                           \
+        acc.x = fmaf(a, vv.x, acc.x); acc.y = fmaf(a, vv.y, acc.y);                              \
+        acc.z = fmaf(a, vv.z, acc.z); acc.w = fmaf(a, vv.w, acc.w);                              \
+    }
+                        ELG_VACC(0) ELG_VACC(1) ELG_VACC(2) ELG_VACC(3)
+#undef ELG_VACC
+                    }
+                }
+            } else if (save) {
+#pragma unroll
+                for (int k = 0; k < GB; ++k) save->e[g0 + k] = 0.f;
+            }
+        } else if (save) {
+#pragma unroll
+            for (int k = 0; k < GB; ++k) save->e[g0 + k] = 0.f;
+        }
+    }
+    // denominators: lanes of one head = the quad in both half-waves
+    float l = l_run;
+    l += quad_xor1(l);
+    l += quad_xor2(l);
+    l += shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    acc.x += shfl_xor(acc.x, 32); acc.y += shfl_xor(acc.y, 32);
+    acc.z += shfl_xor(acc.z, 32); acc.w += shfl_xor(acc.w, 32);
+    if (save) {
+#pragma unroll
+        for (int k = 0; k < NG; ++k) save->e[k] *= inv;
+        save->q4 = q4;
+    }
+    return make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pointer scores s[n] = o . PK[n] + pb[n]   (models.py:341-352 with combine folded into PK).
+// o is broadcast through the wave's LDS scratch; every lane walks its own rows of PK.
+// ---------------------------------------------------------------------------------------------
+template <int NCH, bool LDSK>
+__device__ __forceinline__ void pointer_scores(const Inst& I, int N1, int lane, const float4 o4, float* sb,
+                                               float (&s)[NCH]) {
+    if (lane < 32) *reinterpret_cast<float4*>(sb + 4 * lane) = o4;
+    wave_lds_fence();
+    float acc[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) acc[ch] = 0.f;
+#pragma unroll 8
+    for (int c4 = 0; c4 < 32; ++c4) {
+        const float4 o = *reinterpret_cast<const float4*>(sb + 4 * c4);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int n = lane + 64 * ch;
+            if (n < N1) {
+                const int chunk = LDSK ? (c4 ^ (n & 31)) : c4;
+                const float4 pk = *reinterpret_cast<const float4*>(I.PK + (size_t)n * ELG_E + 4 * chunk);
+                acc[ch] = dot4(o, pk, acc[ch]);
+            }
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int n = lane + 64 * ch;
+        s[ch] = (n < N1) ? acc[ch] + I.pb[n] : 0.f;
+    }
+    wave_lds_fence();
+}
+
+}  // namespace elg

@@ -1,0 +1,360 @@
+"""Host side of the MI355X ELG-POMO rollout engine: folds the decoder / local-policy weights into
+the per-instance tables the HIP kernels consume, launches the kernels through the C ABI
+(include/elg_hip.h) and provides the autograd glue for training.
+
+PyTorch is plumbing here (device memory, streams, the small dense folds that autograd carries back
+to the parameters); every per-step operation of the reference runs inside libelg_hip.so.
+There is NO CPU fallback: without a GPU + the built library these functions raise."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib as L
+
+E, H, DK = 128, 8, 16
+LE, LH, LDK = 32, 4, 8
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"elg_amd: {what} must live on the GPU -- the HIP path has no CPU fallback")
+
+
+# ----------------------------------------------------------------------------------------------
+# small ops
+# ----------------------------------------------------------------------------------------------
+def aug8(xy: torch.Tensor) -> torch.Tensor:
+    """utils.augment_xy_data_by_8_fold (reference CVRP/utils.py:69-87): (B,N,2) -> (8B,N,2)."""
+    _need_cuda(xy, "xy")
+    xy = xy.contiguous().float()
+    B, N, _ = xy.shape
+    out = torch.empty(8 * B, N, 2, device=xy.device, dtype=torch.float32)
+    L.check(L.lib().elg_aug8(_ptr(xy), _ptr(out), B, N, _stream()), "elg_aug8")
+    return out
+
+
+def dist_matrix(xy: torch.Tensor) -> torch.Tensor:
+    _need_cuda(xy, "xy")
+    xy = xy.contiguous().float()
+    B, N, _ = xy.shape
+    out = torch.empty(B, N, N, device=xy.device, dtype=torch.float32)
+    L.check(L.lib().elg_dist_matrix(_ptr(xy), _ptr(out), B, N, _stream()), "elg_dist_matrix")
+    return out
+
+
+@dataclass
+class NbrTables:
+    idx: torch.Tensor      # (B,N,N) int32   neighbours of every node sorted by (dist, index)
+    dist: torch.Tensor     # (B,N,N) f32
+    theta: torch.Tensor    # (B,N,N) f32     atan2(y_n - y_c, x_n - x_c)
+
+
+def nbr_tables(xy: torch.Tensor) -> NbrTables:
+    _need_cuda(xy, "xy")
+    xy = xy.contiguous().float()
+    B, N, _ = xy.shape
+    idx = torch.empty(B, N, N, device=xy.device, dtype=torch.int32)
+    dist = torch.empty(B, N, N, device=xy.device, dtype=torch.float32)
+    theta = torch.empty(B, N, N, device=xy.device, dtype=torch.float32)
+    L.check(L.lib().elg_nbr_tables(_ptr(xy), _ptr(idx), _ptr(dist), _ptr(theta), B, N, _stream()), "elg_nbr_tables")
+    return NbrTables(idx, dist, theta)
+
+
+def route_length(xy: torch.Tensor, tour: torch.Tensor, rounding: bool = False) -> torch.Tensor:
+    """Closed-tour length (reference CVRPEnv.py:251-288, TSPEnv.py:158-184).  xy (B,N,2) f32,
+    tour (B,M,T) int64 -> (B,M) f32 (positive length)."""
+    _need_cuda(xy, "xy")
+    xy = xy.contiguous().float()
+    tour = tour.contiguous().to(torch.int64)
+    B, M, T = tour.shape
+    out = torch.empty(B, M, device=xy.device, dtype=torch.float32)
+    L.check(L.lib().elg_route_length(_ptr(xy), _ptr(tour), _ptr(out), B, M, T, xy.shape[1], int(bool(rounding)),
+                                     _stream()), "elg_route_length")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# weight folding (differentiable torch: autograd carries the kernel's table gradients back)
+# ----------------------------------------------------------------------------------------------
+def position_encoding(Lslots: int, emb: int, device) -> torch.Tensor:
+    """Sinusoid table of the local policy, sin block then cos block (reference models.py:28-49)."""
+    nts = emb // 2
+    inc = math.log(10000.0) / max(nts - 1, 1)
+    inv = torch.exp(torch.arange(nts, dtype=torch.float32, device=device) * -inc)
+    pos = torch.arange(Lslots, dtype=torch.float32, device=device)
+    st = pos[:, None] * inv[None, :]
+    return torch.cat([torch.sin(st), torch.cos(st)], dim=1)
+
+
+def fold_local_tables(lp: Dict[str, torch.Tensor], nfeat: int, n_slots: int) -> torch.Tensor:
+    """Fold local_policy_att's projections into slot tables (layout: include/elg_hip.h ELG_LOC_*).
+
+    reference models.py:133-166:  e_j = We f_j + be + PE[j];  q = Wq c;  k_j = Wk e_j;  v_j = Wv e_j;
+    u_j = (Wc softmax(q k / sqrt 8) v + bc) . e_j / sqrt 32.  Everything that does not depend on the
+    features f_j is precomputed per slot j here."""
+    We, be = lp["init_emb.weight"], lp["init_emb.bias"]
+    dev = We.device
+    pe = position_encoding(n_slots, LE, dev)
+    base = be[None, :] + pe                                        # (L,32)  be + PE[j]
+    q = (lp["Wq.weight"] @ lp["cur_token_emb"]).view(LH, LDK)
+    WkWe = (lp["Wk.weight"] @ We).view(LH, LDK, nfeat)
+    la = torch.einsum("hd,hdf->hf", q, WkWe) / math.sqrt(LDK)      # (4,F)
+    kb = (base @ lp["Wk.weight"].T).view(n_slots, LH, LDK)
+    lt = torch.einsum("hd,jhd->jh", q, kb) / math.sqrt(LDK)        # (L,4)
+    lAv = lp["Wv.weight"] @ We                                     # (32,F)
+    lcv = base @ lp["Wv.weight"].T                                 # (L,32)
+    lWc = lp["multi_head_combine.weight"]
+    lbc = lp["multi_head_combine.bias"]
+    lWe = We / math.sqrt(LE)
+    lpe = base / math.sqrt(LE)
+
+    def pad_cols(x, cols):
+        return torch.nn.functional.pad(x, (0, cols - x.shape[1]))
+
+    def pad_rows(x, rows):
+        return torch.nn.functional.pad(x, (0, 0, 0, rows - x.shape[0]))
+    pieces = [
+        torch.nn.functional.pad(pad_cols(la, 3).reshape(-1), (0, 4)),          # LA   16
+        pad_rows(lt, L.LOC_ROWS).reshape(-1),                                   # LT   256
+        pad_cols(lAv, 3).reshape(-1),                                           # LAV  96
+        pad_rows(lcv, L.LOC_ROWS).reshape(-1),                                  # LCV  2048
+        lWc.reshape(-1),                                                        # LWC  1024
+        lbc.reshape(-1),                                                        # LBC  32
+        pad_cols(lWe, 3).reshape(-1),                                           # LWE  96
+        pad_rows(lpe, L.LOC_ROWS).reshape(-1),                                  # LPE  2048
+    ]
+    out = torch.cat(pieces).contiguous()
+    assert out.numel() == L.LOC_SIZE
+    return out
+
+
+def fold_decoder_tables(dec: Dict[str, torch.Tensor], enc: torch.Tensor, problem: int) -> Dict[str, torch.Tensor]:
+    """Per-instance tables of the pointer decoder (reference models.py:300-352, TSP/models.py:231-270):
+    K = Wk enc, V = Wv enc, PK = enc Wc / sqrt(E) (pointer keys with multi_head_combine folded in),
+    pb = enc . bc / sqrt(E), Q1/Q2 = the per-node query contributions."""
+    Wc, bc = dec["multi_head_combine.weight"], dec["multi_head_combine.bias"]
+    t = {
+        "K": (enc @ dec["Wk.weight"].T).contiguous(),
+        "V": (enc @ dec["Wv.weight"].T).contiguous(),
+        "PK": ((enc @ Wc) / math.sqrt(E)).contiguous(),
+        "pb": ((enc @ bc) / math.sqrt(E)).contiguous(),
+    }
+    if problem == L.PROBLEM_CVRP:
+        Wq = dec["Wq_last.weight"]
+        t["Q1"] = (enc @ Wq[:, :E].T).contiguous()
+        t["wl"] = Wq[:, E].contiguous()
+        t["Q2"] = None
+    else:
+        t["Q1"] = (enc @ dec["Wq_last.weight"].T).contiguous()
+        t["Q2"] = (enc @ dec["Wq_first.weight"].T).contiguous()
+        t["wl"] = None
+    return t
+
+
+# ----------------------------------------------------------------------------------------------
+# launch configuration
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class Problem:
+    """Device-resident description of one batch of instances."""
+    kind: int                       # L.PROBLEM_*
+    xy: torch.Tensor                # (B,N1,2)
+    demand: Optional[torch.Tensor]  # (B,N1) CVRP
+    nbr: NbrTables
+
+    @property
+    def B(self):
+        return self.xy.shape[0]
+
+    @property
+    def N1(self):
+        return self.xy.shape[1]
+
+
+@dataclass
+class Policy:
+    """Folded weights of one (model, batch) pair."""
+    tables: Dict[str, torch.Tensor]
+    loc: Optional[torch.Tensor]
+    K: int
+    xi: float
+    clip: float
+    inv_ens: float
+    has_local: bool
+    has_penalty: bool
+
+
+def launch_geometry(B: int, M: int, N1: int):
+    """(waves, tiles, lds_stage).  256 CUs, one workgroup per CU when K/V/PK are staged in LDS:
+    aim for ~256 workgroups; 13 waves per workgroup cover a 25-trajectory tile in two rounds."""
+    lds = 1 if N1 <= 104 else 0
+    waves = 13 if lds else 8
+    n_cu = 256
+    tiles = max(1, min(M, (n_cu + B - 1) // B))
+    if not lds:
+        tiles = max(tiles, min(M, (4 * n_cu + B - 1) // B))
+    return waves, tiles, lds
+
+
+def max_steps(kind: int, N1: int) -> int:
+    # CVRP: depot + every customer + at most one depot return per customer
+    return N1 if kind == L.PROBLEM_TSP else 2 * N1
+
+
+def _fill_common(a: L.RolloutArgs, prob: Problem, pol: Policy, M: int, geometry=None):
+    waves, tiles, lds = geometry or launch_geometry(prob.B, M, prob.N1)
+    a.problem, a.B, a.M, a.N1, a.K = prob.kind, prob.B, M, prob.N1, pol.K
+    a.has_local, a.has_penalty = int(pol.has_local), int(pol.has_penalty)
+    a.waves, a.tiles, a.lds_stage = waves, tiles, lds
+    a.xi, a.clip, a.inv_ens = pol.xi, pol.clip, pol.inv_ens
+    t = pol.tables
+    for k in ("K", "V", "PK", "pb", "Q1"):
+        _need_cuda(t[k], k)
+        assert t[k].dtype == torch.float32 and t[k].is_contiguous()
+    a.Kmat, a.Vmat, a.PK, a.pb, a.Q1 = _ptr(t["K"]), _ptr(t["V"]), _ptr(t["PK"]), _ptr(t["pb"]), _ptr(t["Q1"])
+    a.Q2, a.wl = _ptr(t.get("Q2")), _ptr(t.get("wl"))
+    a.xy, a.demand = _ptr(prob.xy), _ptr(prob.demand)
+    a.nbr_idx, a.nbr_dist, a.nbr_theta = _ptr(prob.nbr.idx), _ptr(prob.nbr.dist), _ptr(prob.nbr.theta)
+    a.loc = _ptr(pol.loc)
+
+
+@dataclass
+class RolloutResult:
+    actions: torch.Tensor           # (B,M,Tcap) int32 (slice [:, :, :T])
+    probs: torch.Tensor             # (B,Tcap,M) f32
+    reward: torch.Tensor            # (B,M) f32 = -length on the scaled coordinates
+    tlen: torch.Tensor              # (B,M) int32
+    full_probs: Optional[torch.Tensor] = None
+
+
+def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mode: int, *, forced=None, seed: int = 0,
+                    uniforms=None, dump_T: int = 0, geometry=None, Tcap: Optional[int] = None) -> RolloutResult:
+    """Run every trajectory to completion in one persistent launch (reference CVRP/utils.py:7-29)."""
+    dev = prob.xy.device
+    B, N1 = prob.B, prob.N1
+    Tcap = Tcap or max_steps(prob.kind, N1)
+    actions = torch.zeros(B, M, Tcap, device=dev, dtype=torch.int32)       # finished -> depot (0)
+    probs = torch.ones(B, Tcap, M, device=dev, dtype=torch.float32)        # ... with probability 1
+    reward = torch.empty(B, M, device=dev, dtype=torch.float32)
+    tlen = torch.empty(B, M, device=dev, dtype=torch.int32)
+    full = torch.zeros(B, M, dump_T, N1, device=dev, dtype=torch.float32) if dump_T > 0 else None
+    a = L.RolloutArgs()
+    _fill_common(a, prob, pol, M, geometry)
+    a.Tmax, a.mode, a.max_steps, a.do_decode, a.do_update, a.use_state = Tcap, mode, 0, 1, 1, 0
+    a.seed = seed & 0xFFFFFFFFFFFFFFFF
+    starts = starts.to(device=dev, dtype=torch.int32).contiguous()
+    a.starts = _ptr(starts)
+    if forced is not None:
+        forced = forced.to(device=dev, dtype=torch.int32).contiguous()
+        a.forced, a.Tforced = _ptr(forced), forced.shape[2]
+    if uniforms is not None:
+        uniforms = uniforms.to(device=dev, dtype=torch.float32).contiguous()
+        assert uniforms.shape == (B, M, Tcap)
+        a.uniforms = _ptr(uniforms)
+    a.actions, a.probs, a.reward, a.tlen = _ptr(actions), _ptr(probs), _ptr(reward), _ptr(tlen)
+    a.full_probs, a.dump_T = _ptr(full), dump_T
+    L.check(L.lib().elg_rollout_fwd(C.byref(a), _stream()), "elg_rollout_fwd")
+    return RolloutResult(actions, probs, reward, tlen, full)
+
+
+# ----------------------------------------------------------------------------------------------
+# backward: replay kernel -> row factors -> dense contractions (hipBLASLt via torch.matmul)
+# ----------------------------------------------------------------------------------------------
+class _ChosenProbs(torch.autograd.Function):
+    """probs[b,t,m] of the recorded actions as a differentiable function of the folded tables."""
+
+    @staticmethod
+    def forward(ctx, prob: Problem, pol_meta: Policy, M, actions, probs_val, T, geometry,
+                Kt, Vt, PKt, pbt, Q1t, Q2t, wlt, loct):
+        ctx.prob, ctx.pol_meta, ctx.M, ctx.T, ctx.geometry = prob, pol_meta, M, T, geometry
+        ctx.save_for_backward(actions, Kt, Vt, PKt, pbt, Q1t, Q2t if Q2t is not None else Kt.new_empty(0),
+                              wlt if wlt is not None else Kt.new_empty(0), loct if loct is not None else Kt.new_empty(0))
+        ctx.has = (Q2t is not None, wlt is not None, loct is not None)
+        return probs_val.clone()
+
+    @staticmethod
+    def backward(ctx, gprob):
+        actions, Kt, Vt, PKt, pbt, Q1t, Q2t, wlt, loct = ctx.saved_tensors
+        hasQ2, haswl, hasloc = ctx.has
+        prob, meta, M, T = ctx.prob, ctx.pol_meta, ctx.M, ctx.T
+        dev = Kt.device
+        B, N1 = prob.B, prob.N1
+        R = M * T
+        tables = dict(K=Kt, V=Vt, PK=PKt, pb=pbt, Q1=Q1t, Q2=Q2t if hasQ2 else None, wl=wlt if haswl else None)
+        pol = Policy(tables, loct if hasloc else None, meta.K, meta.xi, meta.clip, meta.inv_ens, meta.has_local,
+                     meta.has_penalty)
+        ba = L.BwdArgs()
+        _fill_common(ba.fwd, prob, pol, M, ctx.geometry)
+        forced = actions[:, :, :T].contiguous()
+        ba.fwd.Tmax, ba.fwd.mode, ba.fwd.max_steps, ba.fwd.do_decode, ba.fwd.do_update = T, L.MODE_FORCED, 0, 1, 1
+        ba.fwd.forced, ba.fwd.Tforced = _ptr(forced), T
+        ba.T = T
+        g = gprob[:, :T, :].contiguous().float()
+        rowA = torch.empty(B, H, R, N1, device=dev)
+        rowDS = torch.empty(B, H, R, N1, device=dev)
+        rowDL = torch.empty(B, R, N1, device=dev)
+        rowQ = torch.empty(B, R, E, device=dev)
+        rowO = torch.empty(B, R, E, device=dev)
+        rowDO = torch.empty(B, R, E, device=dev)
+        rowDQ = torch.empty(B, R, E, device=dev)
+        gloc = torch.zeros(L.LOC_SIZE, device=dev)
+        ba.gprob = _ptr(g)
+        ba.rowA, ba.rowDS, ba.rowDL = _ptr(rowA), _ptr(rowDS), _ptr(rowDL)
+        ba.rowQ, ba.rowO, ba.rowDO, ba.rowDQ, ba.gloc = _ptr(rowQ), _ptr(rowO), _ptr(rowDO), _ptr(rowDQ), _ptr(gloc)
+        L.check(L.lib().elg_rollout_bwd(C.byref(ba), _stream()), "elg_rollout_bwd")
+        # per-instance contractions over the R = M*T decode rows
+        Qh = rowQ.view(B, R, H, DK).permute(0, 2, 1, 3)                    # (B,H,R,16)
+        DOh = rowDO.view(B, R, H, DK).permute(0, 2, 1, 3)
+        dK = torch.matmul(rowDS.transpose(2, 3), Qh).permute(0, 2, 1, 3).reshape(B, N1, E)
+        dV = torch.matmul(rowA.transpose(2, 3), DOh).permute(0, 2, 1, 3).reshape(B, N1, E)
+        dPK = torch.matmul(rowDL.transpose(1, 2), rowO)                    # (B,N1,128)
+        dpb = rowDL.sum(dim=1)
+        cur = forced.permute(0, 1, 2).reshape(B, R).long()                 # node whose query row was used: prev action
+        # the query of step t is gathered at cur = action[t-1]
+        prev = torch.cat([torch.zeros(B, M, 1, dtype=torch.long, device=dev), forced[:, :, :-1].long()], dim=2).reshape(B, R)
+        dQ1 = torch.zeros(B, N1, E, device=dev).index_add_(1, prev[0], rowDQ[0]) if B == 1 else \
+            torch.zeros(B, N1, E, device=dev).scatter_add_(1, prev[:, :, None].expand(B, R, E), rowDQ)
+        dQ2 = dwl = None
+        if hasQ2:
+            first = forced[:, :, :1].long().expand(B, M, T).reshape(B, R)
+            dQ2 = torch.zeros(B, N1, E, device=dev).scatter_add_(1, first[:, :, None].expand(B, R, E), rowDQ)
+        if haswl:
+            # q = Q1[cur] + load * wl  ->  d wl = sum_rows load * dq ; the kernel stores load*dq separately? no:
+            # load is replayed on the host from the recorded actions (cheap, exact fp32 sequence not needed here)
+            dwl = ctx.load_rows(forced, prob, rowDQ) if hasattr(ctx, "load_rows") else _dwl_from_rows(prob, forced, rowDQ)
+        return (None, None, None, None, None, None, None,
+                dK, dV, dPK, dpb, dQ1, dQ2, dwl, gloc if hasloc else None)
+
+
+def _dwl_from_rows(prob: Problem, forced: torch.Tensor, rowDQ: torch.Tensor) -> torch.Tensor:
+    """d wl = sum over decode rows of load_before_step * dq.  The load sequence is replayed with
+    torch ops from the recorded actions (reference CVRPEnv.py:211-212)."""
+    B, M, T = forced.shape
+    dem = torch.gather(prob.demand[:, None, :].expand(B, M, prob.N1), 2, forced.long())     # (B,M,T) demand of action t
+    load = torch.ones(B, M, device=forced.device)
+    loads = []
+    for t in range(T):
+        loads.append(load)                      # load seen by the decode of step t (before action t)
+        load = torch.where(forced[:, :, t] == 0, torch.ones_like(load), load - dem[:, :, t])
+    lb = torch.stack(loads, dim=2).reshape(B, M * T)
+    return torch.einsum("br,bre->e", lb, rowDQ)
+
+
+def chosen_probs(prob: Problem, pol: Policy, M: int, res: RolloutResult, T: int, geometry=None) -> torch.Tensor:
+    """Differentiable view of res.probs[:, :T, :] (gradients flow to pol.tables / pol.loc)."""
+    t = pol.tables
+    return _ChosenProbs.apply(prob, pol, M, res.actions, res.probs[:, :T, :], T, geometry,
+                              t["K"], t["V"], t["PK"], t["pb"], t["Q1"], t.get("Q2"), t.get("wl"), pol.loc)

@@ -1,0 +1,145 @@
+/* elg_hip.h -- C ABI of libelg_hip.so, the MI355X (gfx950) ELG-POMO rollout engine.
+ *
+ * Drop-in boundary for the reference's construction hot path (gaocrr/ELG).  The reference has no
+ * FFI: its "plugin interface" is the duck-typed Python protocol CVRPEnv / CVRPModel / rollout
+ * (SURVEY.md section 8b).  These entry points are what a binding for that protocol calls; the
+ * Python classes in elg_amd/{CVRP,TSP}/ are that binding (ctypes, raw device pointers).
+ *
+ * Conventions: every pointer is a DEVICE pointer into caller-owned memory (no ownership transfer),
+ * row-major, fp32 / int32 unless stated; `stream` is a hipStream_t passed as void*; every function
+ * only enqueues work on `stream` (no allocation, no synchronisation -- graph-capturable) and
+ * returns 0 or a negative ELG_E* code; elg_last_error() gives the message for the calling thread.
+ */
+#ifndef ELG_HIP_H
+#define ELG_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ELG_OK 0
+#define ELG_EINVAL (-1)     /* bad argument / unsupported shape   (Python: ValueError)        */
+#define ELG_ELAUNCH (-2)    /* HIP launch failure                 (Python: RuntimeError)      */
+#define ELG_ENOTIMPL (-3)   /* configuration not built            (Python: NotImplementedError) */
+
+#define ELG_PROBLEM_CVRP 0
+#define ELG_PROBLEM_TSP 1
+#define ELG_MODE_GREEDY 0   /* argmax, ties -> lowest node index  (CVRPModel.py:70-73)         */
+#define ELG_MODE_SAMPLE 1   /* categorical sample                 (CVRPModel.py:59-68)         */
+#define ELG_MODE_FORCED 2   /* teacher forcing: actions given, probabilities returned          */
+
+/* layout of the folded local-policy table buffer (floats); rows padded to ELG_LOC_ROWS slots */
+#define ELG_LOC_ROWS 64
+#define ELG_LOC_LA 0        /* [4][3]   q_h^T Wk We / sqrt(8)          (pad to 16 floats)      */
+#define ELG_LOC_LT 16       /* [64][4]  q_h . Wk(be + PE[j]) / sqrt(8)                        */
+#define ELG_LOC_LAV 272     /* [32][3]  Wv We                                                 */
+#define ELG_LOC_LCV 368     /* [64][32] Wv (be + PE[j])                                       */
+#define ELG_LOC_LWC 2416    /* [32][32] multi_head_combine.weight                             */
+#define ELG_LOC_LBC 3440    /* [32]     multi_head_combine.bias                               */
+#define ELG_LOC_LWE 3472    /* [32][3]  We / sqrt(32)                                         */
+#define ELG_LOC_LPE 3568    /* [64][32] (be + PE[j]) / sqrt(32)                               */
+#define ELG_LOC_SIZE 5616
+
+const char* elg_version(void);
+const char* elg_last_error(void);
+
+/* utils.augment_xy_data_by_8_fold (CVRP/utils.py:69-87): in (B,N,2) -> out (8B,N,2). */
+int elg_aug8(const float* xy_in, float* xy_out, int B, int N, void* stream);
+
+/* Distance matrix (CVRPEnv.py:148, TSPEnv.py:65): xy (B,N,2) -> dist (B,N,N). */
+int elg_dist_matrix(const float* xy, float* dist, int B, int N, void* stream);
+
+/* Per-instance neighbour tables: for every node c the list of all nodes sorted by
+ * (dist(c,n), n) ascending, with the distance and polar angle atan2(y_n-y_c, x_n-x_c).
+ * Replaces the per-step take_along_dim / atan2 / topk of CVRPEnv.get_cur_feature
+ * (CVRPEnv.py:291-318) and models.py:55-120,355-403.  Outputs are (B,N,N).  N <= 8192. */
+int elg_nbr_tables(const float* xy, int32_t* nbr_idx, float* nbr_dist, float* nbr_theta,
+                   int B, int N, void* stream);
+
+/* Closed-tour length (CVRPEnv._get_reward / compute_unscaled_reward, CVRPEnv.py:251-288;
+ * TSPEnv.py:158-184).  xy (Bxy,N,2) with instance b using row b % Bxy... no: Bxy == B.
+ * tour (B,M,T) int64, out (B,M) = +length.  rounding != 0 rounds every segment (half-even). */
+int elg_route_length(const float* xy, const int64_t* tour, float* out, int B, int M, int T, int N,
+                     int rounding, void* stream);
+
+/* Arguments of the construction kernels.  One trajectory = one wavefront. */
+typedef struct elg_rollout_args {
+    int32_t problem;        /* ELG_PROBLEM_*                                                    */
+    int32_t B, M, N1;       /* instances, POMO trajectories per instance, nodes (CVRP: + depot) */
+    int32_t K;              /* model_params['local_size'][0]                                    */
+    int32_t Tmax;           /* time capacity of actions / probs                                 */
+    int32_t mode;           /* ELG_MODE_*                                                       */
+    int32_t Tforced;        /* time extent of `forced`                                          */
+    int32_t has_local;      /* decoder.local (add_local_policy called) and model_params.ensemble */
+    int32_t has_penalty;    /* model_params.distance_penalty                                    */
+    int32_t max_steps;      /* <=0: run every trajectory to completion; >0: at most that many   */
+    int32_t do_decode;      /* 0: env update only with forced actions (CVRPEnv.step)            */
+    int32_t do_update;      /* 0: decode only (CVRPModel.one_step_rollout)                      */
+    int32_t use_state;      /* 1: load/store the st_* arrays (step-wise protocol)               */
+    int32_t waves;          /* wavefronts per workgroup: 8 or 13                                */
+    int32_t tiles;          /* workgroups per instance                                          */
+    int32_t lds_stage;      /* 1: K/V/PK of the instance staged in LDS (N1 <= 104)              */
+    int32_t dump_T;         /* time extent of full_probs (0 = no dump)                          */
+    float xi;               /* model_params.xi                                                  */
+    float clip;             /* model_params.logit_clipping                                      */
+    float inv_ens;          /* 1 / ensemble_size                                                */
+    float pad0;
+    uint64_t seed;          /* sampling seed (Philox key)                                       */
+    const float* Kmat;      /* (B,N1,128) decoder.Wk enc                                        */
+    const float* Vmat;      /* (B,N1,128) decoder.Wv enc                                        */
+    const float* PK;        /* (B,N1,128) enc Wc / sqrt(128)  (pointer keys folded with combine) */
+    const float* pb;        /* (B,N1)     enc . bc / sqrt(128)                                  */
+    const float* Q1;        /* (B,N1,128) CVRP: Wq_last[:, :128] enc ; TSP: Wq_last enc         */
+    const float* Q2;        /* (B,N1,128) TSP: Wq_first enc ; CVRP: NULL                        */
+    const float* wl;        /* (128)      CVRP: Wq_last[:, 128] (load column)                   */
+    const float* xy;        /* (B,N1,2)                                                         */
+    const float* demand;    /* (B,N1) CVRP, demand[:,0] = 0                                     */
+    const int32_t* nbr_idx; /* (B,N1,N1) from elg_nbr_tables                                    */
+    const float* nbr_dist;
+    const float* nbr_theta;
+    const float* loc;       /* (ELG_LOC_SIZE) folded local-policy tables, NULL if !has_local    */
+    const int32_t* starts;  /* (M) POMO start nodes (CVRPModel.py:46-51 / TSPModel.py:30-34)    */
+    const int32_t* forced;  /* (B,M,Tforced) or NULL                                            */
+    const float* uniforms;  /* (B,M,Tmax) externally drawn U[0,1) or NULL (Philox)              */
+    int32_t* st_cur;        /* (B,M)   state, step-wise protocol                                */
+    int32_t* st_cnt;        /* (B,M)                                                            */
+    int32_t* st_fin;        /* (B,M)                                                            */
+    int32_t* st_first;      /* (B,M)   TSP first node                                           */
+    float* st_load;         /* (B,M)                                                            */
+    float* st_len;          /* (B,M)                                                            */
+    uint64_t* st_vis;       /* (B,M,ceil(N1/64)) visited bitmask                                */
+    int32_t* actions;       /* (B,M,Tmax) out                                                   */
+    float* probs;           /* (B,Tmax,M) out, probability of the chosen node                   */
+    float* reward;          /* (B,M) out, -tour length on `xy`                                  */
+    int32_t* tlen;          /* (B,M) out, number of steps taken                                 */
+    float* full_probs;      /* (B,M,dump_T,N1) out or NULL: whole probability rows (tests)      */
+} elg_rollout_args;
+
+/* POMO construction: CVRPEnv.reset/step + CVRPModel.one_step_rollout + utils.rollout fused into one
+ * persistent launch (CVRP/utils.py:7-29), or single steps of it (use_state / max_steps). */
+int elg_rollout_fwd(const elg_rollout_args* args, void* stream);
+
+/* Backward of the chosen-node probabilities w.r.t. the instance tables and the folded local tables.
+ * Replays the recorded actions (no tape), recomputes each step and emits the row factors of the
+ * per-instance gradient contractions; see DESIGN.md "backward". */
+typedef struct elg_bwd_args {
+    elg_rollout_args fwd;   /* same tables; fwd.forced = recorded actions, mode = FORCED          */
+    int32_t T;              /* steps to replay (== fwd.Tforced)                                   */
+    int32_t pad1;
+    const float* gprob;     /* (B,T,M) dJ/d prob[b,t,m]                                           */
+    float* rowA;            /* (B,8,R,N1)  glimpse attention weights a_h[n],  R = M*T             */
+    float* rowDS;           /* (B,8,R,N1)  d score_h[n] (already / sqrt(16))                      */
+    float* rowDL;           /* (B,R,N1)    d pointer score s[n]                                   */
+    float* rowQ;            /* (B,R,128)   glimpse query q                                        */
+    float* rowO;            /* (B,R,128)   glimpse output o                                       */
+    float* rowDO;           /* (B,R,128)   d o                                                    */
+    float* rowDQ;           /* (B,R,128)   d q                                                    */
+    float* gloc;            /* (ELG_LOC_SIZE) accumulated gradient of the folded local tables     */
+} elg_bwd_args;
+int elg_rollout_bwd(const elg_bwd_args* args, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
