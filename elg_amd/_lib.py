@@ -41,7 +41,7 @@ class BwdArgs(C.Structure):
     _fields_ = [
         ("fwd", RolloutArgs), ("T", C.c_int32), ("pad1", C.c_int32),
         ("gprob", _vp), ("rowA", _vp), ("rowDS", _vp), ("rowDL", _vp), ("rowQ", _vp), ("rowO", _vp),
-        ("rowDO", _vp), ("rowDQ", _vp), ("gloc", _vp),
+        ("rowDO", _vp), ("rowDQ", _vp), ("rowDU", _vp), ("gwl", _vp), ("gloc", _vp),
     ]
 
 

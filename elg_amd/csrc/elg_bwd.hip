@@ -1,8 +1,544 @@
-// Backward replay kernel (placeholder until the real kernel lands in this file).
+// Backward of the POMO construction: replay kernels.
+//
+// The reference differentiates through a Python tape of ~1000 aten ops per step (CVRP/train.py:112-125
+// over utils.py:14-21).  Here the recorded actions are replayed: per-step state is a pure function
+// of the action prefix, so each step is recomputed and differentiated inside one wavefront.
+//   rollout_bwd_kernel : glimpse / pointer / softmax backward, emits the row factors of the
+//                        per-instance gradient contractions (see include/elg_hip.h) + d u_slot
+//   local_bwd_kernel   : k-NN + local-policy replay, gradient of the folded local tables reduced
+//                        in LDS accumulators, one flush per workgroup
 #include "elg_rollout.h"
 #include <string>
-namespace elg { int fail(int code, const std::string& msg); }
+
+namespace elg {
+int fail(int code, const std::string& msg);
+
+// ---------------------------------------------------------------------------------------------
+// common prologue: instance pointers + LDS staging (same carve as the forward kernel)
+// ---------------------------------------------------------------------------------------------
+template <bool TSP, bool LDSK, int NT>
+__device__ __forceinline__ float* stage_instance(const elg_rollout_args& A, int b, float* lds, Inst& I) {
+    const int N1 = A.N1, NE = N1 * ELG_E;
+    float* p = lds;
+    float *sK = nullptr, *sV = nullptr, *sPK = nullptr;
+    if (LDSK) { sK = p; sV = p + NE; sPK = p + 2 * NE; p += 3 * NE; }
+    float* sdem = p; p += (N1 + 3) & ~3;
+    p += 4;
+    const float* gK = A.Kmat + (size_t)b * NE;
+    const float* gV = A.Vmat + (size_t)b * NE;
+    const float* gPK = A.PK + (size_t)b * NE;
+    if (LDSK) {
+        for (int i = threadIdx.x; i < NE / 4; i += NT) {
+            reinterpret_cast<float4*>(sK)[i] = reinterpret_cast<const float4*>(gK)[i];
+            reinterpret_cast<float4*>(sV)[i] = reinterpret_cast<const float4*>(gV)[i];
+            const int n = i >> 5, c4 = i & 31;
+            reinterpret_cast<float4*>(sPK)[n * 32 + (c4 ^ (n & 31))] = reinterpret_cast<const float4*>(gPK)[i];
+        }
+    }
+    if (!TSP)
+        for (int i = threadIdx.x; i < N1; i += NT) sdem[i] = A.demand[(size_t)b * N1 + i];
+    I.K = LDSK ? sK : gK;
+    I.V = LDSK ? sV : gV;
+    I.PK = LDSK ? sPK : gPK;
+    I.pb = A.pb + (size_t)b * N1;
+    I.Q1 = A.Q1 + (size_t)b * NE;
+    I.Q2 = TSP ? A.Q2 + (size_t)b * NE : nullptr;
+    I.wl = A.wl;
+    I.xy = A.xy + (size_t)b * N1 * 2;
+    I.dem = sdem;
+    I.nidx = A.nbr_idx + (size_t)b * N1 * N1;
+    I.ndist = A.nbr_dist + (size_t)b * N1 * N1;
+    I.ntheta = A.nbr_theta + (size_t)b * N1 * N1;
+    I.loc = A.loc;
+    return p;
+}
+
+__device__ __forceinline__ void unit_of_block(const elg_rollout_args& A, int& b, int& m_lo, int& m_hi) {
+    const int G = gridDim.x;
+    int u = blockIdx.x;
+    if ((G & 7) == 0) u = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    b = u / A.tiles;
+    const int tile = u % A.tiles;
+    const int tile_m = (A.M + A.tiles - 1) / A.tiles;
+    m_lo = tile * tile_m;
+    m_hi = min(A.M, m_lo + tile_m);
+}
+
+// ---------------------------------------------------------------------------------------------
+// one decode step, forward recomputed + backward, for the trajectory of this wave
+// ---------------------------------------------------------------------------------------------
+template <int NCH, bool TSP, bool LDSK>
+__device__ __forceinline__ void bwd_step(const elg_bwd_args& BA, const Inst& I, const Traj<NCH>& st, int lane,
+                                         float* sb, int sel, float gp, size_t b, size_t r, size_t R,
+                                         float4& dwl4) {
+    const elg_rollout_args& A = BA.fwd;
+    constexpr int NG = 8 * NCH;
+    const int N1 = A.N1;
+    const int half = lane >> 5, hq = lane & 31, ql = lane & 3, cb = hq * 4, head = hq >> 2;
+    const bool b0 = ql & 1, b1 = ql & 2;
+    const int rr = 2 * ql + half;
+
+    unsigned long long mk[NCH];
+    build_mask<NCH, TSP>(st, I, N1, lane, mk);
+
+    float4 q4 = *reinterpret_cast<const float4*>(I.Q1 + (size_t)st.cur * ELG_E + cb);
+    if (TSP) {
+        const float4 qf = *reinterpret_cast<const float4*>(I.Q2 + (size_t)st.first * ELG_E + cb);
+        q4.x += qf.x; q4.y += qf.y; q4.z += qf.z; q4.w += qf.w;
+    } else {
+        const float4 w = *reinterpret_cast<const float4*>(I.wl + cb);
+        q4.x = fmaf(st.load, w.x, q4.x); q4.y = fmaf(st.load, w.y, q4.y);
+        q4.z = fmaf(st.load, w.z, q4.z); q4.w = fmaf(st.load, w.w, q4.w);
+    }
+
+    // ---- forward: slots, local policy, glimpse, pointer, softmax
+    float addval = 0.f;
+    int snid = -1;
+    if (A.has_penalty || A.has_local) {
+        const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb);
+        snid = S.snid;
+        float u = 0.f;
+        if (A.has_local) u = local_policy<TSP>(I.loc, lane, S.f0, S.f1, S.f2, S.smask, nullptr);
+        addval = S.pen + u * A.inv_ens;
+    }
+    GlimpseSave<NG> gs;
+    const float4 o4 = glimpse<NCH, LDSK>(I, N1, lane, q4, mk, &gs);
+    float s[NCH];
+    pointer_scores<NCH, LDSK>(I, N1, lane, o4, sb, s);
+
+    const float dflt = A.has_penalty ? A.xi : 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int n = lane + 64 * ch;
+        if (n < N1) sb[n] = dflt;
+    }
+    wave_lds_fence();
+    if (snid >= 0) sb[snid] = addval;
+    wave_lds_fence();
+    float th[NCH], lg[NCH];
+    float mx = ELG_NEG_INF;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int n = lane + 64 * ch;
+        const bool masked = (mk[ch] >> lane) & 1ull;
+        th[ch] = 0.f;
+        lg[ch] = ELG_NEG_INF;
+        if (n < N1 && !masked) {
+            th[ch] = tanhf(s[ch] + sb[n]);
+            lg[ch] = A.clip * th[ch];
+        }
+        mx = fmaxf(mx, lg[ch]);
+    }
+    wave_lds_fence();
+    mx = wave_max(mx);
+    float pn[NCH];
+    float part = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        pn[ch] = (lg[ch] > ELG_NEG_INF) ? __expf(lg[ch] - mx) : 0.f;
+        part += pn[ch];
+    }
+    const float inv = 1.0f / wave_sum(part);
+    float psel = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        pn[ch] *= inv;
+        if ((sel >> 6) == ch) psel = readlane(pn[ch], sel & 63);
+    }
+
+    // ---- softmax + clip backward: d s[n]   (models.py:416-420)
+    const float gsel = gp * psel;
+    float* rDL = BA.rowDL + (b * R + r) * N1;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int n = lane + 64 * ch;
+        if (n < N1) {
+            const float dlogit = gsel * ((n == sel ? 1.f : 0.f) - pn[ch]);
+            const float ds = (lg[ch] > ELG_NEG_INF) ? dlogit * A.clip * (1.f - th[ch] * th[ch]) : 0.f;
+            rDL[n] = ds;
+            sb[n] = ds;
+        }
+    }
+    wave_lds_fence();
+    // d u_slot (local policy output), consumed by local_bwd_kernel
+    if (BA.rowDU && lane < ELG_SLOT_STRIDE) {
+        float du = 0.f;
+        if (snid >= 0) du = sb[snid] * A.inv_ens;
+        BA.rowDU[(b * R + r) * ELG_SLOT_STRIDE + lane] = du;
+    }
+    // ds of this lane's rows in quad layout
+    float dsq[NG];
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        const int row = 8 * k + rr;
+        dsq[k] = (8 * k < N1 && row < N1) ? sb[row] : 0.f;
+    }
+    wave_lds_fence();
+
+    // ---- pointer backward: d o[c] = sum_n ds[n] PK[n][c]
+    float4 do4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        if (8 * k < N1) {
+#define ELG_DOACC(JJ)                                                                            \
+    {                                                                                            \
+        int row = 8 * k + 2 * JJ + half;                                                         \
+        const bool ok = row < N1;                                                                \
+        row = ok ? row : N1 - 1;                                                                 \
+        const int chunk = LDSK ? (hq ^ (row & 31)) : hq;                                         \
+        const float4 pk = *reinterpret_cast<const float4*>(I.PK + (size_t)row * ELG_E + 4 * chunk); \
+        float a = quad_bcast<JJ>(dsq[k]);                                                        \
+        a = ok ? a : 0.f;                                                                        \
+        do4.x = fmaf(a, pk.x, do4.x); do4.y = fmaf(a, pk.y, do4.y);                              \
+        do4.z = fmaf(a, pk.z, do4.z); do4.w = fmaf(a, pk.w, do4.w);                              \
+    }
+            ELG_DOACC(0) ELG_DOACC(1) ELG_DOACC(2) ELG_DOACC(3)
+#undef ELG_DOACC
+        }
+    }
+    do4.x += shfl_xor(do4.x, 32); do4.y += shfl_xor(do4.y, 32);
+    do4.z += shfl_xor(do4.z, 32); do4.w += shfl_xor(do4.w, 32);
+
+    // ---- glimpse backward
+    // sum_n a_h[n] da_h[n] = sum_{c in h} do[c] o[c]
+    float doto = do4.x * o4.x + do4.y * o4.y + do4.z * o4.z + do4.w * o4.w;
+    doto += quad_xor1(doto);
+    doto += quad_xor2(doto);
+    const float* Vp = I.V + cb;
+    const float* Kp = I.K + cb;
+    float dsk[NG];
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        dsk[k] = 0.f;
+        if (8 * k < N1) {
+            float pp[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                int row = 8 * k + 2 * jj + half;
+                if (!LDSK) row = row < N1 ? row : N1 - 1;
+                const float4 vv = *reinterpret_cast<const float4*>(Vp + (size_t)row * ELG_E);
+                pp[jj] = dot4(vv, do4, 0.f);
+            }
+            const float s0 = b0 ? pp[1] : pp[0], t0 = b0 ? pp[0] : pp[1];
+            const float s1 = b0 ? pp[3] : pp[2], t1 = b0 ? pp[2] : pp[3];
+            const float a0 = s0 + quad_xor1(t0), a1 = s1 + quad_xor1(t1);
+            const float keep = b1 ? a1 : a0, send = b1 ? a0 : a1;
+            const float da = keep + quad_xor2(send);                 // d a_h[row] of this lane's row
+            const float a = gs.e[k];                                  // 0 for masked / absent rows
+            dsk[k] = (a != 0.f) ? 0.25f * a * (da - doto) : 0.f;
+        }
+    }
+    // rows of the contractions: a_h[n], d(q.K)_h[n]
+    {
+        float* rA = BA.rowA + ((b * ELG_H + head) * R + r) * N1;
+        float* rS = BA.rowDS + ((b * ELG_H + head) * R + r) * N1;
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int row = 8 * k + rr;
+            if (8 * k < N1 && row < N1) {
+                rA[row] = gs.e[k];
+                rS[row] = dsk[k];
+            }
+        }
+    }
+    // d q[c] = sum_n dsk_h[n] K[n][c]
+    float4 dq4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        if (8 * k < N1) {
+#define ELG_DQACC(JJ)                                                                            \
+    {                                                                                            \
+        int row = 8 * k + 2 * JJ + half;                                                         \
+        const bool ok = row < N1;                                                                \
+        if (!LDSK) row = ok ? row : N1 - 1;                                                      \
+        float4 kv = *reinterpret_cast<const float4*>(Kp + (size_t)row * ELG_E);                  \
+        float a = quad_bcast<JJ>(dsk[k]);                                                        \
+        a = ok ? a : 0.f;                                                                        \
+        if (!ok) kv = make_float4(0.f, 0.f, 0.f, 0.f);                                           \
+        dq4.x = fmaf(a, kv.x, dq4.x); dq4.y = fmaf(a, kv.y, dq4.y);                              \
+        dq4.z = fmaf(a, kv.z, dq4.z); dq4.w = fmaf(a, kv.w, dq4.w);                              \
+    }
+            ELG_DQACC(0) ELG_DQACC(1) ELG_DQACC(2) ELG_DQACC(3)
+#undef ELG_DQACC
+        }
+    }
+    dq4.x += shfl_xor(dq4.x, 32); dq4.y += shfl_xor(dq4.y, 32);
+    dq4.z += shfl_xor(dq4.z, 32); dq4.w += shfl_xor(dq4.w, 32);
+    if (lane < 32) {
+        const size_t off = (b * R + r) * ELG_E + cb;
+        *reinterpret_cast<float4*>(BA.rowQ + off) = q4;
+        *reinterpret_cast<float4*>(BA.rowO + off) = o4;
+        *reinterpret_cast<float4*>(BA.rowDO + off) = do4;
+        *reinterpret_cast<float4*>(BA.rowDQ + off) = dq4;
+        if (!TSP) {
+            dwl4.x = fmaf(st.load, dq4.x, dwl4.x); dwl4.y = fmaf(st.load, dq4.y, dwl4.y);
+            dwl4.z = fmaf(st.load, dq4.z, dwl4.z); dwl4.w = fmaf(st.load, dq4.w, dwl4.w);
+        }
+    }
+}
+
+// rows of a step that is not decoded (first moves, finished trajectories): all zero
+template <int NCH>
+__device__ __forceinline__ void zero_rows(const elg_bwd_args& BA, int lane, size_t b, size_t r, size_t R) {
+    const int N1 = BA.fwd.N1;
+    for (int h = 0; h < ELG_H; ++h) {
+        float* rA = BA.rowA + ((b * ELG_H + h) * R + r) * N1;
+        float* rS = BA.rowDS + ((b * ELG_H + h) * R + r) * N1;
+        for (int n = lane; n < N1; n += 64) { rA[n] = 0.f; rS[n] = 0.f; }
+    }
+    float* rDL = BA.rowDL + (b * R + r) * N1;
+    for (int n = lane; n < N1; n += 64) rDL[n] = 0.f;
+    const size_t off = (b * R + r) * ELG_E;
+    for (int c = lane; c < ELG_E; c += 64) {
+        BA.rowQ[off + c] = 0.f; BA.rowO[off + c] = 0.f; BA.rowDO[off + c] = 0.f; BA.rowDQ[off + c] = 0.f;
+    }
+    if (BA.rowDU && lane < ELG_SLOT_STRIDE) BA.rowDU[(b * R + r) * ELG_SLOT_STRIDE + lane] = 0.f;
+}
+
+template <int NCH, bool TSP, bool LDSK, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void rollout_bwd_kernel(const elg_bwd_args BA) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const elg_rollout_args& A = BA.fwd;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int N1 = A.N1, T = BA.T;
+    int bi, m_lo, m_hi;
+    unit_of_block(A, bi, m_lo, m_hi);
+    Inst I;
+    float* p = stage_instance<TSP, LDSK, WAVES * 64>(A, bi, lds, I);
+    float* sb = p + wave * SbSize<NCH>::value;
+    __syncthreads();
+    const size_t b = bi, R = (size_t)A.M * T;
+    float4 dwl4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int m = m_lo + wave; m < m_hi; m += WAVES) {
+        const size_t bm = b * A.M + m;
+        Traj<NCH> st;
+        st.cur = 0; st.first = 0; st.cnt = 0; st.fin = 0; st.load = 1.0f; st.len = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) st.vis[c] = 0ull;
+        for (int t = 0; t < T; ++t) {
+            const size_t r = (size_t)m * T + t;
+            const int sel = __builtin_amdgcn_readfirstlane(A.forced[bm * A.Tforced + t]);
+            const bool first_move = (!TSP && t <= 1) || (TSP && t == 0);
+            if (st.fin || first_move) {
+                zero_rows<NCH>(BA, lane, b, r, R);
+            } else {
+                const float gp = i2f(__builtin_amdgcn_readfirstlane(f2i(BA.gprob[(b * T + t) * A.M + m])));
+                bwd_step<NCH, TSP, LDSK>(BA, I, st, lane, sb, sel, gp, b, r, R, dwl4);
+            }
+            if (!st.fin) env_update<NCH, TSP>(st, I, N1, sel);
+        }
+    }
+    if (!TSP && BA.gwl && lane < 32) {
+        const int cb = lane * 4;
+        atomicAdd(BA.gwl + cb + 0, dwl4.x); atomicAdd(BA.gwl + cb + 1, dwl4.y);
+        atomicAdd(BA.gwl + cb + 2, dwl4.z); atomicAdd(BA.gwl + cb + 3, dwl4.w);
+    }
+}
+
+// =============================================================================================
+// local-policy replay: gradient of the folded tables (layout ELG_LOC_*), accumulated in LDS
+// =============================================================================================
+template <bool TSP>
+__device__ __forceinline__ void local_bwd_step(const float* __restrict__ loc, float* __restrict__ acc, int lane,
+                                               const Slots& S, float du) {
+    const int j = lane, dd = lane & 31;
+    LocalSave sv;
+    (void)local_policy<TSP>(loc, lane, S.f0, S.f1, S.f2, S.smask, &sv);
+    const float f[3] = {S.f0, S.f1, TSP ? 0.f : S.f2};
+    constexpr int NF = TSP ? 2 : 3;
+    const float* lWe = loc + ELG_LOC_LWE;
+    const float* lpe = loc + ELG_LOC_LPE + 32 * j;
+    const float* lAv = loc + ELG_LOC_LAV;
+    const float* lcv = loc + ELG_LOC_LCV + 32 * j;
+    const bool slot_live = du != 0.f;
+
+    // u_j = sum_d g'[d] e_j[d],  e_j[d] = lpe[j][d] + lWe[d].f
+    float c[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) {
+        float ev = lpe[d];
+#pragma unroll
+        for (int k = 0; k < NF; ++k) ev = fmaf(lWe[3 * d + k], f[k], ev);
+        c[d] = du * ev;                                            // -> d g'[d]
+        const float gd = readlane(sv.g, d);
+        if (slot_live) atomicAdd(acc + ELG_LOC_LPE + 32 * j + d, du * gd);
+    }
+    float dg = reduce_scatter32(c, lane);                          // d g'[lane & 31]
+    {   // d lWe[d][f] = g'[d] * sum_j du_j f_j[f]
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+            const float sf = wave_sum(du * f[k]);
+            if (lane < 32) atomicAdd(acc + ELG_LOC_LWE + 3 * dd + k, sv.g * sf);
+        }
+    }
+    // g' = lWc o' + lbc
+    const float* wrow = loc + ELG_LOC_LWC + 32 * dd;
+    if (lane < 32) atomicAdd(acc + ELG_LOC_LBC + dd, dg);
+#pragma unroll
+    for (int d = 0; d < 32; ++d) {
+        const float opd = readlane(sv.op, d);
+        if (lane < 32) atomicAdd(acc + ELG_LOC_LWC + 32 * dd + d, dg * opd);
+        c[d] = (lane < 32) ? wrow[d] * dg : 0.f;                   // -> d o'[d]
+    }
+    const float dop = reduce_scatter32(c, lane);                   // d o'[lane & 31]
+    // o'[d] = sum_j alpha_{h(d),j} v_j[d],  v_j[d] = lcv[j][d] + lAv[d].f
+    float dal[ELG_LH] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < 32; ++d) {
+        float v = lcv[d];
+#pragma unroll
+        for (int k = 0; k < NF; ++k) v = fmaf(lAv[3 * d + k], f[k], v);
+        const float dopd = readlane(dop, d);
+        dal[d >> 3] = fmaf(dopd, v, dal[d >> 3]);
+        const float dv = sv.al[d >> 3] * dopd;
+        if (sv.al[d >> 3] != 0.f) atomicAdd(acc + ELG_LOC_LCV + 32 * j + d, dv);
+    }
+    {   // d lAv[d][f] = d o'[d] * sum_j alpha_{h(d),j} f_j[f]
+        float af[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) af[i] = 0.f;
+#pragma unroll
+        for (int h = 0; h < ELG_LH; ++h)
+#pragma unroll
+            for (int k = 0; k < NF; ++k) af[3 * h + k] = sv.al[h] * f[k];
+        const float tot = reduce_scatter16(af, lane);              // total of element (lane & 15)
+        const int hsel = dd >> 3;
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+            const float afv = __shfl(tot, 3 * hsel + k, ELG_WAVE);
+            if (lane < 32) atomicAdd(acc + ELG_LOC_LAV + 3 * dd + k, dop * afv);
+        }
+    }
+    // softmax backward -> d sc_h, then la / lt
+    float dsc[ELG_LH];
+#pragma unroll
+    for (int h = 0; h < ELG_LH; ++h) {
+        const float tsum = wave_sum(sv.al[h] * dal[h]);
+        dsc[h] = sv.al[h] * (dal[h] - tsum);
+        if (sv.al[h] != 0.f) atomicAdd(acc + ELG_LOC_LT + 4 * j + h, dsc[h]);
+    }
+    {
+        float sf[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sf[i] = 0.f;
+#pragma unroll
+        for (int h = 0; h < ELG_LH; ++h)
+#pragma unroll
+            for (int k = 0; k < NF; ++k) sf[3 * h + k] = dsc[h] * f[k];
+        const float tot = reduce_scatter16(sf, lane);
+        if (lane < 12) atomicAdd(acc + ELG_LOC_LA + lane, tot);
+    }
+}
+
+template <int NCH, bool TSP, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void local_bwd_kernel(const elg_bwd_args BA) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const elg_rollout_args& A = BA.fwd;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int N1 = A.N1, T = BA.T;
+    int bi, m_lo, m_hi;
+    unit_of_block(A, bi, m_lo, m_hi);
+    Inst I;
+    float* p = stage_instance<TSP, false, WAVES * 64>(A, bi, lds, I);
+    float* acc = p; p += ELG_LOC_SIZE;
+    float* sb = p + wave * SbSize<NCH>::value;
+    for (int i = threadIdx.x; i < ELG_LOC_SIZE; i += WAVES * 64) acc[i] = 0.f;
+    __syncthreads();
+    const size_t b = bi, R = (size_t)A.M * T;
+
+    for (int m = m_lo + wave; m < m_hi; m += WAVES) {
+        const size_t bm = b * A.M + m;
+        Traj<NCH> st;
+        st.cur = 0; st.first = 0; st.cnt = 0; st.fin = 0; st.load = 1.0f; st.len = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) st.vis[c] = 0ull;
+        for (int t = 0; t < T; ++t) {
+            const size_t r = (size_t)m * T + t;
+            const int sel = __builtin_amdgcn_readfirstlane(A.forced[bm * A.Tforced + t]);
+            const bool first_move = (!TSP && t <= 1) || (TSP && t == 0);
+            if (!st.fin && !first_move) {
+                unsigned long long mk[NCH];
+                build_mask<NCH, TSP>(st, I, N1, lane, mk);
+                const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb);
+                const float du = (lane < ELG_SLOT_STRIDE) ? BA.rowDU[(b * R + r) * ELG_SLOT_STRIDE + lane] : 0.f;
+                if (__ballot(du != 0.f)) local_bwd_step<TSP>(I.loc, acc, lane, S, du);
+            }
+            if (!st.fin) env_update<NCH, TSP>(st, I, N1, sel);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ELG_LOC_SIZE; i += WAVES * 64) {
+        const float v = acc[i];
+        if (v != 0.f) atomicAdd(BA.gloc + i, v);
+    }
+}
+
+// =============================================================================================
+// launchers
+// =============================================================================================
+template <int NCH, bool TSP, bool LDSK, int WAVES>
+static int launch_bwd(const elg_bwd_args& BA, hipStream_t stream) {
+    const elg_rollout_args& A = BA.fwd;
+    size_t lds = 0;
+    if (LDSK) lds += (size_t)3 * A.N1 * ELG_E * 4;
+    lds += (size_t)((A.N1 + 3) & ~3) * 4 + 16 + (size_t)WAVES * SbSize<NCH>::value * 4;
+    if (lds > 163840) return fail(ELG_EINVAL, "rollout_bwd: LDS budget exceeded");
+    auto kern = rollout_bwd_kernel<NCH, TSP, LDSK, WAVES>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                163840) != hipSuccess)
+            return fail(ELG_ELAUNCH, "hipFuncSetAttribute failed");
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(A.B * A.tiles), dim3(WAVES * 64), lds, stream, BA);
+    if (hipGetLastError() != hipSuccess) return fail(ELG_ELAUNCH, "rollout_bwd launch failed");
+    if (A.has_local) {
+        constexpr int LW = 8;
+        size_t l2 = (size_t)((A.N1 + 3) & ~3) * 4 + 16 + (size_t)ELG_LOC_SIZE * 4 + (size_t)LW * SbSize<NCH>::value * 4;
+        auto k2 = local_bwd_kernel<NCH, TSP, LW>;
+        static bool attr2 = false;
+        if (!attr2) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    163840) != hipSuccess)
+                return fail(ELG_ELAUNCH, "hipFuncSetAttribute failed");
+            attr2 = true;
+        }
+        hipLaunchKernelGGL(k2, dim3(A.B * A.tiles), dim3(LW * 64), l2, stream, BA);
+        if (hipGetLastError() != hipSuccess) return fail(ELG_ELAUNCH, "local_bwd launch failed");
+    }
+    return ELG_OK;
+}
+
+template <bool TSP>
+static int dispatch_bwd(const elg_bwd_args& BA, hipStream_t stream) {
+    const elg_rollout_args& A = BA.fwd;
+    const int nch = (A.N1 + 63) / 64;
+    const bool lds = A.lds_stage != 0;
+    if (lds && A.N1 > 104) return fail(ELG_EINVAL, "lds_stage needs N1 <= 104");
+    if (nch == 1) { if (lds) return launch_bwd<1, TSP, true, 8>(BA, stream); return launch_bwd<1, TSP, false, 8>(BA, stream); }
+    if (nch == 2) { if (lds) return launch_bwd<2, TSP, true, 8>(BA, stream); return launch_bwd<2, TSP, false, 8>(BA, stream); }
+    if (lds) return fail(ELG_EINVAL, "lds_stage needs N1 <= 104");
+    if (nch <= 4) return launch_bwd<4, TSP, false, 8>(BA, stream);
+    return fail(ELG_ENOTIMPL, "rollout_bwd: N1 > 256 not built");
+}
+
+}  // namespace elg
+
+using namespace elg;
+
 extern "C" int elg_rollout_bwd(const elg_bwd_args* a, void* stream) {
-    (void)a; (void)stream;
-    return elg::fail(ELG_ENOTIMPL, "rollout_bwd not built yet");
+    if (!a) return fail(ELG_EINVAL, "null args");
+    const elg_bwd_args& BA = *a;
+    const elg_rollout_args& A = BA.fwd;
+    if (A.B <= 0 || A.M <= 0 || A.N1 <= 1 || A.tiles <= 0 || BA.T <= 0) return fail(ELG_EINVAL, "rollout_bwd: bad sizes");
+    if (!A.forced || A.Tforced < BA.T) return fail(ELG_EINVAL, "rollout_bwd: recorded actions missing");
+    if (!BA.gprob || !BA.rowA || !BA.rowDS || !BA.rowDL || !BA.rowQ || !BA.rowO || !BA.rowDO || !BA.rowDQ)
+        return fail(ELG_EINVAL, "rollout_bwd: missing row buffers");
+    if (A.has_local && (!A.loc || !BA.rowDU || !BA.gloc)) return fail(ELG_EINVAL, "rollout_bwd: local buffers missing");
+    if (A.K + 1 > ELG_SLOT_STRIDE) return fail(ELG_EINVAL, "rollout_bwd: local_size must be <= 47");
+    if (A.problem == ELG_PROBLEM_CVRP) return dispatch_bwd<false>(BA, (hipStream_t)stream);
+    if (A.problem == ELG_PROBLEM_TSP) return dispatch_bwd<true>(BA, (hipStream_t)stream);
+    return fail(ELG_EINVAL, "rollout_bwd: unknown problem");
 }

@@ -131,42 +131,14 @@ __device__ __forceinline__ FwdOut decode_step(const elg_rollout_args& A, const I
     }
 
     // ---- k-NN slots + distance penalty + local policy (slot layout)
-    constexpr int S0 = TSP ? 0 : 1;
     float addval = 0.f;          // per-slot additive term (penalty + local score)
     int snid = -1;               // node of this lane's slot
     if (A.has_penalty || A.has_local) {
-        const int k = knn_slots<NCH, TSP>(I, N1, A.K, st.cur, lane, mk, sb);
-        wave_lds_fence();
-        const int j = lane;
-        const bool cust = (j >= S0) && (j < S0 + k);                 // a real neighbour slot
-        float sd = 0.f, sth = 0.f;
-        if (cust) {
-            sd = sb[j];
-            sth = sb[ELG_SLOT_STRIDE + j];
-            snid = f2i(sb[2 * ELG_SLOT_STRIDE + j]);
-        }
-        const float dmax = (k > 0) ? sb[S0 + k - 1] : 0.f;            // distance of the k-th neighbour
-        wave_lds_fence();
-        if (!TSP && j == 0) snid = 0;                                 // depot slot
-        float pen = 0.f;
-        if (A.has_penalty && cust) {
-            if (TSP) pen = -(sd / (dmax + 1e-6f));                    // TSP/models.py:290
-            else pen = (dmax != 0.f) ? -(sd / dmax) : -sd;            // models.py:379-405 (no epsilon)
-        }
+        const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb);
+        snid = S.snid;
         float u = 0.f;
-        if (A.has_local) {
-            const float nf = dmax + 1e-6f;                            // models.py:79 / TSP :72
-            float f0 = 0.f, f1 = 0.f, f2 = 0.f;
-            if (cust) {
-                f0 = sd / nf;
-                f1 = sth;
-                if (!TSP) f2 = I.dem[snid] / st.load;                 // CVRPEnv.py:315-316
-            }
-            bool smask = !cust;
-            if (!TSP && j == 0) smask = mk[0] & 1ull;                 // depot slot carries the depot's mask
-            u = local_policy<TSP>(I.loc, lane, f0, f1, f2, smask, nullptr);
-        }
-        addval = pen + u * A.inv_ens;
+        if (A.has_local) u = local_policy<TSP>(I.loc, lane, S.f0, S.f1, S.f2, S.smask, nullptr);
+        addval = S.pen + u * A.inv_ens;
     }
 
     // ---- glimpse + pointer
@@ -290,7 +262,7 @@ __global__ __launch_bounds__(WAVES * 64) void rollout_fwd_kernel(const elg_rollo
     if (LDSK) { sK = p; sV = p + NE; sPK = p + 2 * NE; p += 3 * NE; }
     float* sdem = p; p += (N1 + 3) & ~3;
     int* sctr = reinterpret_cast<int*>(p); p += 4;
-    float* sb = p + wave * ELG_SB_FLOATS;
+    float* sb = p + wave * SbSize<NCH>::value;
 
     const float* gK = A.Kmat + (size_t)b * NE;
     const float* gV = A.Vmat + (size_t)b * NE;
@@ -405,7 +377,7 @@ template <int NCH, bool TSP, bool LDSK, int WAVES>
 static int launch_fwd(const elg_rollout_args& A, hipStream_t stream) {
     size_t lds = 0;
     if (LDSK) lds += (size_t)3 * A.N1 * ELG_E * 4;
-    lds += (size_t)((A.N1 + 3) & ~3) * 4 + 16 + (size_t)WAVES * ELG_SB_FLOATS * 4;
+    lds += (size_t)((A.N1 + 3) & ~3) * 4 + 16 + (size_t)WAVES * SbSize<NCH>::value * 4;
     if (lds > 163840) return fail(ELG_EINVAL, "rollout: LDS budget exceeded");
     auto kern = rollout_fwd_kernel<NCH, TSP, LDSK, WAVES>;
     static bool attr_done = false;

@@ -14,9 +14,13 @@
 #include "../../include/elg_hip.h"
 
 #define ELG_SLOT_STRIDE 48      // max slots (K + 1 <= 48)
-#define ELG_SB_FLOATS 144       // per-wave LDS scratch (>= 3*ELG_SLOT_STRIDE, >= 128)
+#define ELG_SB_MIN 144          // per-wave LDS scratch floats (>= 3*ELG_SLOT_STRIDE, >= 128)
 
 namespace elg {
+
+// per-wave LDS scratch: slot compaction (3*48), o broadcast (128), node-indexed terms (64*NCH)
+template <int NCH>
+struct SbSize { static constexpr int value = (64 * NCH > ELG_SB_MIN) ? 64 * NCH : ELG_SB_MIN; };
 
 struct Inst {                 // per-instance table pointers (global or LDS)
     const float* K;           // [N1][128]
@@ -156,6 +160,53 @@ __device__ __forceinline__ int knn_slots(const Inst& I, int N1, int K, int cur, 
     return found < K ? found : K;
 }
 
+// Everything the slot lanes need for one step: k-NN slot contents, penalty, local features, mask.
+struct Slots {
+    int k;            // valid neighbour slots (uniform)
+    float dmax;       // distance of the k-th neighbour (uniform value)
+    bool cust;        // this lane holds a real neighbour slot
+    int snid;         // node of this lane's slot (-1: none; CVRP lane 0: depot)
+    float pen;        // distance penalty of the slot (0 if none)
+    float f0, f1, f2; // local-policy features
+    bool smask;       // slot masked / absent for the local attention
+};
+
+template <int NCH, bool TSP>
+__device__ __forceinline__ Slots slot_setup(const Inst& I, int N1, int K, bool has_penalty, const Traj<NCH>& st,
+                                            int lane, const unsigned long long (&mk)[NCH], float* sb) {
+    constexpr int S0 = TSP ? 0 : 1;
+    Slots S;
+    S.k = knn_slots<NCH, TSP>(I, N1, K, st.cur, lane, mk, sb);
+    wave_lds_fence();
+    const int j = lane;
+    S.cust = (j >= S0) && (j < S0 + S.k);
+    float sd = 0.f, sth = 0.f;
+    S.snid = -1;
+    if (S.cust) {
+        sd = sb[j];
+        sth = sb[ELG_SLOT_STRIDE + j];
+        S.snid = f2i(sb[2 * ELG_SLOT_STRIDE + j]);
+    }
+    S.dmax = (S.k > 0) ? sb[S0 + S.k - 1] : 0.f;
+    wave_lds_fence();
+    if (!TSP && j == 0) S.snid = 0;                                   // depot slot
+    S.pen = 0.f;
+    if (has_penalty && S.cust) {
+        if (TSP) S.pen = -(sd / (S.dmax + 1e-6f));                    // TSP/models.py:290
+        else S.pen = (S.dmax != 0.f) ? -(sd / S.dmax) : -sd;          // models.py:379-405 (no epsilon)
+    }
+    const float nf = S.dmax + 1e-6f;                                  // models.py:79 / TSP :72
+    S.f0 = S.f1 = S.f2 = 0.f;
+    if (S.cust) {
+        S.f0 = sd / nf;
+        S.f1 = sth;
+        if (!TSP) S.f2 = I.dem[S.snid] / st.load;                     // CVRPEnv.py:315-316
+    }
+    S.smask = !S.cust;
+    if (!TSP && j == 0) S.smask = mk[0] & 1ull;                       // depot slot carries the depot's mask
+    return S;
+}
+
 // 32 per-lane values -> lane l ends with the wave-wide sum of element (l & 31)
 __device__ __forceinline__ float reduce_scatter32(float (&c)[32], int lane) {
     const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
@@ -184,6 +235,32 @@ __device__ __forceinline__ float reduce_scatter32(float (&c)[32], int lane) {
         c[0] = keep + quad_xor1(send);
     }
     return c[0] + shfl_xor(c[0], 32);
+}
+
+// 16 per-lane values -> lane l ends with the wave-wide sum of element (l & 15)
+__device__ __forceinline__ float reduce_scatter16(float (&c)[16], int lane) {
+    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float keep = b3 ? c[i + 8] : c[i], send = b3 ? c[i] : c[i + 8];
+        c[i] = keep + shfl_xor(send, 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float keep = b2 ? c[i + 4] : c[i], send = b2 ? c[i] : c[i + 4];
+        c[i] = keep + shfl_xor(send, 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float keep = b1 ? c[i + 2] : c[i], send = b1 ? c[i] : c[i + 2];
+        c[i] = keep + quad_xor2(send);
+    }
+    {
+        const float keep = b0 ? c[1] : c[0], send = b0 ? c[0] : c[1];
+        c[0] = keep + quad_xor1(send);
+    }
+    float r = c[0] + shfl_xor(c[0], 16);
+    return r + shfl_xor(r, 32);
 }
 
 // Saved intermediates of the local policy for the backward pass.

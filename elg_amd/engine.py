@@ -310,47 +310,33 @@ class _ChosenProbs(torch.autograd.Function):
         rowO = torch.empty(B, R, E, device=dev)
         rowDO = torch.empty(B, R, E, device=dev)
         rowDQ = torch.empty(B, R, E, device=dev)
+        rowDU = torch.empty(B, R, 48, device=dev) if meta.has_local else None
+        gwl = torch.zeros(E, device=dev)
         gloc = torch.zeros(L.LOC_SIZE, device=dev)
         ba.gprob = _ptr(g)
         ba.rowA, ba.rowDS, ba.rowDL = _ptr(rowA), _ptr(rowDS), _ptr(rowDL)
-        ba.rowQ, ba.rowO, ba.rowDO, ba.rowDQ, ba.gloc = _ptr(rowQ), _ptr(rowO), _ptr(rowDO), _ptr(rowDQ), _ptr(gloc)
+        ba.rowQ, ba.rowO, ba.rowDO, ba.rowDQ = _ptr(rowQ), _ptr(rowO), _ptr(rowDO), _ptr(rowDQ)
+        ba.rowDU, ba.gwl, ba.gloc = _ptr(rowDU), _ptr(gwl), _ptr(gloc)
         L.check(L.lib().elg_rollout_bwd(C.byref(ba), _stream()), "elg_rollout_bwd")
-        # per-instance contractions over the R = M*T decode rows
+        # per-instance contractions over the R = M*T decode rows (dense batched GEMMs)
         Qh = rowQ.view(B, R, H, DK).permute(0, 2, 1, 3)                    # (B,H,R,16)
         DOh = rowDO.view(B, R, H, DK).permute(0, 2, 1, 3)
         dK = torch.matmul(rowDS.transpose(2, 3), Qh).permute(0, 2, 1, 3).reshape(B, N1, E)
         dV = torch.matmul(rowA.transpose(2, 3), DOh).permute(0, 2, 1, 3).reshape(B, N1, E)
         dPK = torch.matmul(rowDL.transpose(1, 2), rowO)                    # (B,N1,128)
         dpb = rowDL.sum(dim=1)
-        cur = forced.permute(0, 1, 2).reshape(B, R).long()                 # node whose query row was used: prev action
-        # the query of step t is gathered at cur = action[t-1]
-        prev = torch.cat([torch.zeros(B, M, 1, dtype=torch.long, device=dev), forced[:, :, :-1].long()], dim=2).reshape(B, R)
-        dQ1 = torch.zeros(B, N1, E, device=dev).index_add_(1, prev[0], rowDQ[0]) if B == 1 else \
-            torch.zeros(B, N1, E, device=dev).scatter_add_(1, prev[:, :, None].expand(B, R, E), rowDQ)
+        # the query of decode step t was gathered at cur = action[t-1] (and first = action[0] for TSP)
+        fl = forced.long()
+        prev = torch.cat([torch.zeros(B, M, 1, dtype=torch.long, device=dev), fl[:, :, :-1]], dim=2).reshape(B, R)
+        dQ1 = torch.zeros(B, N1, E, device=dev).scatter_add_(1, prev[:, :, None].expand(B, R, E), rowDQ)
         dQ2 = dwl = None
         if hasQ2:
-            first = forced[:, :, :1].long().expand(B, M, T).reshape(B, R)
+            first = fl[:, :, :1].expand(B, M, T).reshape(B, R)
             dQ2 = torch.zeros(B, N1, E, device=dev).scatter_add_(1, first[:, :, None].expand(B, R, E), rowDQ)
         if haswl:
-            # q = Q1[cur] + load * wl  ->  d wl = sum_rows load * dq ; the kernel stores load*dq separately? no:
-            # load is replayed on the host from the recorded actions (cheap, exact fp32 sequence not needed here)
-            dwl = ctx.load_rows(forced, prob, rowDQ) if hasattr(ctx, "load_rows") else _dwl_from_rows(prob, forced, rowDQ)
+            dwl = gwl
         return (None, None, None, None, None, None, None,
                 dK, dV, dPK, dpb, dQ1, dQ2, dwl, gloc if hasloc else None)
-
-
-def _dwl_from_rows(prob: Problem, forced: torch.Tensor, rowDQ: torch.Tensor) -> torch.Tensor:
-    """d wl = sum over decode rows of load_before_step * dq.  The load sequence is replayed with
-    torch ops from the recorded actions (reference CVRPEnv.py:211-212)."""
-    B, M, T = forced.shape
-    dem = torch.gather(prob.demand[:, None, :].expand(B, M, prob.N1), 2, forced.long())     # (B,M,T) demand of action t
-    load = torch.ones(B, M, device=forced.device)
-    loads = []
-    for t in range(T):
-        loads.append(load)                      # load seen by the decode of step t (before action t)
-        load = torch.where(forced[:, :, t] == 0, torch.ones_like(load), load - dem[:, :, t])
-    lb = torch.stack(loads, dim=2).reshape(B, M * T)
-    return torch.einsum("br,bre->e", lb, rowDQ)
 
 
 def chosen_probs(prob: Problem, pol: Policy, M: int, res: RolloutResult, T: int, geometry=None) -> torch.Tensor:

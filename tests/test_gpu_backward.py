@@ -1,0 +1,110 @@
+"""GPU parity of the backward replay kernels: gradients of a loss over the chosen-node probabilities
+w.r.t. the decoder / local-policy parameters and the encoder output, against the oracle's autograd
+(which itself is pinned on the reference's train() step, tests/test_oracle_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import elg_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _imports():
+    import gpu_common as gc
+    from elg_amd import _lib as L
+    from elg_amd import engine as eng
+    return gc, L, eng
+
+
+def _grad_check(got: dict, ref: dict, rtol=2e-3):
+    rms = max(float(v.norm()) / np.sqrt(v.numel()) for v in ref.values())
+    atol = 2e-3 * rms
+    worst = {}
+    for k, r in ref.items():
+        g = got[k].detach().cpu()
+        err = float((g - r).abs().max())
+        lim = rtol * float(r.abs().max()) + atol
+        worst[k] = err / lim
+        assert err <= lim, f"{k}: max abs err {err:.3e} > {lim:.3e} (ref max {float(r.abs().max()):.3e})"
+    return worst
+
+
+def _run(problem, tag, loss_kind, geometry=None):
+    gc, L, eng = _imports()
+    if problem == "cvrp":
+        fx, cfg, P, xy, dem, B, N, M = gc.cvrp_fixture(tag)
+        kind = L.PROBLEM_CVRP
+        lp_prefix, nfeat, nslots = "decoder.local_policies.0.", 3, cfg.local_size + 1
+    else:
+        fx, cfg, P, xy, B, N, M = gc.tsp_fixture(tag)
+        dem = None
+        kind = L.PROBLEM_TSP
+        lp_prefix, nfeat, nslots = "decoder.local_policy_0.", 2, cfg.local_size
+    acts = torch.from_numpy(fx["actions"].astype(np.int64))
+    T = acts.shape[2]
+    torch.manual_seed(3)
+    W = torch.randn(B, T, M)
+    # perturb the rewards: an instance whose trajectories all found the same tour has advantage == rounding
+    # noise, and the reference's scale_norm then divides by ~0 -- ill-conditioned
+    rew = torch.from_numpy(fx["reward"]) + 0.3 * torch.randn(B, M)
+
+    def loss_fn(probs):
+        if loss_kind == "weighted":
+            return (probs * W.to(probs.device)).sum()
+        return orc.pomo_loss(probs, rew.to(probs.device), guard_zero=(problem == "tsp"))
+
+    # ---------------- oracle (CPU autograd)
+    Po = {k: v.clone().requires_grad_(k.startswith("decoder.")) for k, v in P.items()}
+    with torch.no_grad():
+        enc0 = orc.encoder_forward(P, cfg, xy, dem) if problem == "cvrp" else orc.encoder_forward(P, cfg, xy)
+    enc_o = enc0.clone().requires_grad_(True)
+    if problem == "cvrp":
+        out = orc.rollout_cvrp(Po, cfg, xy, dem, M, starts=acts[0, :, 1], forced=acts, enc=enc_o)
+    else:
+        out = orc.rollout_tsp(Po, cfg, xy, M, starts=acts[0, :, 0], forced=acts, enc=enc_o)
+    Jo = loss_fn(out["probs"])
+    Jo.backward()
+    ref = {k: v.grad.clone() for k, v in Po.items() if v.grad is not None}
+    ref["enc"] = enc_o.grad.clone()
+
+    # ---------------- engine
+    Pg = {k: v.clone().to(gc.DEV).requires_grad_(k.startswith("decoder.")) for k, v in P.items()}
+    enc_g = enc0.clone().to(gc.DEV).requires_grad_(True)
+    tables = eng.fold_decoder_tables(gc.sub(Pg, "decoder."), enc_g, kind)
+    loc = eng.fold_local_tables(gc.sub(Pg, lp_prefix), nfeat, nslots)
+    pol = eng.Policy(tables, loc, cfg.local_size, cfg.xi, cfg.logit_clipping, 1.0 / cfg.ensemble_size, True, True)
+    prob = gc.make_problem(xy, dem, kind)
+    starts = acts[0, :, 1] if problem == "cvrp" else acts[0, :, 0]
+    res = eng.rollout_forward(prob, pol, M, starts, L.MODE_FORCED, forced=acts, geometry=geometry)
+    pr = eng.chosen_probs(prob, pol, M, res, T, geometry=geometry)
+    np.testing.assert_allclose(pr.detach().cpu().numpy(), out["probs"].detach().numpy(), rtol=5e-4)
+    Jg = loss_fn(pr)
+    assert abs(Jg.item() - Jo.item()) <= 2e-4 * max(1.0, abs(Jo.item()))
+    Jg.backward()
+    got = {k: v.grad for k, v in Pg.items() if v.grad is not None}
+    got["enc"] = enc_g.grad
+    assert set(got) == set(ref)
+    worst = _grad_check(got, ref)
+    print(problem, tag, loss_kind, "worst err/limit:", {k.split(".")[-2] + "." + k.split(".")[-1] if "." in k else k: round(v, 3)
+                                                        for k, v in worst.items()})
+
+
+@pytest.mark.parametrize("tag", ["n20", "n20k8", "n50"])
+@pytest.mark.parametrize("loss_kind", ["weighted", "pomo"])
+def test_cvrp_backward(tag, loss_kind):
+    _run("cvrp", tag, loss_kind)
+
+
+def test_cvrp_backward_global_memory_variant():
+    _run("cvrp", "n20", "weighted", geometry=(8, 2, 0))
+
+
+def test_cvrp_backward_n100():
+    _run("cvrp", "n100", "pomo")
+
+
+@pytest.mark.parametrize("tag", ["n20", "n50"])
+def test_tsp_backward(tag):
+    _run("tsp", tag, "pomo")
