@@ -1,0 +1,68 @@
+"""CVRPModel with the reference's interface (gaocrr/ELG CVRP/CVRPModel.py:10-75): encoder once per
+batch, then node selection.  `one_step_rollout` keeps the per-step protocol (one small HIP launch per
+call, inference only); training and evaluation go through utils.rollout, which fuses the whole
+construction into one persistent launch."""
+from __future__ import annotations
+
+import ctypes as C
+import random
+
+import torch
+import torch.nn as nn
+
+from elg_amd import _lib as L
+from elg_amd import engine as eng
+from elg_amd.CVRP.models import CVRP_Decoder, CVRP_Encoder
+
+
+class CVRPModel(nn.Module):
+    def __init__(self, **model_params):
+        super().__init__()
+        self.model_params = model_params
+        self.encoder = CVRP_Encoder(**model_params)
+        self.decoder = CVRP_Decoder(**model_params)
+        self.encoded_nodes = None            # (batch, problem+1, embedding)
+
+    def pre_forward(self, reset_state):
+        node_xy_demand = torch.cat((reset_state.node_xy, reset_state.node_demand[:, :, None]), dim=2)
+        self.encoded_nodes = self.encoder(reset_state.depot_xy, node_xy_demand, reset_state.dist)
+        self.decoder.set_kv(self.encoded_nodes)
+
+    @staticmethod
+    def draw_starts(problem_size, multi_width):
+        """Second move of every trajectory: the reference's exact draw (CVRPModel.py:46-51) -- Python's
+        `random`, the same nodes for every instance, values in [0, N) (may contain the depot)."""
+        return random.sample(range(0, problem_size), multi_width)
+
+    def one_step_rollout(self, state, cur_dist=None, cur_theta=None, xy=None, norm_demand=None, eval_type='greedy'):
+        env = getattr(state, "_env", None)
+        if env is None:
+            raise RuntimeError("one_step_rollout needs a Step_State produced by elg_amd's CVRPEnv")
+        B, M = env.batch_size, env.multi_width
+        dev = env.device
+        if state.selected_count == 0:
+            return torch.zeros(B, M, dtype=torch.long, device=dev), torch.ones(B, M, device=dev)
+        if state.selected_count == 1:
+            starts = torch.tensor(self.draw_starts(env.problem_size, M), device=dev)
+            return starts[None, :].expand(B, M), torch.ones(B, M, device=dev)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("the step-wise protocol is inference-only; train through utils.rollout()")
+        a = L.RolloutArgs()
+        eng._fill_common(a, env.problem, self.decoder.policy, M)
+        a.Tmax, a.max_steps, a.do_decode, a.do_update = 1, 1, 1, 0
+        a.mode = L.MODE_SAMPLE if eval_type == 'sample' else L.MODE_GREEDY
+        a.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        sel = torch.zeros(B, M, 1, dtype=torch.int32, device=dev)
+        pr = torch.ones(B, 1, M, dtype=torch.float32, device=dev)
+        a.actions, a.probs = eng._ptr(sel), eng._ptr(pr)
+        dummy = torch.zeros(M, dtype=torch.int32, device=dev)
+        a.starts = eng._ptr(dummy)
+        env._state_args(a)
+        L.check(L.lib().elg_rollout_fwd(C.byref(a), eng._stream()), "elg_rollout_fwd(decode)")
+        selected = sel[:, :, 0].long()
+        if eval_type != 'sample':
+            return selected, None
+        prob = pr[:, 0, :]
+        if not bool((prob != 0).all()):      # reference CVRPModel.py:67-68
+            prob = prob + 1e-6
+        return selected, prob

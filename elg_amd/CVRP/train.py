@@ -1,0 +1,152 @@
+"""REINFORCE training with the POMO shared baseline -- the reference's `python train.py` entry point
+(gaocrr/ELG CVRP/train.py) on the MI355X engine.  Same config.yml, same checkpoint dictionary
+({'step','model_state_dict','optimizer_state_dict'} at weights/{name}_{ts}_{seed}/model_epoch_{k}.pt), same
+log JSON.  New: launched under `python -m torch.distributed.run` it shards the batch over the GPUs of the
+node and all-reduces the gradient over RCCL (elg_amd/parallel.py)."""
+from __future__ import annotations
+
+import datetime
+import os
+import sys
+
+import numpy as np
+import torch
+import yaml
+from torch.optim import Adam as Optimizer
+from torch.utils.data import DataLoader
+
+if __package__ in (None, ""):                      # `cd elg_amd/CVRP && python train.py`, as the reference is run
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+from elg_amd import parallel
+from elg_amd.CVRP.CVRPEnv import CVRPEnv
+from elg_amd.CVRP.CVRPModel import CVRPModel
+from elg_amd.CVRP.generate_data import VRPDataset, generate_vrp_data
+from elg_amd.CVRP.utils import Logger, check_feasible, rollout, seed_everything
+
+
+def softmax(x):
+    e = np.exp(x)
+    return e / e.sum(axis=0)
+
+
+def pomo_loss(probs, rewards, scale_norm=True):
+    """reference train.py:112-121: shared baseline = mean reward over the POMO trajectories of an instance."""
+    advantage = rewards - rewards.mean(dim=1)[:, None]
+    J = -advantage * probs.log().sum(dim=1)
+    if scale_norm:
+        J = J / advantage.max(dim=1)[0][:, None]
+    return J.mean()
+
+
+def train_step(model, env, optimizer, batch, scale_norm=True, bucket=None, world=1, check=True):
+    """One optimisation step (reference train.py:103-125): load -> encoder -> sampled rollout -> loss ->
+    backward -> [gradient all-reduce] -> Adam.  Returns (loss, rewards)."""
+    env.load_random_problems(batch)
+    reset_state, _, _ = env.reset()
+    model.pre_forward(reset_state)
+    solutions, probs, rewards = rollout(model=model, env=env, eval_type='sample')
+    if check:
+        check_feasible(solutions[0:1], reset_state.node_demand[0:1])
+    optimizer.zero_grad()
+    J = pomo_loss(probs, rewards, scale_norm)
+    J.backward()
+    if bucket is not None:
+        bucket.allreduce(world)
+    optimizer.step()
+    return J.detach(), rewards
+
+
+def test_rollout(loader, env, model):
+    total, batches = 0.0, 0
+    for batch in loader:
+        env.load_random_problems(batch)
+        reset_state, _, _ = env.reset()
+        model.eval()
+        with torch.no_grad():
+            model.pre_forward(reset_state)
+            solutions, _, rewards = rollout(model=model, env=env, eval_type='greedy')
+        check_feasible(solutions[0:1], reset_state.node_demand[0:1])
+        total += float(-rewards.max(1)[0].mean())
+        batches += 1
+    return total / max(batches, 1)
+
+
+def validate(model, multiple_width, device, mixed=True):
+    """reference train.py:42-80 (needs the data/*.pkl validation sets next to this file)."""
+    env = CVRPEnv(multi_width=multiple_width, device=device)
+    if mixed:
+        sets = [('data/vrp_uniform100_1000_seed1234.pkl', 1000, 1000), ('data/vrp_cluster100_1000_seed1234.pkl', 1000, 1000),
+                ('data/vrp_mixed100_1000_seed1234.pkl', 1000, 1000)]
+    else:
+        sets = [('data/vrp100_val.pkl', 1000, 1000), ('data/vrp200_val.pkl', 1000, 1000), ('data/vrp500_val.pkl', 100, 10)]
+    return [test_rollout(DataLoader(VRPDataset(f, num_samples=n), batch_size=bs), env, model) for f, n, bs in sets]
+
+
+def train(model, training, T, start_steps, train_steps, mixed, train_batch_size, problem_size, distribution,
+          multiple_width, lr, device, logger, scale_norm, fileLogger, dir_path, log_step):
+    rank, world, _ = parallel.world_info()
+    env = CVRPEnv(multi_width=multiple_width, device=device)
+    distribution_ = dict(distribution)
+    gaps = np.array([1, 1, 1])
+    optimizer = Optimizer(model.parameters(), lr=lr, weight_decay=1e-6)
+    bucket = parallel.GradBucket(model.parameters()) if world > 1 else None
+    local_batch = train_batch_size // world
+    for i in range(train_steps - start_steps + 1):
+        model.train()
+        if i == T - start_steps and training == 'joint':           # enable the local policy (train.py:93-96)
+            print("Enable joint training.")
+            model.decoder.add_local_policy(device)
+            parallel.broadcast_parameters(model)
+            optimizer = Optimizer(model.parameters(), lr=lr, weight_decay=1e-6)
+            bucket = parallel.GradBucket(model.parameters()) if world > 1 else None
+        if mixed:
+            kind = np.random.choice(['uniform', 'cluster', 'mixed'], size=1, p=softmax(gaps))[0]
+            if world > 1:                                           # every rank must draw the same family
+                obj = [kind]
+                torch.distributed.broadcast_object_list(obj, src=0)
+                kind = obj[0]
+            distribution_['data_type'] = kind
+        else:
+            distribution_['data_type'] = 'uniform'
+        batch = generate_vrp_data(batch_size=local_batch, problem_size=problem_size, distribution=distribution_)
+        train_step(model, env, optimizer, batch, scale_norm, bucket, world)
+        if (i + 1) % log_step == 0 and rank == 0:
+            val_info = validate(model, multiple_width, device, mixed)
+            fileLogger.log(val_info)
+            if logger is not None:
+                logger.log({'val_100_cost': val_info[0], 'val_300_cost': val_info[1], 'val_500_cost': val_info[2]}, step=i)
+            torch.save({'step': i, 'model_state_dict': model.state_dict(), 'optimizer_state_dict': optimizer.state_dict()},
+                       dir_path + '/model_epoch_{}.pt'.format(int((i + 1) / log_step)))
+            if mixed:
+                opts = np.array([15.740834, 7.909336, 14.294179])  # reference solver means (train.py:146)
+                gaps = (np.array(val_info) - opts) / opts
+
+
+if __name__ == "__main__":
+    with open('config.yml', 'r', encoding='utf-8') as fh:
+        config = yaml.load(fh.read(), Loader=yaml.FullLoader)
+    rank, world, local = parallel.init_distributed()
+    p = config['params']
+    device = "cuda:{}".format(local if world > 1 else config['cuda_device_num']) if config['use_cuda'] else 'cpu'
+    seed_everything(config['seed'] + rank)
+    ts = datetime.datetime.utcnow() + datetime.timedelta(hours=+8)
+    ts_name = f'-ts{ts.month}-{ts.day}-{ts.hour}-{ts.minute}-{ts.second}'
+    dir_path = 'weights/{}_{}_{}'.format(config['name'], ts_name, config['seed'])
+    fileLogger = None
+    if rank == 0:
+        os.makedirs(dir_path, exist_ok=True)
+        os.makedirs('log', exist_ok=True)
+        fileLogger = Logger('log/{}_{}'.format(config['name'], ts_name), config)
+    model = CVRPModel(**config['model_params'])
+    if config['load_checkpoint'] is not None:
+        checkpoint = torch.load(config['load_checkpoint'], map_location=device)
+        if any(k.startswith('decoder.local_policies') for k in checkpoint['model_state_dict']):
+            model.decoder.add_local_policy(device)
+        model.load_state_dict(checkpoint['model_state_dict'])
+    model.to(device)
+    parallel.broadcast_parameters(model)
+    train(model=model, training=config['training'], T=p['T'], start_steps=p['start_steps'], train_steps=p['train_steps'],
+          mixed=p['mixed'], train_batch_size=p['train_batch_size'], problem_size=p['problem_size'],
+          distribution=config['distribution'], multiple_width=p['multiple_width'], lr=p['learning_rate'], device=device,
+          logger=None, scale_norm=p['scale_norm'], fileLogger=fileLogger, dir_path=dir_path, log_step=p['log_step'])

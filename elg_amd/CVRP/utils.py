@@ -1,0 +1,88 @@
+"""rollout / augmentation / feasibility helpers with the reference's names (gaocrr/ELG CVRP/utils.py)."""
+from __future__ import annotations
+
+import json
+import random
+
+import numpy as np
+import torch
+
+from elg_amd import _lib as L
+from elg_amd import engine as eng
+
+
+def rollout(model, env, eval_type='greedy'):
+    """reference utils.py:7-29 -> (actions (B,M,T) int64, probs (B,T,M) | None, reward (B,M)).
+
+    The reference loops `get_cur_feature -> one_step_rollout -> step` in Python until every trajectory
+    is finished; here the whole construction is ONE persistent HIP launch.  With autograd enabled the
+    returned probabilities carry a grad_fn whose backward is the replay kernel pair of csrc/elg_bwd.hip."""
+    env.reset()
+    B, M, N = env.batch_size, env.multi_width, env.problem_size
+    pol = model.decoder.policy
+    if pol is None:
+        raise RuntimeError("call model.pre_forward(reset_state) before rollout")
+    starts = torch.tensor(model.draw_starts(N, M), dtype=torch.int32)
+    mode = L.MODE_SAMPLE if eval_type == 'sample' else L.MODE_GREEDY
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if mode == L.MODE_SAMPLE else 0
+    res = eng.rollout_forward(env.problem, pol, M, starts, mode, seed=seed)
+    T = int(res.tlen.max().item())                  # the one host sync of the rollout
+    actions = res.actions[:, :, :T].long()
+    env.selected_count = T
+    env.selected_node_list = actions
+    env.current_node = actions[:, :, -1]
+    reward = env.compute_unscaled_reward() if env.vrplib else res.reward
+    if eval_type == 'greedy':
+        return actions, None, reward
+    needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
+    probs = eng.chosen_probs(env.problem, pol, M, res, T) if needs_grad else res.probs[:, :T, :]
+    # reference CVRPModel.py:67-68: a step in which some chosen probability is exactly 0 gets +1e-6
+    zero_step = (probs.detach() == 0).flatten(2).any(dim=2).any(dim=0)
+    probs = probs + 1e-6 * zero_step[None, :, None].to(probs.dtype)
+    return actions, probs, reward
+
+
+def augment_xy_data_by_8_fold(problems):
+    """reference utils.py:69-87 (elg_aug8 kernel)."""
+    return eng.aug8(problems)
+
+
+def check_feasible(pi, demand):
+    """reference utils.py:90-119: every customer exactly once, capacity never exceeded.
+    pi (1, multi, T) node ids, demand (1, problem)."""
+    pi = pi.squeeze(0)
+    multi, n = pi.shape[0], demand.shape[1]
+    srt = pi.sort(1)[0]
+    ok = (srt[:, -n:] == torch.arange(1, n + 1, device=pi.device)[None]).all() and (srt[:, :-n] == 0).all()
+    assert ok, "Invalid tour"
+    d = torch.cat((torch.full((1, 1), -1.0, device=demand.device), demand), 1).expand(multi, n + 1).gather(1, pi)
+    # running load with reset at the depot == running sum minus its running minimum prefix (clamped at 0)
+    used = torch.zeros(multi, device=pi.device)
+    worst = torch.zeros(multi, device=pi.device)
+    for i in range(pi.size(1)):
+        used = (used + d[:, i]).clamp_(min=0)
+        worst = torch.maximum(worst, used)
+    assert (worst <= 1 + 1e-4).all(), "Used more than capacity"
+
+
+def seed_everything(seed=2022):
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+class Logger(object):
+    """JSON log of the validation costs, same file format as the reference (utils.py:130-151)."""
+
+    def __init__(self, filename, config):
+        self.filename = filename
+        self.logger = config
+        self.logger['result'] = {'val_100': [], 'val_200': [], 'val_500': []}
+
+    def log(self, info):
+        for key, v in zip(('val_100', 'val_200', 'val_500'), info):
+            self.logger['result'][key].append(v)
+        with open(self.filename, 'w') as f:
+            json.dump(self.logger, f)

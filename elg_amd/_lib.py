@@ -57,6 +57,13 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: the HIP extension is mandatory (no CPU fallback). "
                               "Build it with `python -m elg_amd.build`.")
+        # ONE HIP runtime per process: PyTorch bundles its own libamdhip64.so.7; load it first so that
+        # libelg_hip.so's DT_NEEDED libamdhip64.so.7 resolves to the same runtime (shared streams,
+        # device pointers) instead of pulling /opt/rocm's copy next to it.
+        import torch
+        bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(bundled):
+            C.CDLL(bundled, mode=C.RTLD_GLOBAL)
         L = C.CDLL(LIB_PATH)
         L.elg_version.restype = C.c_char_p
         L.elg_last_error.restype = C.c_char_p

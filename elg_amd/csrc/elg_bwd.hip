@@ -12,6 +12,7 @@
 
 namespace elg {
 int fail(int code, const std::string& msg);
+int launch_status(const char* what);
 
 // ---------------------------------------------------------------------------------------------
 // common prologue: instance pointers + LDS staging (same carve as the forward kernel)
@@ -492,8 +493,9 @@ static int launch_bwd(const elg_bwd_args& BA, hipStream_t stream) {
             return fail(ELG_ELAUNCH, "hipFuncSetAttribute failed");
         attr_done = true;
     }
+    (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3(A.B * A.tiles), dim3(WAVES * 64), lds, stream, BA);
-    if (hipGetLastError() != hipSuccess) return fail(ELG_ELAUNCH, "rollout_bwd launch failed");
+    if (launch_status("rollout_bwd") != ELG_OK) return ELG_ELAUNCH;
     if (A.has_local) {
         constexpr int LW = 8;
         size_t l2 = (size_t)((A.N1 + 3) & ~3) * 4 + 16 + (size_t)ELG_LOC_SIZE * 4 + (size_t)LW * SbSize<NCH>::value * 4;
@@ -505,8 +507,9 @@ static int launch_bwd(const elg_bwd_args& BA, hipStream_t stream) {
                 return fail(ELG_ELAUNCH, "hipFuncSetAttribute failed");
             attr2 = true;
         }
-        hipLaunchKernelGGL(k2, dim3(A.B * A.tiles), dim3(LW * 64), l2, stream, BA);
-        if (hipGetLastError() != hipSuccess) return fail(ELG_ELAUNCH, "local_bwd launch failed");
+        (void)hipGetLastError();
+    hipLaunchKernelGGL(k2, dim3(A.B * A.tiles), dim3(LW * 64), l2, stream, BA);
+        if (launch_status("local_bwd") != ELG_OK) return ELG_ELAUNCH;
     }
     return ELG_OK;
 }

@@ -13,6 +13,11 @@ namespace elg {
 static thread_local std::string g_err;
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 const char* last_error() { return g_err.c_str(); }
+int launch_status(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return ELG_OK;
+    return fail(ELG_ELAUNCH, std::string(what) + " launch failed: " + hipGetErrorString(e));
+}
 
 // =============================================================================================
 // small kernels
@@ -388,8 +393,9 @@ static int launch_fwd(const elg_rollout_args& A, hipStream_t stream) {
         attr_done = true;
     }
     dim3 grid(A.B * A.tiles), block(WAVES * 64);
+    (void)hipGetLastError();
     hipLaunchKernelGGL(kern, grid, block, lds, stream, A);
-    if (hipGetLastError() != hipSuccess) return fail(ELG_ELAUNCH, "rollout_fwd launch failed");
+    if (launch_status("rollout_fwd") != ELG_OK) return ELG_ELAUNCH;
     return ELG_OK;
 }
 
@@ -424,14 +430,16 @@ const char* elg_last_error(void) { return elg::last_error(); }
 int elg_aug8(const float* xy_in, float* xy_out, int B, int N, void* stream) {
     if (B <= 0 || N <= 0) return fail(ELG_EINVAL, "aug8: empty input");
     const int n = B * N;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(aug8_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, xy_in, xy_out, B, N);
-    return hipGetLastError() == hipSuccess ? ELG_OK : fail(ELG_ELAUNCH, "aug8 launch failed");
+    return launch_status("aug8");
 }
 
 int elg_dist_matrix(const float* xy, float* dist, int B, int N, void* stream) {
     if (B <= 0 || N <= 0) return fail(ELG_EINVAL, "dist_matrix: empty input");
+    (void)hipGetLastError();
     hipLaunchKernelGGL(dist_matrix_kernel, dim3(N, B), dim3(128), 0, (hipStream_t)stream, xy, dist, N);
-    return hipGetLastError() == hipSuccess ? ELG_OK : fail(ELG_ELAUNCH, "dist_matrix launch failed");
+    return launch_status("dist_matrix");
 }
 
 int elg_nbr_tables(const float* xy, int32_t* nbr_idx, float* nbr_dist, float* nbr_theta, int B, int N, void* stream) {
@@ -440,18 +448,20 @@ int elg_nbr_tables(const float* xy, int32_t* nbr_idx, float* nbr_dist, float* nb
     int NP = 64;
     while (NP < N) NP <<= 1;
     const int threads = NP >= 512 ? 256 : 64;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(nbr_tables_kernel, dim3(N, B), dim3(threads), (size_t)NP * 8, (hipStream_t)stream, xy, nbr_idx,
                        nbr_dist, nbr_theta, N, NP);
-    return hipGetLastError() == hipSuccess ? ELG_OK : fail(ELG_ELAUNCH, "nbr_tables launch failed");
+    return launch_status("nbr_tables");
 }
 
 int elg_route_length(const float* xy, const int64_t* tour, float* out, int B, int M, int T, int N, int rounding,
                      void* stream) {
     if (B <= 0 || M <= 0 || T <= 0) return fail(ELG_EINVAL, "route_length: empty input");
     const int n = B * M;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(route_length_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, xy,
                        reinterpret_cast<const long long*>(tour), out, B, M, T, N, rounding);
-    return hipGetLastError() == hipSuccess ? ELG_OK : fail(ELG_ELAUNCH, "route_length launch failed");
+    return launch_status("route_length");
 }
 
 int elg_rollout_fwd(const elg_rollout_args* a, void* stream) {
