@@ -338,98 +338,111 @@ __global__ __launch_bounds__(WAVES * 64) void rollout_bwd_kernel(const elg_bwd_a
 }
 
 // =============================================================================================
-// local-policy replay: gradient of the folded tables (layout ELG_LOC_*), accumulated in LDS
+// local-policy replay: gradient of the folded tables (layout ELG_LOC_*).  Every lane owns the rows
+// of the tables it reads (slot rows j = lane, channel rows d = lane & 31) and keeps their gradient
+// in registers for the whole launch; one LDS reduction + one global flush per workgroup at the end.
 // =============================================================================================
+struct LocAcc {
+    float lpe[32];   // d lpe[j][*]      (lane j)
+    float lcv[32];   // d lcv[j][*]      (lane j)
+    float lwc[32];   // d lWc[d'][*]     (lane d' < 32)
+    float lt[ELG_LH];
+    float lwe[3];    // d lWe[d][*]      (lane d < 32)
+    float lav[3];    // d lAv[d][*]      (lane d < 32)
+    float lbc;       // d lbc[d]         (lane d < 32)
+    float la;        // d la[3h+f]       (lane 3h+f < 12)
+};
+
 template <bool TSP>
-__device__ __forceinline__ void local_bwd_step(const float* __restrict__ loc, float* __restrict__ acc, int lane,
+__device__ __forceinline__ void local_bwd_step(const float* __restrict__ loc, LocAcc& A, int lane,
                                                const Slots& S, float du) {
-    const int j = lane, dd = lane & 31;
+    const int j = lane, dd = lane & 31, hh = dd >> 3;
+    constexpr int NF = TSP ? 2 : 3;
     LocalSave sv;
     (void)local_policy<TSP>(loc, lane, S.f0, S.f1, S.f2, S.smask, &sv);
     const float f[3] = {S.f0, S.f1, TSP ? 0.f : S.f2};
-    constexpr int NF = TSP ? 2 : 3;
-    const float* lWe = loc + ELG_LOC_LWE;
     const float* lpe = loc + ELG_LOC_LPE + 32 * j;
-    const float* lAv = loc + ELG_LOC_LAV;
     const float* lcv = loc + ELG_LOC_LCV + 32 * j;
-    const bool slot_live = du != 0.f;
+    const float* lWe = loc + ELG_LOC_LWE + 3 * dd;
+    const float* lAv = loc + ELG_LOC_LAV + 3 * dd;
+    const float* wrow = loc + ELG_LOC_LWC + 32 * dd;
+    const bool lo = lane < 32;
 
-    // u_j = sum_d g'[d] e_j[d],  e_j[d] = lpe[j][d] + lWe[d].f
-    float c[32];
+    // u_j = sum_d g'[d] lpe[j][d] + (sum_d g'[d] lWe[d]) . f_j
+    float Sf[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int d = 0; d < 32; ++d) {
-        float ev = lpe[d];
+    for (int k = 0; k < NF; ++k) Sf[k] = wave_sum(du * f[k]);
+    float dg;                                                       // d g'[dd]
+    {
+        float c[16];
 #pragma unroll
-        for (int k = 0; k < NF; ++k) ev = fmaf(lWe[3 * d + k], f[k], ev);
-        c[d] = du * ev;                                            // -> d g'[d]
-        const float gd = readlane(sv.g, d);
-        if (slot_live) atomicAdd(acc + ELG_LOC_LPE + 32 * j + d, du * gd);
-    }
-    float dg = reduce_scatter32(c, lane);                          // d g'[lane & 31]
-    {   // d lWe[d][f] = g'[d] * sum_j du_j f_j[f]
+        for (int d = 0; d < 16; ++d) { c[d] = du * lpe[d]; A.lpe[d] = fmaf(du, readlane(sv.g, d), A.lpe[d]); }
+        const float glo_ = reduce_scatter16(c, lane);
+#pragma unroll
+        for (int d = 0; d < 16; ++d) { c[d] = du * lpe[16 + d]; A.lpe[16 + d] = fmaf(du, readlane(sv.g, 16 + d), A.lpe[16 + d]); }
+        const float ghi_ = reduce_scatter16(c, lane);
+        dg = (lane & 16) ? ghi_ : glo_;
 #pragma unroll
         for (int k = 0; k < NF; ++k) {
-            const float sf = wave_sum(du * f[k]);
-            if (lane < 32) atomicAdd(acc + ELG_LOC_LWE + 3 * dd + k, sv.g * sf);
+            dg = fmaf(lWe[k], Sf[k], dg);
+            A.lwe[k] = fmaf(sv.g, Sf[k], A.lwe[k]);
         }
     }
     // g' = lWc o' + lbc
-    const float* wrow = loc + ELG_LOC_LWC + 32 * dd;
-    if (lane < 32) atomicAdd(acc + ELG_LOC_LBC + dd, dg);
+    A.lbc += dg;
+    float dop;                                                      // d o'[dd]
+    {
+        const float dgl = lo ? dg : 0.f;
+        float c[16];
 #pragma unroll
-    for (int d = 0; d < 32; ++d) {
-        const float opd = readlane(sv.op, d);
-        if (lane < 32) atomicAdd(acc + ELG_LOC_LWC + 32 * dd + d, dg * opd);
-        c[d] = (lane < 32) ? wrow[d] * dg : 0.f;                   // -> d o'[d]
+        for (int d = 0; d < 16; ++d) { c[d] = wrow[d] * dgl; A.lwc[d] = fmaf(dg, readlane(sv.op, d), A.lwc[d]); }
+        const float plo = reduce_scatter16(c, lane);
+#pragma unroll
+        for (int d = 0; d < 16; ++d) { c[d] = wrow[16 + d] * dgl; A.lwc[16 + d] = fmaf(dg, readlane(sv.op, 16 + d), A.lwc[16 + d]); }
+        const float phi = reduce_scatter16(c, lane);
+        dop = (lane & 16) ? phi : plo;
     }
-    const float dop = reduce_scatter32(c, lane);                   // d o'[lane & 31]
-    // o'[d] = sum_j alpha_{h(d),j} v_j[d],  v_j[d] = lcv[j][d] + lAv[d].f
-    float dal[ELG_LH] = {0.f, 0.f, 0.f, 0.f};
+    // o'[d] = P[d] + lAv[d] . F_{h(d)}
+    float G[ELG_LH][3];                                             // G[h][f] = sum_{d in h} do'[d] lAv[d][f]  (uniform)
 #pragma unroll
-    for (int d = 0; d < 32; ++d) {
-        float v = lcv[d];
+    for (int k = 0; k < 3; ++k) {
+        if (k < NF) {
+            A.lav[k] = fmaf(dop, __shfl(sv.Ftot, 3 * hh + k, ELG_WAVE), A.lav[k]);
+            const float t = oct_sum(dop * lAv[k]);
 #pragma unroll
-        for (int k = 0; k < NF; ++k) v = fmaf(lAv[3 * d + k], f[k], v);
-        const float dopd = readlane(dop, d);
-        dal[d >> 3] = fmaf(dopd, v, dal[d >> 3]);
-        const float dv = sv.al[d >> 3] * dopd;
-        if (sv.al[d >> 3] != 0.f) atomicAdd(acc + ELG_LOC_LCV + 32 * j + d, dv);
-    }
-    {   // d lAv[d][f] = d o'[d] * sum_j alpha_{h(d),j} f_j[f]
-        float af[16];
+            for (int h = 0; h < ELG_LH; ++h) G[h][k] = readlane(t, 8 * h);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) af[i] = 0.f;
-#pragma unroll
-        for (int h = 0; h < ELG_LH; ++h)
-#pragma unroll
-            for (int k = 0; k < NF; ++k) af[3 * h + k] = sv.al[h] * f[k];
-        const float tot = reduce_scatter16(af, lane);              // total of element (lane & 15)
-        const int hsel = dd >> 3;
-#pragma unroll
-        for (int k = 0; k < NF; ++k) {
-            const float afv = __shfl(tot, 3 * hsel + k, ELG_WAVE);
-            if (lane < 32) atomicAdd(acc + ELG_LOC_LAV + 3 * dd + k, dop * afv);
+            for (int h = 0; h < ELG_LH; ++h) G[h][k] = 0.f;
         }
     }
-    // softmax backward -> d sc_h, then la / lt
-    float dsc[ELG_LH];
+    float dal[ELG_LH];
+#pragma unroll
+    for (int h = 0; h < ELG_LH; ++h) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < NF; ++k) a = fmaf(f[k], G[h][k], a);
+        dal[h] = a;
+    }
+#pragma unroll
+    for (int d = 0; d < 32; ++d) {
+        const float dopd = readlane(dop, d);
+        dal[d >> 3] = fmaf(dopd, lcv[d], dal[d >> 3]);
+        A.lcv[d] = fmaf(sv.al[d >> 3], dopd, A.lcv[d]);
+    }
+    // softmax backward, then la / lt
+    float sf[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sf[i] = 0.f;
 #pragma unroll
     for (int h = 0; h < ELG_LH; ++h) {
         const float tsum = wave_sum(sv.al[h] * dal[h]);
-        dsc[h] = sv.al[h] * (dal[h] - tsum);
-        if (sv.al[h] != 0.f) atomicAdd(acc + ELG_LOC_LT + 4 * j + h, dsc[h]);
+        const float dsc = sv.al[h] * (dal[h] - tsum);
+        A.lt[h] += dsc;
+#pragma unroll
+        for (int k = 0; k < NF; ++k) sf[3 * h + k] = dsc * f[k];
     }
-    {
-        float sf[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sf[i] = 0.f;
-#pragma unroll
-        for (int h = 0; h < ELG_LH; ++h)
-#pragma unroll
-            for (int k = 0; k < NF; ++k) sf[3 * h + k] = dsc[h] * f[k];
-        const float tot = reduce_scatter16(sf, lane);
-        if (lane < 12) atomicAdd(acc + ELG_LOC_LA + lane, tot);
-    }
+    A.la += reduce_scatter16(sf, lane);
 }
 
 template <int NCH, bool TSP, int WAVES>
@@ -447,6 +460,14 @@ __global__ __launch_bounds__(WAVES * 64) void local_bwd_kernel(const elg_bwd_arg
     for (int i = threadIdx.x; i < ELG_LOC_SIZE; i += WAVES * 64) acc[i] = 0.f;
     __syncthreads();
     const size_t b = bi, R = (size_t)A.M * T;
+    LocAcc LA;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) { LA.lpe[d] = 0.f; LA.lcv[d] = 0.f; LA.lwc[d] = 0.f; }
+#pragma unroll
+    for (int h = 0; h < ELG_LH; ++h) LA.lt[h] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { LA.lwe[k] = 0.f; LA.lav[k] = 0.f; }
+    LA.lbc = 0.f; LA.la = 0.f;
 
     for (int m = m_lo + wave; m < m_hi; m += WAVES) {
         const size_t bm = b * A.M + m;
@@ -459,14 +480,37 @@ __global__ __launch_bounds__(WAVES * 64) void local_bwd_kernel(const elg_bwd_arg
             const int sel = __builtin_amdgcn_readfirstlane(A.forced[bm * A.Tforced + t]);
             const bool first_move = (!TSP && t <= 1) || (TSP && t == 0);
             if (!st.fin && !first_move) {
-                unsigned long long mk[NCH];
-                build_mask<NCH, TSP>(st, I, N1, lane, mk);
-                const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb);
                 const float du = (lane < ELG_SLOT_STRIDE) ? BA.rowDU[(b * R + r) * ELG_SLOT_STRIDE + lane] : 0.f;
-                if (__ballot(du != 0.f)) local_bwd_step<TSP>(I.loc, acc, lane, S, du);
+                if (__ballot(du != 0.f)) {
+                    unsigned long long mk[NCH];
+                    build_mask<NCH, TSP>(st, I, N1, lane, mk);
+                    const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb);
+                    local_bwd_step<TSP>(I.loc, LA, lane, S, du);
+                }
             }
             if (!st.fin) env_update<NCH, TSP>(st, I, N1, sel);
         }
+    }
+    // reduce the per-lane accumulators of the workgroup in LDS, then one flush to global memory
+    {
+        const int j = lane, dd = lane & 31;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) {
+            atomicAdd(acc + ELG_LOC_LPE + 32 * j + d, LA.lpe[d]);
+            atomicAdd(acc + ELG_LOC_LCV + 32 * j + d, LA.lcv[d]);
+            if (lane < 32) atomicAdd(acc + ELG_LOC_LWC + 32 * dd + d, LA.lwc[d]);
+        }
+#pragma unroll
+        for (int h = 0; h < ELG_LH; ++h) atomicAdd(acc + ELG_LOC_LT + 4 * j + h, LA.lt[h]);
+        if (lane < 32) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                atomicAdd(acc + ELG_LOC_LWE + 3 * dd + k, LA.lwe[k]);
+                atomicAdd(acc + ELG_LOC_LAV + 3 * dd + k, LA.lav[k]);
+            }
+            atomicAdd(acc + ELG_LOC_LBC + dd, LA.lbc);
+        }
+        if (lane < 12) atomicAdd(acc + ELG_LOC_LA + lane, LA.la);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < ELG_LOC_SIZE; i += WAVES * 64) {

@@ -32,28 +32,63 @@ __device__ __forceinline__ float quad_bcast(float v) { return dpp<J * 0x55>(v); 
 __device__ __forceinline__ float shfl_xor(float v, int m) { return __shfl_xor(v, m, ELG_WAVE); }
 __device__ __forceinline__ int shfl_xor(int v, int m) { return __shfl_xor(v, m, ELG_WAVE); }
 
-__device__ __forceinline__ float wave_max(float v) {
-    v = fmaxf(v, quad_xor1(v));
-    v = fmaxf(v, quad_xor2(v));
-#pragma unroll
-    for (int m = 4; m < 64; m <<= 1) v = fmaxf(v, shfl_xor(v, m));
-    return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
+// row (16-lane) all-reduce with DPP only: quad butterflies, then row_half_mirror / row_mirror
+__device__ __forceinline__ float row16_sum(float v) {
     v += quad_xor1(v);
     v += quad_xor2(v);
-#pragma unroll
-    for (int m = 4; m < 64; m <<= 1) v += shfl_xor(v, m);
+    v += dpp<0x141>(v);          // row_half_mirror
+    v += dpp<0x140>(v);          // row_mirror
     return v;
 }
-// inclusive prefix sum over the 64 lanes (Hillis-Steele)
-__device__ __forceinline__ float wave_scan_incl(float v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        float o = __shfl_up(v, d, ELG_WAVE);
-        if (lane >= d) v += o;
-    }
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, quad_xor1(v));
+    v = fmaxf(v, quad_xor2(v));
+    v = fmaxf(v, dpp<0x141>(v));
+    v = fmaxf(v, dpp<0x140>(v));
     return v;
+}
+// 8-lane (aligned group) all-reduce
+__device__ __forceinline__ float oct_sum(float v) {
+    v += quad_xor1(v);
+    v += quad_xor2(v);
+    v += dpp<0x141>(v);
+    return v;
+}
+// wave all-reduce, result wave-uniform: four row totals are combined through SGPRs (no LDS crossbar)
+__device__ __forceinline__ float wave_max(float v) {
+    v = row16_max(v);
+    const float a = i2f(__builtin_amdgcn_readlane(f2i(v), 0)), b = i2f(__builtin_amdgcn_readlane(f2i(v), 16));
+    const float c = i2f(__builtin_amdgcn_readlane(f2i(v), 32)), d = i2f(__builtin_amdgcn_readlane(f2i(v), 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    const float a = i2f(__builtin_amdgcn_readlane(f2i(v), 0)), b = i2f(__builtin_amdgcn_readlane(f2i(v), 16));
+    const float c = i2f(__builtin_amdgcn_readlane(f2i(v), 32)), d = i2f(__builtin_amdgcn_readlane(f2i(v), 48));
+    return (a + b) + (c + d);
+}
+// sum over lanes 0..31 only (lanes >= 32 are ignored), wave-uniform
+__device__ __forceinline__ float half_sum_lo(float v) {
+    v = row16_sum(v);
+    const float a = i2f(__builtin_amdgcn_readlane(f2i(v), 0)), b = i2f(__builtin_amdgcn_readlane(f2i(v), 16));
+    return a + b;
+}
+// inclusive prefix sum over the 64 lanes: Hillis-Steele inside each 16-lane row with DPP row_shr
+// (out-of-row sources read 0), then the row totals are added through SGPRs
+__device__ __forceinline__ float wave_scan_incl(float v, int lane) {
+    v += dpp<0x111>(v);          // row_shr:1
+    v += dpp<0x112>(v);          // row_shr:2
+    v += dpp<0x114>(v);          // row_shr:4
+    v += dpp<0x118>(v);          // row_shr:8
+    const float t0 = i2f(__builtin_amdgcn_readlane(f2i(v), 15));
+    const float t1 = i2f(__builtin_amdgcn_readlane(f2i(v), 31));
+    const float t2 = i2f(__builtin_amdgcn_readlane(f2i(v), 47));
+    const int row = lane >> 4;
+    float off = 0.f;
+    if (row >= 1) off = t0;
+    if (row >= 2) off += t1;
+    if (row >= 3) off += t2;
+    return v + off;
 }
 __device__ __forceinline__ float readlane(float v, int l) { return i2f(__builtin_amdgcn_readlane(f2i(v), l)); }
 __device__ __forceinline__ int readlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }

@@ -265,63 +265,80 @@ __device__ __forceinline__ float reduce_scatter16(float (&c)[16], int lane) {
 
 // Saved intermediates of the local policy for the backward pass.
 struct LocalSave {
-    float f0, f1, f2;        // slot features
     float al[ELG_LH];        // attention weights alpha_h of this slot
     float op;                // o'[lane & 31]
     float g;                 // g'[lane & 31]
-    bool smask;              // slot masked / absent
+    float Ftot;              // element (lane & 15) of F_h[f] = sum_j alpha_hj f_j[f]   (index 3h+f)
 };
 
 // ---------------------------------------------------------------------------------------------
-// Local policy on the k-NN slots (slot layout).  Returns u_j of this lane's slot.
-// models.py:133-166 with the projections folded:  k_j = Wk(We f_j + be + PE[j]) etc.
-//   sc_h   = la[h].f_j + lt[j][h]                      (q is the same learned vector for all)
+// Local policy on the k-NN slots (slot layout: lane j = slot j).  Returns u_j of this lane's slot.
+// models.py:133-166 with every projection that does not depend on the features folded on the host:
+//   sc_h   = la[h].f_j + lt[j][h]                        (q is one learned vector for all trajectories)
 //   alpha  = softmax_j(sc_h + mask)
-//   o'[d]  = sum_j alpha_{h(d),j} (lAv[d].f_j + lcv[j][d])
+//   o'[d]  = sum_j alpha_{h(d),j} lcv[j][d]  +  lAv[d] . F_{h(d)},     F_h = sum_j alpha_{h,j} f_j
 //   g'     = lWc o' + lbc
-//   u_j    = g'.(lWe f_j + lpe[j])                      (1/sqrt(32) folded into lWe, lpe)
+//   u_j    = sum_d g'[d] lpe[j][d]  +  w . f_j,                        w = sum_d g'[d] lWe[d]
+// (1/sqrt(8) is folded into la/lt, 1/sqrt(32) into lWe/lpe).  All cross-lane sums are DPP/readlane.
 // ---------------------------------------------------------------------------------------------
 template <bool TSP>
 __device__ __forceinline__ float local_policy(const float* __restrict__ loc, int lane, float f0, float f1,
                                               float f2, bool smask, LocalSave* save) {
-    const int j = lane;
+    const int j = lane, dd = lane & 31, hh = dd >> 3;
+    constexpr int NF = TSP ? 2 : 3;
+    const float f[3] = {f0, f1, TSP ? 0.f : f2};
     const float* la = loc + ELG_LOC_LA;
     const float4 lt = *reinterpret_cast<const float4*>(loc + ELG_LOC_LT + 4 * j);
-    float sc[ELG_LH] = {lt.x, lt.y, lt.z, lt.w};
+    const float sc0[ELG_LH] = {lt.x, lt.y, lt.z, lt.w};
     float al[ELG_LH];
 #pragma unroll
     for (int h = 0; h < ELG_LH; ++h) {
-        float s = sc[h];
-        s = fmaf(la[3 * h + 0], f0, s);
-        s = fmaf(la[3 * h + 1], f1, s);
-        if (!TSP) s = fmaf(la[3 * h + 2], f2, s);
+        float s = sc0[h];
+#pragma unroll
+        for (int k = 0; k < NF; ++k) s = fmaf(la[3 * h + k], f[k], s);
         s = smask ? ELG_NEG_INF : s;
         const float mx = wave_max(s);
         const float e = smask ? 0.f : __expf(s - mx);
         const float den = wave_sum(e);
         al[h] = den > 0.f ? e / den : 0.f;
     }
-    // o' contributions of this slot
-    float c[32];
-    const float* lAv = loc + ELG_LOC_LAV;
+    // F_h[f] = sum_j alpha_hj f_j[f]  -> lane (l & 15) holds element 3h+f
+    float fr[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) fr[i] = 0.f;
+#pragma unroll
+    for (int h = 0; h < ELG_LH; ++h)
+#pragma unroll
+        for (int k = 0; k < NF; ++k) fr[3 * h + k] = al[h] * f[k];
+    const float Ftot = reduce_scatter16(fr, lane);
+    // P[d] = sum_j alpha_{h(d),j} lcv[j][d]  -> lane (l & 31) holds element d, two halves of 16
     const float* lcv = loc + ELG_LOC_LCV + 32 * j;
+    float P;
+    {
+        float c[16];
 #pragma unroll
-    for (int d4 = 0; d4 < 8; ++d4) {
-        const float4 cv = *reinterpret_cast<const float4*>(lcv + 4 * d4);
-        const float cvv[4] = {cv.x, cv.y, cv.z, cv.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int d = 4 * d4 + e;
-            float v = cvv[e];
-            v = fmaf(lAv[3 * d + 0], f0, v);
-            v = fmaf(lAv[3 * d + 1], f1, v);
-            if (!TSP) v = fmaf(lAv[3 * d + 2], f2, v);
-            c[d] = al[d >> 3] * v;
+        for (int d4 = 0; d4 < 4; ++d4) {
+            const float4 cv = *reinterpret_cast<const float4*>(lcv + 4 * d4);
+            c[4 * d4 + 0] = al[(4 * d4) >> 3] * cv.x; c[4 * d4 + 1] = al[(4 * d4) >> 3] * cv.y;
+            c[4 * d4 + 2] = al[(4 * d4) >> 3] * cv.z; c[4 * d4 + 3] = al[(4 * d4) >> 3] * cv.w;
         }
+        const float plo = reduce_scatter16(c, lane);               // element (l & 15) of d = 0..15
+#pragma unroll
+        for (int d4 = 0; d4 < 4; ++d4) {
+            const float4 cv = *reinterpret_cast<const float4*>(lcv + 16 + 4 * d4);
+            c[4 * d4 + 0] = al[2 + ((4 * d4) >> 3)] * cv.x; c[4 * d4 + 1] = al[2 + ((4 * d4) >> 3)] * cv.y;
+            c[4 * d4 + 2] = al[2 + ((4 * d4) >> 3)] * cv.z; c[4 * d4 + 3] = al[2 + ((4 * d4) >> 3)] * cv.w;
+        }
+        const float phi = reduce_scatter16(c, lane);               // element (l & 15) of d = 16..31
+        P = (lane & 16) ? phi : plo;
     }
-    const float op = reduce_scatter32(c, lane);          // o'[lane & 31]
+    float op = P;                                                   // o'[dd]
+    {
+        const float* lAv = loc + ELG_LOC_LAV + 3 * dd;
+#pragma unroll
+        for (int k = 0; k < NF; ++k) op = fmaf(lAv[k], __shfl(Ftot, 3 * hh + k, ELG_WAVE), op);
+    }
     // g' = lWc o' + lbc  (lane d' computes g'[d'])
-    const int dd = lane & 31;
     const float* wrow = loc + ELG_LOC_LWC + 32 * dd;
     float g = loc[ELG_LOC_LBC + dd];
 #pragma unroll
@@ -332,29 +349,27 @@ __device__ __forceinline__ float local_policy(const float* __restrict__ loc, int
         g = fmaf(w.z, readlane(op, 4 * d4 + 2), g);
         g = fmaf(w.w, readlane(op, 4 * d4 + 3), g);
     }
-    // u_j = sum_d g'[d] (lpe[j][d] + lWe[d].f_j)
-    const float* lWe = loc + ELG_LOC_LWE;
+    // u_j = sum_d g'[d] lpe[j][d] + w . f_j
     const float* lpe = loc + ELG_LOC_LPE + 32 * j;
     float u = 0.f;
 #pragma unroll
     for (int d4 = 0; d4 < 8; ++d4) {
         const float4 pe = *reinterpret_cast<const float4*>(lpe + 4 * d4);
-        const float pev[4] = {pe.x, pe.y, pe.z, pe.w};
+        u = fmaf(readlane(g, 4 * d4 + 0), pe.x, u);
+        u = fmaf(readlane(g, 4 * d4 + 1), pe.y, u);
+        u = fmaf(readlane(g, 4 * d4 + 2), pe.z, u);
+        u = fmaf(readlane(g, 4 * d4 + 3), pe.w, u);
+    }
+    {
+        const float* lWe = loc + ELG_LOC_LWE + 3 * dd;
+        const float glo = (lane < 32) ? g : 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int d = 4 * d4 + e;
-            float ev = pev[e];
-            ev = fmaf(lWe[3 * d + 0], f0, ev);
-            ev = fmaf(lWe[3 * d + 1], f1, ev);
-            if (!TSP) ev = fmaf(lWe[3 * d + 2], f2, ev);
-            u = fmaf(readlane(g, d), ev, u);
-        }
+        for (int k = 0; k < NF; ++k) u = fmaf(half_sum_lo(glo * lWe[k]), f[k], u);
     }
     if (save) {
-        save->f0 = f0; save->f1 = f1; save->f2 = f2;
 #pragma unroll
         for (int h = 0; h < ELG_LH; ++h) save->al[h] = al[h];
-        save->op = op; save->g = g; save->smask = smask;
+        save->op = op; save->g = g; save->Ftot = Ftot;
     }
     return u;
 }

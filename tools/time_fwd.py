@@ -1,5 +1,7 @@
-import sys, time, torch, numpy as np
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+"""Ablation timing of the forward rollout kernel at the bench shape (runtime flags only)."""
+import sys, os, time, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import golden_util as gu, gpu_common as gc
 from oracle import elg_oracle as orc
 from elg_amd import _lib as L, engine as eng
@@ -12,14 +14,15 @@ enc = orc.encoder_forward(P, cfg, xy, dem)
 prob = gc.make_problem(xy, dem, L.PROBLEM_CVRP)
 pol = gc.make_policy(P, cfg, enc.to(gc.DEV), L.PROBLEM_CVRP)
 starts = torch.randperm(N)[:M]
-for geom in [None, (8, 4, 1), (13, 4, 1), (8, 4, 0), (8, 8, 0), (8, 16, 0)]:
-    for mode in (L.MODE_SAMPLE, L.MODE_GREEDY):
-        res = eng.rollout_forward(prob, pol, M, starts, mode, seed=1, geometry=geom)
-        torch.cuda.synchronize()
-        t0 = time.time()
-        for i in range(5):
-            res = eng.rollout_forward(prob, pol, M, starts, mode, seed=i, geometry=geom)
-        torch.cuda.synchronize()
-        dt = (time.time() - t0) / 5
-        T = res.tlen.max().item(); steps = res.tlen.sum().item()
-        print(f"geom={geom} mode={mode}: {dt*1e3:.2f} ms/rollout  T={T} mean_len={steps/(B*M):.1f}  {dt/T*1e6:.1f} us/step  traj-steps/s={steps/dt:.3e}")
+def run(tag, pol, geom, mode=L.MODE_SAMPLE):
+    res = eng.rollout_forward(prob, pol, M, starts, mode, seed=1, geometry=geom); torch.cuda.synchronize()
+    t0 = time.time()
+    for i in range(5): res = eng.rollout_forward(prob, pol, M, starts, mode, seed=i, geometry=geom)
+    torch.cuda.synchronize(); dt = (time.time() - t0) / 5
+    steps = res.tlen.sum().item()
+    print(f"{tag:32s} geom={geom}: {dt*1e3:7.2f} ms  mean_len={steps/(B*M):.1f}  ns/traj-step={dt/steps*1e9:.1f}")
+import copy
+for geom in [(13, 4, 1), (8, 4, 1)]:
+    run("full", pol, geom)
+    p2 = copy.copy(pol); p2.has_local = False; run("no local (penalty only)", p2, geom)
+    p3 = copy.copy(pol); p3.has_local = False; p3.has_penalty = False; run("no local, no penalty", p3, geom)
