@@ -40,8 +40,8 @@ class RolloutArgs(C.Structure):
 class BwdArgs(C.Structure):
     _fields_ = [
         ("fwd", RolloutArgs), ("T", C.c_int32), ("pad1", C.c_int32),
-        ("gprob", _vp), ("rowA", _vp), ("rowDS", _vp), ("rowDL", _vp), ("rowQ", _vp), ("rowO", _vp),
-        ("rowDO", _vp), ("rowDQ", _vp), ("rowDU", _vp), ("gwl", _vp), ("gloc", _vp),
+        ("gprob", _vp), ("rowA", _vp), ("rowDL", _vp), ("rowQ", _vp), ("rowO", _vp), ("rowLoad", _vp),
+        ("rowDU", _vp), ("gloc", _vp),
     ]
 
 

@@ -70,13 +70,11 @@ __device__ __forceinline__ void unit_of_block(const elg_rollout_args& A, int& b,
 // ---------------------------------------------------------------------------------------------
 template <int NCH, bool TSP, bool LDSK>
 __device__ __forceinline__ void bwd_step(const elg_bwd_args& BA, const Inst& I, const Traj<NCH>& st, int lane,
-                                         float* sb, int sel, float gp, size_t b, size_t r, size_t R,
-                                         float4& dwl4) {
+                                         float* sb, int sel, float gp, size_t b, size_t r, size_t R) {
     const elg_rollout_args& A = BA.fwd;
     constexpr int NG = 8 * NCH;
     const int N1 = A.N1;
     const int half = lane >> 5, hq = lane & 31, ql = lane & 3, cb = hq * 4, head = hq >> 2;
-    const bool b0 = ql & 1, b1 = ql & 2;
     const int rr = 2 * ql + half;
 
     unsigned long long mk[NCH];
@@ -167,115 +165,22 @@ __device__ __forceinline__ void bwd_step(const elg_bwd_args& BA, const Inst& I, 
         if (snid >= 0) du = sb[snid] * A.inv_ens;
         BA.rowDU[(b * R + r) * ELG_SLOT_STRIDE + lane] = du;
     }
-    // ds of this lane's rows in quad layout
-    float dsq[NG];
-#pragma unroll
-    for (int k = 0; k < NG; ++k) {
-        const int row = 8 * k + rr;
-        dsq[k] = (8 * k < N1 && row < N1) ? sb[row] : 0.f;
-    }
-    wave_lds_fence();
-
-    // ---- pointer backward: d o[c] = sum_n ds[n] PK[n][c]
-    float4 do4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int k = 0; k < NG; ++k) {
-        if (8 * k < N1) {
-#define ELG_DOACC(JJ)                                                                            \
-    {                                                                                            \
-        int row = 8 * k + 2 * JJ + half;                                                         \
-        const bool ok = row < N1;                                                                \
-        row = ok ? row : N1 - 1;                                                                 \
-        const int chunk = LDSK ? (hq ^ (row & 31)) : hq;                                         \
-        const float4 pk = *reinterpret_cast<const float4*>(I.PK + (size_t)row * ELG_E + 4 * chunk); \
-        float a = quad_bcast<JJ>(dsq[k]);                                                        \
-        a = ok ? a : 0.f;                                                                        \
-        do4.x = fmaf(a, pk.x, do4.x); do4.y = fmaf(a, pk.y, do4.y);                              \
-        do4.z = fmaf(a, pk.z, do4.z); do4.w = fmaf(a, pk.w, do4.w);                              \
-    }
-            ELG_DOACC(0) ELG_DOACC(1) ELG_DOACC(2) ELG_DOACC(3)
-#undef ELG_DOACC
-        }
-    }
-    do4.x += shfl_xor(do4.x, 32); do4.y += shfl_xor(do4.y, 32);
-    do4.z += shfl_xor(do4.z, 32); do4.w += shfl_xor(do4.w, 32);
-
-    // ---- glimpse backward
-    // sum_n a_h[n] da_h[n] = sum_{c in h} do[c] o[c]
-    float doto = do4.x * o4.x + do4.y * o4.y + do4.z * o4.z + do4.w * o4.w;
-    doto += quad_xor1(doto);
-    doto += quad_xor2(doto);
-    const float* Vp = I.V + cb;
-    const float* Kp = I.K + cb;
-    float dsk[NG];
-#pragma unroll
-    for (int k = 0; k < NG; ++k) {
-        dsk[k] = 0.f;
-        if (8 * k < N1) {
-            float pp[4];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                int row = 8 * k + 2 * jj + half;
-                if (!LDSK) row = row < N1 ? row : N1 - 1;
-                const float4 vv = *reinterpret_cast<const float4*>(Vp + (size_t)row * ELG_E);
-                pp[jj] = dot4(vv, do4, 0.f);
-            }
-            const float s0 = b0 ? pp[1] : pp[0], t0 = b0 ? pp[0] : pp[1];
-            const float s1 = b0 ? pp[3] : pp[2], t1 = b0 ? pp[2] : pp[3];
-            const float a0 = s0 + quad_xor1(t0), a1 = s1 + quad_xor1(t1);
-            const float keep = b1 ? a1 : a0, send = b1 ? a0 : a1;
-            const float da = keep + quad_xor2(send);                 // d a_h[row] of this lane's row
-            const float a = gs.e[k];                                  // 0 for masked / absent rows
-            dsk[k] = (a != 0.f) ? 0.25f * a * (da - doto) : 0.f;
-        }
-    }
-    // rows of the contractions: a_h[n], d(q.K)_h[n]
+    // rows consumed by the dense part of the backward (host: batched GEMMs, see engine.py):
+    // a_h[n] (glimpse attention), q and o of this step, the load seen by the query
     {
         float* rA = BA.rowA + ((b * ELG_H + head) * R + r) * N1;
-        float* rS = BA.rowDS + ((b * ELG_H + head) * R + r) * N1;
 #pragma unroll
         for (int k = 0; k < NG; ++k) {
             const int row = 8 * k + rr;
-            if (8 * k < N1 && row < N1) {
-                rA[row] = gs.e[k];
-                rS[row] = dsk[k];
-            }
+            if (8 * k < N1 && row < N1) rA[row] = gs.e[k];
         }
     }
-    // d q[c] = sum_n dsk_h[n] K[n][c]
-    float4 dq4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int k = 0; k < NG; ++k) {
-        if (8 * k < N1) {
-#define ELG_DQACC(JJ)                                                                            \
-    {                                                                                            \
-        int row = 8 * k + 2 * JJ + half;                                                         \
-        const bool ok = row < N1;                                                                \
-        if (!LDSK) row = ok ? row : N1 - 1;                                                      \
-        float4 kv = *reinterpret_cast<const float4*>(Kp + (size_t)row * ELG_E);                  \
-        float a = quad_bcast<JJ>(dsk[k]);                                                        \
-        a = ok ? a : 0.f;                                                                        \
-        if (!ok) kv = make_float4(0.f, 0.f, 0.f, 0.f);                                           \
-        dq4.x = fmaf(a, kv.x, dq4.x); dq4.y = fmaf(a, kv.y, dq4.y);                              \
-        dq4.z = fmaf(a, kv.z, dq4.z); dq4.w = fmaf(a, kv.w, dq4.w);                              \
-    }
-            ELG_DQACC(0) ELG_DQACC(1) ELG_DQACC(2) ELG_DQACC(3)
-#undef ELG_DQACC
-        }
-    }
-    dq4.x += shfl_xor(dq4.x, 32); dq4.y += shfl_xor(dq4.y, 32);
-    dq4.z += shfl_xor(dq4.z, 32); dq4.w += shfl_xor(dq4.w, 32);
     if (lane < 32) {
         const size_t off = (b * R + r) * ELG_E + cb;
         *reinterpret_cast<float4*>(BA.rowQ + off) = q4;
         *reinterpret_cast<float4*>(BA.rowO + off) = o4;
-        *reinterpret_cast<float4*>(BA.rowDO + off) = do4;
-        *reinterpret_cast<float4*>(BA.rowDQ + off) = dq4;
-        if (!TSP) {
-            dwl4.x = fmaf(st.load, dq4.x, dwl4.x); dwl4.y = fmaf(st.load, dq4.y, dwl4.y);
-            dwl4.z = fmaf(st.load, dq4.z, dwl4.z); dwl4.w = fmaf(st.load, dq4.w, dwl4.w);
-        }
     }
+    if (lane == 0 && BA.rowLoad) BA.rowLoad[b * R + r] = st.load;
 }
 
 // rows of a step that is not decoded (first moves, finished trajectories): all zero
@@ -284,16 +189,14 @@ __device__ __forceinline__ void zero_rows(const elg_bwd_args& BA, int lane, size
     const int N1 = BA.fwd.N1;
     for (int h = 0; h < ELG_H; ++h) {
         float* rA = BA.rowA + ((b * ELG_H + h) * R + r) * N1;
-        float* rS = BA.rowDS + ((b * ELG_H + h) * R + r) * N1;
-        for (int n = lane; n < N1; n += 64) { rA[n] = 0.f; rS[n] = 0.f; }
+        for (int n = lane; n < N1; n += 64) rA[n] = 0.f;
     }
     float* rDL = BA.rowDL + (b * R + r) * N1;
     for (int n = lane; n < N1; n += 64) rDL[n] = 0.f;
     const size_t off = (b * R + r) * ELG_E;
-    for (int c = lane; c < ELG_E; c += 64) {
-        BA.rowQ[off + c] = 0.f; BA.rowO[off + c] = 0.f; BA.rowDO[off + c] = 0.f; BA.rowDQ[off + c] = 0.f;
-    }
+    for (int c = lane; c < ELG_E; c += 64) { BA.rowQ[off + c] = 0.f; BA.rowO[off + c] = 0.f; }
     if (BA.rowDU && lane < ELG_SLOT_STRIDE) BA.rowDU[(b * R + r) * ELG_SLOT_STRIDE + lane] = 0.f;
+    if (lane == 0 && BA.rowLoad) BA.rowLoad[b * R + r] = 0.f;
 }
 
 template <int NCH, bool TSP, bool LDSK, int WAVES>
@@ -309,7 +212,6 @@ __global__ __launch_bounds__(WAVES * 64) void rollout_bwd_kernel(const elg_bwd_a
     float* sb = p + wave * SbSize<NCH>::value;
     __syncthreads();
     const size_t b = bi, R = (size_t)A.M * T;
-    float4 dwl4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     for (int m = m_lo + wave; m < m_hi; m += WAVES) {
         const size_t bm = b * A.M + m;
@@ -325,15 +227,10 @@ __global__ __launch_bounds__(WAVES * 64) void rollout_bwd_kernel(const elg_bwd_a
                 zero_rows<NCH>(BA, lane, b, r, R);
             } else {
                 const float gp = i2f(__builtin_amdgcn_readfirstlane(f2i(BA.gprob[(b * T + t) * A.M + m])));
-                bwd_step<NCH, TSP, LDSK>(BA, I, st, lane, sb, sel, gp, b, r, R, dwl4);
+                bwd_step<NCH, TSP, LDSK>(BA, I, st, lane, sb, sel, gp, b, r, R);
             }
             if (!st.fin) env_update<NCH, TSP>(st, I, N1, sel);
         }
-    }
-    if (!TSP && BA.gwl && lane < 32) {
-        const int cb = lane * 4;
-        atomicAdd(BA.gwl + cb + 0, dwl4.x); atomicAdd(BA.gwl + cb + 1, dwl4.y);
-        atomicAdd(BA.gwl + cb + 2, dwl4.z); atomicAdd(BA.gwl + cb + 3, dwl4.w);
     }
 }
 
@@ -581,7 +478,7 @@ extern "C" int elg_rollout_bwd(const elg_bwd_args* a, void* stream) {
     const elg_rollout_args& A = BA.fwd;
     if (A.B <= 0 || A.M <= 0 || A.N1 <= 1 || A.tiles <= 0 || BA.T <= 0) return fail(ELG_EINVAL, "rollout_bwd: bad sizes");
     if (!A.forced || A.Tforced < BA.T) return fail(ELG_EINVAL, "rollout_bwd: recorded actions missing");
-    if (!BA.gprob || !BA.rowA || !BA.rowDS || !BA.rowDL || !BA.rowQ || !BA.rowO || !BA.rowDO || !BA.rowDQ)
+    if (!BA.gprob || !BA.rowA || !BA.rowDL || !BA.rowQ || !BA.rowO)
         return fail(ELG_EINVAL, "rollout_bwd: missing row buffers");
     if (A.has_local && (!A.loc || !BA.rowDU || !BA.gloc)) return fail(ELG_EINVAL, "rollout_bwd: local buffers missing");
     if (A.K + 1 > ELG_SLOT_STRIDE) return fail(ELG_EINVAL, "rollout_bwd: local_size must be <= 47");

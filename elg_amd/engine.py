@@ -304,37 +304,41 @@ class _ChosenProbs(torch.autograd.Function):
         ba.T = T
         g = gprob[:, :T, :].contiguous().float()
         rowA = torch.empty(B, H, R, N1, device=dev)
-        rowDS = torch.empty(B, H, R, N1, device=dev)
         rowDL = torch.empty(B, R, N1, device=dev)
         rowQ = torch.empty(B, R, E, device=dev)
         rowO = torch.empty(B, R, E, device=dev)
-        rowDO = torch.empty(B, R, E, device=dev)
-        rowDQ = torch.empty(B, R, E, device=dev)
+        rowLoad = torch.empty(B, R, device=dev) if haswl else None
         rowDU = torch.empty(B, R, 48, device=dev) if meta.has_local else None
-        gwl = torch.zeros(E, device=dev)
         gloc = torch.zeros(L.LOC_SIZE, device=dev)
         ba.gprob = _ptr(g)
-        ba.rowA, ba.rowDS, ba.rowDL = _ptr(rowA), _ptr(rowDS), _ptr(rowDL)
-        ba.rowQ, ba.rowO, ba.rowDO, ba.rowDQ = _ptr(rowQ), _ptr(rowO), _ptr(rowDO), _ptr(rowDQ)
-        ba.rowDU, ba.gwl, ba.gloc = _ptr(rowDU), _ptr(gwl), _ptr(gloc)
+        ba.rowA, ba.rowDL, ba.rowQ, ba.rowO = _ptr(rowA), _ptr(rowDL), _ptr(rowQ), _ptr(rowO)
+        ba.rowLoad, ba.rowDU, ba.gloc = _ptr(rowLoad), _ptr(rowDU), _ptr(gloc)
         L.check(L.lib().elg_rollout_bwd(C.byref(ba), _stream()), "elg_rollout_bwd")
-        # per-instance contractions over the R = M*T decode rows (dense batched GEMMs)
-        Qh = rowQ.view(B, R, H, DK).permute(0, 2, 1, 3)                    # (B,H,R,16)
-        DOh = rowDO.view(B, R, H, DK).permute(0, 2, 1, 3)
-        dK = torch.matmul(rowDS.transpose(2, 3), Qh).permute(0, 2, 1, 3).reshape(B, N1, E)
-        dV = torch.matmul(rowA.transpose(2, 3), DOh).permute(0, 2, 1, 3).reshape(B, N1, E)
-        dPK = torch.matmul(rowDL.transpose(1, 2), rowO)                    # (B,N1,128)
+        # ---- dense part: glimpse / pointer backward over the R = M*T decode rows of every instance
+        # (batched GEMMs on the matrix cores; formulas in include/elg_hip.h)
+        def heads(x):                                               # (B,X,128) -> (B,H,X,16)
+            return x.view(B, x.shape[1], H, DK).permute(0, 2, 1, 3)
+        Kh, Vh, Qh, Oh = heads(Kt), heads(Vt), heads(rowQ), heads(rowO)
+        dO = torch.bmm(rowDL, PKt)                                  # (B,R,128)
+        dOh = heads(dO)
+        dA = torch.matmul(dOh, Vh.transpose(2, 3))                  # (B,H,R,N1)
+        doto = (dOh * Oh).sum(dim=3, keepdim=True)
+        dS = dA.sub_(doto).mul_(rowA).mul_(0.25)                    # d(q.K) rows (zero where a == 0)
+        dQ = torch.matmul(dS, Kh).permute(0, 2, 1, 3).reshape(B, R, E)
+        dK = torch.matmul(dS.transpose(2, 3), Qh).permute(0, 2, 1, 3).reshape(B, N1, E)
+        dV = torch.matmul(rowA.transpose(2, 3), dOh).permute(0, 2, 1, 3).reshape(B, N1, E)
+        dPK = torch.bmm(rowDL.transpose(1, 2), rowO)
         dpb = rowDL.sum(dim=1)
         # the query of decode step t was gathered at cur = action[t-1] (and first = action[0] for TSP)
         fl = forced.long()
         prev = torch.cat([torch.zeros(B, M, 1, dtype=torch.long, device=dev), fl[:, :, :-1]], dim=2).reshape(B, R)
-        dQ1 = torch.zeros(B, N1, E, device=dev).scatter_add_(1, prev[:, :, None].expand(B, R, E), rowDQ)
+        dQ1 = torch.zeros(B, N1, E, device=dev).scatter_add_(1, prev[:, :, None].expand(B, R, E), dQ)
         dQ2 = dwl = None
         if hasQ2:
             first = fl[:, :, :1].expand(B, M, T).reshape(B, R)
-            dQ2 = torch.zeros(B, N1, E, device=dev).scatter_add_(1, first[:, :, None].expand(B, R, E), rowDQ)
+            dQ2 = torch.zeros(B, N1, E, device=dev).scatter_add_(1, first[:, :, None].expand(B, R, E), dQ)
         if haswl:
-            dwl = gwl
+            dwl = torch.einsum("br,bre->e", rowLoad, dQ)
         return (None, None, None, None, None, None, None,
                 dK, dV, dPK, dpb, dQ1, dQ2, dwl, gloc if hasloc else None)
 

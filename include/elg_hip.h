@@ -122,29 +122,29 @@ int elg_rollout_fwd(const elg_rollout_args* args, void* stream);
 
 /* Backward of the chosen-node probabilities w.r.t. the per-instance tables and the folded local
  * tables (replaces autograd's tape over CVRP/utils.py:14-21 + models.py:322-423; train.py:112-125).
- * The recorded actions are replayed (no tape): every step is recomputed and differentiated in
- * registers.  Launch 1 (rollout_bwd_kernel) emits, per decode row r = m*T + t, the factors of the
- * per-instance contractions
- *     dK[n]  = sum_r rowDS[h,r,n] * rowQ[r]      dV[n] = sum_r rowA[h,r,n] * rowDO[r]
- *     dPK[n] = sum_r rowDL[r,n]  * rowO[r]       dpb[n] = sum_r rowDL[r,n]
- *     dQ1[cur_r] += rowDQ[r]   (TSP: dQ2[first] += rowDQ[r])      d wl = gwl
- * which the host finishes with dense batched GEMMs, and the per-slot gradient rowDU of the local
- * policy's output.  Launch 2 (local_bwd_kernel) replays the k-NN/local policy only and reduces the
- * gradient of the folded local tables on chip (LDS accumulators) into gloc. */
+ * The recorded actions are replayed (no tape): every step is recomputed inside one wavefront.
+ * Launch 1 (rollout_bwd_kernel) differentiates the softmax / clipping and emits, per decode row
+ * r = m*T + t, what the dense part of the backward needs:
+ *     rowDL[r,n] = d s[n] (pointer scores)      rowA[h,r,n] = a_h[n] (glimpse attention weights)
+ *     rowQ[r], rowO[r] = glimpse query / output  rowLoad[r] = load seen by the query
+ *     rowDU[r,j] = d u_slot[j] (local policy output)
+ * The glimpse / pointer backward itself is batched dense algebra over the R = M*T rows of an instance
+ *     dO = rowDL PK,  dA_h = dO_h V_h^T,  dS = a (dA - <dO_h, O_h>) / 4,  dQ_h = dS_h K_h,
+ *     dK_h = dS_h^T Q_h,  dV_h = a_h^T dO_h,  dPK = rowDL^T rowO,  dpb = sum_r rowDL
+ * and is run by the host as library GEMMs on the matrix cores (engine.py).
+ * Launch 2 (local_bwd_kernel) replays the k-NN/local policy only and reduces the gradient of the
+ * folded local tables on chip (register accumulators, one flush per workgroup) into gloc. */
 typedef struct elg_bwd_args {
     elg_rollout_args fwd;   /* same tables; fwd.forced = recorded actions (B,M,T), fwd.Tforced = T  */
     int32_t T;              /* steps to replay                                                      */
     int32_t pad1;
     const float* gprob;     /* (B,T,M) dJ/d prob[b,t,m]                                             */
     float* rowA;            /* (B,8,R,N1)  glimpse attention weights a_h[n],  R = M*T               */
-    float* rowDS;           /* (B,8,R,N1)  d(q_h . K_h[n]) (includes the 1/sqrt(16))                */
     float* rowDL;           /* (B,R,N1)    d pointer score s[n]                                     */
     float* rowQ;            /* (B,R,128)   glimpse query q                                          */
     float* rowO;            /* (B,R,128)   glimpse output o                                         */
-    float* rowDO;           /* (B,R,128)   d o                                                      */
-    float* rowDQ;           /* (B,R,128)   d q                                                      */
+    float* rowLoad;         /* (B,R)       load at the step (CVRP), may be NULL                     */
     float* rowDU;           /* (B,R,48)    d u_slot (already includes 1/ensemble_size)              */
-    float* gwl;             /* (128)       accumulated d wl (CVRP), caller zeroes                   */
     float* gloc;            /* (ELG_LOC_SIZE) accumulated d loc, caller zeroes                      */
 } elg_bwd_args;
 int elg_rollout_bwd(const elg_bwd_args* args, void* stream);
