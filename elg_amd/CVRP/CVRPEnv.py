@@ -107,12 +107,14 @@ class CVRPEnv:
         scaled and of the raw coordinates, demand / capacity."""
         self.vrplib = True
         self.batch_size = 1
-        coord = torch.as_tensor(instance['node_coord'], dtype=torch.float32, device=self.device)[None]
-        demand = torch.as_tensor(instance['demand'], dtype=torch.float32, device=self.device)[None] / instance['capacity']
+        # once-per-instance preprocessing in host fp32 (IEEE division), exactly the reference's arithmetic
+        coord = torch.as_tensor(instance['node_coord'], dtype=torch.float32)[None]
+        demand = torch.as_tensor(instance['demand'], dtype=torch.float32)[None] / instance['capacity']
         lo = coord.min(dim=1, keepdim=True)[0]
         hi = coord.max(dim=1, keepdim=True)[0]
-        scaled = (coord - lo) / (hi - lo)
-        unscaled = coord
+        scaled = ((coord - lo) / (hi - lo)).to(self.device)
+        unscaled = coord.to(self.device)
+        demand = demand.to(self.device)
         depot_idx = torch.as_tensor(instance['depot']).reshape(-1).long().to(self.device)
         depot = scaled[:, depot_idx, :]
         if aug_factor > 1:

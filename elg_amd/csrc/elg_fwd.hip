@@ -335,7 +335,8 @@ __global__ __launch_bounds__(WAVES * 64) void rollout_fwd_kernel(const elg_rollo
             int sel = 0;
             float pr = 1.0f;
             int fsel = 0;
-            if (A.forced && t < A.Tforced) fsel = __builtin_amdgcn_readfirstlane(A.forced[bm * A.Tforced + t]);
+            const int tf = A.use_state ? steps : t;      // step-wise protocol: `forced` holds this call's actions
+            if (A.forced && tf < A.Tforced) fsel = __builtin_amdgcn_readfirstlane(A.forced[bm * A.Tforced + tf]);
             const bool first_move = (!TSP && t <= 1) || (TSP && t == 0);
             if (!A.do_decode) {
                 sel = fsel;                                          // CVRPEnv.step with a given action

@@ -1,0 +1,126 @@
+"""Host-side logic on CPU: weight folds against the oracle's unfolded math, state-dict / seeded-init
+compatibility with the reference, data generation, VRPLIB reader."""
+import math
+import os
+import random
+
+import numpy as np
+import torch
+
+import golden_util as gu
+from oracle import elg_oracle as orc
+from elg_amd import _lib as L
+from elg_amd import engine as eng
+
+
+def _weights(problem, seed, mp):
+    return {k: torch.from_numpy(v) for k, v in gu.golden_weights(problem, seed, mp, True, 1.0).items()}
+
+
+def _sub(P, prefix):
+    return {k[len(prefix):]: v for k, v in P.items() if k.startswith(prefix)}
+
+
+def _folded_local(loc, feats, smask, nf):
+    """The kernel's folded evaluation of the local policy (csrc/elg_rollout.h::local_policy), in torch."""
+    Ls = feats.shape[0]
+    la = loc[L.LOC_LA:L.LOC_LA + 12].view(4, 3)[:, :nf]
+    lt = loc[L.LOC_LT:L.LOC_LT + 256].view(64, 4)[:Ls]
+    lAv = loc[L.LOC_LAV:L.LOC_LAV + 96].view(32, 3)[:, :nf]
+    lcv = loc[L.LOC_LCV:L.LOC_LCV + 2048].view(64, 32)[:Ls]
+    lWc = loc[L.LOC_LWC:L.LOC_LWC + 1024].view(32, 32)
+    lbc = loc[L.LOC_LBC:L.LOC_LBC + 32]
+    lWe = loc[L.LOC_LWE:L.LOC_LWE + 96].view(32, 3)[:, :nf]
+    lpe = loc[L.LOC_LPE:L.LOC_LPE + 2048].view(64, 32)[:Ls]
+    sc = feats @ la.T + lt
+    sc = sc.masked_fill(smask[:, None], float("-inf"))
+    al = torch.softmax(sc, dim=0)                                  # (L,4)
+    F = al.T @ feats                                               # (4,nf)
+    P = (al.repeat_interleave(8, dim=1) * lcv).sum(0)              # (32)
+    op = P + (lAv * F.repeat_interleave(8, dim=0)).sum(1)
+    g = lWc @ op + lbc
+    return lpe @ g + feats @ (lWe.T @ g)
+
+
+def test_fold_local_tables_matches_unfolded_math():
+    for problem, mp, nf in (("cvrp", gu.CVRP_MODEL_PARAMS, 3), ("tsp", gu.TSP_MODEL_PARAMS, 2)):
+        P = _weights(problem, 3, mp)
+        cfg = orc.ModelCfg.from_model_params(mp, problem)
+        pre = "decoder.local_policies.0." if problem == "cvrp" else "decoder.local_policy_0."
+        Ls = cfg.local_size + (1 if problem == "cvrp" else 0)
+        loc = eng.fold_local_tables(_sub(P, pre), nf, Ls)
+        assert loc.numel() == L.LOC_SIZE
+        torch.manual_seed(1)
+        feats = torch.rand(1, 1, Ls, nf)
+        smask = torch.zeros(1, 1, Ls, dtype=torch.bool)
+        smask[0, 0, Ls - 5:] = True
+        feats[0, 0, Ls - 5:] = 0
+        ref = orc._local_policy(P, cfg, pre, feats, smask)[0, 0]
+        got = _folded_local(loc, feats[0, 0], smask[0, 0], nf)
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_fold_decoder_tables_matches_decoder_math():
+    mp = gu.CVRP_MODEL_PARAMS
+    P = _weights("cvrp", 4, mp)
+    cfg = orc.ModelCfg.from_model_params(mp, "cvrp")
+    torch.manual_seed(2)
+    enc = torch.randn(2, 11, 128)
+    t = eng.fold_decoder_tables(_sub(P, "decoder."), enc, L.PROBLEM_CVRP)
+    kh, vh = orc.set_kv(P, cfg, enc)
+    np.testing.assert_allclose(t["K"].view(2, 11, 8, 16).transpose(1, 2).numpy(), kh.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(t["V"].view(2, 11, 8, 16).transpose(1, 2).numpy(), vh.numpy(), rtol=1e-5, atol=1e-6)
+    o = torch.randn(2, 5, 128)
+    g = o @ P["decoder.multi_head_combine.weight"].T + P["decoder.multi_head_combine.bias"]
+    s_ref = g @ enc.transpose(1, 2) / math.sqrt(128)
+    s_got = o @ t["PK"].transpose(1, 2) + t["pb"][:, None, :]
+    np.testing.assert_allclose(s_got.numpy(), s_ref.numpy(), rtol=2e-4, atol=2e-5)
+    cur = torch.tensor([[0, 3, 7], [1, 1, 10]])
+    load = torch.rand(2, 3)
+    h = enc[torch.arange(2)[:, None], cur]
+    q_ref = torch.cat([h, load[:, :, None]], 2) @ P["decoder.Wq_last.weight"].T
+    q_got = t["Q1"][torch.arange(2)[:, None], cur] + load[:, :, None] * t["wl"]
+    np.testing.assert_allclose(q_got.numpy(), q_ref.numpy(), rtol=2e-4, atol=2e-5)
+
+
+def test_state_dict_layout_and_seeded_init_match_reference():
+    """Same seed -> bit-identical default weights and the same POMO start draw as the reference
+    (fixture generated from the real reference by tools/make_golden.py)."""
+    from elg_amd.CVRP.CVRPModel import CVRPModel
+    from elg_amd.CVRP.utils import seed_everything
+    fx = gu.load_golden("cvrp_init_seed924.npz")
+    seed_everything(924)
+    m = CVRPModel(**dict(gu.CVRP_MODEL_PARAMS))
+    m.decoder.add_local_policy("cpu")
+    starts = random.sample(range(0, 100), 100)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(gu.model_param_shapes("cvrp", gu.CVRP_MODEL_PARAMS).keys())
+    for k, v in sd.items():
+        a = v.numpy().astype(np.float64).reshape(-1)
+        assert a.sum() == float(fx["sum/" + k]) and np.abs(a).sum() == float(fx["abs/" + k]), k
+        assert np.array_equal(v.numpy().reshape(-1)[:4], fx["head/" + k]), k
+    assert starts == list(fx["starts"])
+    assert sum(p.numel() for p in m.parameters()) == 1258304
+
+
+def test_generate_data_and_vrplib_reader():
+    from elg_amd.CVRP.generate_data import generate_vrp_data, CAPACITIES
+    from elg_amd import vrplib_io
+    dist = dict(data_type="uniform", n_cluster=3, n_cluster_mix=1, lower=0.2, upper=0.8, std=0.07)
+    torch.manual_seed(5)
+    d = generate_vrp_data(4, 100, dist)
+    torch.manual_seed(5)                     # the reference's draw order: depot, nodes, demand
+    dep, loc = torch.rand(4, 1, 2), torch.rand(4, 100, 2)
+    dem = torch.randint(1, 10, (4, 100)).float() / 50.0
+    assert torch.equal(d["depot"], dep) and torch.equal(d["loc"], loc) and torch.equal(d["demand"], dem)
+    for kind in ("cluster", "mixed"):
+        x = generate_vrp_data(3, 50, dict(dist, data_type=kind))
+        assert x["loc"].shape == (3, 50, 2) and x["depot"].shape == (3, 1, 2)
+        assert (x["loc"] >= 0).all() and (x["loc"] <= 1).all()
+        assert torch.all(x["demand"] * CAPACITIES[50] == torch.round(x["demand"] * CAPACITIES[50]))
+    p = os.path.join(gu.GOLDEN_DIR, "vrplib", "X", "X-n101-k25")
+    a, b = vrplib_io.read_instance(p + ".vrp"), orc.read_vrp(p + ".vrp")
+    assert np.array_equal(a["node_coord"], b["node_coord"]) and np.array_equal(a["demand"], b["demand"])
+    assert a["capacity"] == b["capacity"] == 206 and list(a["depot"]) == [0]
+    s = vrplib_io.read_solution(p + ".sol")
+    assert s["cost"] == 27591 and len(s["routes"]) == 26

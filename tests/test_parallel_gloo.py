@@ -1,0 +1,65 @@
+"""Data-parallel plumbing on CPU with the gloo backend, world_size 2: flat gradient bucket all-reduce
+(mean over ranks), parameter broadcast, and the DP == large-batch identity the engine relies on
+(loss is a mean over independent instances)."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from elg_amd import parallel
+    r, w, _ = parallel.init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)                  # different initial weights per rank ...
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 1))
+    parallel.broadcast_parameters(model)           # ... until rank 0's are broadcast
+    torch.manual_seed(7)
+    full = torch.randn(8, 6)                        # the "global batch"; each rank takes its shard
+    shard = full[rank * 4:(rank + 1) * 4]
+    loss = model(shard).pow(2).mean()
+    loss.backward()
+    bucket = parallel.GradBucket(model.parameters())
+    bucket.allreduce(world)
+    parallel.barrier()
+    out[rank] = dict(params=[p.detach().clone() for p in model.parameters()],
+                     grads=[p.grad.detach().clone() for p in model.parameters()], numel=bucket.numel)
+    torch.distributed.destroy_process_group()
+
+
+def test_gradient_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    out = mgr.dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    a, b = out[0], out[1]
+    for x, y in zip(a["params"], b["params"]):
+        assert torch.equal(x, y)                    # identical replicas after broadcast
+    for x, y in zip(a["grads"], b["grads"]):
+        assert torch.allclose(x, y, atol=0)        # identical averaged gradients
+    # equals the single-process gradient on the whole batch (mean over independent samples)
+    torch.manual_seed(100)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 1))
+    torch.manual_seed(7)
+    full = torch.randn(8, 6)
+    model(full).pow(2).mean().backward()
+    for p, g in zip(model.parameters(), a["grads"]):
+        assert torch.allclose(p.grad, g, rtol=1e-5, atol=1e-7)
+    assert a["numel"] == sum(p.numel() for p in model.parameters())

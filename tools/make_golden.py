@@ -206,6 +206,18 @@ def gen_cvrp():
 
     train_fixture("n20", B=4, N=20, M=20, wseed=16, rseed=7)
 
+    # ---------------- seeded default initialisation (drop-in: same seed -> same weights) ----------------
+    ref_utils.seed_everything(924)
+    m0 = ref_model_mod.CVRPModel(**dict(gu.CVRP_MODEL_PARAMS))
+    m0.decoder.add_local_policy("cpu")
+    starts0 = random.sample(range(0, 100), 100)                      # the draw CVRPModel.py:47 would make next
+    init = {}
+    for k, v in m0.state_dict().items():
+        a = v.numpy().astype(np.float64).reshape(-1)
+        init["sum/" + k] = np.float64(a.sum()); init["abs/" + k] = np.float64(np.abs(a).sum())
+        init["head/" + k] = v.numpy().reshape(-1)[:4].copy()
+    np.savez_compressed(os.path.join(OUT, "cvrp_init_seed924.npz"), starts=np.array(starts0), **init)
+
     # ---------------- aug8 (utils.py:69-87) ----------------
     x = torch.from_numpy(np.random.RandomState(3).uniform(size=(3, 7, 2)).astype(np.float32))
     np.savez_compressed(os.path.join(OUT, "aug8.npz"), x=x.numpy(), y=ref_utils.augment_xy_data_by_8_fold(x).numpy())
