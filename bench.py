@@ -102,7 +102,7 @@ def main():
     model.to(dev)
     parallel.broadcast_parameters(model)
     env = CVRPEnv(multi_width=POMO, device=dev)
-    opt = torch.optim.Adam(model.parameters(), lr=cfg["params"]["learning_rate"], weight_decay=1e-6)
+    opt = torch.optim.Adam(model.parameters(), lr=cfg["params"]["learning_rate"], weight_decay=1e-6, fused=True)
     bucket = parallel.GradBucket(model.parameters()) if world > 1 else None
     dist_cfg = dict(cfg["distribution"], data_type="uniform")
 

@@ -417,6 +417,79 @@ __global__ __launch_bounds__(WAVES * 64) void local_bwd_kernel(const elg_bwd_arg
 }
 
 // =============================================================================================
+// dense-row part of the glimpse backward that is not a plain GEMM: per decode row r and head h
+//     dA[n] = sum_d dO[r,h,d] V[n,h,d]            (K = 16: cheaper on the fly than as a GEMM + a pass)
+//     dS[n] = a[n] (dA[n] - <dO_h, O_h>) / 4      softmax backward, /sqrt(qkv_dim)
+//     dQ[d] = sum_n dS[n] K[n,h,d]
+// rowA (B,8,R,N1) is read once and dS written once (both streamed, coalesced); V_h/K_h of the
+// (instance, head) pair sit transposed in LDS.  One wavefront per row, lanes over nodes.
+// =============================================================================================
+template <int NCH>
+__global__ __launch_bounds__(256) void glimpse_rows_kernel(const float* __restrict__ rowA, const float* __restrict__ dO,
+                                                           const float* __restrict__ rowO, const float* __restrict__ Kmat,
+                                                           const float* __restrict__ Vmat, float* __restrict__ dS,
+                                                           float* __restrict__ dQ, int R, int N1, int rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bh = blockIdx.y, b = bh >> 3, h = bh & 7;
+    const int NP = 64 * NCH;                       // padded node stride of the transposed tiles
+    float* sV = lds;                               // [16][NP]
+    float* sK = lds + 16 * NP;                     // [16][NP]
+    for (int i = threadIdx.x; i < 16 * NP; i += 256) {
+        const int d = i / NP, n = i - d * NP;
+        float v = 0.f, k = 0.f;
+        if (n < N1) {
+            v = Vmat[((size_t)b * N1 + n) * ELG_E + h * 16 + d];
+            k = Kmat[((size_t)b * N1 + n) * ELG_E + h * 16 + d];
+        }
+        sV[i] = v; sK[i] = k;
+    }
+    __syncthreads();
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(R, r0 + rows_per_block);
+    for (int r = r0 + wave; r < r1; r += 4) {
+        const size_t rowoff = ((size_t)bh * R + r) * N1;
+        const size_t voff = ((size_t)b * R + r) * ELG_E + h * 16;
+        float a[NCH];
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int n = lane + 64 * c;
+            a[c] = (n < N1) ? rowA[rowoff + n] : 0.f;
+            any = any || (a[c] != 0.f);
+        }
+        if (!__ballot(any)) {                      // inactive row (first moves / finished): all zero
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { const int n = lane + 64 * c; if (n < N1) dS[rowoff + n] = 0.f; }
+            if (lane < 16) dQ[voff + lane] = 0.f;
+            continue;
+        }
+        float dov[16], doto = 0.f;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            dov[d] = dO[voff + d];                 // wave-uniform
+            doto = fmaf(dov[d], rowO[voff + d], doto);
+        }
+        float part[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) part[d] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int n = lane + 64 * c;
+            float da = 0.f;
+#pragma unroll
+            for (int d = 0; d < 16; ++d) da = fmaf(dov[d], sV[d * NP + n], da);
+            const float ds = 0.25f * a[c] * (da - doto);
+            if (n < N1) dS[rowoff + n] = ds;
+#pragma unroll
+            for (int d = 0; d < 16; ++d) part[d] = fmaf(ds, sK[d * NP + n], part[d]);
+        }
+        const float tot = reduce_scatter16(part, lane);
+        if (lane < 16) dQ[voff + lane] = tot;
+    }
+}
+
+// =============================================================================================
 // launchers
 // =============================================================================================
 template <int NCH, bool TSP, bool LDSK, int WAVES>
@@ -471,6 +544,22 @@ static int dispatch_bwd(const elg_bwd_args& BA, hipStream_t stream) {
 }  // namespace elg
 
 using namespace elg;
+
+extern "C" int elg_glimpse_rows_bwd(const float* rowA, const float* dO, const float* rowO, const float* Kmat,
+                                    const float* Vmat, float* dS, float* dQ, int B, int R, int N1, void* stream) {
+    if (B <= 0 || R <= 0 || N1 <= 1) return fail(ELG_EINVAL, "glimpse_rows_bwd: bad sizes");
+    const int nch = (N1 + 63) / 64;
+    const int rpb = 128;
+    dim3 grid((R + rpb - 1) / rpb, B * 8);
+    const size_t lds = (size_t)2 * 16 * 64 * nch * 4;
+    (void)hipGetLastError();
+    if (nch == 1) hipLaunchKernelGGL(glimpse_rows_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, rowA, dO, rowO, Kmat, Vmat, dS, dQ, R, N1, rpb);
+    else if (nch == 2) hipLaunchKernelGGL(glimpse_rows_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, rowA, dO, rowO, Kmat, Vmat, dS, dQ, R, N1, rpb);
+    else if (nch <= 4) hipLaunchKernelGGL(glimpse_rows_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, rowA, dO, rowO, Kmat, Vmat, dS, dQ, R, N1, rpb);
+    else if (nch <= 8) hipLaunchKernelGGL(glimpse_rows_kernel<8>, grid, dim3(256), lds, (hipStream_t)stream, rowA, dO, rowO, Kmat, Vmat, dS, dQ, R, N1, rpb);
+    else return fail(ELG_ENOTIMPL, "glimpse_rows_bwd: N1 > 512 not built");
+    return launch_status("glimpse_rows_bwd");
+}
 
 extern "C" int elg_rollout_bwd(const elg_bwd_args* a, void* stream) {
     if (!a) return fail(ELG_EINVAL, "null args");

@@ -318,15 +318,13 @@ class _ChosenProbs(torch.autograd.Function):
         # (batched GEMMs on the matrix cores; formulas in include/elg_hip.h)
         def heads(x):                                               # (B,X,128) -> (B,H,X,16)
             return x.view(B, x.shape[1], H, DK).permute(0, 2, 1, 3)
-        Kh, Vh, Qh, Oh = heads(Kt), heads(Vt), heads(rowQ), heads(rowO)
-        dO = torch.bmm(rowDL, PKt)                                  # (B,R,128)
-        dOh = heads(dO)
-        dA = torch.matmul(dOh, Vh.transpose(2, 3))                  # (B,H,R,N1)
-        doto = (dOh * Oh).sum(dim=3, keepdim=True)
-        dS = dA.sub_(doto).mul_(rowA).mul_(0.25)                    # d(q.K) rows (zero where a == 0)
-        dQ = torch.matmul(dS, Kh).permute(0, 2, 1, 3).reshape(B, R, E)
-        dK = torch.matmul(dS.transpose(2, 3), Qh).permute(0, 2, 1, 3).reshape(B, N1, E)
-        dV = torch.matmul(rowA.transpose(2, 3), dOh).permute(0, 2, 1, 3).reshape(B, N1, E)
+        dO = torch.bmm(rowDL, PKt)                                  # (B,R,128)   d o = d s . PK
+        dS = torch.empty_like(rowA)                                 # (B,H,R,N1)  d(q.K)
+        dQ = torch.empty(B, R, E, device=dev)
+        L.check(L.lib().elg_glimpse_rows_bwd(_ptr(rowA), _ptr(dO), _ptr(rowO), _ptr(Kt), _ptr(Vt), _ptr(dS), _ptr(dQ),
+                                             B, R, N1, _stream()), "elg_glimpse_rows_bwd")
+        dK = torch.matmul(dS.transpose(2, 3), heads(rowQ)).permute(0, 2, 1, 3).reshape(B, N1, E)
+        dV = torch.matmul(rowA.transpose(2, 3), heads(dO)).permute(0, 2, 1, 3).reshape(B, N1, E)
         dPK = torch.bmm(rowDL.transpose(1, 2), rowO)
         dpb = rowDL.sum(dim=1)
         # the query of decode step t was gathered at cur = action[t-1] (and first = action[0] for TSP)

@@ -149,6 +149,12 @@ typedef struct elg_bwd_args {
 } elg_bwd_args;
 int elg_rollout_bwd(const elg_bwd_args* args, void* stream);
 
+/* Row-wise part of the glimpse backward (softmax backward of models.py:478-500 on the saved weights):
+ * per decode row r and head h:  dS = a (dO_h V_h^T - <dO_h, O_h>) / 4,  dQ_h = dS K_h.
+ * rowA, dS (B,8,R,N1); dO, rowO, dQ (B,R,128); Kmat, Vmat (B,N1,128).  dS may alias nothing else. */
+int elg_glimpse_rows_bwd(const float* rowA, const float* dO, const float* rowO, const float* Kmat,
+                         const float* Vmat, float* dS, float* dQ, int B, int R, int N1, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
