@@ -429,22 +429,25 @@ __global__ __launch_bounds__(256) void glimpse_rows_kernel(const float* __restri
                                                            const float* __restrict__ rowO, const float* __restrict__ Kmat,
                                                            const float* __restrict__ Vmat, float* __restrict__ dS,
                                                            float* __restrict__ dQ, int R, int N1, int rows_per_block) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int bh = blockIdx.y, b = bh >> 3, h = bh & 7;
-    const int NP = 64 * NCH;                       // padded node stride of the transposed tiles
-    float* sV = lds;                               // [16][NP]
-    float* sK = lds + 16 * NP;                     // [16][NP]
-    for (int i = threadIdx.x; i < 16 * NP; i += 256) {
-        const int d = i / NP, n = i - d * NP;
-        float v = 0.f, k = 0.f;
-        if (n < N1) {
-            v = Vmat[((size_t)b * N1 + n) * ELG_E + h * 16 + d];
-            k = Kmat[((size_t)b * N1 + n) * ELG_E + h * 16 + d];
+    // every lane owns the same nodes n = lane + 64 c for all rows: keep their K_h / V_h rows in registers
+    float vreg[NCH][16], kreg[NCH][16];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int n = lane + 64 * c;
+        const size_t off = ((size_t)b * N1 + (n < N1 ? n : 0)) * ELG_E + h * 16;
+#pragma unroll
+        for (int d4 = 0; d4 < 4; ++d4) {
+            const float4 v = *reinterpret_cast<const float4*>(Vmat + off + 4 * d4);
+            const float4 k = *reinterpret_cast<const float4*>(Kmat + off + 4 * d4);
+            const bool ok = n < N1;
+            vreg[c][4 * d4 + 0] = ok ? v.x : 0.f; vreg[c][4 * d4 + 1] = ok ? v.y : 0.f;
+            vreg[c][4 * d4 + 2] = ok ? v.z : 0.f; vreg[c][4 * d4 + 3] = ok ? v.w : 0.f;
+            kreg[c][4 * d4 + 0] = ok ? k.x : 0.f; kreg[c][4 * d4 + 1] = ok ? k.y : 0.f;
+            kreg[c][4 * d4 + 2] = ok ? k.z : 0.f; kreg[c][4 * d4 + 3] = ok ? k.w : 0.f;
         }
-        sV[i] = v; sK[i] = k;
     }
-    __syncthreads();
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(R, r0 + rows_per_block);
     for (int r = r0 + wave; r < r1; r += 4) {
@@ -464,11 +467,14 @@ __global__ __launch_bounds__(256) void glimpse_rows_kernel(const float* __restri
             if (lane < 16) dQ[voff + lane] = 0.f;
             continue;
         }
+        // dO_h, O_h of the row: 16 values each, loaded by lanes 0..15 and broadcast through SGPRs
+        const float dol = (lane < 16) ? dO[voff + lane] : 0.f;
+        const float ol = (lane < 16) ? rowO[voff + lane] : 0.f;
         float dov[16], doto = 0.f;
 #pragma unroll
         for (int d = 0; d < 16; ++d) {
-            dov[d] = dO[voff + d];                 // wave-uniform
-            doto = fmaf(dov[d], rowO[voff + d], doto);
+            dov[d] = readlane(dol, d);
+            doto = fmaf(dov[d], readlane(ol, d), doto);
         }
         float part[16];
 #pragma unroll
@@ -478,11 +484,11 @@ __global__ __launch_bounds__(256) void glimpse_rows_kernel(const float* __restri
             const int n = lane + 64 * c;
             float da = 0.f;
 #pragma unroll
-            for (int d = 0; d < 16; ++d) da = fmaf(dov[d], sV[d * NP + n], da);
+            for (int d = 0; d < 16; ++d) da = fmaf(dov[d], vreg[c][d], da);
             const float ds = 0.25f * a[c] * (da - doto);
             if (n < N1) dS[rowoff + n] = ds;
 #pragma unroll
-            for (int d = 0; d < 16; ++d) part[d] = fmaf(ds, sK[d * NP + n], part[d]);
+            for (int d = 0; d < 16; ++d) part[d] = fmaf(ds, kreg[c][d], part[d]);
         }
         const float tot = reduce_scatter16(part, lane);
         if (lane < 16) dQ[voff + lane] = tot;
@@ -549,15 +555,14 @@ extern "C" int elg_glimpse_rows_bwd(const float* rowA, const float* dO, const fl
                                     const float* Vmat, float* dS, float* dQ, int B, int R, int N1, void* stream) {
     if (B <= 0 || R <= 0 || N1 <= 1) return fail(ELG_EINVAL, "glimpse_rows_bwd: bad sizes");
     const int nch = (N1 + 63) / 64;
-    const int rpb = 128;
+    const int rpb = 256;
     dim3 grid((R + rpb - 1) / rpb, B * 8);
-    const size_t lds = (size_t)2 * 16 * 64 * nch * 4;
+    const size_t lds = 0;
     (void)hipGetLastError();
     if (nch == 1) hipLaunchKernelGGL(glimpse_rows_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, rowA, dO, rowO, Kmat, Vmat, dS, dQ, R, N1, rpb);
     else if (nch == 2) hipLaunchKernelGGL(glimpse_rows_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, rowA, dO, rowO, Kmat, Vmat, dS, dQ, R, N1, rpb);
     else if (nch <= 4) hipLaunchKernelGGL(glimpse_rows_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, rowA, dO, rowO, Kmat, Vmat, dS, dQ, R, N1, rpb);
-    else if (nch <= 8) hipLaunchKernelGGL(glimpse_rows_kernel<8>, grid, dim3(256), lds, (hipStream_t)stream, rowA, dO, rowO, Kmat, Vmat, dS, dQ, R, N1, rpb);
-    else return fail(ELG_ENOTIMPL, "glimpse_rows_bwd: N1 > 512 not built");
+    else return fail(ELG_ENOTIMPL, "glimpse_rows_bwd: N1 > 256 not built");
     return launch_status("glimpse_rows_bwd");
 }
 
