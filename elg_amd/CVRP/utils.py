@@ -25,7 +25,9 @@ def rollout(model, env, eval_type='greedy'):
     starts = torch.tensor(model.draw_starts(N, M), dtype=torch.int32)
     mode = L.MODE_SAMPLE if eval_type == 'sample' else L.MODE_GREEDY
     seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if mode == L.MODE_SAMPLE else 0
-    res = eng.rollout_forward(env.problem, pol, M, starts, mode, seed=seed)
+    needs_grad = (eval_type != 'greedy' and torch.is_grad_enabled()
+                  and any(p.requires_grad for p in model.parameters()))
+    res = eng.rollout_forward(env.problem, pol, M, starts, mode, seed=seed, train=needs_grad)
     T = int(res.tlen.max().item())                  # the one host sync of the rollout
     actions = res.actions[:, :, :T].long()
     env.selected_count = T
@@ -34,7 +36,6 @@ def rollout(model, env, eval_type='greedy'):
     reward = env.compute_unscaled_reward() if env.vrplib else res.reward
     if eval_type == 'greedy':
         return actions, None, reward
-    needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
     probs = eng.chosen_probs(env.problem, pol, M, res, T) if needs_grad else res.probs[:, :T, :]
     # reference CVRPModel.py:67-68: a step in which some chosen probability is exactly 0 gets +1e-6
     zero_step = (probs.detach() == 0).flatten(2).any(dim=2).any(dim=0)

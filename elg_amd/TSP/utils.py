@@ -20,7 +20,9 @@ def rollout(model, env, eval_type='greedy'):
     starts = torch.tensor(model.draw_starts(N, M), dtype=torch.int32)
     mode = L.MODE_SAMPLE if eval_type == 'sample' else L.MODE_GREEDY
     seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if mode == L.MODE_SAMPLE else 0
-    res = eng.rollout_forward(env.problem, pol, M, starts, mode, seed=seed)
+    needs_grad = (eval_type != 'greedy' and torch.is_grad_enabled()
+                  and any(p.requires_grad for p in model.parameters()))
+    res = eng.rollout_forward(env.problem, pol, M, starts, mode, seed=seed, train=needs_grad)
     actions = res.actions[:, :, :N].long()
     env.selected_count = N
     env.selected_node_list = actions
@@ -28,7 +30,6 @@ def rollout(model, env, eval_type='greedy'):
     reward = env.compute_unscaled_distance() if env.tsplib else res.reward
     if eval_type == 'greedy':
         return actions, None, reward
-    needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
     probs = eng.chosen_probs(env.problem, pol, M, res, N) if needs_grad else res.probs[:, :N, :]
     return actions, probs, reward
 

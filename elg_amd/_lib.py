@@ -34,6 +34,7 @@ class RolloutArgs(C.Structure):
         ("st_cur", _vp), ("st_cnt", _vp), ("st_fin", _vp), ("st_first", _vp), ("st_load", _vp), ("st_len", _vp),
         ("st_vis", _vp),
         ("actions", _vp), ("probs", _vp), ("reward", _vp), ("tlen", _vp), ("full_probs", _vp),
+        ("trA", _vp), ("trPC", _vp), ("trCsel", _vp), ("trQ", _vp), ("trO", _vp), ("trLoad", _vp), ("trSlot", _vp),
     ]
 
 
@@ -41,7 +42,8 @@ class BwdArgs(C.Structure):
     _fields_ = [
         ("fwd", RolloutArgs), ("T", C.c_int32), ("pad1", C.c_int32),
         ("gprob", _vp), ("rowA", _vp), ("rowDL", _vp), ("rowQ", _vp), ("rowO", _vp), ("rowLoad", _vp),
-        ("rowDU", _vp), ("gloc", _vp),
+        ("rowDU", _vp), ("gloc", _vp), ("time_major", C.c_int32), ("local_only", C.c_int32),
+        ("row_stride", C.c_int64),
     ]
 
 
@@ -74,7 +76,7 @@ def lib() -> C.CDLL:
         L.elg_route_length.argtypes = [f, f, f, i, i, i, i, i, f]
         L.elg_rollout_fwd.argtypes = [C.POINTER(RolloutArgs), f]
         L.elg_rollout_bwd.argtypes = [C.POINTER(BwdArgs), f]
-        L.elg_glimpse_rows_bwd.argtypes = [f, f, f, f, f, f, f, i, i, i, f]
+        L.elg_glimpse_rows_bwd.argtypes = [f, f, f, f, f, f, f, i, i, i, C.c_int64, C.c_int64, f]
         for n in ("elg_aug8", "elg_dist_matrix", "elg_nbr_tables", "elg_route_length", "elg_rollout_fwd",
                   "elg_rollout_bwd", "elg_glimpse_rows_bwd"):
             getattr(L, n).restype = C.c_int

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(WAVES * 64) void local_bwd_kernel(const elg_bwd_arg
     float* sb = p + wave * SbSize<NCH>::value;
     for (int i = threadIdx.x; i < ELG_LOC_SIZE; i += WAVES * 64) acc[i] = 0.f;
     __syncthreads();
-    const size_t b = bi, R = (size_t)A.M * T;
+    const size_t b = bi, R = BA.row_stride > 0 ? (size_t)BA.row_stride : (size_t)A.M * T;
     LocAcc LA;
 #pragma unroll
     for (int d = 0; d < 32; ++d) { LA.lpe[d] = 0.f; LA.lcv[d] = 0.f; LA.lwc[d] = 0.f; }
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(WAVES * 64) void local_bwd_kernel(const elg_bwd_arg
 #pragma unroll
         for (int c = 0; c < NCH; ++c) st.vis[c] = 0ull;
         for (int t = 0; t < T; ++t) {
-            const size_t r = (size_t)m * T + t;
+            const size_t r = BA.time_major ? (size_t)t * A.M + m : (size_t)m * T + t;
             const int sel = __builtin_amdgcn_readfirstlane(A.forced[bm * A.Tforced + t]);
             const bool first_move = (!TSP && t <= 1) || (TSP && t == 0);
             if (!st.fin && !first_move) {
@@ -428,7 +428,8 @@ template <int NCH>
 __global__ __launch_bounds__(256) void glimpse_rows_kernel(const float* __restrict__ rowA, const float* __restrict__ dO,
                                                            const float* __restrict__ rowO, const float* __restrict__ Kmat,
                                                            const float* __restrict__ Vmat, float* __restrict__ dS,
-                                                           float* __restrict__ dQ, int R, int N1, int rows_per_block) {
+                                                           float* __restrict__ dQ, int R, int N1, int rows_per_block,
+                                                           size_t rowA_rows, size_t rowO_rows) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int bh = blockIdx.y, b = bh >> 3, h = bh & 7;
     // every lane owns the same nodes n = lane + 64 c for all rows: keep their K_h / V_h rows in registers
@@ -451,14 +452,16 @@ __global__ __launch_bounds__(256) void glimpse_rows_kernel(const float* __restri
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(R, r0 + rows_per_block);
     for (int r = r0 + wave; r < r1; r += 4) {
-        const size_t rowoff = ((size_t)bh * R + r) * N1;
-        const size_t voff = ((size_t)b * R + r) * ELG_E + h * 16;
+        const size_t rowoff = ((size_t)bh * R + r) * N1;                 // dS (dense, R rows)
+        const size_t aoff = ((size_t)bh * rowA_rows + r) * N1;           // rowA (rowA_rows rows per (b,h))
+        const size_t voff = ((size_t)b * R + r) * ELG_E + h * 16;       // dO, dQ
+        const size_t ooff = ((size_t)b * rowO_rows + r) * ELG_E + h * 16;
         float a[NCH];
         bool any = false;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int n = lane + 64 * c;
-            a[c] = (n < N1) ? rowA[rowoff + n] : 0.f;
+            a[c] = (n < N1) ? rowA[aoff + n] : 0.f;
             any = any || (a[c] != 0.f);
         }
         if (!__ballot(any)) {                      // inactive row (first moves / finished): all zero
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(256) void glimpse_rows_kernel(const float* __restri
         }
         // dO_h, O_h of the row: 16 values each, loaded by lanes 0..15 and broadcast through SGPRs
         const float dol = (lane < 16) ? dO[voff + lane] : 0.f;
-        const float ol = (lane < 16) ? rowO[voff + lane] : 0.f;
+        const float ol = (lane < 16) ? rowO[ooff + lane] : 0.f;
         float dov[16], doto = 0.f;
 #pragma unroll
         for (int d = 0; d < 16; ++d) {
@@ -513,9 +516,11 @@ static int launch_bwd(const elg_bwd_args& BA, hipStream_t stream) {
             return fail(ELG_ELAUNCH, "hipFuncSetAttribute failed");
         attr_done = true;
     }
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(kern, dim3(A.B * A.tiles), dim3(WAVES * 64), lds, stream, BA);
-    if (launch_status("rollout_bwd") != ELG_OK) return ELG_ELAUNCH;
+    if (!BA.local_only) {
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(kern, dim3(A.B * A.tiles), dim3(WAVES * 64), lds, stream, BA);
+        if (launch_status("rollout_bwd") != ELG_OK) return ELG_ELAUNCH;
+    }
     if (A.has_local) {
         constexpr int LW = 8;
         size_t l2 = (size_t)((A.N1 + 3) & ~3) * 4 + 16 + (size_t)ELG_LOC_SIZE * 4 + (size_t)LW * SbSize<NCH>::value * 4;
@@ -552,16 +557,18 @@ static int dispatch_bwd(const elg_bwd_args& BA, hipStream_t stream) {
 using namespace elg;
 
 extern "C" int elg_glimpse_rows_bwd(const float* rowA, const float* dO, const float* rowO, const float* Kmat,
-                                    const float* Vmat, float* dS, float* dQ, int B, int R, int N1, void* stream) {
+                                    const float* Vmat, float* dS, float* dQ, int B, int R, int N1,
+                                    int64_t rowA_rows, int64_t rowO_rows, void* stream) {
+    if (rowA_rows < R || rowO_rows < R) return fail(ELG_EINVAL, "glimpse_rows_bwd: row strides smaller than R");
     if (B <= 0 || R <= 0 || N1 <= 1) return fail(ELG_EINVAL, "glimpse_rows_bwd: bad sizes");
     const int nch = (N1 + 63) / 64;
     const int rpb = 256;
     dim3 grid((R + rpb - 1) / rpb, B * 8);
     const size_t lds = 0;
     (void)hipGetLastError();
-    if (nch == 1) hipLaunchKernelGGL(glimpse_rows_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, rowA, dO, rowO, Kmat, Vmat, dS, dQ, R, N1, rpb);
-    else if (nch == 2) hipLaunchKernelGGL(glimpse_rows_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, rowA, dO, rowO, Kmat, Vmat, dS, dQ, R, N1, rpb);
-    else if (nch <= 4) hipLaunchKernelGGL(glimpse_rows_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, rowA, dO, rowO, Kmat, Vmat, dS, dQ, R, N1, rpb);
+    if (nch == 1) hipLaunchKernelGGL(glimpse_rows_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, rowA, dO, rowO, Kmat, Vmat, dS, dQ, R, N1, rpb, (size_t)rowA_rows, (size_t)rowO_rows);
+    else if (nch == 2) hipLaunchKernelGGL(glimpse_rows_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, rowA, dO, rowO, Kmat, Vmat, dS, dQ, R, N1, rpb, (size_t)rowA_rows, (size_t)rowO_rows);
+    else if (nch <= 4) hipLaunchKernelGGL(glimpse_rows_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, rowA, dO, rowO, Kmat, Vmat, dS, dQ, R, N1, rpb, (size_t)rowA_rows, (size_t)rowO_rows);
     else return fail(ELG_ENOTIMPL, "glimpse_rows_bwd: N1 > 256 not built");
     return launch_status("glimpse_rows_bwd");
 }
@@ -572,7 +579,7 @@ extern "C" int elg_rollout_bwd(const elg_bwd_args* a, void* stream) {
     const elg_rollout_args& A = BA.fwd;
     if (A.B <= 0 || A.M <= 0 || A.N1 <= 1 || A.tiles <= 0 || BA.T <= 0) return fail(ELG_EINVAL, "rollout_bwd: bad sizes");
     if (!A.forced || A.Tforced < BA.T) return fail(ELG_EINVAL, "rollout_bwd: recorded actions missing");
-    if (!BA.gprob || !BA.rowA || !BA.rowDL || !BA.rowQ || !BA.rowO)
+    if (!BA.local_only && (!BA.gprob || !BA.rowA || !BA.rowDL || !BA.rowQ || !BA.rowO))
         return fail(ELG_EINVAL, "rollout_bwd: missing row buffers");
     if (A.has_local && (!A.loc || !BA.rowDU || !BA.gloc)) return fail(ELG_EINVAL, "rollout_bwd: local buffers missing");
     if (A.K + 1 > ELG_SLOT_STRIDE) return fail(ELG_EINVAL, "rollout_bwd: local_size must be <= 47");

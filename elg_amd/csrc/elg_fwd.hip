@@ -115,10 +115,10 @@ struct FwdOut {
 };
 
 // One decode step for the trajectory held by this wave.  Returns the chosen node and its probability.
-template <int NCH, bool TSP, bool LDSK>
+template <int NCH, bool TSP, bool LDSK, bool TRAIN>
 __device__ __forceinline__ FwdOut decode_step(const elg_rollout_args& A, const Inst& I, const Traj<NCH>& st,
                                               int lane, float* sb, int forced_sel, float uni,
-                                              float* full_row /* (N1) or null */) {
+                                              float* full_row /* (N1) or null */, size_t b, size_t r, size_t Rcap) {
     const int N1 = A.N1;
     unsigned long long mk[NCH];
     build_mask<NCH, TSP>(st, I, N1, lane, mk);
@@ -145,9 +145,26 @@ __device__ __forceinline__ FwdOut decode_step(const elg_rollout_args& A, const I
         if (A.has_local) u = local_policy<TSP>(I.loc, lane, S.f0, S.f1, S.f2, S.smask, nullptr);
         addval = S.pen + u * A.inv_ens;
     }
+    if (TRAIN && A.trSlot && lane < ELG_SLOT_STRIDE) A.trSlot[(b * Rcap + r) * ELG_SLOT_STRIDE + lane] = snid;
 
     // ---- glimpse + pointer
-    const float4 o4 = glimpse<NCH, LDSK>(I, N1, lane, q4, mk, nullptr);
+    GlimpseSave<8 * NCH> gs;
+    const float4 o4 = glimpse<NCH, LDSK>(I, N1, lane, q4, mk, TRAIN ? &gs : nullptr);
+    if (TRAIN) {
+        const int half = lane >> 5, hq = lane & 31, rr = 2 * (lane & 3) + half;
+        float* rA = A.trA + ((b * ELG_H + (hq >> 2)) * Rcap + r) * N1;
+#pragma unroll
+        for (int k = 0; k < 8 * NCH; ++k) {
+            const int row = 8 * k + rr;
+            if (8 * k < N1 && row < N1) rA[row] = gs.e[k];
+        }
+        if (lane < 32) {
+            const size_t off = (b * Rcap + r) * ELG_E + cb;
+            *reinterpret_cast<float4*>(A.trQ + off) = q4;
+            *reinterpret_cast<float4*>(A.trO + off) = o4;
+        }
+        if (lane == 0 && A.trLoad) A.trLoad[b * Rcap + r] = st.load;
+    }
     float s[NCH];
     pointer_scores<NCH, LDSK>(I, N1, lane, o4, sb, s);
 
@@ -163,14 +180,15 @@ __device__ __forceinline__ FwdOut decode_step(const elg_rollout_args& A, const I
     wave_lds_fence();
 
     // ---- clip, mask, softmax (node layout)   models.py:416-420
-    float lg[NCH];
+    float lg[NCH], th[NCH];
     float mx = ELG_NEG_INF;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         const int n = lane + 64 * ch;
         const bool masked = (mk[ch] >> lane) & 1ull;
         float x = ELG_NEG_INF;
-        if (n < N1 && !masked) x = A.clip * tanhf(s[ch] + sb[n]);
+        th[ch] = 0.f;
+        if (n < N1 && !masked) { th[ch] = tanhf(s[ch] + sb[n]); x = A.clip * th[ch]; }
         lg[ch] = x;
         mx = fmaxf(mx, x);
     }
@@ -240,13 +258,24 @@ __device__ __forceinline__ FwdOut decode_step(const elg_rollout_args& A, const I
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch)
         if ((sel >> 6) == ch) ps = readlane(e[ch], sel & 63) * inv;
+    if (TRAIN) {
+        // p[n] clip (1 - tanh^2): everything the backward needs of the clip / softmax Jacobian
+        float* rPC = A.trPC + (b * Rcap + r) * N1;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int n = lane + 64 * ch;
+            const float cj = A.clip * (1.f - th[ch] * th[ch]);
+            if (n < N1) rPC[n] = e[ch] * inv * cj;
+            if (n == sel) A.trCsel[b * Rcap + r] = cj;
+        }
+    }
     FwdOut o;
     o.sel = sel;
     o.p = ps;
     return o;
 }
 
-template <int NCH, bool TSP, bool LDSK, int WAVES>
+template <int NCH, bool TSP, bool LDSK, int WAVES, bool TRAIN>
 __global__ __launch_bounds__(WAVES * 64) void rollout_fwd_kernel(const elg_rollout_args A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -351,7 +380,8 @@ __global__ __launch_bounds__(WAVES * 64) void rollout_fwd_kernel(const elg_rollo
                 if (A.mode == ELG_MODE_SAMPLE)
                     uni = A.uniforms ? A.uniforms[bm * A.Tmax + t] : philox_uniform(A.seed, (unsigned)bm, (unsigned)t);
                 float* frow = (A.full_probs && t < A.dump_T) ? A.full_probs + (bm * A.dump_T + t) * N1 : nullptr;
-                const FwdOut o = decode_step<NCH, TSP, LDSK>(A, I, st, lane, sb, fsel, uni, frow);
+                const FwdOut o = decode_step<NCH, TSP, LDSK, TRAIN>(A, I, st, lane, sb, fsel, uni, frow, (size_t)b,
+                                                                    (size_t)t * A.M + m, (size_t)A.Tmax * A.M);
                 sel = __builtin_amdgcn_readfirstlane(o.sel);
                 pr = i2f(__builtin_amdgcn_readfirstlane(f2i(o.p)));
             }
@@ -379,13 +409,13 @@ __global__ __launch_bounds__(WAVES * 64) void rollout_fwd_kernel(const elg_rollo
     }
 }
 
-template <int NCH, bool TSP, bool LDSK, int WAVES>
+template <int NCH, bool TSP, bool LDSK, int WAVES, bool TRAIN = false>
 static int launch_fwd(const elg_rollout_args& A, hipStream_t stream) {
     size_t lds = 0;
     if (LDSK) lds += (size_t)3 * A.N1 * ELG_E * 4;
     lds += (size_t)((A.N1 + 3) & ~3) * 4 + 16 + (size_t)WAVES * SbSize<NCH>::value * 4;
     if (lds > 163840) return fail(ELG_EINVAL, "rollout: LDS budget exceeded");
-    auto kern = rollout_fwd_kernel<NCH, TSP, LDSK, WAVES>;
+    auto kern = rollout_fwd_kernel<NCH, TSP, LDSK, WAVES, TRAIN>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -405,8 +435,15 @@ static int dispatch_fwd(const elg_rollout_args& A, hipStream_t stream) {
     const int nch = (A.N1 + 63) / 64;
     const bool lds = A.lds_stage != 0;
     if (lds && A.N1 > 104) return fail(ELG_EINVAL, "lds_stage needs N1 <= 104");
-    if (A.waves != 8 && A.waves != 13) return fail(ELG_EINVAL, "waves must be 8 or 13");
+    if (A.waves != 8 && A.waves != 13 && !A.trA) return fail(ELG_EINVAL, "waves must be 8 or 13");
 #define ELG_GO(NCHV, L, W) return launch_fwd<NCHV, TSP, L, W>(A, stream)
+    if (A.trA) {        // training forward: saves the backward rows; built for N1 <= 128, 8 waves
+        if (!A.trPC || !A.trCsel || !A.trQ || !A.trO) return fail(ELG_EINVAL, "rollout: incomplete training rows");
+        if (A.use_state) return fail(ELG_EINVAL, "rollout: training rows need the fused rollout");
+        if (nch == 1) { if (lds) return launch_fwd<1, TSP, true, 8, true>(A, stream); return launch_fwd<1, TSP, false, 8, true>(A, stream); }
+        if (nch == 2) { if (lds) return launch_fwd<2, TSP, true, 8, true>(A, stream); return launch_fwd<2, TSP, false, 8, true>(A, stream); }
+        return fail(ELG_ENOTIMPL, "rollout: training rows for N1 > 128 not built");
+    }
     if (nch == 1) { if (lds) { if (A.waves == 8) ELG_GO(1, true, 8); else ELG_GO(1, true, 13); }
                     else { if (A.waves == 8) ELG_GO(1, false, 8); else ELG_GO(1, false, 13); } }
     if (nch == 2) { if (lds) { if (A.waves == 8) ELG_GO(2, true, 8); else ELG_GO(2, true, 13); }

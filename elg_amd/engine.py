@@ -231,6 +231,45 @@ def _fill_common(a: L.RolloutArgs, prob: Problem, pol: Policy, M: int, geometry=
     a.loc = _ptr(pol.loc)
 
 
+class TrainRows:
+    """Workspace for the rows a training forward saves (time-major, Rcap = Tcap*M rows per instance).
+    Cached per shape and reused every step; `gen` detects reuse before the matching backward ran."""
+    _cache: Dict[tuple, "TrainRows"] = {}
+
+    def __init__(self, B, M, N1, Tcap, dev):
+        Rcap = Tcap * M
+        self.B, self.M, self.N1, self.Tcap, self.Rcap = B, M, N1, Tcap, Rcap
+        self.A = torch.empty(B, H, Rcap, N1, device=dev)
+        self.PC = torch.empty(B, Rcap, N1, device=dev)
+        self.Csel = torch.empty(B, Rcap, device=dev)
+        self.Q = torch.empty(B, Rcap, E, device=dev)
+        self.O = torch.empty(B, Rcap, E, device=dev)
+        self.Load = torch.empty(B, Rcap, device=dev)
+        self.Slot = torch.empty(B, Rcap, 48, device=dev, dtype=torch.int32)
+        self.gen = 0
+        self.Tz = Tcap            # rows [0, Tz*M) are zero-filled before a launch
+        self.T_hint = None
+
+    @classmethod
+    def get(cls, B, M, N1, Tcap, dev):
+        key = (B, M, N1, Tcap, str(dev))
+        ws = cls._cache.get(key)
+        if ws is None:
+            ws = cls._cache[key] = TrainRows(B, M, N1, Tcap, dev)
+        return ws
+
+    def prepare(self):
+        """Zero-fill the prefix the kernel may leave untouched (first moves, finished trajectories).  The
+        prefix follows the recent maximum tour length (+20 %); a longer rollout falls back to the replay."""
+        self.gen += 1
+        self.Tz = self.Tcap if self.T_hint is None else min(self.Tcap, int(1.2 * self.T_hint) + 8)
+        n = self.Tz * self.M
+        self.A[:, :, :n].zero_()
+        for t in (self.PC, self.Csel, self.Q, self.O, self.Load):
+            t[:, :n].zero_()
+        self.Slot[:, :n].fill_(-1)
+
+
 @dataclass
 class RolloutResult:
     actions: torch.Tensor           # (B,M,Tcap) int32 (slice [:, :, :T])
@@ -238,10 +277,12 @@ class RolloutResult:
     reward: torch.Tensor            # (B,M) f32 = -length on the scaled coordinates
     tlen: torch.Tensor              # (B,M) int32
     full_probs: Optional[torch.Tensor] = None
+    rows: Optional["TrainRows"] = None      # backward rows saved by a training forward
 
 
 def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mode: int, *, forced=None, seed: int = 0,
-                    uniforms=None, dump_T: int = 0, geometry=None, Tcap: Optional[int] = None) -> RolloutResult:
+                    uniforms=None, dump_T: int = 0, geometry=None, Tcap: Optional[int] = None,
+                    train: bool = False) -> RolloutResult:
     """Run every trajectory to completion in one persistent launch (reference CVRP/utils.py:7-29)."""
     dev = prob.xy.device
     B, N1 = prob.B, prob.N1
@@ -266,8 +307,19 @@ def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mo
         a.uniforms = _ptr(uniforms)
     a.actions, a.probs, a.reward, a.tlen = _ptr(actions), _ptr(probs), _ptr(reward), _ptr(tlen)
     a.full_probs, a.dump_T = _ptr(full), dump_T
+    rows = None
+    if train and N1 <= 128:
+        rows = TrainRows.get(B, M, N1, Tcap, dev)
+        rows.prepare()
+        a.trA, a.trPC, a.trCsel, a.trQ, a.trO = _ptr(rows.A), _ptr(rows.PC), _ptr(rows.Csel), _ptr(rows.Q), _ptr(rows.O)
+        a.trLoad, a.trSlot = _ptr(rows.Load), _ptr(rows.Slot)
+        a.waves = 8
     L.check(L.lib().elg_rollout_fwd(C.byref(a), _stream()), "elg_rollout_fwd")
-    return RolloutResult(actions, probs, reward, tlen, full)
+    res = RolloutResult(actions, probs, reward, tlen, full)
+    if rows is not None:
+        res.rows = rows
+        res.rows_gen = rows.gen
+    return res
 
 
 # ----------------------------------------------------------------------------------------------
@@ -278,8 +330,10 @@ class _ChosenProbs(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, prob: Problem, pol_meta: Policy, M, actions, probs_val, T, geometry,
-                Kt, Vt, PKt, pbt, Q1t, Q2t, wlt, loct):
+                Kt, Vt, PKt, pbt, Q1t, Q2t, wlt, loct, rows=None, rows_gen=-1):
         ctx.prob, ctx.pol_meta, ctx.M, ctx.T, ctx.geometry = prob, pol_meta, M, T, geometry
+        ctx.rows, ctx.rows_gen = rows, rows_gen
+        ctx.probs_val = probs_val
         ctx.save_for_backward(actions, Kt, Vt, PKt, pbt, Q1t, Q2t if Q2t is not None else Kt.new_empty(0),
                               wlt if wlt is not None else Kt.new_empty(0), loct if loct is not None else Kt.new_empty(0))
         ctx.has = (Q2t is not None, wlt is not None, loct is not None)
@@ -296,53 +350,82 @@ class _ChosenProbs(torch.autograd.Function):
         tables = dict(K=Kt, V=Vt, PK=PKt, pb=pbt, Q1=Q1t, Q2=Q2t if hasQ2 else None, wl=wlt if haswl else None)
         pol = Policy(tables, loct if hasloc else None, meta.K, meta.xi, meta.clip, meta.inv_ens, meta.has_local,
                      meta.has_penalty)
+        forced = actions[:, :, :T].contiguous()
+        fl = forced.long()
+        g = gprob[:, :T, :].contiguous().float()
+        rows = ctx.rows
+        use_saved = rows is not None and rows.gen == ctx.rows_gen and T <= rows.Tz
         ba = L.BwdArgs()
         _fill_common(ba.fwd, prob, pol, M, ctx.geometry)
-        forced = actions[:, :, :T].contiguous()
         ba.fwd.Tmax, ba.fwd.mode, ba.fwd.max_steps, ba.fwd.do_decode, ba.fwd.do_update = T, L.MODE_FORCED, 0, 1, 1
         ba.fwd.forced, ba.fwd.Tforced = _ptr(forced), T
         ba.T = T
-        g = gprob[:, :T, :].contiguous().float()
-        rowA = torch.empty(B, H, R, N1, device=dev)
-        rowDL = torch.empty(B, R, N1, device=dev)
-        rowQ = torch.empty(B, R, E, device=dev)
-        rowO = torch.empty(B, R, E, device=dev)
-        rowLoad = torch.empty(B, R, device=dev) if haswl else None
-        rowDU = torch.empty(B, R, 48, device=dev) if meta.has_local else None
         gloc = torch.zeros(L.LOC_SIZE, device=dev)
-        ba.gprob = _ptr(g)
-        ba.rowA, ba.rowDL, ba.rowQ, ba.rowO = _ptr(rowA), _ptr(rowDL), _ptr(rowQ), _ptr(rowO)
-        ba.rowLoad, ba.rowDU, ba.gloc = _ptr(rowLoad), _ptr(rowDU), _ptr(gloc)
-        L.check(L.lib().elg_rollout_bwd(C.byref(ba), _stream()), "elg_rollout_bwd")
-        # ---- dense part: glimpse / pointer backward over the R = M*T decode rows of every instance
-        # (batched GEMMs on the matrix cores; formulas in include/elg_hip.h)
+        ba.gloc = _ptr(gloc)
+        if use_saved:
+            # rows saved by the training forward (time-major r = t*M + m): no glimpse replay needed
+            rowA, rowO_rows = rows.A, rows.Rcap
+            rowO, rowQ = rows.O, rows.Q[:, :R]
+            W = (g * ctx.probs_val[:, :T, :]).reshape(B, R)                               # gp * p_sel per row
+            sel_tm = fl.permute(0, 2, 1).reshape(B, R)
+            rowDL = rows.PC[:, :R] * (-W)[:, :, None]                                       # -p c W
+            rowDL.scatter_add_(2, sel_tm[:, :, None], (W * rows.Csel[:, :R])[:, :, None])   # + c_sel W at the chosen node
+            rowLoad = rows.Load[:, :R] if haswl else None
+            prev = torch.cat([torch.zeros(B, 1, M, dtype=torch.long, device=dev), fl.permute(0, 2, 1)[:, :-1]], dim=1).reshape(B, R)
+            first = fl[:, :, 0][:, None, :].expand(B, T, M).reshape(B, R) if hasQ2 else None
+            if meta.has_local:
+                slot = rows.Slot[:, :R].long()
+                rowDU = (torch.gather(rowDL, 2, slot.clamp(min=0)) * (slot >= 0) * meta.inv_ens).contiguous()
+                ba.rowDU, ba.time_major, ba.local_only, ba.row_stride = _ptr(rowDU), 1, 1, R
+                L.check(L.lib().elg_rollout_bwd(C.byref(ba), _stream()), "elg_rollout_bwd(local)")
+            rowA_rows = rows.Rcap
+            rowA_v = rows.A[:, :, :R]
+            rowO_v = rows.O[:, :R]
+        else:
+            rowA = torch.empty(B, H, R, N1, device=dev)
+            rowDL = torch.empty(B, R, N1, device=dev)
+            rowQ = torch.empty(B, R, E, device=dev)
+            rowO = torch.empty(B, R, E, device=dev)
+            rowLoad = torch.empty(B, R, device=dev) if haswl else None
+            rowDU = torch.empty(B, R, 48, device=dev) if meta.has_local else None
+            ba.gprob = _ptr(g)
+            ba.rowA, ba.rowDL, ba.rowQ, ba.rowO = _ptr(rowA), _ptr(rowDL), _ptr(rowQ), _ptr(rowO)
+            ba.rowLoad, ba.rowDU = _ptr(rowLoad), _ptr(rowDU)
+            L.check(L.lib().elg_rollout_bwd(C.byref(ba), _stream()), "elg_rollout_bwd")
+            rowA_rows = rowO_rows = R
+            rowA_v, rowO_v = rowA, rowO
+            # the query of decode step t was gathered at cur = action[t-1] (and first = action[0] for TSP)
+            prev = torch.cat([torch.zeros(B, M, 1, dtype=torch.long, device=dev), fl[:, :, :-1]], dim=2).reshape(B, R)
+            first = fl[:, :, :1].expand(B, M, T).reshape(B, R) if hasQ2 else None
+        # ---- dense part: glimpse / pointer backward over the R decode rows of every instance
+        # (batched GEMMs on the matrix cores + one fused row kernel; formulas in include/elg_hip.h)
         def heads(x):                                               # (B,X,128) -> (B,H,X,16)
             return x.view(B, x.shape[1], H, DK).permute(0, 2, 1, 3)
         dO = torch.bmm(rowDL, PKt)                                  # (B,R,128)   d o = d s . PK
-        dS = torch.empty_like(rowA)                                 # (B,H,R,N1)  d(q.K)
+        dS = torch.empty(B, H, R, N1, device=dev)                   # d(q.K)
         dQ = torch.empty(B, R, E, device=dev)
         L.check(L.lib().elg_glimpse_rows_bwd(_ptr(rowA), _ptr(dO), _ptr(rowO), _ptr(Kt), _ptr(Vt), _ptr(dS), _ptr(dQ),
-                                             B, R, N1, _stream()), "elg_glimpse_rows_bwd")
+                                             B, R, N1, rowA_rows, rowO_rows, _stream()), "elg_glimpse_rows_bwd")
         dK = torch.matmul(dS.transpose(2, 3), heads(rowQ)).permute(0, 2, 1, 3).reshape(B, N1, E)
-        dV = torch.matmul(rowA.transpose(2, 3), heads(dO)).permute(0, 2, 1, 3).reshape(B, N1, E)
-        dPK = torch.bmm(rowDL.transpose(1, 2), rowO)
+        dV = torch.matmul(rowA_v.transpose(2, 3), heads(dO)).permute(0, 2, 1, 3).reshape(B, N1, E)
+        dPK = torch.bmm(rowDL.transpose(1, 2), rowO_v)
         dpb = rowDL.sum(dim=1)
-        # the query of decode step t was gathered at cur = action[t-1] (and first = action[0] for TSP)
-        fl = forced.long()
-        prev = torch.cat([torch.zeros(B, M, 1, dtype=torch.long, device=dev), fl[:, :, :-1]], dim=2).reshape(B, R)
         dQ1 = torch.zeros(B, N1, E, device=dev).scatter_add_(1, prev[:, :, None].expand(B, R, E), dQ)
         dQ2 = dwl = None
         if hasQ2:
-            first = fl[:, :, :1].expand(B, M, T).reshape(B, R)
             dQ2 = torch.zeros(B, N1, E, device=dev).scatter_add_(1, first[:, :, None].expand(B, R, E), dQ)
         if haswl:
             dwl = torch.einsum("br,bre->e", rowLoad, dQ)
         return (None, None, None, None, None, None, None,
-                dK, dV, dPK, dpb, dQ1, dQ2, dwl, gloc if hasloc else None)
+                dK, dV, dPK, dpb, dQ1, dQ2, dwl, gloc if hasloc else None, None, None)
 
 
 def chosen_probs(prob: Problem, pol: Policy, M: int, res: RolloutResult, T: int, geometry=None) -> torch.Tensor:
     """Differentiable view of res.probs[:, :T, :] (gradients flow to pol.tables / pol.loc)."""
     t = pol.tables
+    rows = getattr(res, "rows", None)
+    if rows is not None:
+        rows.T_hint = T if rows.T_hint is None else max(T, int(0.9 * rows.T_hint))
     return _ChosenProbs.apply(prob, pol, M, res.actions, res.probs[:, :T, :], T, geometry,
-                              t["K"], t["V"], t["PK"], t["pb"], t["Q1"], t.get("Q2"), t.get("wl"), pol.loc)
+                              t["K"], t["V"], t["PK"], t["pb"], t["Q1"], t.get("Q2"), t.get("wl"), pol.loc,
+                              rows, getattr(res, "rows_gen", -1))

@@ -114,6 +114,16 @@ typedef struct elg_rollout_args {
     float* reward;          /* (B,M) out, -tour length on `xy`                                  */
     int32_t* tlen;          /* (B,M) out, number of steps taken                                 */
     float* full_probs;      /* (B,M,dump_T,N1) out or NULL: whole probability rows (tests)      */
+    /* training rows (all NULL for inference): saved per decode step so that the backward needs no
+     * replay of the glimpse.  Row index r = t*M + m (time-major), Rcap = Tmax*M rows per instance;
+     * rows of steps that are not decoded are left untouched (caller zero-fills). */
+    float* trA;             /* (B,8,Rcap,N1)  glimpse attention weights a_h[n]                  */
+    float* trPC;            /* (B,Rcap,N1)    p[n] * clip * (1 - tanh^2)  (softmax x clip Jacobian) */
+    float* trCsel;          /* (B,Rcap)       clip * (1 - tanh^2) at the chosen node            */
+    float* trQ;             /* (B,Rcap,128)   glimpse query                                     */
+    float* trO;             /* (B,Rcap,128)   glimpse output                                    */
+    float* trLoad;          /* (B,Rcap)       load at the step (CVRP)                           */
+    int32_t* trSlot;        /* (B,Rcap,48)    node of every k-NN slot (-1: none)                */
 } elg_rollout_args;
 
 /* POMO construction: CVRPEnv.reset/step + CVRPModel.one_step_rollout + utils.rollout fused into one
@@ -146,6 +156,9 @@ typedef struct elg_bwd_args {
     float* rowLoad;         /* (B,R)       load at the step (CVRP), may be NULL                     */
     float* rowDU;           /* (B,R,48)    d u_slot (already includes 1/ensemble_size)              */
     float* gloc;            /* (ELG_LOC_SIZE) accumulated d loc, caller zeroes                      */
+    int32_t time_major;     /* 0: r = m*T + t (replay rows); 1: r = t*M + m (rows saved by the forward) */
+    int32_t local_only;     /* 1: skip launch 1 (rows came from the forward), run the local replay only */
+    int64_t row_stride;     /* rows per instance in rowDU (R, or Rcap for forward-saved rows)        */
 } elg_bwd_args;
 int elg_rollout_bwd(const elg_bwd_args* args, void* stream);
 
@@ -153,7 +166,9 @@ int elg_rollout_bwd(const elg_bwd_args* args, void* stream);
  * per decode row r and head h:  dS = a (dO_h V_h^T - <dO_h, O_h>) / 4,  dQ_h = dS K_h.
  * rowA, dS (B,8,R,N1); dO, rowO, dQ (B,R,128); Kmat, Vmat (B,N1,128).  dS may alias nothing else. */
 int elg_glimpse_rows_bwd(const float* rowA, const float* dO, const float* rowO, const float* Kmat,
-                         const float* Vmat, float* dS, float* dQ, int B, int R, int N1, void* stream);
+                         const float* Vmat, float* dS, float* dQ, int B, int R, int N1,
+                         int64_t rowA_rows, int64_t rowO_rows, void* stream);
+/* rowA_rows / rowO_rows: rows per (instance[, head]) in the rowA / rowO buffers (>= R; R for dense buffers). */
 
 #ifdef __cplusplus
 }

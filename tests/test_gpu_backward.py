@@ -31,7 +31,7 @@ def _grad_check(got: dict, ref: dict, rtol=2e-3):
     return worst
 
 
-def _run(problem, tag, loss_kind, geometry=None):
+def _run(problem, tag, loss_kind, geometry=None, train=False):
     gc, L, eng = _imports()
     if problem == "cvrp":
         fx, cfg, P, xy, dem, B, N, M = gc.cvrp_fixture(tag)
@@ -77,7 +77,8 @@ def _run(problem, tag, loss_kind, geometry=None):
     pol = eng.Policy(tables, loc, cfg.local_size, cfg.xi, cfg.logit_clipping, 1.0 / cfg.ensemble_size, True, True)
     prob = gc.make_problem(xy, dem, kind)
     starts = acts[0, :, 1] if problem == "cvrp" else acts[0, :, 0]
-    res = eng.rollout_forward(prob, pol, M, starts, L.MODE_FORCED, forced=acts, geometry=geometry)
+    res = eng.rollout_forward(prob, pol, M, starts, L.MODE_FORCED, forced=acts, geometry=geometry, train=train)
+    assert (res.rows is not None) == train
     pr = eng.chosen_probs(prob, pol, M, res, T, geometry=geometry)
     np.testing.assert_allclose(pr.detach().cpu().numpy(), out["probs"].detach().numpy(), rtol=5e-4)
     Jg = loss_fn(pr)
@@ -93,18 +94,22 @@ def _run(problem, tag, loss_kind, geometry=None):
 
 @pytest.mark.parametrize("tag", ["n20", "n20k8", "n50"])
 @pytest.mark.parametrize("loss_kind", ["weighted", "pomo"])
-def test_cvrp_backward(tag, loss_kind):
-    _run("cvrp", tag, loss_kind)
+@pytest.mark.parametrize("train", [False, True], ids=["replay", "saved_rows"])
+def test_cvrp_backward(tag, loss_kind, train):
+    """replay: rows recomputed by rollout_bwd_kernel; saved_rows: rows written by the training forward."""
+    _run("cvrp", tag, loss_kind, train=train)
 
 
 def test_cvrp_backward_global_memory_variant():
     _run("cvrp", "n20", "weighted", geometry=(8, 2, 0))
 
 
-def test_cvrp_backward_n100():
-    _run("cvrp", "n100", "pomo")
+@pytest.mark.parametrize("train", [False, True], ids=["replay", "saved_rows"])
+def test_cvrp_backward_n100(train):
+    _run("cvrp", "n100", "pomo", train=train)
 
 
 @pytest.mark.parametrize("tag", ["n20", "n50"])
-def test_tsp_backward(tag):
-    _run("tsp", tag, "pomo")
+@pytest.mark.parametrize("train", [False, True], ids=["replay", "saved_rows"])
+def test_tsp_backward(tag, train):
+    _run("tsp", tag, "pomo", train=train)
