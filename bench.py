@@ -147,6 +147,11 @@ def main():
         mean_T = float(torch.stack([t.float().mean() for t in fwd_steps]).mean().item())
         max_T = float(torch.stack([t.float().max() for t in fwd_steps]).mean().item())
         bytes_launch = algorithmic_bytes_per_decode_step(LOCAL_BATCH, POMO, N_NODES + 1) * mean_T
+        traffic = None                       # measured HBM bytes per launch (PMC passes, see profiles/)
+        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
         achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "CVRP-100 train instances/sec", "value": round(LOCAL_BATCH * world * args.steps / dt, 2),
@@ -158,7 +163,8 @@ def main():
                        "parallelism": f"dp{world}"},
             "roofline": {"kernel": "rollout_fwd_kernel (persistent decode: all steps of all trajectories)",
                          "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(bytes_launch),
                          "launch_ms": round(kern_ms, 4), "decode_steps_mean": round(mean_T, 2),
                          "decode_steps_max": round(max_T, 2),
                          "algorithmic_MB_per_decode_step": round(algorithmic_bytes_per_decode_step(
