@@ -28,6 +28,16 @@ def _stream() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_SIDE = {}
+
+
+def _side_stream(dev) -> "torch.cuda.Stream":
+    key = str(dev)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
+
+
 def _need_cuda(t: torch.Tensor, what: str):
     if not t.is_cuda:
         raise RuntimeError(f"elg_amd: {what} must live on the GPU -- the HIP path has no CPU fallback")
@@ -355,6 +365,7 @@ class _ChosenProbs(torch.autograd.Function):
         g = gprob[:, :T, :].contiguous().float()
         rows = ctx.rows
         use_saved = rows is not None and rows.gen == ctx.rows_gen and T <= rows.Tz
+        join_side = None
         ba = L.BwdArgs()
         _fill_common(ba.fwd, prob, pol, M, ctx.geometry)
         ba.fwd.Tmax, ba.fwd.mode, ba.fwd.max_steps, ba.fwd.do_decode, ba.fwd.do_update = T, L.MODE_FORCED, 0, 1, 1
@@ -377,7 +388,13 @@ class _ChosenProbs(torch.autograd.Function):
                 slot = rows.Slot[:, :R].long()
                 rowDU = (torch.gather(rowDL, 2, slot.clamp(min=0)) * (slot >= 0) * meta.inv_ens).contiguous()
                 ba.rowDU, ba.time_major, ba.local_only, ba.row_stride = _ptr(rowDU), 1, 1, R
-                L.check(L.lib().elg_rollout_bwd(C.byref(ba), _stream()), "elg_rollout_bwd(local)")
+                # the local-policy replay is independent of the dense glimpse/pointer backward: run it on a
+                # side stream so its latency-bound waves overlap the bandwidth-bound GEMM / row kernels
+                side = _side_stream(dev)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    L.check(L.lib().elg_rollout_bwd(C.byref(ba), _stream()), "elg_rollout_bwd(local)")
+                join_side = side
             rowA_rows = rows.Rcap
             rowA_v = rows.A[:, :, :R]
             rowO_v = rows.O[:, :R]
@@ -416,6 +433,8 @@ class _ChosenProbs(torch.autograd.Function):
             dQ2 = torch.zeros(B, N1, E, device=dev).scatter_add_(1, first[:, :, None].expand(B, R, E), dQ)
         if haswl:
             dwl = torch.einsum("br,bre->e", rowLoad, dQ)
+        if join_side is not None:
+            torch.cuda.current_stream().wait_stream(join_side)
         return (None, None, None, None, None, None, None,
                 dK, dV, dPK, dpb, dQ1, dQ2, dwl, gloc if hasloc else None, None, None)
 
