@@ -5,6 +5,7 @@ construction into one persistent launch."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 import random
 
 import torch
@@ -15,6 +16,23 @@ from elg_amd import engine as eng
 from elg_amd.CVRP.models import CVRP_Decoder, CVRP_Encoder
 
 
+class _EncodeAndFold(nn.Module):
+    """encoder + table folds as ONE static-shape callable, so that a training step can replay them (forward
+    and backward) as two hipGraphs instead of ~400 eager launches (the encoder is launch-bound at B=64)."""
+
+    def __init__(self, encoder, decoder):
+        super().__init__()
+        self.encoder, self.decoder = encoder, decoder
+
+    def forward(self, depot_xy, node_xy_demand):
+        enc = self.encoder(depot_xy, node_xy_demand)
+        t, loc = self.decoder.fold(enc)
+        outs = [enc, t["K"], t["V"], t["PK"], t["pb"], t["Q1"], t["wl"]]
+        if loc is not None:
+            outs.append(loc)
+        return tuple(outs)
+
+
 class CVRPModel(nn.Module):
     def __init__(self, **model_params):
         super().__init__()
@@ -22,10 +40,38 @@ class CVRPModel(nn.Module):
         self.encoder = CVRP_Encoder(**model_params)
         self.decoder = CVRP_Decoder(**model_params)
         self.encoded_nodes = None            # (batch, problem+1, embedding)
+        self.__dict__["_graphs"] = {}        # (shape, param ids) -> graphed _EncodeAndFold (not a submodule)
+        self.use_graphs = os.environ.get("ELG_HIPGRAPH", "1") != "0"
+
+    def _graphed(self, depot_xy, node_xy_demand):
+        """hipGraph-captured encoder+folds for this input shape / parameter set (training mode only)."""
+        key = (tuple(depot_xy.shape), tuple(node_xy_demand.shape), str(depot_xy.device),
+               tuple(id(p) for p in self.parameters()))
+        g = self._graphs.get(key)
+        if g is None:
+            try:
+                mod = _EncodeAndFold(self.encoder, self.decoder)
+                g = torch.cuda.make_graphed_callables(mod, (depot_xy.detach().clone(), node_xy_demand.detach().clone()))
+            except Exception as e:          # capture is an optimisation only: eager PyTorch is the same math
+                print(f"[elg_amd] hipGraph capture of the encoder failed ({type(e).__name__}: {e}); running eager")
+                g = False
+            self._graphs.clear()            # one live graph set (static buffers) at a time
+            self._graphs[key] = g
+        return g
 
     def pre_forward(self, reset_state):
         node_xy_demand = torch.cat((reset_state.node_xy, reset_state.node_demand[:, :, None]), dim=2)
-        self.encoded_nodes = self.encoder(reset_state.depot_xy, node_xy_demand, reset_state.dist)
+        depot_xy = reset_state.depot_xy
+        g = None
+        if self.use_graphs and self.training and torch.is_grad_enabled() and depot_xy.is_cuda:
+            g = self._graphed(depot_xy, node_xy_demand)
+        if g:
+            outs = g(depot_xy.contiguous(), node_xy_demand.contiguous())
+            self.encoded_nodes = outs[0]
+            tables = dict(K=outs[1], V=outs[2], PK=outs[3], pb=outs[4], Q1=outs[5], wl=outs[6], Q2=None)
+            self.decoder.set_tables(self.encoded_nodes, tables, outs[7] if len(outs) > 7 else None)
+            return
+        self.encoded_nodes = self.encoder(depot_xy, node_xy_demand, reset_state.dist)
         self.decoder.set_kv(self.encoded_nodes)
 
     @staticmethod

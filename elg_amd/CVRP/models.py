@@ -129,18 +129,27 @@ class CVRP_Decoder(nn.Module):
         self.local_policies = nn.ModuleList([local_policy_att(self.model_params, idx=i).to(device) for i in range(n)])
         self.local = True
 
-    def set_kv(self, encoded_nodes):
-        """reference models.py:300-308, plus the folds described in engine.fold_decoder_tables."""
+    def fold(self, encoded_nodes):
+        """(tables, loc): decoder / local-policy weights folded for the HIP kernels (engine.fold_*)."""
         mp = self.model_params
         dec = {"Wq_last.weight": self.Wq_last.weight, "Wk.weight": self.Wk.weight, "Wv.weight": self.Wv.weight,
                "multi_head_combine.weight": self.multi_head_combine.weight,
                "multi_head_combine.bias": self.multi_head_combine.bias}
         tables = eng.fold_decoder_tables(dec, encoded_nodes, L.PROBLEM_CVRP)
         has_local = bool(mp['ensemble'] and self.local)
-        K = int(mp['local_size'][0])
-        loc = self.local_policies[0].folded_tables(K + 1) if has_local else None
-        self.policy = eng.Policy(tables, loc, K, float(mp['xi']), float(mp['logit_clipping']),
+        loc = self.local_policies[0].folded_tables(int(mp['local_size'][0]) + 1) if has_local else None
+        return tables, loc
+
+    def set_tables(self, encoded_nodes, tables, loc):
+        mp = self.model_params
+        has_local = bool(mp['ensemble'] and self.local)
+        self.policy = eng.Policy(tables, loc, int(mp['local_size'][0]), float(mp['xi']), float(mp['logit_clipping']),
                                  1.0 / float(mp['ensemble_size']), has_local, bool(mp['distance_penalty']))
         # attributes the reference exposes after set_kv
         self.k, self.v = tables["K"], tables["V"]
         self.single_head_key = encoded_nodes.transpose(1, 2)
+
+    def set_kv(self, encoded_nodes):
+        """reference models.py:300-308, plus the folds described in engine.fold_decoder_tables."""
+        tables, loc = self.fold(encoded_nodes)
+        self.set_tables(encoded_nodes, tables, loc)
