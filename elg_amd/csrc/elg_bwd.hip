@@ -24,6 +24,7 @@ __device__ __forceinline__ float* stage_instance(const elg_rollout_args& A, int 
     float *sK = nullptr, *sV = nullptr, *sPK = nullptr;
     if (LDSK) { sK = p; sV = p + NE; sPK = p + 2 * NE; p += 3 * NE; }
     float* sdem = p; p += (N1 + 3) & ~3;
+    float* sxy = p; if (LDSK) p += (2 * N1 + 3) & ~3;
     p += 4;
     const float* gK = A.Kmat + (size_t)b * NE;
     const float* gV = A.Vmat + (size_t)b * NE;
@@ -38,6 +39,8 @@ __device__ __forceinline__ float* stage_instance(const elg_rollout_args& A, int 
     }
     if (!TSP)
         for (int i = threadIdx.x; i < N1; i += NT) sdem[i] = A.demand[(size_t)b * N1 + i];
+    if (LDSK)
+        for (int i = threadIdx.x; i < 2 * N1; i += NT) sxy[i] = A.xy[(size_t)b * N1 * 2 + i];
     I.K = LDSK ? sK : gK;
     I.V = LDSK ? sV : gV;
     I.PK = LDSK ? sPK : gPK;
@@ -45,7 +48,7 @@ __device__ __forceinline__ float* stage_instance(const elg_rollout_args& A, int 
     I.Q1 = A.Q1 + (size_t)b * NE;
     I.Q2 = TSP ? A.Q2 + (size_t)b * NE : nullptr;
     I.wl = A.wl;
-    I.xy = A.xy + (size_t)b * N1 * 2;
+    I.xy = LDSK ? sxy : A.xy + (size_t)b * N1 * 2;
     I.dem = sdem;
     I.nidx = A.nbr_idx + (size_t)b * N1 * N1;
     I.ndist = A.nbr_dist + (size_t)b * N1 * N1;
@@ -123,7 +126,7 @@ __device__ __forceinline__ void bwd_step(const elg_bwd_args& BA, const Inst& I, 
         th[ch] = 0.f;
         lg[ch] = ELG_NEG_INF;
         if (n < N1 && !masked) {
-            th[ch] = tanhf(s[ch] + sb[n]);
+            th[ch] = fast_tanh(s[ch] + sb[n]);
             lg[ch] = A.clip * th[ch];
         }
         mx = fmaxf(mx, lg[ch]);
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(WAVES * 64) void rollout_bwd_kernel(const elg_bwd_a
     for (int m = m_lo + wave; m < m_hi; m += WAVES) {
         const size_t bm = b * A.M + m;
         Traj<NCH> st;
-        st.cur = 0; st.first = 0; st.cnt = 0; st.fin = 0; st.load = 1.0f; st.len = 0.f;
+        st.cur = 0; st.first = 0; st.cnt = 0; st.fin = 0; st.load = 1.0f; st.len = 0.f; st.cx = 0.f; st.cy = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) st.vis[c] = 0ull;
         for (int t = 0; t < T; ++t) {
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(WAVES * 64) void local_bwd_kernel(const elg_bwd_arg
     for (int m = m_lo + wave; m < m_hi; m += WAVES) {
         const size_t bm = b * A.M + m;
         Traj<NCH> st;
-        st.cur = 0; st.first = 0; st.cnt = 0; st.fin = 0; st.load = 1.0f; st.len = 0.f;
+        st.cur = 0; st.first = 0; st.cnt = 0; st.fin = 0; st.load = 1.0f; st.len = 0.f; st.cx = 0.f; st.cy = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) st.vis[c] = 0ull;
         for (int t = 0; t < T; ++t) {
@@ -507,6 +510,7 @@ static int launch_bwd(const elg_bwd_args& BA, hipStream_t stream) {
     size_t lds = 0;
     if (LDSK) lds += (size_t)3 * A.N1 * ELG_E * 4;
     lds += (size_t)((A.N1 + 3) & ~3) * 4 + 16 + (size_t)WAVES * SbSize<NCH>::value * 4;
+    if (LDSK) lds += (size_t)((2 * A.N1 + 3) & ~3) * 4;
     if (lds > 163840) return fail(ELG_EINVAL, "rollout_bwd: LDS budget exceeded");
     auto kern = rollout_bwd_kernel<NCH, TSP, LDSK, WAVES>;
     static bool attr_done = false;

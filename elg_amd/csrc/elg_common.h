@@ -102,6 +102,21 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// tanh through one v_exp + one v_rcp: 1 - 2/(e^{2x}+1).  Exact limits (+-1) for |x| large, absolute error
+// ~1e-7 (the clipped logit 50*tanh moves by < 1e-5, far inside the 1e-4 relative parity bar).
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float e = __expf(2.0f * x);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+// lane i <- lane i^8 / i^4 inside each 16-lane row, DPP only (row_ror; no LDS crossbar)
+__device__ __forceinline__ float row_xor8(float v) { return dpp<0x128>(v); }            // row_ror:8
+__device__ __forceinline__ float row_xor4(float v, bool bit2) {
+    const float up = dpp<0x12C>(v);      // row_ror:12 : lane i <- lane (i+4) & 15
+    const float dn = dpp<0x124>(v);      // row_ror:4  : lane i <- lane (i-4) & 15
+    return bit2 ? dn : up;
+}
+
 __device__ __forceinline__ float dot4(const float4 a, const float4 b, float acc) {
     acc = fmaf(a.x, b.x, acc);
     acc = fmaf(a.y, b.y, acc);

@@ -188,7 +188,7 @@ __device__ __forceinline__ FwdOut decode_step(const elg_rollout_args& A, const I
         const bool masked = (mk[ch] >> lane) & 1ull;
         float x = ELG_NEG_INF;
         th[ch] = 0.f;
-        if (n < N1 && !masked) { th[ch] = tanhf(s[ch] + sb[n]); x = A.clip * th[ch]; }
+        if (n < N1 && !masked) { th[ch] = fast_tanh(s[ch] + sb[n]); x = A.clip * th[ch]; }
         lg[ch] = x;
         mx = fmaxf(mx, x);
     }
@@ -295,7 +295,8 @@ __global__ __launch_bounds__(WAVES * 64) void rollout_fwd_kernel(const elg_rollo
     float *sK = nullptr, *sV = nullptr, *sPK = nullptr;
     if (LDSK) { sK = p; sV = p + NE; sPK = p + 2 * NE; p += 3 * NE; }
     float* sdem = p; p += (N1 + 3) & ~3;
-    int* sctr = reinterpret_cast<int*>(p); p += 4;
+    float* sxy = p; if (LDSK) p += (2 * N1 + 3) & ~3;
+    p += 4;
     float* sb = p + wave * SbSize<NCH>::value;
 
     const float* gK = A.Kmat + (size_t)b * NE;
@@ -312,6 +313,8 @@ __global__ __launch_bounds__(WAVES * 64) void rollout_fwd_kernel(const elg_rollo
     }
     if (!TSP)
         for (int i = threadIdx.x; i < N1; i += WAVES * 64) sdem[i] = A.demand[(size_t)b * N1 + i];
+    if (LDSK)
+        for (int i = threadIdx.x; i < 2 * N1; i += WAVES * 64) sxy[i] = A.xy[(size_t)b * N1 * 2 + i];
     __syncthreads();
 
     Inst I;
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(WAVES * 64) void rollout_fwd_kernel(const elg_rollo
     I.Q1 = A.Q1 + (size_t)b * NE;
     I.Q2 = TSP ? A.Q2 + (size_t)b * NE : nullptr;
     I.wl = A.wl;
-    I.xy = A.xy + (size_t)b * N1 * 2;
+    I.xy = LDSK ? sxy : A.xy + (size_t)b * N1 * 2;
     I.dem = sdem;
     I.nidx = A.nbr_idx + (size_t)b * N1 * N1;
     I.ndist = A.nbr_dist + (size_t)b * N1 * N1;
@@ -343,6 +346,8 @@ __global__ __launch_bounds__(WAVES * 64) void rollout_fwd_kernel(const elg_rollo
             st.first = TSP ? __builtin_amdgcn_readfirstlane(A.st_first[bm]) : 0;
             st.load = i2f(__builtin_amdgcn_readfirstlane(f2i(A.st_load[bm])));
             st.len = i2f(__builtin_amdgcn_readfirstlane(f2i(A.st_len[bm])));
+            st.cx = i2f(__builtin_amdgcn_readfirstlane(f2i(A.xy[((size_t)b * N1 + st.cur) * 2])));
+            st.cy = i2f(__builtin_amdgcn_readfirstlane(f2i(A.xy[((size_t)b * N1 + st.cur) * 2 + 1])));
 #pragma unroll
             for (int c = 0; c < NW; ++c) {
                 const unsigned long long v = A.st_vis[bm * NW + c];
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(WAVES * 64) void rollout_fwd_kernel(const elg_rollo
                 st.vis[c] = ((unsigned long long)hi << 32) | lo;
             }
         } else {
-            st.cur = 0; st.first = 0; st.cnt = 0; st.fin = 0; st.load = 1.0f; st.len = 0.f;
+            st.cur = 0; st.first = 0; st.cnt = 0; st.fin = 0; st.load = 1.0f; st.len = 0.f; st.cx = 0.f; st.cy = 0.f;
 #pragma unroll
             for (int c = 0; c < NW; ++c) st.vis[c] = 0ull;
         }
@@ -414,6 +419,7 @@ static int launch_fwd(const elg_rollout_args& A, hipStream_t stream) {
     size_t lds = 0;
     if (LDSK) lds += (size_t)3 * A.N1 * ELG_E * 4;
     lds += (size_t)((A.N1 + 3) & ~3) * 4 + 16 + (size_t)WAVES * SbSize<NCH>::value * 4;
+    if (LDSK) lds += (size_t)((2 * A.N1 + 3) & ~3) * 4;
     if (lds > 163840) return fail(ELG_EINVAL, "rollout: LDS budget exceeded");
     auto kern = rollout_fwd_kernel<NCH, TSP, LDSK, WAVES, TRAIN>;
     static bool attr_done = false;
@@ -435,7 +441,7 @@ static int dispatch_fwd(const elg_rollout_args& A, hipStream_t stream) {
     const int nch = (A.N1 + 63) / 64;
     const bool lds = A.lds_stage != 0;
     if (lds && A.N1 > 104) return fail(ELG_EINVAL, "lds_stage needs N1 <= 104");
-    if (A.waves != 8 && A.waves != 13 && !A.trA) return fail(ELG_EINVAL, "waves must be 8 or 13");
+    if (A.waves != 8) return fail(ELG_EINVAL, "waves must be 8");
 #define ELG_GO(NCHV, L, W) return launch_fwd<NCHV, TSP, L, W>(A, stream)
     if (A.trA) {        // training forward: saves the backward rows; built for N1 <= 128, 8 waves
         if (!A.trPC || !A.trCsel || !A.trQ || !A.trO) return fail(ELG_EINVAL, "rollout: incomplete training rows");
@@ -444,10 +450,8 @@ static int dispatch_fwd(const elg_rollout_args& A, hipStream_t stream) {
         if (nch == 2) { if (lds) return launch_fwd<2, TSP, true, 8, true>(A, stream); return launch_fwd<2, TSP, false, 8, true>(A, stream); }
         return fail(ELG_ENOTIMPL, "rollout: training rows for N1 > 128 not built");
     }
-    if (nch == 1) { if (lds) { if (A.waves == 8) ELG_GO(1, true, 8); else ELG_GO(1, true, 13); }
-                    else { if (A.waves == 8) ELG_GO(1, false, 8); else ELG_GO(1, false, 13); } }
-    if (nch == 2) { if (lds) { if (A.waves == 8) ELG_GO(2, true, 8); else ELG_GO(2, true, 13); }
-                    else { if (A.waves == 8) ELG_GO(2, false, 8); else ELG_GO(2, false, 13); } }
+    if (nch == 1) { if (lds) ELG_GO(1, true, 8); else ELG_GO(1, false, 8); }
+    if (nch == 2) { if (lds) ELG_GO(2, true, 8); else ELG_GO(2, false, 8); }
     if (lds) return fail(ELG_EINVAL, "lds_stage needs N1 <= 104");
     if (nch <= 4) { ELG_GO(4, false, 8); }
     if (nch <= 8) { ELG_GO(8, false, 8); }

@@ -30,7 +30,7 @@ struct Inst {                 // per-instance table pointers (global or LDS)
     const float* Q1;          // [N1][128] global
     const float* Q2;          // [N1][128] global (TSP) or null
     const float* wl;          // [128] global (CVRP)
-    const float* xy;          // [N1][2]   global (two uniform reads per step)
+    const float* xy;          // [N1][2]   LDS when K/V/PK are staged, else global (one uniform read per step)
     const float* dem;         // [N1]      LDS (CVRP)
     const int* nidx;          // [N1][N1] global
     const float* ndist;
@@ -46,6 +46,7 @@ struct Traj {                 // wave-uniform trajectory state
     int fin;
     float load;
     float len;                // running tour length (closed at the end for TSP)
+    float cx, cy;             // coordinates of `cur` (valid once cnt > 0)
     unsigned long long vis[NCH];
 };
 
@@ -88,11 +89,10 @@ __device__ __forceinline__ void build_mask(const Traj<NCH>& st, const Inst& I, i
 // ---------------------------------------------------------------------------------------------
 template <int NCH, bool TSP>
 __device__ __forceinline__ void env_update(Traj<NCH>& st, const Inst& I, int N1, int sel) {
-    const float sx = I.xy[2 * sel], sy = I.xy[2 * sel + 1];
-    if (st.cnt > 0) {
-        const float px = I.xy[2 * st.cur], py = I.xy[2 * st.cur + 1];
-        st.len += dist2d(px, py, sx, sy);
-    }
+    const float2 sxy = *reinterpret_cast<const float2*>(I.xy + 2 * sel);
+    const float sx = i2f(__builtin_amdgcn_readfirstlane(f2i(sxy.x))), sy = i2f(__builtin_amdgcn_readfirstlane(f2i(sxy.y)));
+    if (st.cnt > 0) st.len += dist2d(st.cx, st.cy, sx, sy);
+    st.cx = sx; st.cy = sy;
     if (TSP) {
         if (st.cnt == 0) st.first = sel;
     } else {
@@ -145,13 +145,15 @@ __device__ __forceinline__ int knn_slots(const Inst& I, int N1, int K, int cur, 
             const int i = lane + 64 * ch;
             const bool valid = i < N1;
             const int nid = valid ? I.nidx[row + i] : 0;
+            const float nd = valid ? I.ndist[row + i] : 0.f;        // issued together with the index load
+            const float nth = valid ? I.ntheta[row + i] : 0.f;
             bool cand = valid && !test_bit<NCH>(mk, nid);
             if (!TSP) cand = cand && (nid != 0);
             const unsigned long long bal = __ballot(cand);
             const int rank = found + lanes_below(bal);
             if (cand && rank < K) {
-                sb[S0 + rank] = I.ndist[row + i];
-                sb[ELG_SLOT_STRIDE + S0 + rank] = I.ntheta[row + i];
+                sb[S0 + rank] = nd;
+                sb[ELG_SLOT_STRIDE + S0 + rank] = nth;
                 sb[2 * ELG_SLOT_STRIDE + S0 + rank] = i2f(nid);
             }
             found += __popcll(bal);
@@ -237,18 +239,20 @@ __device__ __forceinline__ float reduce_scatter32(float (&c)[32], int lane) {
     return c[0] + shfl_xor(c[0], 32);
 }
 
-// 16 per-lane values -> lane l ends with the wave-wide sum of element (l & 15)
+// 16 per-lane values -> lane l ends with the wave-wide sum of element (l & 15).
+// The three in-row butterfly stages are DPP (row_ror / quad_perm); only the two cross-row adds use the
+// LDS crossbar.
 __device__ __forceinline__ float reduce_scatter16(float (&c)[16], int lane) {
     const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const float keep = b3 ? c[i + 8] : c[i], send = b3 ? c[i] : c[i + 8];
-        c[i] = keep + shfl_xor(send, 8);
+        c[i] = keep + row_xor8(send);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float keep = b2 ? c[i + 4] : c[i], send = b2 ? c[i] : c[i + 4];
-        c[i] = keep + shfl_xor(send, 4);
+        c[i] = keep + row_xor4(send, b2);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {

@@ -209,9 +209,9 @@ class Policy:
 
 def launch_geometry(B: int, M: int, N1: int):
     """(waves, tiles, lds_stage).  256 CUs, one workgroup per CU when K/V/PK are staged in LDS:
-    aim for ~256 workgroups; 13 waves per workgroup cover a 25-trajectory tile in two rounds."""
+    aim for ~256 workgroups of 8 waves (2 per SIMD, 256-VGPR budget: no spills)."""
     lds = 1 if N1 <= 104 else 0
-    waves = 13 if lds else 8
+    waves = 8
     n_cu = 256
     tiles = max(1, min(M, (n_cu + B - 1) // B))
     if not lds:
@@ -323,7 +323,6 @@ def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mo
         rows.prepare()
         a.trA, a.trPC, a.trCsel, a.trQ, a.trO = _ptr(rows.A), _ptr(rows.PC), _ptr(rows.Csel), _ptr(rows.Q), _ptr(rows.O)
         a.trLoad, a.trSlot = _ptr(rows.Load), _ptr(rows.Slot)
-        a.waves = 8
     L.check(L.lib().elg_rollout_fwd(C.byref(a), _stream()), "elg_rollout_fwd")
     res = RolloutResult(actions, probs, reward, tlen, full)
     if rows is not None:
