@@ -26,7 +26,7 @@ class RolloutArgs(C.Structure):
         ("has_penalty", C.c_int32), ("max_steps", C.c_int32), ("do_decode", C.c_int32), ("do_update", C.c_int32),
         ("use_state", C.c_int32), ("waves", C.c_int32), ("tiles", C.c_int32), ("lds_stage", C.c_int32),
         ("dump_T", C.c_int32),
-        ("xi", C.c_float), ("clip", C.c_float), ("inv_ens", C.c_float), ("pad0", C.c_float),
+        ("xi", C.c_float), ("clip", C.c_float), ("inv_ens", C.c_float), ("debug_skip", C.c_int32),
         ("seed", C.c_uint64),
         ("Kmat", _vp), ("Vmat", _vp), ("PK", _vp), ("pb", _vp), ("Q1", _vp), ("Q2", _vp), ("wl", _vp),
         ("xy", _vp), ("demand", _vp), ("nbr_idx", _vp), ("nbr_dist", _vp), ("nbr_theta", _vp), ("loc", _vp),

@@ -71,11 +71,11 @@ __device__ __forceinline__ void unit_of_block(const elg_rollout_args& A, int& b,
 // ---------------------------------------------------------------------------------------------
 // one decode step, forward recomputed + backward, for the trajectory of this wave
 // ---------------------------------------------------------------------------------------------
-template <int NCH, bool TSP, bool LDSK>
+template <int NCH, bool TSP, bool LDSK, bool SMALL>
 __device__ __forceinline__ void bwd_step(const elg_bwd_args& BA, const Inst& I, const Traj<NCH>& st, int lane,
                                          float* sb, int sel, float gp, size_t b, size_t r, size_t R) {
     const elg_rollout_args& A = BA.fwd;
-    constexpr int NG = 8 * NCH;
+    constexpr int NG = GlimpseGroups<NCH, SMALL>::value;
     const int N1 = A.N1;
     const int half = lane >> 5, hq = lane & 31, ql = lane & 3, cb = hq * 4, head = hq >> 2;
     const int rr = 2 * ql + half;
@@ -104,7 +104,7 @@ __device__ __forceinline__ void bwd_step(const elg_bwd_args& BA, const Inst& I, 
         addval = S.pen + u * A.inv_ens;
     }
     GlimpseSave<NG> gs;
-    const float4 o4 = glimpse<NCH, LDSK>(I, N1, lane, q4, mk, &gs);
+    const float4 o4 = glimpse<NCH, LDSK, NG>(I, N1, lane, q4, mk, &gs);
     float s[NCH];
     pointer_scores<NCH, LDSK>(I, N1, lane, o4, sb, s);
 
@@ -175,7 +175,7 @@ __device__ __forceinline__ void bwd_step(const elg_bwd_args& BA, const Inst& I, 
 #pragma unroll
         for (int k = 0; k < NG; ++k) {
             const int row = 8 * k + rr;
-            if (8 * k < N1 && row < N1) rA[row] = gs.e[k];
+            if (row < N1) rA[row] = gs.e[k];
         }
     }
     if (lane < 32) {
@@ -202,7 +202,7 @@ __device__ __forceinline__ void zero_rows(const elg_bwd_args& BA, int lane, size
     if (lane == 0 && BA.rowLoad) BA.rowLoad[b * R + r] = 0.f;
 }
 
-template <int NCH, bool TSP, bool LDSK, int WAVES>
+template <int NCH, bool TSP, bool LDSK, int WAVES, bool SMALL>
 __global__ __launch_bounds__(WAVES * 64) void rollout_bwd_kernel(const elg_bwd_args BA) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const elg_rollout_args& A = BA.fwd;
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(WAVES * 64) void rollout_bwd_kernel(const elg_bwd_a
                 zero_rows<NCH>(BA, lane, b, r, R);
             } else {
                 const float gp = i2f(__builtin_amdgcn_readfirstlane(f2i(BA.gprob[(b * T + t) * A.M + m])));
-                bwd_step<NCH, TSP, LDSK>(BA, I, st, lane, sb, sel, gp, b, r, R);
+                bwd_step<NCH, TSP, LDSK, SMALL>(BA, I, st, lane, sb, sel, gp, b, r, R);
             }
             if (!st.fin) env_update<NCH, TSP>(st, I, N1, sel);
         }
@@ -504,15 +504,24 @@ __global__ __launch_bounds__(256) void glimpse_rows_kernel(const float* __restri
 // =============================================================================================
 // launchers
 // =============================================================================================
+template <int NCH, bool TSP, bool LDSK, int WAVES, bool SMALL>
+static int launch_bwd_impl(const elg_bwd_args& BA, hipStream_t stream);
+
 template <int NCH, bool TSP, bool LDSK, int WAVES>
 static int launch_bwd(const elg_bwd_args& BA, hipStream_t stream) {
+    if (NCH == 2 && BA.fwd.N1 <= 104) return launch_bwd_impl<NCH, TSP, LDSK, WAVES, (NCH == 2)>(BA, stream);
+    return launch_bwd_impl<NCH, TSP, LDSK, WAVES, false>(BA, stream);
+}
+
+template <int NCH, bool TSP, bool LDSK, int WAVES, bool SMALL>
+static int launch_bwd_impl(const elg_bwd_args& BA, hipStream_t stream) {
     const elg_rollout_args& A = BA.fwd;
     size_t lds = 0;
     if (LDSK) lds += (size_t)3 * A.N1 * ELG_E * 4;
     lds += (size_t)((A.N1 + 3) & ~3) * 4 + 16 + (size_t)WAVES * SbSize<NCH>::value * 4;
     if (LDSK) lds += (size_t)((2 * A.N1 + 3) & ~3) * 4;
     if (lds > 163840) return fail(ELG_EINVAL, "rollout_bwd: LDS budget exceeded");
-    auto kern = rollout_bwd_kernel<NCH, TSP, LDSK, WAVES>;
+    auto kern = rollout_bwd_kernel<NCH, TSP, LDSK, WAVES, SMALL>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

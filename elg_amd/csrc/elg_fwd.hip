@@ -115,7 +115,7 @@ struct FwdOut {
 };
 
 // One decode step for the trajectory held by this wave.  Returns the chosen node and its probability.
-template <int NCH, bool TSP, bool LDSK, bool TRAIN>
+template <int NCH, bool TSP, bool LDSK, bool TRAIN, bool SMALL>
 __device__ __forceinline__ FwdOut decode_step(const elg_rollout_args& A, const Inst& I, const Traj<NCH>& st,
                                               int lane, float* sb, int forced_sel, float uni,
                                               float* full_row /* (N1) or null */, size_t b, size_t r, size_t Rcap) {
@@ -148,15 +148,17 @@ __device__ __forceinline__ FwdOut decode_step(const elg_rollout_args& A, const I
     if (TRAIN && A.trSlot && lane < ELG_SLOT_STRIDE) A.trSlot[(b * Rcap + r) * ELG_SLOT_STRIDE + lane] = snid;
 
     // ---- glimpse + pointer
-    GlimpseSave<8 * NCH> gs;
-    const float4 o4 = glimpse<NCH, LDSK>(I, N1, lane, q4, mk, TRAIN ? &gs : nullptr);
+    constexpr int NG = GlimpseGroups<NCH, SMALL>::value;
+    GlimpseSave<NG> gs;
+    float4 o4 = q4;
+    if (!(A.debug_skip & 1)) o4 = glimpse<NCH, LDSK, NG>(I, N1, lane, q4, mk, TRAIN ? &gs : nullptr);
     if (TRAIN) {
         const int half = lane >> 5, hq = lane & 31, rr = 2 * (lane & 3) + half;
         float* rA = A.trA + ((b * ELG_H + (hq >> 2)) * Rcap + r) * N1;
 #pragma unroll
-        for (int k = 0; k < 8 * NCH; ++k) {
+        for (int k = 0; k < NG; ++k) {
             const int row = 8 * k + rr;
-            if (8 * k < N1 && row < N1) rA[row] = gs.e[k];
+            if (row < N1) rA[row] = gs.e[k];
         }
         if (lane < 32) {
             const size_t off = (b * Rcap + r) * ELG_E + cb;
@@ -166,7 +168,11 @@ __device__ __forceinline__ FwdOut decode_step(const elg_rollout_args& A, const I
         if (lane == 0 && A.trLoad) A.trLoad[b * Rcap + r] = st.load;
     }
     float s[NCH];
-    pointer_scores<NCH, LDSK>(I, N1, lane, o4, sb, s);
+    if (!(A.debug_skip & 2)) pointer_scores<NCH, LDSK>(I, N1, lane, o4, sb, s);
+    else {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) s[ch] = o4.x * (lane + ch);
+    }
 
     // ---- scatter the slot terms to node order (xi everywhere else)   models.py:405-413
     const float dflt = A.has_penalty ? A.xi : 0.f;
@@ -275,7 +281,7 @@ __device__ __forceinline__ FwdOut decode_step(const elg_rollout_args& A, const I
     return o;
 }
 
-template <int NCH, bool TSP, bool LDSK, int WAVES, bool TRAIN>
+template <int NCH, bool TSP, bool LDSK, int WAVES, bool TRAIN, bool SMALL>
 __global__ __launch_bounds__(WAVES * 64) void rollout_fwd_kernel(const elg_rollout_args A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(WAVES * 64) void rollout_fwd_kernel(const elg_rollo
                 if (A.mode == ELG_MODE_SAMPLE)
                     uni = A.uniforms ? A.uniforms[bm * A.Tmax + t] : philox_uniform(A.seed, (unsigned)bm, (unsigned)t);
                 float* frow = (A.full_probs && t < A.dump_T) ? A.full_probs + (bm * A.dump_T + t) * N1 : nullptr;
-                const FwdOut o = decode_step<NCH, TSP, LDSK, TRAIN>(A, I, st, lane, sb, fsel, uni, frow, (size_t)b,
+                const FwdOut o = decode_step<NCH, TSP, LDSK, TRAIN, SMALL>(A, I, st, lane, sb, fsel, uni, frow, (size_t)b,
                                                                     (size_t)t * A.M + m, (size_t)A.Tmax * A.M);
                 sel = __builtin_amdgcn_readfirstlane(o.sel);
                 pr = i2f(__builtin_amdgcn_readfirstlane(f2i(o.p)));
@@ -414,14 +420,14 @@ __global__ __launch_bounds__(WAVES * 64) void rollout_fwd_kernel(const elg_rollo
     }
 }
 
-template <int NCH, bool TSP, bool LDSK, int WAVES, bool TRAIN = false>
-static int launch_fwd(const elg_rollout_args& A, hipStream_t stream) {
+template <int NCH, bool TSP, bool LDSK, int WAVES, bool TRAIN, bool SMALL>
+static int launch_fwd_impl(const elg_rollout_args& A, hipStream_t stream) {
     size_t lds = 0;
     if (LDSK) lds += (size_t)3 * A.N1 * ELG_E * 4;
     lds += (size_t)((A.N1 + 3) & ~3) * 4 + 16 + (size_t)WAVES * SbSize<NCH>::value * 4;
     if (LDSK) lds += (size_t)((2 * A.N1 + 3) & ~3) * 4;
     if (lds > 163840) return fail(ELG_EINVAL, "rollout: LDS budget exceeded");
-    auto kern = rollout_fwd_kernel<NCH, TSP, LDSK, WAVES, TRAIN>;
+    auto kern = rollout_fwd_kernel<NCH, TSP, LDSK, WAVES, TRAIN, SMALL>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -434,6 +440,13 @@ static int launch_fwd(const elg_rollout_args& A, hipStream_t stream) {
     hipLaunchKernelGGL(kern, grid, block, lds, stream, A);
     if (launch_status("rollout_fwd") != ELG_OK) return ELG_ELAUNCH;
     return ELG_OK;
+}
+
+// SMALL: N1 <= 104 in the two-chunk build (13 row groups instead of 16)
+template <int NCH, bool TSP, bool LDSK, int WAVES, bool TRAIN = false>
+static int launch_fwd(const elg_rollout_args& A, hipStream_t stream) {
+    if (NCH == 2 && A.N1 <= 104) return launch_fwd_impl<NCH, TSP, LDSK, WAVES, TRAIN, (NCH == 2)>(A, stream);
+    return launch_fwd_impl<NCH, TSP, LDSK, WAVES, TRAIN, false>(A, stream);
 }
 
 template <bool TSP>

@@ -385,19 +385,22 @@ struct GlimpseSave {
     float4 q4;               // q[cb..cb+3]
 };
 
+// number of 8-row groups the glimpse walks (static: the loops must be branch-free so that the compiler can
+// keep many LDS reads in flight): 13 covers N1 <= 104 (CVRP-100), otherwise whole 64-node chunks
+template <int NCH, bool SMALL>
+struct GlimpseGroups { static constexpr int value = (NCH == 2 && SMALL) ? 13 : 8 * NCH; };
+
 // ---------------------------------------------------------------------------------------------
 // Glimpse: 8-head attention of the trajectory's query over all nodes (models.py:330-341,455-503).
 // K and V are consumed two whole rows (1 KiB) per wave-instruction; the per-head 16-wide dot
 // products are finished with a quad reduce-scatter so that every lane ends up with the scores of
 // its own rows (row = 8k + 2*(lane&3) + (lane>>5), k = 0..NG-1) for head (lane&31)>>2.
 // Returns o[cb..cb+3] (cb = 4*(lane&31)), identical in both half-waves.
-// NG = number of row groups (8 rows each) = ceil(N1/8) rounded up to the template bound.
+// All loops are straight-line (rows past N1 are clamped / masked, never branched around).
 // ---------------------------------------------------------------------------------------------
-template <int NCH, bool LDSK>
+template <int NCH, bool LDSK, int NG>
 __device__ __forceinline__ float4 glimpse(const Inst& I, int N1, int lane, const float4 q4,
-                                          const unsigned long long (&mk)[NCH],
-                                          GlimpseSave<8 * NCH>* save) {
-    constexpr int NG = 8 * NCH;                    // groups of 8 rows
+                                          const unsigned long long (&mk)[NCH], GlimpseSave<NG>* save) {
     const int half = lane >> 5, hq = lane & 31, ql = lane & 3, cb = hq * 4;
     const bool b0 = ql & 1, b1 = ql & 2;
     const int r = 2 * ql + half;                   // row offset of this lane inside a group
@@ -406,81 +409,87 @@ __device__ __forceinline__ float4 glimpse(const Inst& I, int N1, int lane, const
     float m_run = ELG_NEG_INF, l_run = 0.f;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     constexpr int GB = NG < 16 ? NG : 16;          // groups per online-softmax block
+    static_assert(NG % GB == 0, "group count must be a multiple of the block size");
 #pragma unroll
     for (int g0 = 0; g0 < NG; g0 += GB) {
-        if (8 * g0 < N1) {
-            float sc[GB];
-#pragma unroll
-            for (int k = 0; k < GB; ++k) {
-                const int g = g0 + k;
-                sc[k] = ELG_NEG_INF;
-                if (8 * g < N1) {                  // wave-uniform
-                    float p[4];
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        int row = 8 * g + 2 * jj + half;
-                        if (!LDSK) row = row < N1 ? row : N1 - 1;
-                        const float4 kv = *reinterpret_cast<const float4*>(Kp + (size_t)row * ELG_E);
-                        p[jj] = dot4(kv, q4, 0.f);
-                    }
-                    const float s0 = b0 ? p[1] : p[0], t0 = b0 ? p[0] : p[1];
-                    const float s1 = b0 ? p[3] : p[2], t1 = b0 ? p[2] : p[3];
-                    const float a0 = s0 + quad_xor1(t0), a1 = s1 + quad_xor1(t1);
-                    const float keep = b1 ? a1 : a0, send = b1 ? a0 : a1;
-                    const float dotv = keep + quad_xor2(send);
-                    const int myrow = 8 * g + r;
-                    const unsigned byte = (unsigned)(mk[g >> 3] >> (8 * (g & 7))) & 0xffu;   // uniform
-                    const bool masked = (myrow >= N1) || ((byte >> r) & 1u);
-                    sc[k] = masked ? ELG_NEG_INF : dotv * 0.25f;          // / sqrt(qkv_dim)
-                }
-            }
-            float mb = sc[0];
-#pragma unroll
-            for (int k = 1; k < GB; ++k) mb = fmaxf(mb, sc[k]);
-            mb = fmaxf(mb, quad_xor1(mb));
-            mb = fmaxf(mb, quad_xor2(mb));
-            mb = fmaxf(mb, shfl_xor(mb, 32));
-            const float m_new = fmaxf(m_run, mb);
-            if (m_new > ELG_NEG_INF) {             // same for every lane (mask is head-independent)
-                const float scale = (m_run > ELG_NEG_INF) ? __expf(m_run - m_new) : 0.f;
-                l_run *= scale;
-                acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
-                if (save) {
-#pragma unroll
-                    for (int k = 0; k < NG; ++k) if (k < g0) save->e[k] *= scale;
-                }
-                m_run = m_new;
-#pragma unroll
-                for (int k = 0; k < GB; ++k) {
-                    const int g = g0 + k;
-                    const float e = (sc[k] > ELG_NEG_INF) ? __expf(sc[k] - m_new) : 0.f;
-                    l_run += e;
-                    if (save) save->e[g] = e;
-                    if (8 * g < N1) {
-#define ELG_VACC(JJ)                                                                             \
-    {                                                                                            \
-        int row = 8 * g + 2 * JJ + half;                                                         \
-        const bool ok = row < N1;                                                                \
-        if (!LDSK) row = ok ? row : N1 - 1;                                                      \
-        float4 vv = *reinterpret_cast<const float4*>(Vp + (size_t)row * ELG_E);                  \
-        float a = quad_bcast<JJ>(e);                                                             \
-        a = ok ? a : 0.f;                                                                        \
-        if (!ok) vv = make_float4(0.f, 0.f, 0.f, 0.f);                                           \
-        acc.x = fmaf(a, vv.x, acc.x); acc.y = fmaf(a, vv.y, acc.y);                              \
-        acc.z = fmaf(a, vv.z, acc.z); acc.w = fmaf(a, vv.w, acc.w);                              \
-    }
-                        ELG_VACC(0) ELG_VACC(1) ELG_VACC(2) ELG_VACC(3)
-#undef ELG_VACC
-                    }
-                }
-            } else if (save) {
+        if (NG > GB && 8 * g0 >= N1) {             // block-level skip (only for multi-block, large-N builds)
+            if (save) {
 #pragma unroll
                 for (int k = 0; k < GB; ++k) save->e[g0 + k] = 0.f;
             }
-        } else if (save) {
-#pragma unroll
-            for (int k = 0; k < GB; ++k) save->e[g0 + k] = 0.f;
+            continue;
         }
+        float sc[GB];
+#pragma unroll
+        for (int k = 0; k < GB; ++k) {
+            const int g = g0 + k;
+            sc[k] = ELG_NEG_INF;
+            if (8 * g >= N1) continue;                           // wave-uniform (scalar branch)
+            float4 kv[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                int row = 8 * g + 2 * jj + half;
+                if (!LDSK) row = row < N1 ? row : N1 - 1;      // LDS copy: rows past N1 read the next table (masked)
+                kv[jj] = *reinterpret_cast<const float4*>(Kp + (size_t)row * ELG_E);
+            }
+            const float p0 = dot4(kv[0], q4, 0.f), p1 = dot4(kv[1], q4, 0.f);
+            const float p2 = dot4(kv[2], q4, 0.f), p3 = dot4(kv[3], q4, 0.f);
+            const float s0 = b0 ? p1 : p0, t0 = b0 ? p0 : p1;
+            const float s1 = b0 ? p3 : p2, t1 = b0 ? p2 : p3;
+            const float a0 = s0 + quad_xor1(t0), a1 = s1 + quad_xor1(t1);
+            const float keep = b1 ? a1 : a0, send = b1 ? a0 : a1;
+            const float dotv = keep + quad_xor2(send);
+            const int myrow = 8 * g + r;
+            const unsigned byte = (unsigned)(mk[g >> 3] >> (8 * (g & 7))) & 0xffu;   // uniform
+            const bool masked = (myrow >= N1) || ((byte >> r) & 1u);
+            sc[k] = masked ? ELG_NEG_INF : dotv * 0.25f;          // / sqrt(qkv_dim)
+        }
+        float mb = sc[0];
+#pragma unroll
+        for (int k = 1; k < GB; ++k) mb = fmaxf(mb, sc[k]);
+        mb = fmaxf(mb, quad_xor1(mb));
+        mb = fmaxf(mb, quad_xor2(mb));
+        mb = fmaxf(mb, shfl_xor(mb, 32));
+        const float m_new = fmaxf(m_run, mb);
+        // m_new == -inf only if every node seen so far is masked (same for all lanes): nothing to add
+        const bool live = m_new > ELG_NEG_INF;
+        const float scale = (live && m_run > ELG_NEG_INF) ? __expf(m_run - m_new) : 0.f;
+        l_run *= scale;
+        acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
+        if (save) {
+#pragma unroll
+            for (int k = 0; k < NG; ++k) if (k < g0) save->e[k] *= scale;
+        }
+        m_run = m_new;
+        float e[GB];
+#pragma unroll
+        for (int k = 0; k < GB; ++k) {
+            e[k] = (live && sc[k] > ELG_NEG_INF) ? __expf(sc[k] - m_new) : 0.f;
+            l_run += e[k];
+            if (save) save->e[g0 + k] = e[k];
+        }
+#pragma unroll
+        for (int k = 0; k < GB; ++k) {
+            const int g = g0 + k;
+            if (8 * g >= N1) continue;                           // wave-uniform (scalar branch)
+            float4 vv[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                int row = 8 * g + 2 * jj + half;
+                if (!LDSK) row = row < N1 ? row : N1 - 1;
+                vv[jj] = *reinterpret_cast<const float4*>(Vp + (size_t)row * ELG_E);
+            }
+#define ELG_VACC(JJ)                                                                             \
+    {                                                                                            \
+        const bool ok = (8 * g + 2 * JJ + half) < N1;                                            \
+        float a = quad_bcast<JJ>(e[k]);                                                          \
+        a = ok ? a : 0.f;                                                                        \
+        acc.x = fmaf(a, ok ? vv[JJ].x : 0.f, acc.x); acc.y = fmaf(a, ok ? vv[JJ].y : 0.f, acc.y);  \
+        acc.z = fmaf(a, ok ? vv[JJ].z : 0.f, acc.z); acc.w = fmaf(a, ok ? vv[JJ].w : 0.f, acc.w);  \
+    }
+            ELG_VACC(0) ELG_VACC(1) ELG_VACC(2) ELG_VACC(3)
+        }
+#undef ELG_VACC
     }
     // denominators: lanes of one head = the quad in both half-waves
     float l = l_run;
@@ -500,7 +509,8 @@ __device__ __forceinline__ float4 glimpse(const Inst& I, int N1, int lane, const
 
 // ---------------------------------------------------------------------------------------------
 // Pointer scores s[n] = o . PK[n] + pb[n]   (models.py:341-352 with combine folded into PK).
-// o is broadcast through the wave's LDS scratch; every lane walks its own rows of PK.
+// o is broadcast through the wave's LDS scratch; every lane walks its own rows of PK
+// (branch-free: rows past N1 are clamped and their result discarded).
 // ---------------------------------------------------------------------------------------------
 template <int NCH, bool LDSK>
 __device__ __forceinline__ void pointer_scores(const Inst& I, int N1, int lane, const float4 o4, float* sb,
@@ -508,19 +518,23 @@ __device__ __forceinline__ void pointer_scores(const Inst& I, int N1, int lane, 
     if (lane < 32) *reinterpret_cast<float4*>(sb + 4 * lane) = o4;
     wave_lds_fence();
     float acc[NCH];
+    const float* rowp[NCH];
+    int sw[NCH];
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) acc[ch] = 0.f;
+    for (int ch = 0; ch < NCH; ++ch) {
+        acc[ch] = 0.f;
+        const int n = lane + 64 * ch;
+        const int nc = n < N1 ? n : N1 - 1;
+        rowp[ch] = I.PK + (size_t)nc * ELG_E;
+        sw[ch] = LDSK ? (nc & 31) : 0;
+    }
 #pragma unroll 8
     for (int c4 = 0; c4 < 32; ++c4) {
         const float4 o = *reinterpret_cast<const float4*>(sb + 4 * c4);
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
-            const int n = lane + 64 * ch;
-            if (n < N1) {
-                const int chunk = LDSK ? (c4 ^ (n & 31)) : c4;
-                const float4 pk = *reinterpret_cast<const float4*>(I.PK + (size_t)n * ELG_E + 4 * chunk);
-                acc[ch] = dot4(o, pk, acc[ch]);
-            }
+            const float4 pk = *reinterpret_cast<const float4*>(rowp[ch] + 4 * (c4 ^ sw[ch]));
+            acc[ch] = dot4(o, pk, acc[ch]);
         }
     }
 #pragma unroll

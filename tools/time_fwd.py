@@ -14,7 +14,15 @@ enc = orc.encoder_forward(P, cfg, xy, dem)
 prob = gc.make_problem(xy, dem, L.PROBLEM_CVRP)
 pol = gc.make_policy(P, cfg, enc.to(gc.DEV), L.PROBLEM_CVRP)
 starts = torch.randperm(N)[:M]
-def run(tag, pol, geom, mode=L.MODE_SAMPLE):
+import ctypes as C
+DEBUG = 0
+_orig_fill = eng._fill_common
+def _fill(a, *args, **kw):
+    _orig_fill(a, *args, **kw); a.debug_skip = DEBUG
+eng._fill_common = _fill
+def run(tag, pol, geom, mode=L.MODE_SAMPLE, debug=0):
+    global DEBUG
+    DEBUG = debug
     res = eng.rollout_forward(prob, pol, M, starts, mode, seed=1, geometry=geom); torch.cuda.synchronize()
     t0 = time.time()
     for i in range(5): res = eng.rollout_forward(prob, pol, M, starts, mode, seed=i, geometry=geom)
@@ -26,3 +34,7 @@ for geom in [(8, 4, 1)]:
     run("full", pol, geom)
     p2 = copy.copy(pol); p2.has_local = False; run("no local (penalty only)", p2, geom)
     p3 = copy.copy(pol); p3.has_local = False; p3.has_penalty = False; run("no local, no penalty", p3, geom)
+    run("  + skip glimpse", p3, geom, debug=1)
+    run("  + skip pointer", p3, geom, debug=2)
+    run("  + skip glimpse+pointer", p3, geom, debug=3)
+    run("  greedy, skip glimpse+pointer", p3, geom, mode=L.MODE_GREEDY, debug=3)
