@@ -454,17 +454,24 @@ static int dispatch_fwd(const elg_rollout_args& A, hipStream_t stream) {
     const int nch = (A.N1 + 63) / 64;
     const bool lds = A.lds_stage != 0;
     if (lds && A.N1 > 104) return fail(ELG_EINVAL, "lds_stage needs N1 <= 104");
-    if (A.waves != 8) return fail(ELG_EINVAL, "waves must be 8");
+    if (A.waves != 8 && A.waves != 9 && A.waves != 13) return fail(ELG_EINVAL, "waves must be 8, 9 or 13");
 #define ELG_GO(NCHV, L, W) return launch_fwd<NCHV, TSP, L, W>(A, stream)
     if (A.trA) {        // training forward: saves the backward rows; built for N1 <= 128, 8 waves
         if (!A.trPC || !A.trCsel || !A.trQ || !A.trO) return fail(ELG_EINVAL, "rollout: incomplete training rows");
         if (A.use_state) return fail(ELG_EINVAL, "rollout: training rows need the fused rollout");
         if (nch == 1) { if (lds) return launch_fwd<1, TSP, true, 8, true>(A, stream); return launch_fwd<1, TSP, false, 8, true>(A, stream); }
-        if (nch == 2) { if (lds) return launch_fwd<2, TSP, true, 8, true>(A, stream); return launch_fwd<2, TSP, false, 8, true>(A, stream); }
+        if (nch == 2) {
+            if (lds && A.waves == 9) return launch_fwd<2, TSP, true, 9, true>(A, stream);
+            if (lds) return launch_fwd<2, TSP, true, 8, true>(A, stream);
+            return launch_fwd<2, TSP, false, 8, true>(A, stream);
+        }
         return fail(ELG_ENOTIMPL, "rollout: training rows for N1 > 128 not built");
     }
     if (nch == 1) { if (lds) ELG_GO(1, true, 8); else ELG_GO(1, false, 8); }
-    if (nch == 2) { if (lds) ELG_GO(2, true, 8); else ELG_GO(2, false, 8); }
+    if (nch == 2) {
+        if (lds) { if (A.waves == 9) ELG_GO(2, true, 9); if (A.waves == 13) ELG_GO(2, true, 13); ELG_GO(2, true, 8); }
+        else ELG_GO(2, false, 8);
+    }
     if (lds) return fail(ELG_EINVAL, "lds_stage needs N1 <= 104");
     if (nch <= 4) { ELG_GO(4, false, 8); }
     if (nch <= 8) { ELG_GO(8, false, 8); }

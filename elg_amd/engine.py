@@ -256,9 +256,12 @@ class TrainRows:
         self.O = torch.empty(B, Rcap, E, device=dev)
         self.Load = torch.empty(B, Rcap, device=dev)
         self.Slot = torch.empty(B, Rcap, 48, device=dev, dtype=torch.int32)
+        # zero ONCE: afterwards every value ever written is finite, and the backward multiplies the rows of
+        # undecoded steps (first moves, finished trajectories) by an exactly-zero weight, so stale rows are inert
+        for t in (self.A, self.PC, self.Csel, self.Q, self.O, self.Load):
+            t.zero_()
+        self.Slot.fill_(-1)
         self.gen = 0
-        self.Tz = Tcap            # rows [0, Tz*M) are zero-filled before a launch
-        self.T_hint = None
 
     @classmethod
     def get(cls, B, M, N1, Tcap, dev):
@@ -269,15 +272,7 @@ class TrainRows:
         return ws
 
     def prepare(self):
-        """Zero-fill the prefix the kernel may leave untouched (first moves, finished trajectories).  The
-        prefix follows the recent maximum tour length (+20 %); a longer rollout falls back to the replay."""
         self.gen += 1
-        self.Tz = self.Tcap if self.T_hint is None else min(self.Tcap, int(1.2 * self.T_hint) + 8)
-        n = self.Tz * self.M
-        self.A[:, :, :n].zero_()
-        for t in (self.PC, self.Csel, self.Q, self.O, self.Load):
-            t[:, :n].zero_()
-        self.Slot[:, :n].fill_(-1)
 
 
 @dataclass
@@ -339,10 +334,11 @@ class _ChosenProbs(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, prob: Problem, pol_meta: Policy, M, actions, probs_val, T, geometry,
-                Kt, Vt, PKt, pbt, Q1t, Q2t, wlt, loct, rows=None, rows_gen=-1):
+                Kt, Vt, PKt, pbt, Q1t, Q2t, wlt, loct, rows=None, rows_gen=-1, tlen=None):
         ctx.prob, ctx.pol_meta, ctx.M, ctx.T, ctx.geometry = prob, pol_meta, M, T, geometry
         ctx.rows, ctx.rows_gen = rows, rows_gen
         ctx.probs_val = probs_val
+        ctx.tlen = tlen
         ctx.save_for_backward(actions, Kt, Vt, PKt, pbt, Q1t, Q2t if Q2t is not None else Kt.new_empty(0),
                               wlt if wlt is not None else Kt.new_empty(0), loct if loct is not None else Kt.new_empty(0))
         ctx.has = (Q2t is not None, wlt is not None, loct is not None)
@@ -363,7 +359,7 @@ class _ChosenProbs(torch.autograd.Function):
         fl = forced.long()
         g = gprob[:, :T, :].contiguous().float()
         rows = ctx.rows
-        use_saved = rows is not None and rows.gen == ctx.rows_gen and T <= rows.Tz
+        use_saved = rows is not None and rows.gen == ctx.rows_gen and T <= rows.Tcap
         join_side = None
         ba = L.BwdArgs()
         _fill_common(ba.fwd, prob, pol, M, ctx.geometry)
@@ -376,7 +372,10 @@ class _ChosenProbs(torch.autograd.Function):
             # rows saved by the training forward (time-major r = t*M + m): no glimpse replay needed
             rowA, rowO_rows = rows.A, rows.Rcap
             rowO, rowQ = rows.O, rows.Q[:, :R]
-            W = (g * ctx.probs_val[:, :T, :]).reshape(B, R)                               # gp * p_sel per row
+            tt = torch.arange(T, device=dev)[None, :, None]
+            t0 = 1 if prob.kind == L.PROBLEM_TSP else 2
+            valid = (tt >= t0) & (tt < ctx.tlen[:, None, :])                                # decoded steps only
+            W = (g * ctx.probs_val[:, :T, :] * valid).reshape(B, R)                         # gp * p_sel per row
             sel_tm = fl.permute(0, 2, 1).reshape(B, R)
             rowDL = rows.PC[:, :R] * (-W)[:, :, None]                                       # -p c W
             rowDL.scatter_add_(2, sel_tm[:, :, None], (W * rows.Csel[:, :R])[:, :, None])   # + c_sel W at the chosen node
@@ -426,24 +425,26 @@ class _ChosenProbs(torch.autograd.Function):
         dV = torch.matmul(rowA_v.transpose(2, 3), heads(dO)).permute(0, 2, 1, 3).reshape(B, N1, E)
         dPK = torch.bmm(rowDL.transpose(1, 2), rowO_v)
         dpb = rowDL.sum(dim=1)
-        dQ1 = torch.zeros(B, N1, E, device=dev).scatter_add_(1, prev[:, :, None].expand(B, R, E), dQ)
+        # dQ1[n] = sum of dQ over the rows whose query was gathered at node n: a one-hot GEMM (deterministic,
+        # and ~4x faster than 1.6 M float atomics into 100 rows)
+        onehot = torch.zeros(B, R, N1, device=dev).scatter_(2, prev[:, :, None], 1.0)
+        dQ1 = torch.bmm(onehot.transpose(1, 2), dQ)
         dQ2 = dwl = None
         if hasQ2:
-            dQ2 = torch.zeros(B, N1, E, device=dev).scatter_add_(1, first[:, :, None].expand(B, R, E), dQ)
+            onehot = torch.zeros(B, R, N1, device=dev).scatter_(2, first[:, :, None], 1.0)
+            dQ2 = torch.bmm(onehot.transpose(1, 2), dQ)
         if haswl:
             dwl = torch.einsum("br,bre->e", rowLoad, dQ)
         if join_side is not None:
             torch.cuda.current_stream().wait_stream(join_side)
         return (None, None, None, None, None, None, None,
-                dK, dV, dPK, dpb, dQ1, dQ2, dwl, gloc if hasloc else None, None, None)
+                dK, dV, dPK, dpb, dQ1, dQ2, dwl, gloc if hasloc else None, None, None, None)
 
 
 def chosen_probs(prob: Problem, pol: Policy, M: int, res: RolloutResult, T: int, geometry=None) -> torch.Tensor:
     """Differentiable view of res.probs[:, :T, :] (gradients flow to pol.tables / pol.loc)."""
     t = pol.tables
     rows = getattr(res, "rows", None)
-    if rows is not None:
-        rows.T_hint = T if rows.T_hint is None else max(T, int(0.9 * rows.T_hint))
     return _ChosenProbs.apply(prob, pol, M, res.actions, res.probs[:, :T, :], T, geometry,
                               t["K"], t["V"], t["PK"], t["pb"], t["Q1"], t.get("Q2"), t.get("wl"), pol.loc,
-                              rows, getattr(res, "rows_gen", -1))
+                              rows, getattr(res, "rows_gen", -1), res.tlen)

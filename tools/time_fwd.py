@@ -30,7 +30,7 @@ def run(tag, pol, geom, mode=L.MODE_SAMPLE, debug=0):
     steps = res.tlen.sum().item()
     print(f"{tag:32s} geom={geom}: {dt*1e3:7.2f} ms  mean_len={steps/(B*M):.1f}  ns/traj-step={dt/steps*1e9:.1f}")
 import copy
-for geom in [(8, 4, 1)]:
+for geom in [(8, 4, 1), (9, 4, 1), (13, 4, 1)]:
     run("full", pol, geom)
     p2 = copy.copy(pol); p2.has_local = False; run("no local (penalty only)", p2, geom)
     p3 = copy.copy(pol); p3.has_local = False; p3.has_penalty = False; run("no local, no penalty", p3, geom)
