@@ -239,3 +239,32 @@ def test_vrplib_instance_end_to_end():
     assert abs(best - float(fx["best_cost"])) <= 0.01 * float(fx["best_cost"])
     for b in range(8):
         orc.check_feasible(acts[b].cpu().numpy(), fx["demand"][b, 1:])
+
+
+def test_dataset_eval_with_augmentation():
+    """test.py path (SURVEY 8f-1): VRPDataset from the reference's pickle format, x8 augmentation, greedy;
+    the augmented best is never worse than the un-augmented one and matches a direct evaluation."""
+    from torch.utils.data import DataLoader
+    from elg_amd.CVRP.CVRPEnv import CVRPEnv
+    from elg_amd.CVRP.generate_data import VRPDataset
+    from elg_amd.CVRP.test import test
+    from elg_amd.CVRP.utils import rollout
+    ds = VRPDataset(os.path.join(gu.GOLDEN_DIR, "data", "vrp_uniform100_first8.pkl"), num_samples=8)
+    assert len(ds) == 8 and ds[0]["loc"].shape == (100, 2) and float(ds[0]["demand"].max()) <= 9 / 50 + 1e-6
+    model = _model(dict(gu.CVRP_MODEL_PARAMS), 5).eval()
+    env = CVRPEnv(100, DEV)
+    import random
+    random.seed(3)
+    aug, plain = test(DataLoader(ds, batch_size=4), model, env, 8)
+    assert aug <= plain + 1e-6 and 10 < aug < 60
+    # un-augmented number equals a direct greedy rollout with the same POMO starts
+    random.seed(3)
+    tot = 0.0
+    for batch in DataLoader(ds, batch_size=4):
+        env.load_random_problems(batch, 8)        # same draw order as test(): one start draw per batch
+        rs, _, _ = env.reset()
+        with torch.no_grad():
+            model.pre_forward(rs)
+            _, _, r = rollout(model, env, 'greedy')
+        tot += float(-r.reshape(8, 4, 100).max(dim=2)[0][0].mean())
+    assert abs(tot / 2 - plain) < 1e-4
