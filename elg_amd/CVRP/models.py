@@ -16,6 +16,13 @@ from elg_amd import engine as eng
 from elg_amd import _lib as L
 
 
+class Linear(nn.Linear):
+    """nn.Linear (same parameters / state_dict keys) whose weight gradient uses the split-K MFMA GEMM."""
+
+    def forward(self, x):
+        return eng.linear(x, self.weight, self.bias)
+
+
 class local_policy_att(nn.Module):
     """Weights of the k-NN local attention policy (reference models.py:7-36).  Forward lives in
     csrc/elg_rollout.h::local_policy; this module only owns the parameters."""
@@ -58,8 +65,8 @@ class AddAndInstanceNormalization(nn.Module):
 class FeedForward(nn.Module):
     def __init__(self, **model_params):
         super().__init__()
-        self.W1 = nn.Linear(model_params['embedding_dim'], model_params['ff_hidden_dim'])
-        self.W2 = nn.Linear(model_params['ff_hidden_dim'], model_params['embedding_dim'])
+        self.W1 = Linear(model_params['embedding_dim'], model_params['ff_hidden_dim'])
+        self.W2 = Linear(model_params['ff_hidden_dim'], model_params['embedding_dim'])
 
     def forward(self, x):
         return self.W2(F.relu(self.W1(x)))
@@ -70,10 +77,10 @@ class EncoderLayer(nn.Module):
         super().__init__()
         self.model_params = model_params
         e, h, d = model_params['embedding_dim'], model_params['head_num'], model_params['qkv_dim']
-        self.Wq = nn.Linear(e, h * d, bias=False)
-        self.Wk = nn.Linear(e, h * d, bias=False)
-        self.Wv = nn.Linear(e, h * d, bias=False)
-        self.multi_head_combine = nn.Linear(h * d, e)
+        self.Wq = Linear(e, h * d, bias=False)
+        self.Wk = Linear(e, h * d, bias=False)
+        self.Wv = Linear(e, h * d, bias=False)
+        self.multi_head_combine = Linear(h * d, e)
         self.add_n_normalization_1 = AddAndInstanceNormalization(**model_params)
         self.feed_forward = FeedForward(**model_params)
         self.add_n_normalization_2 = AddAndInstanceNormalization(**model_params)

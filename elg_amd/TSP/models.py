@@ -8,7 +8,7 @@ import torch.nn.functional as F
 
 from elg_amd import engine as eng
 from elg_amd import _lib as L
-from elg_amd.CVRP.models import AddAndInstanceNormalization, FeedForward, local_policy_att  # same definitions
+from elg_amd.CVRP.models import AddAndInstanceNormalization, FeedForward, Linear, local_policy_att  # same definitions
 
 
 class EncoderLayer(nn.Module):
@@ -16,10 +16,10 @@ class EncoderLayer(nn.Module):
         super().__init__()
         self.model_params = model_params
         e, h, d = model_params['embedding_dim'], model_params['head_num'], model_params['qkv_dim']
-        self.Wq = nn.Linear(e, h * d, bias=False)
-        self.Wk = nn.Linear(e, h * d, bias=False)
-        self.Wv = nn.Linear(e, h * d, bias=False)
-        self.multi_head_combine = nn.Linear(h * d, e)
+        self.Wq = Linear(e, h * d, bias=False)
+        self.Wk = Linear(e, h * d, bias=False)
+        self.Wv = Linear(e, h * d, bias=False)
+        self.multi_head_combine = Linear(h * d, e)
         self.addAndNormalization1 = AddAndInstanceNormalization(**model_params)
         self.feedForward = FeedForward(**model_params)
         self.addAndNormalization2 = AddAndInstanceNormalization(**model_params)

@@ -1,0 +1,137 @@
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact f32, fmaf-chain numerics) for the
+// encoder's projections / feed-forward layers and their backward passes (reference CVRP/models.py:240-269,
+// 550-561 executed as nn.Linear there).
+//
+//     C[M,N] (+)= op(A)[M,K] * op(B)[K,N]  (+ bias[N]) (ReLU)
+//     op(A) = A (M x K, row-major, lda)  or  A^T (A stored K x M)        -- transA
+//     op(B) = B (K x N, row-major, ldb)  or  B^T (B stored N x K)        -- transB  (nn.Linear weights)
+//
+// Tiling: 64 x 64 x 32 per workgroup of 4 waves; every wave owns a 32 x 32 accumulator (16 AGPR/VGPR),
+// 16 MFMAs per K-tile.  Both operands are staged k-major in LDS ([32][64+pad]) so that a fragment read
+// is 64 consecutive floats per k (conflict-free ds_read_b32): lane l feeds A[i = l&31][k = l>>5] and
+// B[k = l>>5][j = l&31].  Split-K (gridDim.z) with f32 atomics covers the weight-gradient shape
+// (K = batch*nodes = 6464, M,N = 128..512).
+#include "elg_common.h"
+#include "../../include/elg_hip.h"
+#include <string>
+
+namespace elg {
+int fail(int code, const std::string& msg);
+int launch_status(const char* what);
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BM = 64, BN = 64, BK = 32, LDT = 68;   // LDT: padded leading dimension of the k-major tiles
+
+template <bool TRANS>
+__device__ __forceinline__ void stage_tile(const float* __restrict__ G, int ld, int r0, int k0, int R, int K,
+                                           float* __restrict__ S, int tid) {
+    // fills S[k][r] (k < BK, r < 64) with op(G)[r0 + r][k0 + k]; out-of-range elements are zero
+    if (!TRANS) {
+        // G is (R x K) row-major: a thread reads 4 consecutive k of one row, writes them k-major
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + it * 256;            // 512 float4 slots = 64 rows x 8
+            const int r = idx >> 3, kq = (idx & 7) * 4;
+            const int gr = r0 + r, gk = k0 + kq;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gr < R) {
+                if (gk + 3 < K) v = *reinterpret_cast<const float4*>(G + (size_t)gr * ld + gk);
+                else {
+                    if (gk < K) v.x = G[(size_t)gr * ld + gk];
+                    if (gk + 1 < K) v.y = G[(size_t)gr * ld + gk + 1];
+                    if (gk + 2 < K) v.z = G[(size_t)gr * ld + gk + 2];
+                }
+            }
+            S[(kq + 0) * LDT + r] = v.x; S[(kq + 1) * LDT + r] = v.y;
+            S[(kq + 2) * LDT + r] = v.z; S[(kq + 3) * LDT + r] = v.w;
+        }
+    } else {
+        // G is (K x R) row-major: rows of the tile are contiguous along r
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + it * 256;            // 512 float4 slots = 32 k x 16
+            const int k = idx >> 4, rq = (idx & 15) * 4;
+            const int gk = k0 + k, gr = r0 + rq;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gk < K) {
+                if (gr + 3 < R) v = *reinterpret_cast<const float4*>(G + (size_t)gk * ld + gr);
+                else {
+                    if (gr < R) v.x = G[(size_t)gk * ld + gr];
+                    if (gr + 1 < R) v.y = G[(size_t)gk * ld + gr + 1];
+                    if (gr + 2 < R) v.z = G[(size_t)gk * ld + gr + 2];
+                }
+            }
+            *reinterpret_cast<float4*>(S + k * LDT + rq) = v;
+        }
+    }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                       float* __restrict__ C, const float* __restrict__ bias,
+                                                       int M, int N, int K, int lda, int ldb, int ldc, int relu,
+                                                       int k_per_split) {
+    __shared__ __attribute__((aligned(16))) float sA[BK * LDT];
+    __shared__ __attribute__((aligned(16))) float sB[BK * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        // op(A)[m][k]: !TA -> A stored (M x K) ; TA -> A stored (K x M)
+        stage_tile<TA>(A, lda, m0, k0, M, kend, sA, tid);
+        // op(B)[k][n]: !TB -> B stored (K x N) = "k-major rows" -> the transposed-source path; TB -> (N x K)
+        stage_tile<!TB>(B, ldb, n0, k0, N, kend, sB, tid);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a = sA[(kk + (lane >> 5)) * LDT + wm + (lane & 31)];
+            const float b = sB[(kk + (lane >> 5)) * LDT + wn + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    const int col = n0 + wn + (lane & 31);
+    const float bv = (bias && col < N && blockIdx.z == 0) ? bias[col] : 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = m0 + wm + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (row < M && col < N) {
+            float v = acc[reg] + bv;
+            if (gridDim.z > 1) atomicAdd(C + (size_t)row * ldc + col, v);
+            else {
+                if (relu) v = fmaxf(v, 0.f);
+                C[(size_t)row * ldc + col] = v;
+            }
+        }
+    }
+}
+
+}  // namespace elg
+
+using namespace elg;
+
+extern "C" int elg_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                            int lda, int ldb, int ldc, int transA, int transB, int relu, int split_k, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return fail(ELG_EINVAL, "gemm: empty problem");
+    if (split_k < 1) split_k = 1;
+    if (split_k > 1 && relu) return fail(ELG_EINVAL, "gemm: ReLU epilogue needs split_k == 1");
+    if ((lda | ldb) & 3) return fail(ELG_EINVAL, "gemm: lda/ldb must be multiples of 4 floats");
+    if (((uintptr_t)A | (uintptr_t)B) & 15) return fail(ELG_EINVAL, "gemm: operands must be 16-byte aligned");
+    int kps = (K + split_k - 1) / split_k;
+    kps = (kps + BK - 1) / BK * BK;
+    const int splits = (K + kps - 1) / kps;
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, splits), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipGetLastError();
+    if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, relu, kps);
+    else if (!transA && transB) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, relu, kps);
+    else if (transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, relu, kps);
+    else hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, relu, kps);
+    return launch_status("gemm_f32");
+}

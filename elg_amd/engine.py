@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -29,6 +30,7 @@ def _stream() -> C.c_void_p:
 
 
 _SIDE = {}
+_MFMA_DW = os.environ.get("ELG_MFMA_DW", "1") != "0"      # encoder weight gradients on the hand-written MFMA GEMM
 
 
 def _side_stream(dev) -> "torch.cuda.Stream":
@@ -94,6 +96,56 @@ def route_length(xy: torch.Tensor, tour: torch.Tensor, rounding: bool = False) -
     L.check(L.lib().elg_route_length(_ptr(xy), _ptr(tour), _ptr(out), B, M, T, xy.shape[1], int(bool(rounding)),
                                      _stream()), "elg_route_length")
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# fp32 MFMA GEMM (encoder layers)
+# ----------------------------------------------------------------------------------------------
+def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, bias=None, relu=False, split_k=1,
+         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M,N] (+)= op(a) op(b) (+bias)(ReLU) through elg_gemm_f32 (v_mfma_f32_32x32x2_f32).  2-D fp32 inputs."""
+    _need_cuda(a, "a")
+    assert a.dim() == 2 and b.dim() == 2 and a.dtype == torch.float32 and b.dtype == torch.float32
+    a, b = a.contiguous(), b.contiguous()
+    M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    Kb, N = (b.shape[1], b.shape[0]) if trans_b else b.shape
+    assert K == Kb, (a.shape, b.shape, trans_a, trans_b)
+    if out is None:
+        out = torch.zeros(M, N, device=a.device) if split_k > 1 else torch.empty(M, N, device=a.device)
+    L.check(L.lib().elg_gemm_f32(_ptr(a), _ptr(b), _ptr(out), _ptr(bias), M, N, K, a.shape[1], b.shape[1], N,
+                                 int(trans_a), int(trans_b), int(relu), split_k, _stream()), "elg_gemm_f32")
+    return out
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T (+ b) with x (rows, in), W (out, in).  Forward and dX are plain library GEMMs (hipBLASLt is
+    already at ~6 us for these shapes); the weight gradient dW = dY^T X reduces over rows = batch*nodes (6464),
+    where the library's single-pass kernel takes ~39 us: it runs on the hand-written split-K MFMA GEMM
+    (csrc/elg_gemm.hip, 16-31 us)."""
+
+    @staticmethod
+    def forward(ctx, x2, W, b):
+        ctx.save_for_backward(x2, W)
+        ctx.has_bias = b is not None
+        return torch.nn.functional.linear(x2, W, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy @ W if ctx.needs_input_grad[0] else None
+        dW = gemm(dy, x2, trans_a=True, split_k=max(1, min(64, x2.shape[0] // 128)))
+        db = dy.sum(dim=0) if ctx.has_bias else None
+        return dx, dW, db
+
+
+def linear(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """F.linear whose weight gradient runs on the split-K MFMA GEMM (GPU tensors, in/out multiples of 4)."""
+    if (not _MFMA_DW or not x.is_cuda or (x.shape[-1] % 4) or (W.shape[0] % 4) or not torch.is_grad_enabled()):
+        return torch.nn.functional.linear(x, W, b)
+    lead = x.shape[:-1]
+    y = _LinearFn.apply(x.reshape(-1, x.shape[-1]), W, b)
+    return y.view(*lead, W.shape[0])
 
 
 # ----------------------------------------------------------------------------------------------

@@ -170,6 +170,13 @@ int elg_glimpse_rows_bwd(const float* rowA, const float* dO, const float* rowO, 
                          int64_t rowA_rows, int64_t rowO_rows, void* stream);
 /* rowA_rows / rowO_rows: rows per (instance[, head]) in the rowA / rowO buffers (>= R; R for dense buffers). */
 
+/* fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32, exact f32) for the encoder's nn.Linear layers and
+ * their backward (reference CVRP/models.py:240-269,550-561):
+ *   C[M,N] (+)= op(A)[M,K] op(B)[K,N] (+ bias[N]) (ReLU);  transA: A stored KxM;  transB: B stored NxK.
+ * split_k > 1 accumulates with f32 atomics into a caller-zeroed C (weight gradients, K = batch*nodes). */
+int elg_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                 int lda, int ldb, int ldc, int transA, int transB, int relu, int split_k, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
