@@ -117,6 +117,17 @@ __device__ __forceinline__ float row_xor4(float v, bool bit2) {
     return bit2 ? dn : up;
 }
 
+// packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32: two lanes of work per VALU issue slot)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 lo2(const float4 v) { return f32x2{v.x, v.y}; }
+__device__ __forceinline__ f32x2 hi2(const float4 v) { return f32x2{v.z, v.w}; }
+// a . b with two packed ops + one add
+__device__ __forceinline__ float dot4p(const float4 a, const float4 b) {
+    f32x2 t = lo2(a) * lo2(b);
+    t = __builtin_elementwise_fma(hi2(a), hi2(b), t);
+    return t.x + t.y;
+}
+
 __device__ __forceinline__ float dot4(const float4 a, const float4 b, float acc) {
     acc = fmaf(a.x, b.x, acc);
     acc = fmaf(a.y, b.y, acc);

@@ -407,7 +407,7 @@ __device__ __forceinline__ float4 glimpse(const Inst& I, int N1, int lane, const
     const float* Kp = I.K + cb;
     const float* Vp = I.V + cb;
     float m_run = ELG_NEG_INF, l_run = 0.f;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
     constexpr int GB = NG < 16 ? NG : 16;          // groups per online-softmax block
     static_assert(NG % GB == 0, "group count must be a multiple of the block size");
 #pragma unroll
@@ -432,8 +432,8 @@ __device__ __forceinline__ float4 glimpse(const Inst& I, int N1, int lane, const
                 if (!LDSK) row = row < N1 ? row : N1 - 1;      // LDS copy: rows past N1 read the next table (masked)
                 kv[jj] = *reinterpret_cast<const float4*>(Kp + (size_t)row * ELG_E);
             }
-            const float p0 = dot4(kv[0], q4, 0.f), p1 = dot4(kv[1], q4, 0.f);
-            const float p2 = dot4(kv[2], q4, 0.f), p3 = dot4(kv[3], q4, 0.f);
+            const float p0 = dot4p(kv[0], q4), p1 = dot4p(kv[1], q4);
+            const float p2 = dot4p(kv[2], q4), p3 = dot4p(kv[3], q4);
             const float s0 = b0 ? p1 : p0, t0 = b0 ? p0 : p1;
             const float s1 = b0 ? p3 : p2, t1 = b0 ? p2 : p3;
             const float a0 = s0 + quad_xor1(t0), a1 = s1 + quad_xor1(t1);
@@ -455,7 +455,7 @@ __device__ __forceinline__ float4 glimpse(const Inst& I, int N1, int lane, const
         const bool live = m_new > ELG_NEG_INF;
         const float scale = (live && m_run > ELG_NEG_INF) ? __expf(m_run - m_new) : 0.f;
         l_run *= scale;
-        acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
+        acc01 *= scale; acc23 *= scale;
         if (save) {
 #pragma unroll
             for (int k = 0; k < NG; ++k) if (k < g0) save->e[k] *= scale;
@@ -481,11 +481,13 @@ __device__ __forceinline__ float4 glimpse(const Inst& I, int N1, int lane, const
             }
 #define ELG_VACC(JJ)                                                                             \
     {                                                                                            \
+        /* rows past N1 read finite bytes of the next table (or a clamped row): weight 0 */      \
         const bool ok = (8 * g + 2 * JJ + half) < N1;                                            \
         float a = quad_bcast<JJ>(e[k]);                                                          \
         a = ok ? a : 0.f;                                                                        \
-        acc.x = fmaf(a, ok ? vv[JJ].x : 0.f, acc.x); acc.y = fmaf(a, ok ? vv[JJ].y : 0.f, acc.y);  \
-        acc.z = fmaf(a, ok ? vv[JJ].z : 0.f, acc.z); acc.w = fmaf(a, ok ? vv[JJ].w : 0.f, acc.w);  \
+        const f32x2 a2 = {a, a};                                                                 \
+        acc01 = __builtin_elementwise_fma(a2, lo2(vv[JJ]), acc01);                               \
+        acc23 = __builtin_elementwise_fma(a2, hi2(vv[JJ]), acc23);                               \
     }
             ELG_VACC(0) ELG_VACC(1) ELG_VACC(2) ELG_VACC(3)
         }
@@ -497,6 +499,7 @@ __device__ __forceinline__ float4 glimpse(const Inst& I, int N1, int lane, const
     l += quad_xor2(l);
     l += shfl_xor(l, 32);
     const float inv = 1.0f / l;
+    float4 acc = make_float4(acc01.x, acc01.y, acc23.x, acc23.y);
     acc.x += shfl_xor(acc.x, 32); acc.y += shfl_xor(acc.y, 32);
     acc.z += shfl_xor(acc.z, 32); acc.w += shfl_xor(acc.w, 32);
     if (save) {
@@ -517,12 +520,12 @@ __device__ __forceinline__ void pointer_scores(const Inst& I, int N1, int lane, 
                                                float (&s)[NCH]) {
     if (lane < 32) *reinterpret_cast<float4*>(sb + 4 * lane) = o4;
     wave_lds_fence();
-    float acc[NCH];
+    f32x2 acc[NCH];
     const float* rowp[NCH];
     int sw[NCH];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-        acc[ch] = 0.f;
+        acc[ch] = f32x2{0.f, 0.f};
         const int n = lane + 64 * ch;
         const int nc = n < N1 ? n : N1 - 1;
         rowp[ch] = I.PK + (size_t)nc * ELG_E;
@@ -534,13 +537,14 @@ __device__ __forceinline__ void pointer_scores(const Inst& I, int N1, int lane, 
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             const float4 pk = *reinterpret_cast<const float4*>(rowp[ch] + 4 * (c4 ^ sw[ch]));
-            acc[ch] = dot4(o, pk, acc[ch]);
+            acc[ch] = __builtin_elementwise_fma(lo2(o), lo2(pk), acc[ch]);
+            acc[ch] = __builtin_elementwise_fma(hi2(o), hi2(pk), acc[ch]);
         }
     }
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         const int n = lane + 64 * ch;
-        s[ch] = (n < N1) ? acc[ch] + I.pb[n] : 0.f;
+        s[ch] = (n < N1) ? (acc[ch].x + acc[ch].y) + I.pb[n] : 0.f;
     }
     wave_lds_fence();
 }
