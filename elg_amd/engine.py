@@ -266,8 +266,10 @@ def launch_geometry(B: int, M: int, N1: int):
     waves = 8
     n_cu = 256
     tiles = max(1, min(M, (n_cu + B - 1) // B))
-    if not lds:
+    if not lds and N1 <= 128:
         tiles = max(tiles, min(M, (4 * n_cu + B - 1) // B))
+    # N1 > 128: node-tiled kernel, 128 KiB of K/V tiles per workgroup -> one workgroup per CU,
+    # trajectories advance in rounds of `waves`
     return waves, tiles, lds
 
 
@@ -339,7 +341,7 @@ class RolloutResult:
 
 def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mode: int, *, forced=None, seed: int = 0,
                     uniforms=None, dump_T: int = 0, geometry=None, Tcap: Optional[int] = None,
-                    train: bool = False) -> RolloutResult:
+                    train: bool = False, debug: int = 0) -> RolloutResult:
     """Run every trajectory to completion in one persistent launch (reference CVRP/utils.py:7-29)."""
     dev = prob.xy.device
     B, N1 = prob.B, prob.N1
@@ -353,6 +355,7 @@ def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mo
     _fill_common(a, prob, pol, M, geometry)
     a.Tmax, a.mode, a.max_steps, a.do_decode, a.do_update, a.use_state = Tcap, mode, 0, 1, 1, 0
     a.seed = seed & 0xFFFFFFFFFFFFFFFF
+    a.debug_skip = debug
     starts = starts.to(device=dev, dtype=torch.int32).contiguous()
     a.starts = _ptr(starts)
     if forced is not None:

@@ -1,0 +1,135 @@
+"""Large instances (N1 > 128: TSP-200/500, VRPLIB-sized CVRP) go through the node-tiled rollout kernel
+(csrc/elg_fwd.hip::rollout_fwd_tiled_kernel).  Parity: the engine's own sampled tours replayed by the oracle
+(chosen probabilities 1e-4 on the +-50 logits = 5e-4 rel on probabilities, rewards 1e-5, bit-exact feasibility),
+whole teacher-forced probability rows for the first steps, and agreement with the untiled kernel."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import elg_oracle as orc
+
+pytestmark = pytest.mark.gpu
+PROB_RTOL = 5e-4
+
+
+def _imports():
+    import gpu_common as gc
+    from elg_amd import _lib as L, engine as eng
+    return gc, L, eng
+
+
+def _cvrp_case(N, B, seed, local_size=40):
+    mp = dict(gu.CVRP_MODEL_PARAMS)
+    mp["local_size"] = [local_size]
+    cfg = orc.ModelCfg.from_model_params(mp, "cvrp")
+    depot, loc, demand = gu.golden_cvrp_problem(seed, B, N, 50.0)
+    xy = torch.from_numpy(np.concatenate([depot, loc], 1))
+    dem = torch.from_numpy(np.concatenate([np.zeros((B, 1), np.float32), demand], 1))
+    return mp, cfg, xy, dem
+
+
+@pytest.mark.parametrize("N,B,M", [(150, 2, 12), (300, 1, 19), (600, 1, 9)])
+def test_cvrp_large_sampled_replay(N, B, M):
+    gc, L, eng = _imports()
+    mp, cfg, xy, dem = _cvrp_case(N, B, 40 + N)
+    P = gc.weights("cvrp", 5, mp, 1.0)
+    enc = orc.encoder_forward(P, cfg, xy, dem)
+    prob = gc.make_problem(xy, dem, L.PROBLEM_CVRP)
+    pol = gc.make_policy(P, cfg, enc.to(gc.DEV), L.PROBLEM_CVRP)
+    starts = torch.randperm(N, generator=torch.Generator().manual_seed(N))[:M] + 1
+    res = eng.rollout_forward(prob, pol, M, starts, L.MODE_SAMPLE, seed=77)
+    T = int(res.tlen.max().item())
+    acts = res.actions[:, :, :T].cpu().long()
+    assert torch.equal(acts[0, :, 1], starts)
+    for b in range(B):
+        orc.check_feasible(acts[b].numpy(), dem[b, 1:].numpy())
+    out = orc.rollout_cvrp(P, cfg, xy, dem, M, starts=starts, forced=acts, enc=enc)
+    assert out["actions"].shape[2] == T
+    got = res.probs[:, :T].cpu().numpy()
+    assert (got > 0).all()
+    np.testing.assert_allclose(got, out["probs"].numpy(), rtol=PROB_RTOL, atol=1e-9)
+    np.testing.assert_allclose(res.reward.cpu().numpy(), out["reward"].numpy(), rtol=1e-5)
+    # the untiled kernel (every trajectory streams the tables itself) takes the same decisions
+    ref = eng.rollout_forward(prob, pol, M, starts, L.MODE_FORCED, forced=acts, debug=4)
+    np.testing.assert_allclose(ref.probs[:, :T].cpu().numpy(), got, rtol=2e-4, atol=1e-9)
+    np.testing.assert_allclose(ref.reward.cpu().numpy(), res.reward.cpu().numpy(), rtol=1e-6)
+
+
+@pytest.mark.parametrize("N,M", [(150, 10), (333, 17)])
+def test_cvrp_large_probability_rows(N, M):
+    """Teacher-forced along a greedy tour: complete probability rows (masks exact) of the first steps."""
+    gc, L, eng = _imports()
+    B = 2
+    mp, cfg, xy, dem = _cvrp_case(N, B, 11 + N, local_size=20)
+    P = gc.weights("cvrp", 6, mp, 1.0)
+    enc = orc.encoder_forward(P, cfg, xy, dem)
+    prob = gc.make_problem(xy, dem, L.PROBLEM_CVRP)
+    pol = gc.make_policy(P, cfg, enc.to(gc.DEV), L.PROBLEM_CVRP)
+    starts = torch.arange(1, M + 1)
+    g = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY)
+    T = int(g.tlen.max().item())
+    acts = g.actions[:, :, :T].cpu().long()
+    TD = 24
+    res = eng.rollout_forward(prob, pol, M, starts, L.MODE_FORCED, forced=acts, dump_T=TD)
+    assert torch.equal(res.actions[:, :, :T].cpu().long(), acts)
+    out = orc.rollout_cvrp(P, cfg, xy, dem, M, starts=starts, forced=acts, keep_probs=True, max_steps=TD, enc=enc)
+    full = res.full_probs.cpu().numpy()
+    for t in range(2, TD):
+        ref = out["full_probs"][t - 2].numpy()
+        gc.assert_same_mask(full[:, :, t, :], ref, f"t={t}")
+        e = gc.rel_err_probs(full[:, :, t, :], ref)
+        assert e < PROB_RTOL, f"t={t}: {e}"
+        # greedy = argmax of the oracle's row wherever the margin is not a rounding tie
+        top2 = np.sort(ref, -1)[..., -2:]
+        clear = (top2[..., 1] - top2[..., 0]) > 1e-3 * top2[..., 1]
+        assert np.array_equal(ref.argmax(-1)[clear], acts[:, :, t].numpy()[clear])
+
+
+@pytest.mark.parametrize("N,B,M", [(200, 2, 16), (530, 1, 11)])
+def test_tsp_large_sampled_replay(N, B, M):
+    gc, L, eng = _imports()
+    mp = dict(gu.TSP_MODEL_PARAMS)
+    cfg = orc.ModelCfg.from_model_params(mp, "tsp")
+    P = gc.weights("tsp", 8, mp, 1.0)
+    xy = torch.from_numpy(gu.golden_tsp_problem(300 + N, B, N))
+    enc = orc.encoder_forward(P, cfg, xy)
+    prob = gc.make_problem(xy, None, L.PROBLEM_TSP)
+    pol = gc.make_policy(P, cfg, enc.to(gc.DEV), L.PROBLEM_TSP)
+    starts = torch.randperm(N, generator=torch.Generator().manual_seed(N))[:M]
+    res = eng.rollout_forward(prob, pol, M, starts, L.MODE_SAMPLE, seed=5, dump_T=6)
+    assert (res.tlen.cpu() == N).all()
+    acts = res.actions.cpu().long()
+    assert torch.equal(acts[0, :, 0], starts)
+    assert (np.sort(acts.numpy(), -1) == np.arange(N)).all()          # every tour is a permutation
+    out = orc.rollout_tsp(P, cfg, xy, M, starts=starts, forced=acts, keep_probs=True, enc=enc)
+    got = res.probs.cpu().numpy()
+    np.testing.assert_allclose(got, out["probs"].numpy(), rtol=PROB_RTOL, atol=1e-9)
+    np.testing.assert_allclose(res.reward.cpu().numpy(), out["reward"].numpy(), rtol=1e-5)
+    full = res.full_probs.cpu().numpy()
+    for t in range(1, 6):
+        ref = out["full_probs"][t - 1].numpy()
+        gc.assert_same_mask(full[:, :, t, :], ref, f"t={t}")
+        assert gc.rel_err_probs(full[:, :, t, :], ref) < PROB_RTOL
+    ref = eng.rollout_forward(prob, pol, M, starts, L.MODE_FORCED, forced=acts, debug=4)
+    np.testing.assert_allclose(ref.probs.cpu().numpy(), got, rtol=2e-4, atol=1e-9)
+
+
+def test_tiled_uneven_rounds_and_tiles():
+    """pomo not a multiple of the 8 trajectories a workgroup advances per round, several tiles per instance."""
+    gc, L, eng = _imports()
+    N, B, M = 140, 3, 29
+    mp, cfg, xy, dem = _cvrp_case(N, B, 3)
+    P = gc.weights("cvrp", 9, mp, 1.0)
+    enc = orc.encoder_forward(P, cfg, xy, dem)
+    prob = gc.make_problem(xy, dem, L.PROBLEM_CVRP)
+    pol = gc.make_policy(P, cfg, enc.to(gc.DEV), L.PROBLEM_CVRP)
+    starts = torch.arange(1, M + 1)
+    a = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, geometry=(8, 1, 0))
+    for tiles in (2, 3, 29):
+        b = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, geometry=(8, tiles, 0))
+        assert torch.equal(a.actions, b.actions) and torch.equal(a.tlen, b.tlen)
+        assert torch.equal(a.reward, b.reward)
+    c = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, debug=4)
+    agree = (a.actions == c.actions).all(-1).float().mean().item()
+    assert agree > 0.8, agree            # greedy ties can flip a tour; most are identical
