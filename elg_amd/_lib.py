@@ -48,7 +48,7 @@ class BwdArgs(C.Structure):
 
 
 EXPORTS = ["elg_version", "elg_last_error", "elg_aug8", "elg_dist_matrix", "elg_nbr_tables", "elg_route_length",
-           "elg_rollout_fwd", "elg_rollout_bwd", "elg_glimpse_rows_bwd", "elg_gemm_f32"]
+           "elg_rollout_fwd", "elg_rollout_bwd", "elg_glimpse_rows_bwd", "elg_glimpse_bwd_fused", "elg_gemm_f32"]
 
 _lib = None
 
@@ -77,9 +77,10 @@ def lib() -> C.CDLL:
         L.elg_rollout_fwd.argtypes = [C.POINTER(RolloutArgs), f]
         L.elg_rollout_bwd.argtypes = [C.POINTER(BwdArgs), f]
         L.elg_glimpse_rows_bwd.argtypes = [f, f, f, f, f, f, f, i, i, i, C.c_int64, C.c_int64, f]
+        L.elg_glimpse_bwd_fused.argtypes = [f, f, f, f, f, f, f, f, f, i, i, i, C.c_int64, C.c_int64, C.c_int64, i, f]
         L.elg_gemm_f32.argtypes = [f, f, f, f, i, i, i, i, i, i, i, i, i, i, f]
         for n in ("elg_aug8", "elg_dist_matrix", "elg_nbr_tables", "elg_route_length", "elg_rollout_fwd",
-                  "elg_rollout_bwd", "elg_glimpse_rows_bwd", "elg_gemm_f32"):
+                  "elg_rollout_bwd", "elg_glimpse_rows_bwd", "elg_glimpse_bwd_fused", "elg_gemm_f32"):
             getattr(L, n).restype = C.c_int
         _lib = L
     return _lib

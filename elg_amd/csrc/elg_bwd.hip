@@ -566,9 +566,197 @@ static int dispatch_bwd(const elg_bwd_args& BA, hipStream_t stream) {
     return fail(ELG_ENOTIMPL, "rollout_bwd: N1 > 256 not built");
 }
 
+
+// =============================================================================================
+// Fused glimpse backward on the matrix cores (v_mfma_f32_16x16x4_f32: exact f32, fmaf-chain numerics).
+// One workgroup per (instance, head) [x row split], a wavefront per tile of 16 decode rows:
+//     dA  = dO_h V_h^T                       (16 rows x N1)      4 MFMAs per 16 nodes
+//     dS  = a (dA - <dO_h, O_h>) / 4         softmax backward, never written to memory
+//     dQ_h = dS K_h                          contraction over nodes
+//     dK_h += dS^T Q_h ,  dV_h += a^T dO_h   contractions over rows, accumulated in registers
+// The node contraction wants dS with the ROW on the lane (B operand), the row contractions want the NODE on the
+// lane (A operand); instead of transposing 16 x 112 values through LDS per tile, dA is formed in both
+// orientations (dO V^T and V dO^T: 4 extra MFMAs per 16 nodes) and the weights a are loaded in both layouts
+// (the second read hits L1/L2).  Operand maps (lane l, lo = l & 15, hi = l >> 4):
+//     A[i = lo][k = hi]   B[k = hi][j = lo]   D[i = 4 hi + reg][j = lo]
+// and a k-slot may stand for any node / row as long as both operands agree (node 16 nt + 4 hi + v for
+// the dQ product, row 4 hi + v for dK / dV), which is what lets D tiles feed the next MFMA directly.
+// =============================================================================================
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
+
+template <int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void glimpse_bwd_mfma_kernel(
+    const float* __restrict__ rowA, const float* __restrict__ dO, const float* __restrict__ rowO,
+    const float* __restrict__ rowQ, const float* __restrict__ Kmat, const float* __restrict__ Vmat,
+    float* __restrict__ dQ, float* __restrict__ dKp, float* __restrict__ dVp, int B, int R, int N1,
+    size_t rowA_rows, size_t rowO_rows, size_t rowQ_rows, int splits) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lo = lane & 15, hi = lane >> 4;
+    const int bh = blockIdx.y, b = bh >> 3, h = bh & 7;
+    const int split = blockIdx.x;
+
+    float vop[NT][4], kop[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = 16 * nt + lo;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            vop[nt][kk] = (n < N1) ? Vmat[((size_t)b * N1 + n) * ELG_E + h * 16 + 4 * kk + hi] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int n2 = 16 * nt + 4 * hi + v;
+            kop[nt][v] = (n2 < N1) ? Kmat[((size_t)b * N1 + n2) * ELG_E + h * 16 + lo] : 0.f;
+        }
+    }
+    f32x4 dKacc[NT], dVacc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { dKacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dVacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const int ntile = (R + 15) >> 4;
+    const int per = (ntile + splits - 1) / splits;
+    const int t_lo = split * per, t_hi = min(ntile, t_lo + per);
+    const float* Abh = rowA + (size_t)bh * rowA_rows * N1;
+    for (int tile = t_lo + wave; tile < t_hi; tile += 4) {
+        const int r0 = tile << 4;
+        const int rT = r0 + lo;                                    // row of this lane in the row-on-lane layout
+        const bool okT = rT < R;
+        const int rTc = okT ? rT : 0;
+        // ---- weights a in both layouts
+        float a1[NT][4], aT[NT][4];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = 16 * nt + lo;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int r = r0 + 4 * hi + v;
+                a1[nt][v] = (r < R && n < N1) ? Abh[(size_t)r * N1 + n] : 0.f;
+            }
+            const int n2 = 16 * nt + 4 * hi;
+            const float* ap = Abh + (size_t)rTc * N1 + n2;
+            if (n2 + 3 < N1) {
+                const f4u t = *reinterpret_cast<const f4u*>(ap);
+                aT[nt][0] = t.x; aT[nt][1] = t.y; aT[nt][2] = t.z; aT[nt][3] = t.w;
+            } else {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) aT[nt][v] = (n2 + v < N1) ? ap[v] : 0.f;
+            }
+            if (!okT) { aT[nt][0] = 0.f; aT[nt][1] = 0.f; aT[nt][2] = 0.f; aT[nt][3] = 0.f; }
+        }
+        // ---- the 16-wide operands of the tile
+        float doA[4], oA[4], doB[4], qB[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float x = dO[((size_t)b * R + rTc) * ELG_E + h * 16 + 4 * kk + hi];
+            const float y = rowO[((size_t)b * rowO_rows + rTc) * ELG_E + h * 16 + 4 * kk + hi];
+            doA[kk] = okT ? x : 0.f;
+            oA[kk] = okT ? y : 0.f;
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = r0 + 4 * hi + v;
+            const int rc = (r < R) ? r : 0;
+            const float x = dO[((size_t)b * R + rc) * ELG_E + h * 16 + lo];
+            const float y = rowQ[((size_t)b * rowQ_rows + rc) * ELG_E + h * 16 + lo];
+            doB[v] = (r < R) ? x : 0.f;
+            qB[v] = (r < R) ? y : 0.f;
+        }
+        // <dO_h, O_h> per row: partial over this lane's 4 channels, summed over the 4 lane groups
+        float doto = doA[0] * oA[0];
+        doto = fmaf(doA[1], oA[1], doto); doto = fmaf(doA[2], oA[2], doto); doto = fmaf(doA[3], oA[3], doto);
+        doto += shfl_xor(doto, 16);
+        doto += shfl_xor(doto, 32);                                // row lo, in every lane
+        float dv[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) dv[v] = __shfl(doto, 4 * hi + v);   // row 4 hi + v
+        f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x4 dA = {0.f, 0.f, 0.f, 0.f}, dAT = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                dA = __builtin_amdgcn_mfma_f32_16x16x4f32(doA[kk], vop[nt][kk], dA, 0, 0, 0);
+                dAT = __builtin_amdgcn_mfma_f32_16x16x4f32(vop[nt][kk], doA[kk], dAT, 0, 0, 0);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float ds1 = 0.25f * a1[nt][v] * (dA[v] - dv[v]);        // node lo, row 4 hi + v
+                dKacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds1, qB[v], dKacc[nt], 0, 0, 0);
+                dVacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[nt][v], doB[v], dVacc[nt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float ds2 = 0.25f * aT[nt][v] * (dAT[v] - doto);        // node 16 nt + 4 hi + v, row lo
+                dq = __builtin_amdgcn_mfma_f32_16x16x4f32(kop[nt][v], ds2, dq, 0, 0, 0);
+            }
+        }
+        if (okT) *reinterpret_cast<float4*>(dQ + ((size_t)b * R + rT) * ELG_E + h * 16 + 4 * hi) =
+                     make_float4(dq[0], dq[1], dq[2], dq[3]);
+    }
+    // ---- sum the four waves' dK_h / dV_h and write this split's partial (B,N1,128) image
+    float* my = lds + (size_t)wave * (2 * NT * 256);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int idx = (16 * nt + 4 * hi + v) * 16 + lo;
+            my[idx] = dKacc[nt][v];
+            my[NT * 256 + idx] = dVacc[nt][v];
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * NT * 256; i += 256) {
+        const float sum = (lds[i] + lds[2 * NT * 256 + i]) + (lds[4 * NT * 256 + i] + lds[6 * NT * 256 + i]);
+        const int which = i / (NT * 256), idx = i % (NT * 256);
+        const int n = idx >> 4, d = idx & 15;
+        if (n < N1) {
+            float* out = which ? dVp : dKp;
+            out[(((size_t)split * B + b) * N1 + n) * ELG_E + h * 16 + d] = sum;
+        }
+    }
+}
+
+template <int NT>
+static int launch_glimpse_bwd_mfma(const float* rowA, const float* dO, const float* rowO, const float* rowQ,
+                                   const float* Kmat, const float* Vmat, float* dQ, float* dKp, float* dVp, int B,
+                                   int R, int N1, size_t ra, size_t ro, size_t rq, int splits, hipStream_t stream) {
+    const size_t lds = (size_t)4 * 2 * NT * 256 * sizeof(float);
+    auto kern = glimpse_bwd_mfma_kernel<NT>;
+    static bool attr_done = false;
+    if (!attr_done && lds > 65536) {
+        (void)hipGetLastError();
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return fail(ELG_ELAUNCH, "glimpse_bwd_fused: hipFuncSetAttribute failed");
+        attr_done = true;
+    }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3(splits, B * 8), dim3(256), lds, stream, rowA, dO, rowO, rowQ, Kmat, Vmat, dQ, dKp,
+                       dVp, B, R, N1, ra, ro, rq, splits);
+    return launch_status("glimpse_bwd_fused");
+}
+
 }  // namespace elg
 
 using namespace elg;
+
+extern "C" int elg_glimpse_bwd_fused(const float* rowA, const float* dO, const float* rowO, const float* rowQ,
+                                     const float* Kmat, const float* Vmat, float* dQ, float* dK_part, float* dV_part,
+                                     int B, int R, int N1, int64_t rowA_rows, int64_t rowO_rows, int64_t rowQ_rows,
+                                     int splits, void* stream) {
+    if (rowA_rows < R || rowO_rows < R || rowQ_rows < R) return fail(ELG_EINVAL, "glimpse_bwd_fused: row strides smaller than R");
+    if (B <= 0 || R <= 0 || N1 <= 1 || splits <= 0) return fail(ELG_EINVAL, "glimpse_bwd_fused: bad sizes");
+    if (N1 > 128) return fail(ELG_ENOTIMPL, "glimpse_bwd_fused: N1 > 128 not built (use elg_glimpse_rows_bwd)");
+    hipStream_t s = (hipStream_t)stream;
+    const int nt = (N1 + 15) / 16;
+#define ELG_GB(NT) return launch_glimpse_bwd_mfma<NT>(rowA, dO, rowO, rowQ, Kmat, Vmat, dQ, dK_part, dV_part, B, R, N1, \
+                                                      (size_t)rowA_rows, (size_t)rowO_rows, (size_t)rowQ_rows, splits, s)
+    if (nt <= 2) ELG_GB(2);
+    if (nt <= 4) ELG_GB(4);
+    if (nt <= 7) ELG_GB(7);
+    ELG_GB(8);
+#undef ELG_GB
+}
 
 extern "C" int elg_glimpse_rows_bwd(const float* rowA, const float* dO, const float* rowO, const float* Kmat,
                                     const float* Vmat, float* dS, float* dQ, int B, int R, int N1,

@@ -472,12 +472,24 @@ class _ChosenProbs(torch.autograd.Function):
         def heads(x):                                               # (B,X,128) -> (B,H,X,16)
             return x.view(B, x.shape[1], H, DK).permute(0, 2, 1, 3)
         dO = torch.bmm(rowDL, PKt)                                  # (B,R,128)   d o = d s . PK
-        dS = torch.empty(B, H, R, N1, device=dev)                   # d(q.K)
         dQ = torch.empty(B, R, E, device=dev)
-        L.check(L.lib().elg_glimpse_rows_bwd(_ptr(rowA), _ptr(dO), _ptr(rowO), _ptr(Kt), _ptr(Vt), _ptr(dS), _ptr(dQ),
-                                             B, R, N1, rowA_rows, rowO_rows, _stream()), "elg_glimpse_rows_bwd")
-        dK = torch.matmul(dS.transpose(2, 3), heads(rowQ)).permute(0, 2, 1, 3).reshape(B, N1, E)
-        dV = torch.matmul(rowA_v.transpose(2, 3), heads(dO)).permute(0, 2, 1, 3).reshape(B, N1, E)
+        if N1 <= 128 and os.environ.get("ELG_FUSED_GLIMPSE_BWD", "1") != "0":
+            # one MFMA launch: dS stays in registers, dQ / dK / dV come out directly
+            splits = max(1, min(8, 512 // (B * H)))
+            dKp = torch.empty(splits, B, N1, E, device=dev)
+            dVp = torch.empty(splits, B, N1, E, device=dev)
+            L.check(L.lib().elg_glimpse_bwd_fused(_ptr(rowA), _ptr(dO), _ptr(rowO), _ptr(rowQ), _ptr(Kt), _ptr(Vt),
+                                                  _ptr(dQ), _ptr(dKp), _ptr(dVp), B, R, N1, rowA_rows, rowO_rows,
+                                                  rowQ.stride(0) // E, splits, _stream()), "elg_glimpse_bwd_fused")
+            dK = dKp[0] if splits == 1 else dKp.sum(0)
+            dV = dVp[0] if splits == 1 else dVp.sum(0)
+        else:
+            dS = torch.empty(B, H, R, N1, device=dev)               # d(q.K)
+            L.check(L.lib().elg_glimpse_rows_bwd(_ptr(rowA), _ptr(dO), _ptr(rowO), _ptr(Kt), _ptr(Vt), _ptr(dS),
+                                                 _ptr(dQ), B, R, N1, rowA_rows, rowO_rows, _stream()),
+                    "elg_glimpse_rows_bwd")
+            dK = torch.matmul(dS.transpose(2, 3), heads(rowQ)).permute(0, 2, 1, 3).reshape(B, N1, E)
+            dV = torch.matmul(rowA_v.transpose(2, 3), heads(dO)).permute(0, 2, 1, 3).reshape(B, N1, E)
         dPK = torch.bmm(rowDL.transpose(1, 2), rowO_v)
         dpb = rowDL.sum(dim=1)
         # dQ1[n] = sum of dQ over the rows whose query was gathered at node n: a one-hot GEMM (deterministic,

@@ -171,6 +171,18 @@ int elg_glimpse_rows_bwd(const float* rowA, const float* dO, const float* rowO, 
                          int64_t rowA_rows, int64_t rowO_rows, void* stream);
 /* rowA_rows / rowO_rows: rows per (instance[, head]) in the rowA / rowO buffers (>= R; R for dense buffers). */
 
+/* Whole glimpse backward of an instance batch in one launch on the matrix cores (v_mfma_f32_16x16x4_f32; the
+ * autograd of models.py:478-500 + the K/V projections' inputs): per decode row r and head h
+ *     dS = a (dO_h V_h^T - <dO_h, O_h>) / 4 (kept in registers),  dQ_h = dS K_h,
+ *     dK_h = sum_r dS^T Q_h,  dV_h = sum_r a^T dO_h.
+ * rowA (B,8,rowA_rows,N1); dO, dQ (B,R,128); rowO (B,rowO_rows,128); rowQ (B,rowQ_rows,128); Kmat, Vmat (B,N1,128);
+ * dK_part, dV_part (splits,B,N1,128): partial sums over `splits` contiguous row ranges (the caller adds them).
+ * N1 <= 128. */
+int elg_glimpse_bwd_fused(const float* rowA, const float* dO, const float* rowO, const float* rowQ,
+                          const float* Kmat, const float* Vmat, float* dQ, float* dK_part, float* dV_part,
+                          int B, int R, int N1, int64_t rowA_rows, int64_t rowO_rows, int64_t rowQ_rows,
+                          int splits, void* stream);
+
 /* fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32, exact f32) for the encoder's nn.Linear layers and
  * their backward (reference CVRP/models.py:240-269,550-561):
  *   C[M,N] (+)= op(A)[M,K] op(B)[K,N] (+ bias[N]) (ReLU);  transA: A stored KxM;  transB: B stored NxK.
