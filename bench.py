@@ -102,8 +102,9 @@ def main():
     model.to(dev)
     parallel.broadcast_parameters(model)
     env = CVRPEnv(multi_width=POMO, device=dev)
-    opt = torch.optim.Adam(model.parameters(), lr=cfg["params"]["learning_rate"], weight_decay=1e-6, fused=True)
-    bucket = parallel.GradBucket(model.parameters()) if world > 1 else None
+    from elg_amd.optim import Adam
+    opt = Adam(model.parameters(), lr=cfg["params"]["learning_rate"], weight_decay=1e-6)
+    bucket = parallel.GradBucket(model.parameters(), opt) if world > 1 else None
     dist_cfg = dict(cfg["distribution"], data_type="uniform")
 
     # time the persistent rollout kernel with HIP events on the launch stream (torch's current stream)

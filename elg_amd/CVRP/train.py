@@ -12,12 +12,13 @@ import sys
 import numpy as np
 import torch
 import yaml
-from torch.optim import Adam as Optimizer
+from elg_amd.optim import Adam as Optimizer      # one-launch Adam, torch.optim.Adam-compatible checkpoints
 from torch.utils.data import DataLoader
 
 if __package__ in (None, ""):                      # `cd elg_amd/CVRP && python train.py`, as the reference is run
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
+from elg_amd import engine as eng
 from elg_amd import parallel
 from elg_amd.CVRP.CVRPEnv import CVRPEnv
 from elg_amd.CVRP.CVRPModel import CVRPModel
@@ -32,7 +33,9 @@ def softmax(x):
 
 def pomo_loss(probs, rewards, scale_norm=True):
     """reference train.py:112-121: shared baseline = mean reward over the POMO trajectories of an instance."""
-    advantage = rewards - rewards.mean(dim=1)[:, None]
+    if probs.is_cuda:
+        return eng.pomo_loss(probs, rewards, scale_norm)           # fused HIP kernel (csrc/elg_train.hip)
+    advantage = rewards - rewards.mean(dim=1)[:, None]              # host tensors (unit tests of the formula)
     J = -advantage * probs.log().sum(dim=1)
     if scale_norm:
         J = J / advantage.max(dim=1)[0][:, None]
@@ -90,7 +93,7 @@ def train(model, training, T, start_steps, train_steps, mixed, train_batch_size,
     distribution_ = dict(distribution)
     gaps = np.array([1, 1, 1])
     optimizer = Optimizer(model.parameters(), lr=lr, weight_decay=1e-6)
-    bucket = parallel.GradBucket(model.parameters()) if world > 1 else None
+    bucket = parallel.GradBucket(model.parameters(), optimizer) if world > 1 else None
     local_batch = train_batch_size // world
     for i in range(train_steps - start_steps + 1):
         model.train()
@@ -99,7 +102,7 @@ def train(model, training, T, start_steps, train_steps, mixed, train_batch_size,
             model.decoder.add_local_policy(device)
             parallel.broadcast_parameters(model)
             optimizer = Optimizer(model.parameters(), lr=lr, weight_decay=1e-6)
-            bucket = parallel.GradBucket(model.parameters()) if world > 1 else None
+            bucket = parallel.GradBucket(model.parameters(), optimizer) if world > 1 else None
         if mixed:
             kind = np.random.choice(['uniform', 'cluster', 'mixed'], size=1, p=softmax(gaps))[0]
             if world > 1:                                           # every rank must draw the same family

@@ -9,11 +9,12 @@ import sys
 import numpy as np
 import torch
 import yaml
-from torch.optim import Adam as Optimizer
+from elg_amd.optim import Adam as Optimizer      # one-launch Adam, torch.optim.Adam-compatible checkpoints
 
 if __package__ in (None, ""):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
+from elg_amd import engine as eng
 from elg_amd import parallel
 from elg_amd.TSP.TSPEnv import TSPEnv
 from elg_amd.TSP.TSPModel import TSPModel
@@ -23,7 +24,9 @@ from elg_amd.TSP.utils import Logger, check_feasible, rollout, seed_everything
 
 def pomo_loss(probs, rewards, scale_norm=True):
     """reference TSP/train.py:107-118 (scale only when no instance has a zero normaliser)."""
-    advantage = rewards - rewards.mean(dim=1)[:, None]
+    if probs.is_cuda:
+        return eng.pomo_loss(probs, rewards, scale_norm, guard_zero=True)   # fused HIP kernel (csrc/elg_train.hip)
+    advantage = rewards - rewards.mean(dim=1)[:, None]              # host tensors (unit tests of the formula)
     J = -advantage * probs.log().sum(dim=1)
     if scale_norm:
         norm_fac = advantage.max(dim=1)[0][:, None]
@@ -53,7 +56,7 @@ def train(model, training, T, start_steps, train_steps, mixed, train_batch_size,
     env = TSPEnv(multi_width=multiple_width, device=device)
     distribution_ = dict(distribution)
     optimizer = Optimizer(model.parameters(), lr=lr, weight_decay=1e-6)
-    bucket = parallel.GradBucket(model.parameters()) if world > 1 else None
+    bucket = parallel.GradBucket(model.parameters(), optimizer) if world > 1 else None
     for i in range(train_steps - start_steps + 1):
         model.train()
         if (i == T - start_steps) and training == 'joint':
@@ -61,7 +64,7 @@ def train(model, training, T, start_steps, train_steps, mixed, train_batch_size,
             model.decoder.add_local_policy(device)
             parallel.broadcast_parameters(model)
             optimizer = Optimizer(model.parameters(), lr=lr, weight_decay=1e-6)
-            bucket = parallel.GradBucket(model.parameters()) if world > 1 else None
+            bucket = parallel.GradBucket(model.parameters(), optimizer) if world > 1 else None
         distribution_['data_type'] = 'uniform' if not mixed else str(np.random.choice(['uniform', 'cluster', 'mixed']))
         batch = generate_tsp_data(batch_size=train_batch_size // world, problem_size=problem_size, distribution=distribution_)
         train_step(model, env, optimizer, batch, scale_norm, bucket, world)

@@ -48,7 +48,8 @@ class BwdArgs(C.Structure):
 
 
 EXPORTS = ["elg_version", "elg_last_error", "elg_aug8", "elg_dist_matrix", "elg_nbr_tables", "elg_route_length",
-           "elg_rollout_fwd", "elg_rollout_bwd", "elg_glimpse_rows_bwd", "elg_glimpse_bwd_fused", "elg_gemm_f32"]
+           "elg_rollout_fwd", "elg_rollout_bwd", "elg_glimpse_rows_bwd", "elg_glimpse_bwd_fused", "elg_gemm_f32",
+           "elg_pomo_loss", "elg_rows_prep", "elg_adam_step"]
 
 _lib = None
 
@@ -79,8 +80,13 @@ def lib() -> C.CDLL:
         L.elg_glimpse_rows_bwd.argtypes = [f, f, f, f, f, f, f, i, i, i, C.c_int64, C.c_int64, f]
         L.elg_glimpse_bwd_fused.argtypes = [f, f, f, f, f, f, f, f, f, i, i, i, C.c_int64, C.c_int64, C.c_int64, i, f]
         L.elg_gemm_f32.argtypes = [f, f, f, f, i, i, i, i, i, i, i, i, i, i, f]
+        i64, fl = C.c_int64, C.c_float
+        L.elg_pomo_loss.argtypes = [f, f, i, i, i, i64, i64, f, f, f, f, f, f]
+        L.elg_rows_prep.argtypes = [f, f, f, f, f, f, f, f, f, f, f, i, i, i, i, i, i64, i, fl, f]
+        L.elg_adam_step.argtypes = [f, f, f, i, f, f, f, i64, fl, fl, fl, fl, fl, i64, fl, f]
         for n in ("elg_aug8", "elg_dist_matrix", "elg_nbr_tables", "elg_route_length", "elg_rollout_fwd",
-                  "elg_rollout_bwd", "elg_glimpse_rows_bwd", "elg_glimpse_bwd_fused", "elg_gemm_f32"):
+                  "elg_rollout_bwd", "elg_glimpse_rows_bwd", "elg_glimpse_bwd_fused", "elg_gemm_f32",
+                  "elg_pomo_loss", "elg_rows_prep", "elg_adam_step"):
             getattr(L, n).restype = C.c_int
         _lib = L
     return _lib

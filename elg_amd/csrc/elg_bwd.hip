@@ -585,6 +585,13 @@ static int dispatch_bwd(const elg_bwd_args& BA, hipStream_t stream) {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
 
+// Node order inside a 16-node chunk nt: position p = 4 q + e (q = p >> 2, e = p & 3) stands for node
+// min(16 nt + 4 q, N1 - 4) + e, i.e. the natural order except that the 4-node groups that would cross the end of
+// the row are pulled back to end exactly at N1 - 1.  Every group is then a full in-bounds 16-byte run of the
+// row (one unguarded dwordx4 load), at the price of re-visiting up to 3 nodes: the re-visits ("non-owners",
+// node < the group's natural start) get a zero K operand and their dK / dV rows are not stored.
+__device__ __forceinline__ int grp_start(int nt, int q, int N1) { return min(16 * nt + 4 * q, N1 - 4); }
+
 template <int NT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void glimpse_bwd_mfma_kernel(
     const float* __restrict__ rowA, const float* __restrict__ dO, const float* __restrict__ rowO,
@@ -592,24 +599,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float* __restrict__ dQ, float* __restrict__ dKp, float* __restrict__ dVp, int B, int R, int N1,
     size_t rowA_rows, size_t rowO_rows, size_t rowQ_rows, int splits) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // LDS: [K operand image: NT*4 x 64] then the 4 x 2 x NT*256 reduction buffer
+    float* sK = lds;
+    float* sRed = lds + NT * 256;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lo = lane & 15, hi = lane >> 4;
     const int bh = blockIdx.y, b = bh >> 3, h = bh & 7;
     const int split = blockIdx.x;
 
-    float vop[NT][4], kop[NT][4];
+    // V operand (registers; A operand of V dO^T and B operand of dO V^T): node of position lo, channel 4 kk + hi
+    float vop[NT][4];
+    unsigned gl[NT];                                               // node of position lo per chunk
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int n = 16 * nt + lo;
+        gl[nt] = (unsigned)(grp_start(nt, lo >> 2, N1) + (lo & 3));
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
-            vop[nt][kk] = (n < N1) ? Vmat[((size_t)b * N1 + n) * ELG_E + h * 16 + 4 * kk + hi] : 0.f;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int n2 = 16 * nt + 4 * hi + v;
-            kop[nt][v] = (n2 < N1) ? Kmat[((size_t)b * N1 + n2) * ELG_E + h * 16 + lo] : 0.f;
-        }
+            vop[nt][kk] = Vmat[((size_t)b * N1 + gl[nt]) * ELG_E + h * 16 + 4 * kk + hi];
     }
+    // K operand image in LDS (A operand of K^T dS^T): entry (nt, v) of lane (hi, lo) = K[node of (hi, v)][lo],
+    // zero for non-owners.  Written by wave 0 .. 3 in slices, read by every wave once per tile.
+    for (int e = wave; e < NT * 4; e += 4) {
+        const int nt = e >> 2, v = e & 3;
+        const int g = grp_start(nt, hi, N1) + v;
+        const bool own = g >= 16 * nt + 4 * hi;
+        const float x = Kmat[((size_t)b * N1 + g) * ELG_E + h * 16 + lo];
+        sK[e * 64 + lane] = own ? x : 0.f;
+    }
+    __syncthreads();
     f32x4 dKacc[NT], dVacc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { dKacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dVacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -618,49 +635,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int per = (ntile + splits - 1) / splits;
     const int t_lo = split * per, t_hi = min(ntile, t_lo + per);
     const float* Abh = rowA + (size_t)bh * rowA_rows * N1;
-    for (int tile = t_lo + wave; tile < t_hi; tile += 4) {
-        const int r0 = tile << 4;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    for (int tile = t_lo + wave_u; tile < t_hi; tile += 4) {
+        const int r0 = tile << 4;                                  // wave-uniform
         const int rT = r0 + lo;                                    // row of this lane in the row-on-lane layout
-        const bool okT = rT < R;
-        const int rTc = okT ? rT : 0;
-        // ---- weights a in both layouts
+        // ---- weights a in both layouts.  No load is guarded: the compiler turns `ok ? load : 0` (and any
+        // if / else around loads) into branches with their own vmcnt(0) waits, which serialises the ~40 loads
+        // of a tile (27 us per tile instead of one memory latency).  Rows past R are clamped to the last valid
+        // row (finite duplicates): they meet zeroed Q / dO operands in dK / dV and an unstored dQ column.
+        const float* __restrict__ At = Abh + (size_t)r0 * N1;
+        const int rleft = R - 1 - r0;                              // last valid row of the tile, relative
+        unsigned off1[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) off1[v] = (unsigned)(min(4 * hi + v, rleft) * N1);
+        const unsigned offT = (unsigned)(min(lo, rleft) * N1);
         float a1[NT][4], aT[NT][4];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int n = 16 * nt + lo;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int r = r0 + 4 * hi + v;
-                a1[nt][v] = (r < R && n < N1) ? Abh[(size_t)r * N1 + n] : 0.f;
-            }
-            const int n2 = 16 * nt + 4 * hi;
-            const float* ap = Abh + (size_t)rTc * N1 + n2;
-            if (n2 + 3 < N1) {
-                const f4u t = *reinterpret_cast<const f4u*>(ap);
-                aT[nt][0] = t.x; aT[nt][1] = t.y; aT[nt][2] = t.z; aT[nt][3] = t.w;
-            } else {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) aT[nt][v] = (n2 + v < N1) ? ap[v] : 0.f;
-            }
-            if (!okT) { aT[nt][0] = 0.f; aT[nt][1] = 0.f; aT[nt][2] = 0.f; aT[nt][3] = 0.f; }
+            for (int v = 0; v < 4; ++v) a1[nt][v] = At[off1[v] + gl[nt]];          // row 4 hi + v, position lo
+            const f4u t = *reinterpret_cast<const f4u*>(At + (offT + (unsigned)grp_start(nt, hi, N1)));
+            aT[nt][0] = t.x; aT[nt][1] = t.y; aT[nt][2] = t.z; aT[nt][3] = t.w;   // row lo, positions 4 hi + v
         }
-        // ---- the 16-wide operands of the tile
+        // ---- the 16-wide operands of the tile (Q / dO rows past R must be exact zeros: multiply by a 0/1 mask)
+        const float* __restrict__ dOt = dO + ((size_t)b * R + r0) * ELG_E + h * 16;
+        const float* __restrict__ Ot = rowO + ((size_t)b * rowO_rows + r0) * ELG_E + h * 16;
+        const float* __restrict__ Qt = rowQ + ((size_t)b * rowQ_rows + r0) * ELG_E + h * 16;
         float doA[4], oA[4], doB[4], qB[4];
+        const unsigned offA = (unsigned)(min(lo, rleft) * ELG_E + hi);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const float x = dO[((size_t)b * R + rTc) * ELG_E + h * 16 + 4 * kk + hi];
-            const float y = rowO[((size_t)b * rowO_rows + rTc) * ELG_E + h * 16 + 4 * kk + hi];
-            doA[kk] = okT ? x : 0.f;
-            oA[kk] = okT ? y : 0.f;
+            doA[kk] = dOt[offA + 4 * kk];
+            oA[kk] = Ot[offA + 4 * kk];
         }
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const int r = r0 + 4 * hi + v;
-            const int rc = (r < R) ? r : 0;
-            const float x = dO[((size_t)b * R + rc) * ELG_E + h * 16 + lo];
-            const float y = rowQ[((size_t)b * rowQ_rows + rc) * ELG_E + h * 16 + lo];
-            doB[v] = (r < R) ? x : 0.f;
-            qB[v] = (r < R) ? y : 0.f;
+            const int rr = 4 * hi + v;
+            const unsigned offB = (unsigned)(min(rr, rleft) * ELG_E + lo);
+            const float mk = (rr <= rleft) ? 1.f : 0.f;
+            doB[v] = dOt[offB] * mk;
+            qB[v] = Qt[offB] * mk;
         }
         // <dO_h, O_h> per row: partial over this lane's 4 channels, summed over the 4 lane groups
         float doto = doA[0] * oA[0];
@@ -681,21 +695,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const float ds1 = 0.25f * a1[nt][v] * (dA[v] - dv[v]);        // node lo, row 4 hi + v
+                const float ds1 = 0.25f * a1[nt][v] * (dA[v] - dv[v]);        // position lo, row 4 hi + v
                 dKacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds1, qB[v], dKacc[nt], 0, 0, 0);
                 dVacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[nt][v], doB[v], dVacc[nt], 0, 0, 0);
             }
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const float ds2 = 0.25f * aT[nt][v] * (dAT[v] - doto);        // node 16 nt + 4 hi + v, row lo
-                dq = __builtin_amdgcn_mfma_f32_16x16x4f32(kop[nt][v], ds2, dq, 0, 0, 0);
+                const float ds2 = 0.25f * aT[nt][v] * (dAT[v] - doto);        // position 4 hi + v, row lo
+                dq = __builtin_amdgcn_mfma_f32_16x16x4f32(sK[(nt * 4 + v) * 64 + lane], ds2, dq, 0, 0, 0);
             }
         }
-        if (okT) *reinterpret_cast<float4*>(dQ + ((size_t)b * R + rT) * ELG_E + h * 16 + 4 * hi) =
-                     make_float4(dq[0], dq[1], dq[2], dq[3]);
+        if (rT < R) *reinterpret_cast<float4*>(dQ + ((size_t)b * R + rT) * ELG_E + h * 16 + 4 * hi) =
+                        make_float4(dq[0], dq[1], dq[2], dq[3]);
     }
-    // ---- sum the four waves' dK_h / dV_h and write this split's partial (B,N1,128) image
-    float* my = lds + (size_t)wave * (2 * NT * 256);
+    // ---- sum the four waves' dK_h / dV_h and write this split's partial (B,N1,128) image.
+    // D rows are positions 4 hi + v of chunk nt; position -> node, owners only.
+    float* my = sRed + (size_t)wave * (2 * NT * 256);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -706,12 +721,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * NT * 256; i += 256) {
-        const float sum = (lds[i] + lds[2 * NT * 256 + i]) + (lds[4 * NT * 256 + i] + lds[6 * NT * 256 + i]);
+        const float sum = (sRed[i] + sRed[2 * NT * 256 + i]) + (sRed[4 * NT * 256 + i] + sRed[6 * NT * 256 + i]);
         const int which = i / (NT * 256), idx = i % (NT * 256);
-        const int n = idx >> 4, d = idx & 15;
-        if (n < N1) {
+        const int pos = idx >> 4, d = idx & 15;
+        const int nt = pos >> 4, q = (pos >> 2) & 3;
+        const int g = grp_start(nt, q, N1) + (pos & 3);
+        if (g >= 16 * nt + 4 * q) {                                 // owner (implies g < N1)
             float* out = which ? dVp : dKp;
-            out[(((size_t)split * B + b) * N1 + n) * ELG_E + h * 16 + d] = sum;
+            out[(((size_t)split * B + b) * N1 + g) * ELG_E + h * 16 + d] = sum;
         }
     }
 }
@@ -720,7 +737,7 @@ template <int NT>
 static int launch_glimpse_bwd_mfma(const float* rowA, const float* dO, const float* rowO, const float* rowQ,
                                    const float* Kmat, const float* Vmat, float* dQ, float* dKp, float* dVp, int B,
                                    int R, int N1, size_t ra, size_t ro, size_t rq, int splits, hipStream_t stream) {
-    const size_t lds = (size_t)4 * 2 * NT * 256 * sizeof(float);
+    const size_t lds = (size_t)(NT * 256 + 4 * 2 * NT * 256) * sizeof(float);
     auto kern = glimpse_bwd_mfma_kernel<NT>;
     static bool attr_done = false;
     if (!attr_done && lds > 65536) {
@@ -745,7 +762,7 @@ extern "C" int elg_glimpse_bwd_fused(const float* rowA, const float* dO, const f
                                      int B, int R, int N1, int64_t rowA_rows, int64_t rowO_rows, int64_t rowQ_rows,
                                      int splits, void* stream) {
     if (rowA_rows < R || rowO_rows < R || rowQ_rows < R) return fail(ELG_EINVAL, "glimpse_bwd_fused: row strides smaller than R");
-    if (B <= 0 || R <= 0 || N1 <= 1 || splits <= 0) return fail(ELG_EINVAL, "glimpse_bwd_fused: bad sizes");
+    if (B <= 0 || R <= 0 || N1 < 4 || splits <= 0) return fail(ELG_EINVAL, "glimpse_bwd_fused: bad sizes");
     if (N1 > 128) return fail(ELG_ENOTIMPL, "glimpse_bwd_fused: N1 > 128 not built (use elg_glimpse_rows_bwd)");
     hipStream_t s = (hipStream_t)stream;
     const int nt = (N1 + 15) / 16;

@@ -397,7 +397,9 @@ class _ChosenProbs(torch.autograd.Function):
         ctx.save_for_backward(actions, Kt, Vt, PKt, pbt, Q1t, Q2t if Q2t is not None else Kt.new_empty(0),
                               wlt if wlt is not None else Kt.new_empty(0), loct if loct is not None else Kt.new_empty(0))
         ctx.has = (Q2t is not None, wlt is not None, loct is not None)
-        return probs_val.clone()
+        out = probs_val.contiguous().clone()
+        ctx.probs_out = out.detach()
+        return out
 
     @staticmethod
     def backward(ctx, gprob):
@@ -427,19 +429,19 @@ class _ChosenProbs(torch.autograd.Function):
             # rows saved by the training forward (time-major r = t*M + m): no glimpse replay needed
             rowA, rowO_rows = rows.A, rows.Rcap
             rowO, rowQ = rows.O, rows.Q[:, :R]
-            tt = torch.arange(T, device=dev)[None, :, None]
             t0 = 1 if prob.kind == L.PROBLEM_TSP else 2
-            valid = (tt >= t0) & (tt < ctx.tlen[:, None, :])                                # decoded steps only
-            W = (g * ctx.probs_val[:, :T, :] * valid).reshape(B, R)                         # gp * p_sel per row
-            sel_tm = fl.permute(0, 2, 1).reshape(B, R)
-            rowDL = rows.PC[:, :R] * (-W)[:, :, None]                                       # -p c W
-            rowDL.scatter_add_(2, sel_tm[:, :, None], (W * rows.Csel[:, :R])[:, :, None])   # + c_sel W at the chosen node
+            # one launch: row weights (decoded steps only), d loss / d score rows, local-policy cotangents and
+            # the query-gather scatter matrices
+            rowDL = torch.empty(B, R, N1, device=dev)
+            rowDU = torch.empty(B, R, 48, device=dev) if meta.has_local else None
+            onehotP = torch.empty(B, R, N1, device=dev)
+            onehotF = torch.empty(B, R, N1, device=dev) if hasQ2 else None
+            L.check(L.lib().elg_rows_prep(_ptr(g), _ptr(ctx.probs_out), _ptr(ctx.tlen), _ptr(actions), _ptr(rows.PC),
+                                          _ptr(rows.Csel), _ptr(rows.Slot), _ptr(rowDL), _ptr(rowDU), _ptr(onehotP),
+                                          _ptr(onehotF), B, T, M, N1, actions.shape[2], rows.Rcap, t0,
+                                          float(meta.inv_ens), _stream()), "elg_rows_prep")
             rowLoad = rows.Load[:, :R] if haswl else None
-            prev = torch.cat([torch.zeros(B, 1, M, dtype=torch.long, device=dev), fl.permute(0, 2, 1)[:, :-1]], dim=1).reshape(B, R)
-            first = fl[:, :, 0][:, None, :].expand(B, T, M).reshape(B, R) if hasQ2 else None
             if meta.has_local:
-                slot = rows.Slot[:, :R].long()
-                rowDU = (torch.gather(rowDL, 2, slot.clamp(min=0)) * (slot >= 0) * meta.inv_ens).contiguous()
                 ba.rowDU, ba.time_major, ba.local_only, ba.row_stride = _ptr(rowDU), 1, 1, R
                 # the local-policy replay is independent of the dense glimpse/pointer backward: run it on a
                 # side stream so its latency-bound waves overlap the bandwidth-bound GEMM / row kernels
@@ -494,12 +496,13 @@ class _ChosenProbs(torch.autograd.Function):
         dpb = rowDL.sum(dim=1)
         # dQ1[n] = sum of dQ over the rows whose query was gathered at node n: a one-hot GEMM (deterministic,
         # and ~4x faster than 1.6 M float atomics into 100 rows)
-        onehot = torch.zeros(B, R, N1, device=dev).scatter_(2, prev[:, :, None], 1.0)
-        dQ1 = torch.bmm(onehot.transpose(1, 2), dQ)
+        if not use_saved:
+            onehotP = torch.zeros(B, R, N1, device=dev).scatter_(2, prev[:, :, None], 1.0)
+            onehotF = torch.zeros(B, R, N1, device=dev).scatter_(2, first[:, :, None], 1.0) if hasQ2 else None
+        dQ1 = torch.bmm(onehotP.transpose(1, 2), dQ)
         dQ2 = dwl = None
         if hasQ2:
-            onehot = torch.zeros(B, R, N1, device=dev).scatter_(2, first[:, :, None], 1.0)
-            dQ2 = torch.bmm(onehot.transpose(1, 2), dQ)
+            dQ2 = torch.bmm(onehotF.transpose(1, 2), dQ)
         if haswl:
             dwl = torch.einsum("br,bre->e", rowLoad, dQ)
         if join_side is not None:
@@ -515,3 +518,44 @@ def chosen_probs(prob: Problem, pol: Policy, M: int, res: RolloutResult, T: int,
     return _ChosenProbs.apply(prob, pol, M, res.actions, res.probs[:, :T, :], T, geometry,
                               t["K"], t["V"], t["PK"], t["pb"], t["Q1"], t.get("Q2"), t.get("wl"), pol.loc,
                               rows, getattr(res, "rows_gen", -1), res.tlen)
+
+
+# ----------------------------------------------------------------------------------------------
+# REINFORCE / POMO loss (one launch forward, one elementwise op backward)
+# ----------------------------------------------------------------------------------------------
+class _PomoLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, probs, rewards, scale_norm, guard_zero):
+        B, T, M = probs.shape
+        if probs.stride(2) != 1:
+            probs = probs.contiguous()
+        rewards = rewards.contiguous().float()
+        dev = probs.device
+        scal = torch.empty(3, B, device=dev)                       # J_raw, J_scaled, adv_max
+        coef = torch.empty(2, B, M, device=dev)                    # raw, scaled
+        L.check(L.lib().elg_pomo_loss(_ptr(probs), _ptr(rewards), B, T, M, probs.stride(0), probs.stride(1),
+                                      _ptr(scal[0]), _ptr(scal[1]), _ptr(scal[2]), _ptr(coef[0]), _ptr(coef[1]),
+                                      _stream()), "elg_pomo_loss")
+        if not scale_norm:
+            J, c = scal[0].sum(), coef[0]
+        elif guard_zero:                                           # TSP/train.py:113-116, decided on the device
+            zero = (scal[2] == 0).any()
+            J = torch.where(zero, scal[0].sum(), scal[1].sum())
+            c = torch.where(zero, coef[0], coef[1])
+        else:
+            J, c = scal[1].sum(), coef[1]
+        ctx.save_for_backward(probs, c)
+        ctx.scale = 1.0 / (B * M)
+        return J * ctx.scale
+
+    @staticmethod
+    def backward(ctx, gout):
+        probs, c = ctx.saved_tensors
+        return (gout * ctx.scale) * c[:, None, :] / probs, None, None, None
+
+
+def pomo_loss(probs: torch.Tensor, rewards: torch.Tensor, scale_norm: bool = True, guard_zero: bool = False):
+    """mean over (instance, trajectory) of -advantage * sum_t log p, advantage = reward - POMO mean
+    (reference CVRP/train.py:112-121; guard_zero = the TSP variant's batch-wide zero-normaliser check)."""
+    _need_cuda(probs, "probs")
+    return _PomoLoss.apply(probs.float(), rewards, bool(scale_norm), bool(guard_zero))

@@ -30,16 +30,29 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
 
 
 class GradBucket:
-    """Flat fp32 bucket holding every parameter gradient; one all-reduce(SUM) + 1/world scale."""
+    """Flat fp32 bucket holding every parameter gradient; one all-reduce(SUM) + 1/world scale.
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    With `optimizer` = elg_amd.optim.Adam the gradients are packed into its flat buffer by one batched copy, the
+    all-reduce runs on that buffer, and the 1/world factor is folded into the Adam kernel (no scatter back)."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], optimizer=None):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         dev = self.params[0].device
-        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.optimizer = optimizer if hasattr(optimizer, "grad_flat") else None
+        if self.optimizer is not None:
+            assert self.optimizer.numel == self.numel
+            self.flat = self.optimizer.grad_flat
+        else:
+            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
 
     def allreduce(self, world: int):
         if world <= 1:
+            return
+        if self.optimizer is not None:
+            self.optimizer.gather_grads()
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.optimizer.grad_scale = 1.0 / world
             return
         off = 0
         for p in self.params:

@@ -183,6 +183,36 @@ int elg_glimpse_bwd_fused(const float* rowA, const float* dO, const float* rowO,
                           int B, int R, int N1, int64_t rowA_rows, int64_t rowO_rows, int64_t rowQ_rows,
                           int splits, void* stream);
 
+/* ---- training-step glue (one launch each instead of chains of framework kernels) ----------------------------
+ * REINFORCE / POMO loss with the shared baseline (reference CVRP/train.py:112-121, TSP/train.py:107-118):
+ *   adv = reward - mean_m reward;  J[b,m] = -adv * sum_t log probs[b,t,m];  scaled: J / max_m adv.
+ * probs is (B,T,M) with element strides (probs_bstride, probs_tstride, 1).  Outputs per instance: J_raw[b] and
+ * J_scaled[b] = sum_m J, adv_max[b], and coef_*[b,m] = d(sum J)/d(sum_t log p[b,.,m]).  The caller picks the variant
+ * and divides by B*M (the reference's .mean()). */
+int elg_pomo_loss(const float* probs, const float* reward, int B, int T, int M, int64_t probs_bstride,
+                  int64_t probs_tstride, float* J_raw, float* J_scaled, float* adv_max, float* coef_raw,
+                  float* coef_scaled, void* stream);
+
+/* Cotangent rows of the decoder backward from the rows saved by a training forward (time-major r = t*M + m):
+ *   w = gprob * pval * [first_decode_step <= t < tlen[b,m]]
+ *   rowDL[b,r,n] = w (Csel [n == action] - PC[n]);  rowDU[b,r,j] = rowDL[b,r,Slot[j]] * inv_ens (0 for empty slots)
+ *   onehot_prev[b,r,n] = [n == action at t-1 (0 at t = 0)],  onehot_first[b,r,n] = [n == action at t = 0]
+ * gprob, pval (B,T,M) dense; tlen (B,M); actions (B,M,Tcap_actions); PC (B,Rcap,N1); Csel (B,Rcap); Slot (B,Rcap,48);
+ * outputs dense over R = T*M rows.  rowDU / onehot_* may be NULL. */
+int elg_rows_prep(const float* gprob, const float* pval, const int32_t* tlen, const int32_t* actions,
+                  const float* PC, const float* Csel, const int32_t* Slot, float* rowDL, float* rowDU,
+                  float* onehot_prev, float* onehot_first, int B, int T, int M, int N1, int Tcap_actions,
+                  int64_t Rcap, int first_decode_step, float inv_ens, void* stream);
+
+/* torch.optim.Adam update (L2 weight decay added to the gradient, bias correction; reference train.py:101) over n
+ * floats in one launch.  grad / exp_avg / exp_avg_sq are flat.  Parameters: either flat (`param`), or left in place
+ * and addressed through `param_table[k]` (device array of n_tensors device pointers) with element i of the flat
+ * index space belonging to tensor k iff offsets[k] <= i < offsets[k+1] (device array, n_tensors+1 entries).
+ * `step` counts from 1; grad is multiplied by grad_scale first (1/world for summed data-parallel gradients). */
+int elg_adam_step(float* param, float* const* param_table, const int64_t* offsets, int n_tensors, const float* grad,
+                  float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int64_t step, float grad_scale, void* stream);
+
 /* fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32, exact f32) for the encoder's nn.Linear layers and
  * their backward (reference CVRP/models.py:240-269,550-561):
  *   C[M,N] (+)= op(A)[M,K] op(B)[K,N] (+ bias[N]) (ReLU);  transA: A stored KxM;  transB: B stored NxK.

@@ -108,6 +108,7 @@ def test_train_step_against_reference_train():
     from elg_amd import _lib as L, engine as eng
     from elg_amd.CVRP.CVRPEnv import CVRPEnv
     from elg_amd.CVRP.train import pomo_loss
+    from elg_amd.optim import Adam
     fx = gu.load_golden("cvrp_train_n20.npz")
     B, N, M, wseed, rseed = [int(x) for x in fx["meta"]]
     mp = dict(gu.CVRP_MODEL_PARAMS)
@@ -124,7 +125,7 @@ def test_train_step_against_reference_train():
     probs = eng.chosen_probs(env.problem, pol, M, res, T)
     np.testing.assert_allclose(probs.detach().cpu().numpy(), fx["probs"], rtol=5e-4)
     np.testing.assert_allclose(res.reward.cpu().numpy(), fx["rewards"], rtol=1e-5)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-6)
+    opt = Adam(model.parameters(), lr=1e-4, weight_decay=1e-6)
     w0 = {k: v.detach().clone() for k, v in model.named_parameters()}
     opt.zero_grad()
     J = pomo_loss(probs, torch.from_numpy(fx["rewards"]).to(DEV), True)
@@ -167,13 +168,14 @@ def test_fused_training_step_runs_and_learns():
     from elg_amd.CVRP.generate_data import generate_vrp_data
     from elg_amd.CVRP.train import train_step
     from elg_amd.CVRP.utils import seed_everything
+    from elg_amd.optim import Adam
     mp = dict(gu.CVRP_MODEL_PARAMS)
     outs = []
     for rep in range(2):
         seed_everything(11)
         model = _model(mp, 21).train()
         env = CVRPEnv(20, DEV)
-        opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-6)
+        opt = Adam(model.parameters(), lr=1e-4, weight_decay=1e-6)
         batch = generate_vrp_data(8, 20, dict(data_type="uniform"))
         J, rew = train_step(model, env, opt, batch, True)
         assert torch.isfinite(J) and torch.isfinite(rew).all()
