@@ -34,7 +34,7 @@ class RolloutArgs(C.Structure):
         ("st_cur", _vp), ("st_cnt", _vp), ("st_fin", _vp), ("st_first", _vp), ("st_load", _vp), ("st_len", _vp),
         ("st_vis", _vp),
         ("actions", _vp), ("probs", _vp), ("reward", _vp), ("tlen", _vp), ("full_probs", _vp),
-        ("trA", _vp), ("trPC", _vp), ("trCsel", _vp), ("trQ", _vp), ("trO", _vp), ("trLoad", _vp), ("trSlot", _vp),
+        ("trA", _vp), ("trPC", _vp), ("trCsel", _vp), ("trQ", _vp), ("trO", _vp), ("trLoad", _vp), ("trSlot", _vp), ("trF", _vp),
     ]
 
 
@@ -49,7 +49,7 @@ class BwdArgs(C.Structure):
 
 EXPORTS = ["elg_version", "elg_last_error", "elg_aug8", "elg_dist_matrix", "elg_nbr_tables", "elg_route_length",
            "elg_rollout_fwd", "elg_rollout_bwd", "elg_glimpse_rows_bwd", "elg_glimpse_bwd_fused", "elg_gemm_f32",
-           "elg_pomo_loss", "elg_rows_prep", "elg_adam_step"]
+           "elg_pomo_loss", "elg_rows_prep", "elg_adam_step", "elg_local_bwd_rows"]
 
 _lib = None
 
@@ -83,10 +83,11 @@ def lib() -> C.CDLL:
         i64, fl = C.c_int64, C.c_float
         L.elg_pomo_loss.argtypes = [f, f, i, i, i, i64, i64, f, f, f, f, f, f]
         L.elg_rows_prep.argtypes = [f, f, f, f, f, f, f, f, f, f, f, i, i, i, i, i, i64, i, fl, f]
+        L.elg_local_bwd_rows.argtypes = [f, f, f, f, f, i, i, i64, i, f]
         L.elg_adam_step.argtypes = [f, f, f, i, f, f, f, i64, fl, fl, fl, fl, fl, i64, fl, f]
         for n in ("elg_aug8", "elg_dist_matrix", "elg_nbr_tables", "elg_route_length", "elg_rollout_fwd",
                   "elg_rollout_bwd", "elg_glimpse_rows_bwd", "elg_glimpse_bwd_fused", "elg_gemm_f32",
-                  "elg_pomo_loss", "elg_rows_prep", "elg_adam_step"):
+                  "elg_pomo_loss", "elg_rows_prep", "elg_adam_step", "elg_local_bwd_rows"):
             getattr(L, n).restype = C.c_int
         _lib = L
     return _lib

@@ -252,14 +252,24 @@ __device__ __forceinline__ FwdOut decode_step(const elg_rollout_args& A, const I
     // ---- k-NN slots + distance penalty + local policy (slot layout)
     float addval = 0.f;          // per-slot additive term (penalty + local score)
     int snid = -1;               // node of this lane's slot
+    int ssave = -1;              // what the backward needs to know about the slot
+    float sf0 = 0.f, sf1 = 0.f, sf2 = 0.f;
     if (A.has_penalty || A.has_local) {
         const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb);
         snid = S.snid;
+        ssave = (S.smask && S.snid >= 0) ? -2 : S.snid;              // present but masked (the CVRP depot slot)
+        sf0 = S.f0; sf1 = S.f1; sf2 = S.f2;
         float u = 0.f;
         if (A.has_local) u = local_policy<TSP>(I.loc, lane, S.f0, S.f1, S.f2, S.smask, nullptr);
         addval = S.pen + u * A.inv_ens;
     }
-    if (TRAIN && A.trSlot && lane < ELG_SLOT_STRIDE) A.trSlot[(b * Rcap + r) * ELG_SLOT_STRIDE + lane] = snid;
+    if (TRAIN && A.trSlot && lane < ELG_SLOT_STRIDE) {
+        A.trSlot[(b * Rcap + r) * ELG_SLOT_STRIDE + lane] = ssave;
+        if (A.trF) {
+            float* fr = A.trF + (b * Rcap + r) * (3 * ELG_SLOT_STRIDE) + lane;
+            fr[0] = sf0; fr[ELG_SLOT_STRIDE] = sf1; fr[2 * ELG_SLOT_STRIDE] = sf2;
+        }
+    }
 
     // ---- glimpse + pointer
     constexpr int NG = GlimpseGroups<NCH, SMALL>::value;

@@ -1,0 +1,469 @@
+// Local-policy backward over independent decode rows, on the matrix cores.
+//
+// The training forward saves, per decode row r = (trajectory, step), the features f_j and the node of each k-NN
+// slot j; elg_rows_prep turns the loss gradient into du_j = d loss / d u_j.  Given those, rows are independent,
+// so instead of replaying every trajectory step by step (one wavefront per trajectory, ~600 dependent cross-lane
+// operations per row) a wavefront takes 16 rows at once and every contraction with a shared folded table becomes
+// v_mfma_f32_16x16x4_f32 (exact f32).  Math (reference models.py:133-166, folded as in elg_rollout.h):
+//   sc_h[j]  = la[h].f_j + lt[j][h]            alpha_h = softmax_j(sc_h)          F_h = sum_j alpha_h[j] f_j
+//   o'[d]    = sum_j alpha_{h(d)}[j] lcv[j][d] + lAv[d].F_{h(d)}                  g' = lWc o' + lbc
+//   u_j      = lpe[j].g' + (sum_d g'[d] lWe[d]).f_j
+// backward for the tables only (the features carry no gradient):
+//   dw = sum_j du_j f_j      dg' = lpe^T du + lWe dw      do' = lWc^T dg'      dF_h = sum_{d in h} do'[d] lAv[d]
+//   dalpha_h[j] = sum_{d in h} lcv[j][d] do'[d] + dF_h.f_j      dsc_h = alpha_h (dalpha_h - <alpha_h, dalpha_h>)
+//   d lpe = du (x) g'   d lWe = g' (x) dw   d lbc = dg'   d lWc = dg' (x) o'   d lAv[d] = do'[d] F_{h(d)}
+//   d lcv[j][d] = alpha_{h(d)}[j] do'[d]   d lt[j][h] = dsc_h[j]   d la[h] = sum_j dsc_h[j] f_j       (summed over rows)
+//
+// Layouts (lane l: lo = l & 15, hi = l >> 4).  MFMA: A[i = lo][k = hi], B[k = hi][j = lo], D[i = 4 hi + reg][j = lo].
+//   L1 "feature-major": X1[t][v] = X[feature 16 t + 4 hi + v][row lo]   -- what a D tile looks like when the row is
+//       the B operand's column; it feeds the next feature contraction directly as a B operand (k-slot hi of step
+//       v <-> feature 16 t + 4 hi + v).  The whole per-row chain runs in L1.
+//   L2 "row-major":     X2[t][v] = X[row 4 hi + v][feature 16 t + lo]   -- both operands of a contraction over rows
+//       (the table gradients) must look like this.  L2 copies come from a 16 x 16 transpose through per-wave LDS
+//       (one ds_write_b128 + four ds_read_b32 per tile, conflict-free with a 20-float pitch).
+#include "elg_common.h"
+#include "elg_rollout.h"
+#include "../../include/elg_hip.h"
+#include <string>
+
+namespace elg {
+int fail(int code, const std::string& msg);
+int launch_status(const char* what);
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+#define ELG_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+constexpr int LP = 33;                       // padded pitch of the 32-wide tables in LDS
+constexpr int TP = 20;                       // pitch of a transpose tile
+constexpr int S_LCV = 0;                     // [48][33]
+constexpr int S_LPE = S_LCV + 48 * LP;       // [48][33]
+constexpr int S_LWC = S_LPE + 48 * LP;       // [32][33]
+constexpr int S_LT = S_LWC + 32 * LP;        // [48][4]
+constexpr int S_LAV = S_LT + 48 * 4;         // [32][3]
+constexpr int S_LWE = S_LAV + 96;            // [32][3]
+constexpr int S_LBC = S_LWE + 96;            // [32]
+constexpr int S_TABLES = S_LBC + 32;         // = 4640 floats
+constexpr int S_TR = 16 * TP;                // one transpose tile (320 floats)
+constexpr int NTRB = 4;                      // transpose buffers per wave
+
+// X (L1 or L2 tile in registers) -> X^T in the same register layout, through the per-wave buffer `buf`.
+__device__ __forceinline__ f32x4 transpose16(f32x4 x, float* buf, int lo, int hi) {
+    *reinterpret_cast<float4*>(buf + lo * TP + 4 * hi) = make_float4(x[0], x[1], x[2], x[3]);
+    wave_lds_fence();
+    f32x4 y;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) y[v] = buf[(4 * hi + v) * TP + lo];
+    wave_lds_fence();
+    return y;
+}
+
+template <int JT>
+__global__ __launch_bounds__(256) void local_bwd_rows_kernel(const float* __restrict__ loc, const float* __restrict__ trF,
+                                                             const int* __restrict__ trSlot,
+                                                             const float* __restrict__ rowDU, float* __restrict__ gloc,
+                                                             int B, int R, long long Rcap) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lo = lane & 15, hi = lane >> 4;
+    float* sT = lds;                                            // tables
+    float* trb = lds + S_TABLES + wave * (NTRB * S_TR);         // this wave's transpose buffers
+    float* sAcc = lds + S_TABLES + 4 * NTRB * S_TR;             // ELG_LOC_SIZE accumulators of the workgroup
+    // ---- stage the tables (padded pitches) and clear the accumulators
+    for (int i = tid; i < 48 * 32; i += 256) {
+        const int j = i >> 5, d = i & 31;
+        sT[S_LCV + j * LP + d] = loc[ELG_LOC_LCV + i];
+        sT[S_LPE + j * LP + d] = loc[ELG_LOC_LPE + i];
+    }
+    for (int i = tid; i < 32 * 32; i += 256) sT[S_LWC + (i >> 5) * LP + (i & 31)] = loc[ELG_LOC_LWC + i];
+    for (int i = tid; i < 48 * 4; i += 256) sT[S_LT + i] = loc[ELG_LOC_LT + i];
+    for (int i = tid; i < 96; i += 256) { sT[S_LAV + i] = loc[ELG_LOC_LAV + i]; sT[S_LWE + i] = loc[ELG_LOC_LWE + i]; }
+    for (int i = tid; i < 32; i += 256) sT[S_LBC + i] = loc[ELG_LOC_LBC + i];
+    for (int i = tid; i < ELG_LOC_SIZE; i += 256) sAcc[i] = 0.f;
+    float la[ELG_LH][3];                                         // uniform
+#pragma unroll
+    for (int h = 0; h < ELG_LH; ++h)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) la[h][k] = loc[ELG_LOC_LA + 3 * h + k];
+    __syncthreads();
+
+    // ---- table-gradient accumulators
+    f32x4 aLpe[JT][2], aLcv[JT][2], aLwc[2][2], aLav[2], aLwe[2];
+    float aLbc[2], aLt[ELG_LH][JT], aLa[ELG_LH][3];
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) { aLpe[jt][0] = z4; aLpe[jt][1] = z4; aLcv[jt][0] = z4; aLcv[jt][1] = z4; }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) { aLwc[a][0] = z4; aLwc[a][1] = z4; aLav[a] = z4; aLwe[a] = z4; aLbc[a] = 0.f; }
+#pragma unroll
+    for (int h = 0; h < ELG_LH; ++h) {
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) aLt[h][jt] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) aLa[h][k] = 0.f;
+    }
+
+    const int tiles_per_b = (R + 15) >> 4;
+    const long long ntiles = (long long)B * tiles_per_b;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    for (long long tile = (long long)blockIdx.x * 4 + wave_u; tile < ntiles; tile += (long long)gridDim.x * 4) {
+        const int b = (int)(tile / tiles_per_b);
+        const int row0 = (int)(tile % tiles_per_b) << 4;
+        const int rleft = R - 1 - row0;                          // last valid row of the tile, relative (>= 0)
+        // ---- L1 loads: row lo (clamped; rows past R get du = 0 and so contribute nothing)
+        const int rl = min(lo, rleft);
+        const float live = (lo <= rleft) ? 1.f : 0.f;
+        const float* duRow = rowDU + ((size_t)b * R + row0 + rl) * ELG_SLOT_STRIDE + 4 * hi;
+        f32x4 du1[JT];
+        bool any = false;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            const float4 t = *reinterpret_cast<const float4*>(duRow + 16 * jt);
+            du1[jt] = f32x4{t.x * live, t.y * live, t.z * live, t.w * live};
+            any = any || du1[jt][0] != 0.f || du1[jt][1] != 0.f || du1[jt][2] != 0.f || du1[jt][3] != 0.f;
+        }
+        if (!__ballot(any)) continue;                            // first moves / finished trajectories / padding
+        const size_t src = (size_t)b * Rcap + row0 + rl;
+        const int* slRow = trSlot + src * ELG_SLOT_STRIDE + 4 * hi;
+        const float* fRow = trF + src * (3 * ELG_SLOT_STRIDE) + 4 * hi;
+        f32x4 f1[3][JT];
+        bool msk[JT][4];
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            const int4 sl = *reinterpret_cast<const int4*>(slRow + 16 * jt);
+            msk[jt][0] = sl.x < 0; msk[jt][1] = sl.y < 0; msk[jt][2] = sl.z < 0; msk[jt][3] = sl.w < 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float4 t = *reinterpret_cast<const float4*>(fRow + k * ELG_SLOT_STRIDE + 16 * jt);
+                f1[k][jt] = f32x4{t.x, t.y, t.z, t.w};
+            }
+        }
+        // ---- forward recompute: attention weights, F, o', g'   (L1)
+        f32x4 al[ELG_LH][JT];
+        float F[ELG_LH][3];
+#pragma unroll
+        for (int h = 0; h < ELG_LH; ++h) {
+            float mx = ELG_NEG_INF;
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    float s = sT[S_LT + (16 * jt + 4 * hi + v) * 4 + h];
+                    s = fmaf(la[h][0], f1[0][jt][v], s);
+                    s = fmaf(la[h][1], f1[1][jt][v], s);
+                    s = fmaf(la[h][2], f1[2][jt][v], s);
+                    s = msk[jt][v] ? ELG_NEG_INF : s;
+                    al[h][jt][v] = s;
+                    mx = fmaxf(mx, s);
+                }
+            mx = fmaxf(mx, shfl_xor(mx, 16));
+            mx = fmaxf(mx, shfl_xor(mx, 32));
+            float den = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float e = msk[jt][v] ? 0.f : __expf(al[h][jt][v] - mx);
+                    al[h][jt][v] = e;
+                    den += e;
+                }
+            den += shfl_xor(den, 16);
+            den += shfl_xor(den, 32);
+            const float inv = den > 0.f ? 1.0f / den : 0.f;
+            float fk[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float a = al[h][jt][v] * inv;
+                    al[h][jt][v] = a;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) fk[k] = fmaf(a, f1[k][jt][v], fk[k]);
+                }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                fk[k] += shfl_xor(fk[k], 16);
+                fk[k] += shfl_xor(fk[k], 32);
+                F[h][k] = fk[k];
+            }
+        }
+        float dw[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) dw[k] = fmaf(du1[jt][v], f1[k][jt][v], dw[k]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { dw[k] += shfl_xor(dw[k], 16); dw[k] += shfl_xor(dw[k], 32); }
+
+        const bool up = hi >= 2;                                 // rows 4 hi + v of a d-tile belong to head 2 dt + up
+        f32x4 o1[2], g1[2], dg1[2], do1[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            f32x4 Pa = z4, Pb = z4;
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float a = sT[S_LCV + (16 * jt + 4 * hi + v) * LP + 16 * dt + lo];
+                    Pa = ELG_MFMA(a, al[2 * dt][jt][v], Pa);
+                    Pb = ELG_MFMA(a, al[2 * dt + 1][jt][v], Pb);
+                }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int d = 16 * dt + 4 * hi + v;
+                float x = up ? Pb[v] : Pa[v];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) x = fmaf(sT[S_LAV + 3 * d + k], up ? F[2 * dt + 1][k] : F[2 * dt][k], x);
+                o1[dt][v] = x;
+            }
+        }
+#pragma unroll
+        for (int dq = 0; dq < 2; ++dq) {                         // g'[d'] tile dq
+            f32x4 acc;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[v] = sT[S_LBC + 16 * dq + 4 * hi + v];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    acc = ELG_MFMA(sT[S_LWC + (16 * dq + lo) * LP + 16 * dt + 4 * hi + v], o1[dt][v], acc);
+            g1[dq] = acc;
+        }
+        // ---- backward chain (L1)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            f32x4 acc = z4;
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    acc = ELG_MFMA(sT[S_LPE + (16 * jt + 4 * hi + v) * LP + 16 * dt + lo], du1[jt][v], acc);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int d = 16 * dt + 4 * hi + v;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) acc[v] = fmaf(sT[S_LWE + 3 * d + k], dw[k], acc[v]);
+            }
+            dg1[dt] = acc;
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            f32x4 acc = z4;
+#pragma unroll
+            for (int dq = 0; dq < 2; ++dq)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    acc = ELG_MFMA(sT[S_LWC + (16 * dq + 4 * hi + v) * LP + 16 * dt + lo], dg1[dq][v], acc);
+            do1[dt] = acc;
+        }
+        float dF[ELG_LH][3];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float part = 0.f;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) part = fmaf(do1[dt][v], sT[S_LAV + 3 * (16 * dt + 4 * hi + v) + k], part);
+                part += shfl_xor(part, 16);                      // the two hi groups of one head
+                dF[2 * dt][k] = __shfl(part, lo, ELG_WAVE);       // held by hi = 0, 1
+                dF[2 * dt + 1][k] = __shfl(part, lo + 32, ELG_WAVE);   // held by hi = 2, 3
+            }
+        // per head: dalpha, dsc; d la in place; dsc / alpha transposed for d lt / d lcv
+        f32x4 o2[2], g2[2], dg2[2], do2[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            o2[dt] = transpose16(o1[dt], trb + 0 * S_TR, lo, hi);
+            g2[dt] = transpose16(g1[dt], trb + 1 * S_TR, lo, hi);
+            dg2[dt] = transpose16(dg1[dt], trb + 2 * S_TR, lo, hi);
+            do2[dt] = transpose16(do1[dt], trb + 3 * S_TR, lo, hi);
+        }
+#pragma unroll
+        for (int h = 0; h < ELG_LH; ++h) {
+            const int dt = h >> 1;
+            const bool mine = up == bool(h & 1);                 // this lane's d rows belong to head h
+            f32x4 dob;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) dob[v] = mine ? do1[dt][v] : 0.f;
+            f32x4 dal[JT];
+            float ts = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                f32x4 acc = z4;
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    acc = ELG_MFMA(sT[S_LCV + (16 * jt + lo) * LP + 16 * dt + 4 * hi + v], dob[v], acc);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) acc[v] = fmaf(dF[h][k], f1[k][jt][v], acc[v]);
+                    ts = fmaf(al[h][jt][v], acc[v], ts);
+                }
+                dal[jt] = acc;
+            }
+            ts += shfl_xor(ts, 16);
+            ts += shfl_xor(ts, 32);
+            const bool lane_lo_half = lo < 8;
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                f32x4 dsc;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    dsc[v] = al[h][jt][v] * (dal[jt][v] - ts);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) aLa[h][k] = fmaf(dsc[v], f1[k][jt][v], aLa[h][k]);
+                }
+                const f32x4 dsc2 = transpose16(dsc, trb + 0 * S_TR, lo, hi);      // [row 4 hi + v][slot 16 jt + lo]
+                aLt[h][jt] += (dsc2[0] + dsc2[1]) + (dsc2[2] + dsc2[3]);
+                const f32x4 al2 = transpose16(al[h][jt], trb + 1 * S_TR, lo, hi);
+                // d lcv[j][d] += alpha_h[r][j] do'[r][d] for the 8 channels d of head h (columns lo of tile dt)
+                const bool col = lane_lo_half == !(h & 1);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) aLcv[jt][dt] = ELG_MFMA(al2[v], col ? do2[dt][v] : 0.f, aLcv[jt][dt]);
+            }
+        }
+        // ---- remaining table gradients: contractions over the 16 rows (L2 operands)
+        const int rr = min(4 * hi, rleft);
+        (void)rr;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            f32x4 du2;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int r = 4 * hi + v;
+                const float x = rowDU[((size_t)b * R + row0 + min(r, rleft)) * ELG_SLOT_STRIDE + 16 * jt + lo];
+                du2[v] = x * ((r <= rleft) ? 1.f : 0.f);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) aLpe[jt][dt] = ELG_MFMA(du2[v], g2[dt][v], aLpe[jt][dt]);
+        }
+#pragma unroll
+        for (int dq = 0; dq < 2; ++dq)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) aLwc[dq][dt] = ELG_MFMA(dg2[dq][v], o2[dt][v], aLwc[dq][dt]);
+        // F and dw as row-major tiles: feature column c = 3 h + k (12 of 16) / c = k (3 of 16)
+        f32x4 Ft, dwt;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            // element c = 4 hi + v of this row (row = lo): F flattened as c = 3 h + k
+            float x0 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 12; ++c) x0 = (4 * hi + v == c) ? F[c / 3][c % 3] : x0;
+            Ft[v] = x0;
+            dwt[v] = (hi == 0 && v < 3) ? dw[v] : 0.f;
+        }
+        const f32x4 F2 = transpose16(Ft, trb + 2 * S_TR, lo, hi);               // [row 4 hi + v][c = lo]
+        const f32x4 dw2 = transpose16(dwt, trb + 3 * S_TR, lo, hi);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                aLav[dt] = ELG_MFMA(do2[dt][v], F2[v], aLav[dt]);                // D[d = 16 dt + 4 hi + v'][c = lo]
+                aLwe[dt] = ELG_MFMA(g2[dt][v], dw2[v], aLwe[dt]);
+            }
+            aLbc[dt] += (dg2[dt][0] + dg2[dt][1]) + (dg2[dt][2] + dg2[dt][3]);  // column d = 16 dt + lo, rows 4 hi + v
+        }
+    }
+
+    // ---- fold this wave's accumulators into the workgroup's image of the table gradient, then one flush
+#pragma unroll
+    for (int h = 0; h < ELG_LH; ++h) {
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) { aLt[h][jt] += shfl_xor(aLt[h][jt], 16); aLt[h][jt] += shfl_xor(aLt[h][jt], 32); }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) aLa[h][k] = wave_sum(aLa[h][k]);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) { aLbc[dt] += shfl_xor(aLbc[dt], 16); aLbc[dt] += shfl_xor(aLbc[dt], 32); }
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int j = 16 * jt + 4 * hi + v, d = 16 * dt + lo;
+                        sAcc[ELG_LOC_LPE + 32 * j + d] += aLpe[jt][dt][v];
+                        sAcc[ELG_LOC_LCV + 32 * j + d] += aLcv[jt][dt][v];
+                    }
+#pragma unroll
+            for (int dq = 0; dq < 2; ++dq)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        sAcc[ELG_LOC_LWC + 32 * (16 * dq + 4 * hi + v) + 16 * dt + lo] += aLwc[dq][dt][v];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int d = 16 * dt + 4 * hi + v, h = d >> 3;
+                    // D[d][c]: d lAv[d][k] sits at column c = 3 h(d) + k, d lWe[d][k] at column c = k
+                    if (lo >= 3 * h && lo < 3 * h + 3) sAcc[ELG_LOC_LAV + 3 * d + (lo - 3 * h)] += aLav[dt][v];
+                    if (lo < 3) sAcc[ELG_LOC_LWE + 3 * d + lo] += aLwe[dt][v];
+                }
+            if (hi == 0) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) sAcc[ELG_LOC_LBC + 16 * dt + lo] += aLbc[dt];
+#pragma unroll
+                for (int h = 0; h < ELG_LH; ++h)
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt) sAcc[ELG_LOC_LT + 4 * (16 * jt + lo) + h] += aLt[h][jt];
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int h = 0; h < ELG_LH; ++h)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) sAcc[ELG_LOC_LA + 3 * h + k] += aLa[h][k];
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < ELG_LOC_SIZE; i += 256) {
+        const float v = sAcc[i];
+        if (v != 0.f) atomicAdd(gloc + i, v);
+    }
+}
+
+}  // namespace elg
+
+using namespace elg;
+
+extern "C" int elg_local_bwd_rows(const float* loc, const float* trF, const int32_t* trSlot, const float* rowDU,
+                                  float* gloc, int B, int R, int64_t Rcap, int n_slots, void* stream) {
+    if (!loc || !trF || !trSlot || !rowDU || !gloc) return fail(ELG_EINVAL, "local_bwd_rows: null buffer");
+    if (B <= 0 || R <= 0 || Rcap < R) return fail(ELG_EINVAL, "local_bwd_rows: bad sizes");
+    if (n_slots <= 0 || n_slots > ELG_SLOT_STRIDE) return fail(ELG_EINVAL, "local_bwd_rows: local_size must be <= 47");
+    const size_t lds = (size_t)(S_TABLES + 4 * NTRB * S_TR + ELG_LOC_SIZE) * sizeof(float);
+    const long long ntiles = (long long)B * ((R + 15) / 16);
+    const int grid = (int)std::min<long long>((ntiles + 3) / 4, 256);   // 464 registers: one workgroup per CU
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipGetLastError();
+    if (n_slots <= 32) {
+        static bool done = false;
+        if (!done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(local_bwd_rows_kernel<2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return fail(ELG_ELAUNCH, "local_bwd_rows: hipFuncSetAttribute failed");
+            done = true;
+        }
+        hipLaunchKernelGGL(local_bwd_rows_kernel<2>, dim3(grid), dim3(256), lds, s, loc, trF, trSlot, rowDU, gloc, B, R,
+                           (long long)Rcap);
+    } else {
+        static bool done = false;
+        if (!done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(local_bwd_rows_kernel<3>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return fail(ELG_ELAUNCH, "local_bwd_rows: hipFuncSetAttribute failed");
+            done = true;
+        }
+        hipLaunchKernelGGL(local_bwd_rows_kernel<3>, dim3(grid), dim3(256), lds, s, loc, trF, trSlot, rowDU, gloc, B, R,
+                           (long long)Rcap);
+    }
+    return launch_status("local_bwd_rows");
+}

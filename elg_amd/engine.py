@@ -310,9 +310,10 @@ class TrainRows:
         self.O = torch.empty(B, Rcap, E, device=dev)
         self.Load = torch.empty(B, Rcap, device=dev)
         self.Slot = torch.empty(B, Rcap, 48, device=dev, dtype=torch.int32)
+        self.F = torch.empty(B, Rcap, 3, 48, device=dev)
         # zero ONCE: afterwards every value ever written is finite, and the backward multiplies the rows of
         # undecoded steps (first moves, finished trajectories) by an exactly-zero weight, so stale rows are inert
-        for t in (self.A, self.PC, self.Csel, self.Q, self.O, self.Load):
+        for t in (self.A, self.PC, self.Csel, self.Q, self.O, self.Load, self.F):
             t.zero_()
         self.Slot.fill_(-1)
         self.gen = 0
@@ -372,7 +373,7 @@ def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mo
         rows = TrainRows.get(B, M, N1, Tcap, dev)
         rows.prepare()
         a.trA, a.trPC, a.trCsel, a.trQ, a.trO = _ptr(rows.A), _ptr(rows.PC), _ptr(rows.Csel), _ptr(rows.Q), _ptr(rows.O)
-        a.trLoad, a.trSlot = _ptr(rows.Load), _ptr(rows.Slot)
+        a.trLoad, a.trSlot, a.trF = _ptr(rows.Load), _ptr(rows.Slot), _ptr(rows.F)
     L.check(L.lib().elg_rollout_fwd(C.byref(a), _stream()), "elg_rollout_fwd")
     res = RolloutResult(actions, probs, reward, tlen, full)
     if rows is not None:
@@ -441,10 +442,14 @@ class _ChosenProbs(torch.autograd.Function):
                                           _ptr(onehotF), B, T, M, N1, actions.shape[2], rows.Rcap, t0,
                                           float(meta.inv_ens), _stream()), "elg_rows_prep")
             rowLoad = rows.Load[:, :R] if haswl else None
-            if meta.has_local:
+            if meta.has_local and os.environ.get("ELG_LOCAL_BWD_MFMA", "1") != "0":
+                # rows are independent given the saved slot features: 16 rows per wavefront on the matrix cores
+                n_slots = meta.K + (0 if prob.kind == L.PROBLEM_TSP else 1)
+                L.check(L.lib().elg_local_bwd_rows(_ptr(loct), _ptr(rows.F), _ptr(rows.Slot), _ptr(rowDU), _ptr(gloc),
+                                                   B, R, rows.Rcap, n_slots, _stream()), "elg_local_bwd_rows")
+            elif meta.has_local:
                 ba.rowDU, ba.time_major, ba.local_only, ba.row_stride = _ptr(rowDU), 1, 1, R
-                # the local-policy replay is independent of the dense glimpse/pointer backward: run it on a
-                # side stream so its latency-bound waves overlap the bandwidth-bound GEMM / row kernels
+                # per-trajectory replay of the environment + local policy (register accumulators), side stream
                 side = _side_stream(dev)
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):

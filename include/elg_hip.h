@@ -124,7 +124,8 @@ typedef struct elg_rollout_args {
     float* trQ;             /* (B,Rcap,128)   glimpse query                                     */
     float* trO;             /* (B,Rcap,128)   glimpse output                                    */
     float* trLoad;          /* (B,Rcap)       load at the step (CVRP)                           */
-    int32_t* trSlot;        /* (B,Rcap,48)    node of every k-NN slot (-1: none)                */
+    int32_t* trSlot;        /* (B,Rcap,48)    node of every k-NN slot (-1: none, -2: depot slot, masked) */
+    float* trF;             /* (B,Rcap,3,48)  local-policy features of every slot (NULL: not saved)   */
 } elg_rollout_args;
 
 /* POMO construction: CVRPEnv.reset/step + CVRPModel.one_step_rollout + utils.rollout fused into one
@@ -162,6 +163,13 @@ typedef struct elg_bwd_args {
     int64_t row_stride;     /* rows per instance in rowDU (R, or Rcap for forward-saved rows)        */
 } elg_bwd_args;
 int elg_rollout_bwd(const elg_bwd_args* args, void* stream);
+
+/* Local-policy backward over independent decode rows on the matrix cores (autograd of models.py:133-166 w.r.t.
+ * the folded tables): 16 rows per wavefront tile, every contraction with a shared table as v_mfma_f32_16x16x4_f32.
+ * loc (ELG_LOC_SIZE); trF (B,Rcap,3,48) / trSlot (B,Rcap,48) as saved by a training forward; rowDU (B,R,48) from
+ * elg_rows_prep; gloc (ELG_LOC_SIZE) accumulated (caller zeroes).  n_slots = local_size (+1 for the CVRP depot). */
+int elg_local_bwd_rows(const float* loc, const float* trF, const int32_t* trSlot, const float* rowDU, float* gloc,
+                       int B, int R, int64_t Rcap, int n_slots, void* stream);
 
 /* Row-wise part of the glimpse backward (softmax backward of models.py:478-500 on the saved weights):
  * per decode row r and head h:  dS = a (dO_h V_h^T - <dO_h, O_h>) / 4,  dQ_h = dS K_h.
