@@ -82,7 +82,7 @@ def lib() -> C.CDLL:
         L.elg_gemm_f32.argtypes = [f, f, f, f, i, i, i, i, i, i, i, i, i, i, f]
         i64, fl = C.c_int64, C.c_float
         L.elg_pomo_loss.argtypes = [f, f, i, i, i, i64, i64, f, f, f, f, f, f]
-        L.elg_rows_prep.argtypes = [f, f, f, f, f, f, f, f, f, f, f, i, i, i, i, i, i64, i, fl, f]
+        L.elg_rows_prep.argtypes = [f, f, f, f, f, f, f, f, f, f, f, f, i, i, i, i, i, i64, i, fl, f]
         L.elg_local_bwd_rows.argtypes = [f, f, f, f, f, i, i, i64, i, f]
         L.elg_adam_step.argtypes = [f, f, f, i, f, f, f, i64, fl, fl, fl, fl, fl, i64, fl, f]
         for n in ("elg_aug8", "elg_dist_matrix", "elg_nbr_tables", "elg_route_length", "elg_rollout_fwd",

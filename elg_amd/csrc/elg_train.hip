@@ -68,12 +68,15 @@ __global__ __launch_bounds__(256) void pomo_loss_kernel(const float* __restrict_
 // One wavefront per row.  w = gprob * p * valid (valid: decoded step of an unfinished trajectory);
 //   rowDL[r,n]  = w (c_sel [n == sel] - p_n c_n)           d loss / d (pre-clip score)      (PC holds p_n c_n)
 //   rowDU[r,j]  = rowDL[r, slot_j] / ensemble_size         d loss / d (local policy output of slot j)
-//   onehotP[r,n] = [n == previous node]   onehotF[r,n] = [n == first node]   (query-gather scatter matrices)
+//   onehotP[r,n] = [n == previous node]   onehotF[r,n] = [n == first node]   (query-gather scatter matrices;
+//   with `load` given, onehotP has one more column holding the vehicle load of the row, so that the same
+//   GEMM onehotP^T dQ also yields d wl = sum_r load_r dQ_r)
 __global__ __launch_bounds__(256) void rows_prep_kernel(
     const float* __restrict__ gprob, const float* __restrict__ pval, const int* __restrict__ tlen,
     const int* __restrict__ actions, const float* __restrict__ PC, const float* __restrict__ Csel,
-    const int* __restrict__ Slot, float* __restrict__ rowDL, float* __restrict__ rowDU, float* __restrict__ onehotP,
-    float* __restrict__ onehotF, int B, int T, int M, int N1, int Tcap_act, long long Rcap, int t0, float inv_ens) {
+    const int* __restrict__ Slot, const float* __restrict__ load, float* __restrict__ rowDL, float* __restrict__ rowDU,
+    float* __restrict__ onehotP, float* __restrict__ onehotF, int B, int T, int M, int N1, int Tcap_act, long long Rcap,
+    int t0, float inv_ens) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);      // over B * R
     const long long R = (long long)T * M;
@@ -93,13 +96,15 @@ __global__ __launch_bounds__(256) void rows_prep_kernel(
     const float wc = w * Csel[src];
     const float* pc = PC + src * N1;
     float* dl = rowDL + (size_t)row * N1;
+    const int pw = load ? N1 + 1 : N1;                                  // pitch of onehotP
     for (int n = lane; n < N1; n += 64) {
         float v = -w * pc[n];
         if (n == sel) v += wc;
         dl[n] = v;
-        if (onehotP) onehotP[(size_t)row * N1 + n] = (n == prev) ? 1.f : 0.f;
+        if (onehotP) onehotP[(size_t)row * pw + n] = (n == prev) ? 1.f : 0.f;
         if (onehotF) onehotF[(size_t)row * N1 + n] = (n == first) ? 1.f : 0.f;
     }
+    if (onehotP && load && lane == 0) onehotP[(size_t)row * pw + N1] = load[src];
     if (rowDU && lane < 48) {
         const int s = Slot[src * 48 + lane];
         float v = 0.f;
@@ -161,8 +166,8 @@ extern "C" int elg_pomo_loss(const float* probs, const float* reward, int B, int
 }
 
 extern "C" int elg_rows_prep(const float* gprob, const float* pval, const int32_t* tlen, const int32_t* actions,
-                             const float* PC, const float* Csel, const int32_t* Slot, float* rowDL, float* rowDU,
-                             float* onehot_prev, float* onehot_first, int B, int T, int M, int N1, int Tcap_actions,
+                             const float* PC, const float* Csel, const int32_t* Slot, const float* load, float* rowDL,
+                             float* rowDU, float* onehot_prev, float* onehot_first, int B, int T, int M, int N1, int Tcap_actions,
                              int64_t Rcap, int first_decode_step, float inv_ens, void* stream) {
     if (B <= 0 || T <= 0 || M <= 0 || N1 <= 1) return fail(ELG_EINVAL, "rows_prep: bad sizes");
     if (Rcap < (int64_t)T * M || Tcap_actions < T) return fail(ELG_EINVAL, "rows_prep: row capacity smaller than T*M");
@@ -171,7 +176,7 @@ extern "C" int elg_rows_prep(const float* gprob, const float* pval, const int32_
     const long long rows = (long long)B * T * M;
     (void)hipGetLastError();
     hipLaunchKernelGGL(rows_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, gprob, pval,
-                       tlen, actions, PC, Csel, Slot, rowDL, rowDU, onehot_prev, onehot_first, B, T, M, N1, Tcap_actions,
+                       tlen, actions, PC, Csel, Slot, load, rowDL, rowDU, onehot_prev, onehot_first, B, T, M, N1, Tcap_actions,
                        (long long)Rcap, first_decode_step, inv_ens);
     return launch_status("rows_prep");
 }

@@ -435,10 +435,11 @@ class _ChosenProbs(torch.autograd.Function):
             # the query-gather scatter matrices
             rowDL = torch.empty(B, R, N1, device=dev)
             rowDU = torch.empty(B, R, 48, device=dev) if meta.has_local else None
-            onehotP = torch.empty(B, R, N1, device=dev)
+            onehotP = torch.empty(B, R, N1 + (1 if haswl else 0), device=dev)     # [+ load column -> d wl]
             onehotF = torch.empty(B, R, N1, device=dev) if hasQ2 else None
             L.check(L.lib().elg_rows_prep(_ptr(g), _ptr(ctx.probs_out), _ptr(ctx.tlen), _ptr(actions), _ptr(rows.PC),
-                                          _ptr(rows.Csel), _ptr(rows.Slot), _ptr(rowDL), _ptr(rowDU), _ptr(onehotP),
+                                          _ptr(rows.Csel), _ptr(rows.Slot), _ptr(rows.Load) if haswl else None,
+                                          _ptr(rowDL), _ptr(rowDU), _ptr(onehotP),
                                           _ptr(onehotF), B, T, M, N1, actions.shape[2], rows.Rcap, t0,
                                           float(meta.inv_ens), _stream()), "elg_rows_prep")
             rowLoad = rows.Load[:, :R] if haswl else None
@@ -508,7 +509,10 @@ class _ChosenProbs(torch.autograd.Function):
         dQ2 = dwl = None
         if hasQ2:
             dQ2 = torch.bmm(onehotF.transpose(1, 2), dQ)
-        if haswl:
+        if haswl and use_saved:
+            dwl = dQ1[:, N1].sum(dim=0)                              # the load column of onehotP
+            dQ1 = dQ1[:, :N1]
+        elif haswl:
             dwl = torch.einsum("br,bre->e", rowLoad, dQ)
         if join_side is not None:
             torch.cuda.current_stream().wait_stream(join_side)

@@ -206,10 +206,12 @@ int elg_pomo_loss(const float* probs, const float* reward, int B, int T, int M, 
  *   rowDL[b,r,n] = w (Csel [n == action] - PC[n]);  rowDU[b,r,j] = rowDL[b,r,Slot[j]] * inv_ens (0 for empty slots)
  *   onehot_prev[b,r,n] = [n == action at t-1 (0 at t = 0)],  onehot_first[b,r,n] = [n == action at t = 0]
  * gprob, pval (B,T,M) dense; tlen (B,M); actions (B,M,Tcap_actions); PC (B,Rcap,N1); Csel (B,Rcap); Slot (B,Rcap,48);
- * outputs dense over R = T*M rows.  rowDU / onehot_* may be NULL. */
+ * outputs dense over R = T*M rows.  rowDU / onehot_* may be NULL.  If `load` (B,Rcap: vehicle load of the row, CVRP)
+ * is given, onehot_prev is (B,R,N1+1) and its last column holds the load, so that onehot_prev^T dQ also produces
+ * d wl (the load column of Wq_last) in row N1. */
 int elg_rows_prep(const float* gprob, const float* pval, const int32_t* tlen, const int32_t* actions,
-                  const float* PC, const float* Csel, const int32_t* Slot, float* rowDL, float* rowDU,
-                  float* onehot_prev, float* onehot_first, int B, int T, int M, int N1, int Tcap_actions,
+                  const float* PC, const float* Csel, const int32_t* Slot, const float* load, float* rowDL,
+                  float* rowDU, float* onehot_prev, float* onehot_first, int B, int T, int M, int N1, int Tcap_actions,
                   int64_t Rcap, int first_decode_step, float inv_ens, void* stream);
 
 /* torch.optim.Adam update (L2 weight decay added to the gradient, bias correction; reference train.py:101) over n

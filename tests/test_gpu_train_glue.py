@@ -68,10 +68,11 @@ def test_rows_prep_matches_torch(tsp):
     inv = 0.5
     rowDL = torch.full((B, R, N1), float("nan"), device=DEV)
     rowDU = torch.full((B, R, 48), float("nan"), device=DEV)
-    ohP = torch.full((B, R, N1), float("nan"), device=DEV)
+    Load = torch.rand(B, Rcap, generator=g).to(DEV)
+    ohP = torch.full((B, R, N1 + (0 if tsp else 1)), float("nan"), device=DEV)
     ohF = torch.full((B, R, N1), float("nan"), device=DEV) if tsp else None
     L.check(L.lib().elg_rows_prep(eng._ptr(gp), eng._ptr(pv), eng._ptr(tlen), eng._ptr(acts), eng._ptr(PC), eng._ptr(Csel),
-                                  eng._ptr(Slot), eng._ptr(rowDL), eng._ptr(rowDU), eng._ptr(ohP), eng._ptr(ohF),
+                                  eng._ptr(Slot), eng._ptr(Load) if not tsp else None, eng._ptr(rowDL), eng._ptr(rowDU), eng._ptr(ohP), eng._ptr(ohF),
                                   B, T, M, N1, Tcap, Rcap, t0, inv, eng._stream()), "rows_prep")
     # the torch chain this kernel replaces (engine._ChosenProbs.backward before the fusion)
     fl = acts[:, :, :T].long()
@@ -87,7 +88,9 @@ def test_rows_prep_matches_torch(tsp):
     refP = torch.zeros(B, R, N1, device=DEV).scatter_(2, prev[:, :, None], 1.0)
     np.testing.assert_allclose(rowDL.cpu().numpy(), ref.cpu().numpy(), rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(rowDU.cpu().numpy(), refU.cpu().numpy(), rtol=1e-6, atol=1e-7)
-    assert torch.equal(ohP, refP)
+    assert torch.equal(ohP[:, :, :N1], refP)
+    if not tsp:
+        assert torch.equal(ohP[:, :, N1], Load[:, :R])
     if tsp:
         first = fl[:, :, 0][:, None, :].expand(B, T, M).reshape(B, R)
         assert torch.equal(ohF, torch.zeros(B, R, N1, device=DEV).scatter_(2, first[:, :, None], 1.0))
