@@ -84,9 +84,9 @@ class CVRPEnv:
 
     def load_random_problems(self, batch, aug_factor=1):
         """reference CVRPEnv.py:125-150."""
-        node = batch['loc'].to(self.device).float()
-        demand = batch['demand'].to(self.device).float()
-        depot = batch['depot'].to(self.device).float()
+        node = eng.h2d(batch['loc'].float(), self.device)
+        demand = eng.h2d(batch['demand'].float(), self.device)
+        depot = eng.h2d(batch['depot'].float(), self.device)
         if depot.dim() == 2:
             depot = depot[:, None, :]
         self.vrplib = False

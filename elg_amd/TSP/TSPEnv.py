@@ -62,7 +62,7 @@ class TSPEnv:
     def load_random_problems(self, problems, aug_factor=1):
         """reference TSPEnv.py:53-67."""
         self.tsplib = False
-        self.problems = problems.to(self.device).float()
+        self.problems = eng.h2d(problems.float(), self.device)
         if aug_factor > 1:
             if aug_factor != 8:
                 raise NotImplementedError

@@ -40,6 +40,31 @@ def _side_stream(dev) -> "torch.cuda.Stream":
     return _SIDE[key]
 
 
+_PINNED = {}
+
+
+def h2d(t: torch.Tensor, dev) -> torch.Tensor:
+    """Host -> HBM copy that does not stall the host behind the work already queued on the stream: the tensor is
+    staged in a cached pinned buffer and copied asynchronously (a pageable .to(device) blocks until every kernel
+    queued before it has finished, i.e. the previous step's backward, and the GPU then idles while the host
+    enqueues the next step)."""
+    if t.is_cuda:
+        return t
+    key = (tuple(t.shape), t.dtype, str(dev))
+    ent = _PINNED.get(key)
+    if ent is None:
+        ent = _PINNED[key] = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True), None]
+    buf, ev = ent
+    if ev is not None:
+        ev.synchronize()                        # the previous copy out of this buffer has completed
+    buf.copy_(t)
+    out = buf.to(dev, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    ent[1] = ev
+    return out
+
+
 def _need_cuda(t: torch.Tensor, what: str):
     if not t.is_cuda:
         raise RuntimeError(f"elg_amd: {what} must live on the GPU -- the HIP path has no CPU fallback")
