@@ -9,6 +9,7 @@
 #include <string>
 
 namespace elg {
+using f32x4c = __attribute__((ext_vector_type(4))) float;
 
 static thread_local std::string g_err;
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -463,6 +464,538 @@ static int launch_fwd_impl(const elg_rollout_args& A, hipStream_t stream) {
 }
 
 // =============================================================================================
+// Cooperative rollout kernel for N1 <= 112 (the CVRP/TSP-100 training shape): lockstep + matrix cores.
+//
+// rollout_fwd_kernel gives every trajectory its own wavefront for the whole decode step; its glimpse and pointer
+// stages are then LDS-bandwidth bound (each trajectory re-reads the instance's K, V and PK -- 155 KB -- every
+// step).  Here the <= 32 trajectories a workgroup owns advance in lockstep, and the three table contractions of
+// a step run once for all of them on v_mfma_f32_16x16x4_f32 with the tables as step-invariant operands held in
+// REGISTERS: wave h keeps K_h and V_h (its head's 16 channels of every node: 56 VGPRs) and wave w < 7 keeps the
+// 16-node slice w of PK (32 VGPRs).  LDS only carries the per-step exchange: queries in, glimpse outputs back,
+// pointer scores out.  Per step:
+//   owners   (wave w owns trajectories w, w+8, w+16, w+24): mask, query q -> LDS
+//   glimpse  (wave h = head h): S^T[n][traj] = K_h[n] . q_h[traj] for 2 x 7 tiles, softmax over n (registers +
+//            two cross-quarter shuffles), O^T[d][traj] = sum_n V_h[n][d] P^T[n][traj]; the D tile of the first
+//            product is the B operand of the second (node on the k-slot), nothing is transposed
+//   pointer  (wave w < 7 = node tile w): s^T[n][traj] = sum_c PK[n][c] o[traj][c] + pb[n] -> LDS
+//   owners:  k-NN slots, local policy, clip/softmax/choice, env update (the per-trajectory code of the other
+//            kernel, unchanged), then the next step's mask and query.
+// Trajectory state lives in LDS between phases (12 dwords), wave-uniform in SGPRs while a wave works on it.
+// =============================================================================================
+constexpr int CO_QP = 132;      // pitch of the query / glimpse-output exchange rows (conflict-free column reads)
+constexpr int CO_SP = 116;      // pitch of the score exchange rows
+constexpr int CO_NT = 7;        // node tiles of 16
+constexpr int CO_MAXTR = 32;    // trajectories in lockstep per workgroup
+
+// ---- slot exchange block of a trajectory (floats): f0 | f1 | f2 | slot code | penalty | u   (48 each)
+constexpr int CO_XP = 6 * ELG_SLOT_STRIDE;
+constexpr int CO_XF = 0, CO_XS = 3 * ELG_SLOT_STRIDE, CO_XPEN = 4 * ELG_SLOT_STRIDE, CO_XU = 5 * ELG_SLOT_STRIDE;
+// ---- folded local-policy tables staged in LDS with conflict-free pitches (same images as csrc/elg_local.hip)
+constexpr int CL_P = 33;
+constexpr int CL_LCV = 0, CL_LPE = CL_LCV + 48 * CL_P, CL_LWC = CL_LPE + 48 * CL_P, CL_LT = CL_LWC + 32 * CL_P;
+constexpr int CL_LAV = CL_LT + 48 * 4, CL_LWE = CL_LAV + 96, CL_LBC = CL_LWE + 96, CL_SIZE = CL_LBC + 32;
+
+__device__ __forceinline__ void co_stage_local(const float* __restrict__ loc, float* sT, int tid, int nthreads) {
+    for (int i = tid; i < 48 * 32; i += nthreads) {
+        const int j = i >> 5, d = i & 31;
+        sT[CL_LCV + j * CL_P + d] = loc[ELG_LOC_LCV + i];
+        sT[CL_LPE + j * CL_P + d] = loc[ELG_LOC_LPE + i];
+    }
+    for (int i = tid; i < 32 * 32; i += nthreads) sT[CL_LWC + (i >> 5) * CL_P + (i & 31)] = loc[ELG_LOC_LWC + i];
+    for (int i = tid; i < 48 * 4; i += nthreads) sT[CL_LT + i] = loc[ELG_LOC_LT + i];
+    for (int i = tid; i < 96; i += nthreads) { sT[CL_LAV + i] = loc[ELG_LOC_LAV + i]; sT[CL_LWE + i] = loc[ELG_LOC_LWE + i]; }
+    for (int i = tid; i < 32; i += nthreads) sT[CL_LBC + i] = loc[ELG_LOC_LBC + i];
+}
+
+// Local policy of 16 lockstep trajectories at once (models.py:133-166, folded as in elg_rollout.h::local_policy):
+// feature-major tiles X[slot 16 jt + 4 hi + v][trajectory lo]; the three table contractions (alpha -> o', o' -> g',
+// g' -> u) are MFMAs whose D tiles are the next B operands.  Reads the trajectories' slot blocks, writes u_j.
+__device__ __forceinline__ void co_local16(const float* __restrict__ sT, const float (&la)[ELG_LH][3], float* sXrows,
+                                           int lo, int hi) {
+    constexpr int JT = 3;
+    float* X = sXrows + lo * CO_XP;                                 // this lane's trajectory
+    const bool up = hi >= 2;
+    const f32x4c z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4c o1[2], g1[2];
+    // two heads at a time (the 16 channels of d-tile dt belong to heads 2 dt and 2 dt + 1): 24 live weights, not 48
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        f32x4c f1[3][JT];                                             // re-read per head pair: not live across the MFMAs
+        bool msk[JT][4];
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            const int4 sl = *reinterpret_cast<const int4*>(X + CO_XS + 16 * jt + 4 * hi);
+            msk[jt][0] = sl.x < 0; msk[jt][1] = sl.y < 0; msk[jt][2] = sl.z < 0; msk[jt][3] = sl.w < 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float4 t = *reinterpret_cast<const float4*>(X + CO_XF + k * ELG_SLOT_STRIDE + 16 * jt + 4 * hi);
+                f1[k][jt] = f32x4c{t.x, t.y, t.z, t.w};
+            }
+        }
+        f32x4c al[2][JT];
+        float F[2][3];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int h = 2 * dt + hh;
+            float mx = ELG_NEG_INF;
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    float sc = sT[CL_LT + (16 * jt + 4 * hi + v) * 4 + h];
+                    sc = fmaf(la[h][0], f1[0][jt][v], sc);
+                    sc = fmaf(la[h][1], f1[1][jt][v], sc);
+                    sc = fmaf(la[h][2], f1[2][jt][v], sc);
+                    sc = msk[jt][v] ? ELG_NEG_INF : sc;
+                    al[hh][jt][v] = sc;
+                    mx = fmaxf(mx, sc);
+                }
+            mx = fmaxf(mx, shfl_xor(mx, 16));
+            mx = fmaxf(mx, shfl_xor(mx, 32));
+            float den = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float e = msk[jt][v] ? 0.f : __expf(al[hh][jt][v] - mx);
+                    al[hh][jt][v] = e;
+                    den += e;
+                }
+            den += shfl_xor(den, 16);
+            den += shfl_xor(den, 32);
+            float fk[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float a = den > 0.f ? al[hh][jt][v] / den : 0.f;      // same expression as local_policy()
+                    al[hh][jt][v] = a;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) fk[k] = fmaf(a, f1[k][jt][v], fk[k]);
+                }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                fk[k] += shfl_xor(fk[k], 16);
+                fk[k] += shfl_xor(fk[k], 32);
+                F[hh][k] = fk[k];
+            }
+        }
+        f32x4c Pa = z4, Pb = z4;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float a = sT[CL_LCV + (16 * jt + 4 * hi + v) * CL_P + 16 * dt + lo];
+                Pa = __builtin_amdgcn_mfma_f32_16x16x4f32(a, al[0][jt][v], Pa, 0, 0, 0);
+                Pb = __builtin_amdgcn_mfma_f32_16x16x4f32(a, al[1][jt][v], Pb, 0, 0, 0);
+            }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int d = 16 * dt + 4 * hi + v;
+            float x = up ? Pb[v] : Pa[v];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) x = fmaf(sT[CL_LAV + 3 * d + k], up ? F[1][k] : F[0][k], x);
+            o1[dt][v] = x;
+        }
+    }
+    float w[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dq = 0; dq < 2; ++dq) {
+        f32x4c acc;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] = sT[CL_LBC + 16 * dq + 4 * hi + v];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[CL_LWC + (16 * dq + lo) * CL_P + 16 * dt + 4 * hi + v],
+                                                           o1[dt][v], acc, 0, 0, 0);
+        g1[dq] = acc;
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) w[k] = fmaf(acc[v], sT[CL_LWE + 3 * (16 * dq + 4 * hi + v) + k], w[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { w[k] += shfl_xor(w[k], 16); w[k] += shfl_xor(w[k], 32); }
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        f32x4c acc = z4;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[CL_LPE + (16 * jt + lo) * CL_P + 16 * dt + 4 * hi + v],
+                                                           g1[dt][v], acc, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float4 t = *reinterpret_cast<const float4*>(X + CO_XF + k * ELG_SLOT_STRIDE + 16 * jt + 4 * hi);
+            acc[0] = fmaf(w[k], t.x, acc[0]); acc[1] = fmaf(w[k], t.y, acc[1]);
+            acc[2] = fmaf(w[k], t.z, acc[2]); acc[3] = fmaf(w[k], t.w, acc[3]);
+        }
+        *reinterpret_cast<float4*>(X + CO_XU + 16 * jt + 4 * hi) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
+template <bool TSP>
+__device__ __forceinline__ void co_store_state(int* sS, const Traj<2>& st, int lane) {
+    if (lane == 0) {
+        sS[0] = st.cur; sS[1] = st.first; sS[2] = st.cnt; sS[3] = st.fin;
+        sS[4] = f2i(st.load); sS[5] = f2i(st.len); sS[6] = f2i(st.cx); sS[7] = f2i(st.cy);
+        sS[8] = (int)(unsigned)st.vis[0]; sS[9] = (int)(unsigned)(st.vis[0] >> 32);
+        sS[10] = (int)(unsigned)st.vis[1]; sS[11] = (int)(unsigned)(st.vis[1] >> 32);
+    }
+}
+__device__ __forceinline__ void co_load_state(const int* sS, Traj<2>& st, int lane) {
+    const int x = sS[lane & 15];
+    st.cur = readlane(x, 0); st.first = readlane(x, 1); st.cnt = readlane(x, 2); st.fin = readlane(x, 3);
+    st.load = i2f(readlane(x, 4)); st.len = i2f(readlane(x, 5)); st.cx = i2f(readlane(x, 6)); st.cy = i2f(readlane(x, 7));
+    st.vis[0] = ((unsigned long long)(unsigned)readlane(x, 9) << 32) | (unsigned)readlane(x, 8);
+    st.vis[1] = ((unsigned long long)(unsigned)readlane(x, 11) << 32) | (unsigned)readlane(x, 10);
+}
+
+// mask, query and k-NN slots of the step a trajectory is about to decode -> exchange buffers
+// (TRAIN: also the q / load / slot rows of that step)
+template <bool TSP, bool TRAIN>
+__device__ __forceinline__ void co_prepare(const elg_rollout_args& A, const Inst& I, const Traj<2>& st, int N1, int lane,
+                                           bool decode, unsigned long long* sMaskQ, float* sQrow, float* sXrow, float* sb,
+                                           size_t b, size_t r, size_t Rcap) {
+    unsigned long long mk[2] = {~0ull, ~0ull};
+    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int ssave = -1;
+    float sf0 = 0.f, sf1 = 0.f, sf2 = 0.f, pen = 0.f;
+    if (decode) {
+        build_mask<2, TSP>(st, I, N1, lane, mk);
+        const int cb = (lane & 31) * 4;
+        q4 = *reinterpret_cast<const float4*>(I.Q1 + (size_t)st.cur * ELG_E + cb);
+        if (TSP) {
+            const float4 qf = *reinterpret_cast<const float4*>(I.Q2 + (size_t)st.first * ELG_E + cb);
+            q4.x += qf.x; q4.y += qf.y; q4.z += qf.z; q4.w += qf.w;
+        } else {
+            const float4 w = *reinterpret_cast<const float4*>(I.wl + cb);
+            q4.x = fmaf(st.load, w.x, q4.x); q4.y = fmaf(st.load, w.y, q4.y);
+            q4.z = fmaf(st.load, w.z, q4.z); q4.w = fmaf(st.load, w.w, q4.w);
+        }
+        if (TRAIN && lane < 32) *reinterpret_cast<float4*>(A.trQ + (b * Rcap + r) * ELG_E + cb) = q4;
+        if (TRAIN && lane == 0 && A.trLoad) A.trLoad[b * Rcap + r] = st.load;
+        if (A.has_penalty || A.has_local) {
+            const Slots S = slot_setup<2, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb);
+            ssave = (S.smask && S.snid >= 0) ? -2 : S.snid;           // -2: present but masked (CVRP depot slot)
+            sf0 = S.f0; sf1 = S.f1; sf2 = S.f2; pen = S.pen;
+        }
+        if (TRAIN && A.trSlot && lane < ELG_SLOT_STRIDE) {
+            A.trSlot[(b * Rcap + r) * ELG_SLOT_STRIDE + lane] = ssave;
+            if (A.trF) {
+                float* fr = A.trF + (b * Rcap + r) * (3 * ELG_SLOT_STRIDE) + lane;
+                fr[0] = sf0; fr[ELG_SLOT_STRIDE] = sf1; fr[2 * ELG_SLOT_STRIDE] = sf2;
+            }
+        }
+    }
+    if (lane == 0) { sMaskQ[0] = mk[0]; sMaskQ[1] = mk[1]; }
+    if (lane < 32) *reinterpret_cast<float4*>(sQrow + 4 * lane) = q4;
+    if (lane < ELG_SLOT_STRIDE) {
+        sXrow[CO_XF + lane] = sf0; sXrow[CO_XF + ELG_SLOT_STRIDE + lane] = sf1; sXrow[CO_XF + 2 * ELG_SLOT_STRIDE + lane] = sf2;
+        reinterpret_cast<int*>(sXrow)[CO_XS + lane] = ssave;
+        sXrow[CO_XPEN + lane] = pen;
+        sXrow[CO_XU + lane] = 0.f;
+    }
+}
+
+template <bool TSP, bool TRAIN>
+__global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout_args A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lo = lane & 15, hi = lane >> 4;
+    const int N1 = A.N1;
+    const int G = gridDim.x;
+    int u = blockIdx.x;
+    if ((G & 7) == 0) u = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int b = u / A.tiles, tile = u % A.tiles;
+    const int tile_m = (A.M + A.tiles - 1) / A.tiles;
+    const int m_lo = tile * tile_m, m_hi = min(A.M, m_lo + tile_m);
+    const size_t NE = (size_t)N1 * ELG_E;
+    const size_t Rcap = (size_t)A.Tmax * A.M;
+
+    // ---- LDS: exchange rows | scores | masks | states | dem | xy | per-wave scratch
+    float* sQ = lds;                                                  // [32][CO_QP]  q in, glimpse output back
+    float* sSc = sQ + CO_MAXTR * CO_QP;                               // [32][CO_SP]
+    unsigned long long* sMask = reinterpret_cast<unsigned long long*>(sSc + CO_MAXTR * CO_SP);   // [32][2]
+    int* sState = reinterpret_cast<int*>(sMask + 2 * CO_MAXTR);       // [32][16]
+    float* sdem = reinterpret_cast<float*>(sState + 16 * CO_MAXTR);
+    float* sxy = sdem + ((N1 + 3) & ~3);
+    float* sX = sxy + ((2 * N1 + 3) & ~3);                            // [32][CO_XP] slot exchange blocks
+    float* sT = sX + CO_MAXTR * CO_XP;                                // local-policy tables
+    float* sP = sT + CL_SIZE;                                         // [7][32][64] PK operand image
+    float* sPb = sP + CO_NT * 32 * 64;                                // [112] pointer bias
+    float* sb = sPb + 16 * CO_NT + wave * SbSize<2>::value;
+    if (!TSP)
+        for (int i = tid; i < N1; i += 512) sdem[i] = A.demand[(size_t)b * N1 + i];
+    for (int i = tid; i < 2 * N1; i += 512) sxy[i] = A.xy[(size_t)b * N1 * 2 + i];
+    float la[ELG_LH][3];
+#pragma unroll
+    for (int h = 0; h < ELG_LH; ++h)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) la[h][k] = A.has_local ? A.loc[ELG_LOC_LA + 3 * h + k] : 0.f;
+    if (A.has_local) co_stage_local(A.loc, sT, tid, 512);
+
+    Inst I;
+    I.K = nullptr; I.V = nullptr; I.PK = nullptr;
+    I.pb = A.pb + (size_t)b * N1;
+    I.Q1 = A.Q1 + b * NE;
+    I.Q2 = TSP ? A.Q2 + b * NE : nullptr;
+    I.wl = A.wl;
+    I.xy = sxy;
+    I.dem = sdem;
+    I.nidx = A.nbr_idx + (size_t)b * N1 * N1;
+    I.ndist = A.nbr_dist + (size_t)b * N1 * N1;
+    I.ntheta = A.nbr_theta + (size_t)b * N1 * N1;
+    I.loc = A.loc;
+
+    // ---- step-invariant MFMA operands in registers
+    // glimpse: wave = head h.  kop[nt][kk] = K[n = 16 nt + lo][16 h + 4 kk + hi]   (A operand of S^T = K Q^T)
+    //                         vop[nt][v]  = V[n = 16 nt + 4 hi + v][16 h + lo]     (A operand of O^T = V^T P^T)
+    // pointer: wave = node tile w (w < 7).  pop[s] = PK[n = 16 w + lo][4 s + hi]   (A operand of s^T = PK o^T)
+    const float* gK = A.Kmat + b * NE + wave * 16;
+    const float* gV = A.Vmat + b * NE + wave * 16;
+#define ELG_CO_LOAD_KV()                                                                                   \
+    _Pragma("unroll") for (int nt = 0; nt < CO_NT; ++nt) {                                                  \
+        const int n = 16 * nt + lo_t;                                                                       \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                    \
+            kop[nt][kk] = gK[(unsigned)(min(n, N1 - 1) * ELG_E + 4 * kk + hi_t)] * ((n < N1) ? 1.f : 0.f); \
+        _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                                     \
+            const int n2 = 16 * nt + 4 * hi_t + v;                                                          \
+            vop[nt][v] = gV[(unsigned)(min(n2, N1 - 1) * ELG_E + lo_t)] * ((n2 < N1) ? 1.f : 0.f);         \
+        }                                                                                                   \
+    }
+    {
+        // the PK operand image goes to LDS ([tile][k-step][lane], read back conflict-free): with it in registers
+        // too, the batched local policy no longer fits the 256-VGPR budget of 2 waves/SIMD
+        const int np = 16 * wave + lo;
+        const float* gP = A.PK + b * NE + (size_t)min(np, N1 - 1) * ELG_E;
+        if (wave < CO_NT)
+            for (int s4 = 0; s4 < 32; ++s4) sP[(wave * 32 + s4) * 64 + lane] = (np < N1) ? gP[4 * s4 + hi] : 0.f;
+    }
+    for (int i = tid; i < 16 * CO_NT; i += 512) sPb[i] = (i < N1) ? I.pb[i] : 0.f;
+    __syncthreads();
+
+    for (int g_lo = m_lo; g_lo < m_hi; g_lo += CO_MAXTR) {           // groups of <= 32 lockstep trajectories
+        const int ntraj = min(CO_MAXTR, m_hi - g_lo);
+        const bool two_rt = ntraj > 16;
+        // ---- reset: every trajectory at the depot / nowhere, step 0 (nothing to decode at t = 0)
+        for (int q = wave; q < CO_MAXTR; q += 8) {
+            Traj<2> st;
+            st.cur = 0; st.first = 0; st.cnt = 0; st.fin = (q < ntraj) ? 0 : 1; st.load = 1.0f; st.len = 0.f;
+            st.cx = 0.f; st.cy = 0.f; st.vis[0] = 0ull; st.vis[1] = 0ull;
+            co_store_state<TSP>(sState + 16 * q, st, lane);
+            if (lane == 0) { sMask[2 * q] = ~0ull; sMask[2 * q + 1] = ~0ull; }
+            if (lane < 33) *reinterpret_cast<float4*>(sQ + q * CO_QP + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = lane; i < CO_XP; i += 64) sX[q * CO_XP + i] = (i >= CO_XS && i < CO_XPEN) ? i2f(-1) : 0.f;
+        }
+        __syncthreads();
+        const int step_cap = TSP ? N1 : 2 * N1 + 2;
+        float kop[CO_NT][4], vop[CO_NT][4];                         // (re)loaded at the end of every owners' phase
+#pragma unroll
+        for (int nt = 0; nt < CO_NT; ++nt)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { kop[nt][v] = 0.f; vop[nt][v] = 0.f; }
+        for (int t = 0; t < step_cap && t < A.Tmax; ++t) {
+            // Opaque per-iteration copy of the lane id: every address below is a function of it, so the compiler cannot
+            // hoist the (loop-invariant) address arithmetic of ~300 loads out of the step loop -- it did, and then
+            // spilled ~250 VGPRs of precomputed 64-bit addresses; recomputing them costs a few hundred VALU ops a step.
+            int lane_t = lane;
+            asm volatile("" : "+v"(lane_t));
+            const int lo_t = lane_t & 15, hi_t = lane_t >> 4;
+            const bool decode_step = TSP ? (t >= 1) : (t >= 2);     // uniform over the workgroup: lockstep
+            if (decode_step && !(A.debug_skip & 16)) {
+                // =============== glimpse: wave = head ===============
+                // (kop / vop: this head's K_h / V_h operand images, 56 registers, re-read from L2 for every step right
+                // after the owners' phase so the latency hides behind the barrier.  The instance's 103 KB of K / V stay
+                // L2-resident; keeping the images live across the whole step does not fit beside the batched local policy.)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    if (rt == 1 && !two_rt) break;
+                    const int traj = 16 * rt + lo_t;
+                    const float* qrow = sQ + traj * CO_QP + 16 * wave;
+                    float qb[4];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) qb[kk] = qrow[4 * kk + hi_t];
+                    const unsigned long long w0 = sMask[2 * traj], w1 = sMask[2 * traj + 1];
+                    f32x4c sc[CO_NT];
+                    float mx = ELG_NEG_INF;
+#pragma unroll
+                    for (int nt = 0; nt < CO_NT; ++nt) {
+                        f32x4c acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kop[nt][kk], qb[kk], acc, 0, 0, 0);
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int n = 16 * nt + 4 * hi_t + v;
+                            const unsigned long long w = (nt < 4) ? w0 : w1;
+                            const bool masked = (n >= N1) || ((w >> (n & 63)) & 1ull);
+                            const float x = masked ? ELG_NEG_INF : acc[v] * 0.25f;
+                            acc[v] = x;
+                            mx = fmaxf(mx, x);
+                        }
+                        sc[nt] = acc;
+                    }
+                    mx = fmaxf(mx, shfl_xor(mx, 16));
+                    mx = fmaxf(mx, shfl_xor(mx, 32));
+                    float den = 0.f;
+#pragma unroll
+                    for (int nt = 0; nt < CO_NT; ++nt)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const float e = (sc[nt][v] > ELG_NEG_INF) ? __expf(sc[nt][v] - mx) : 0.f;
+                            sc[nt][v] = e;
+                            den += e;
+                        }
+                    den += shfl_xor(den, 16);
+                    den += shfl_xor(den, 32);
+                    const bool live = den > 0.f;                    // a decoding trajectory has an open node
+                    const float inv = live ? 1.0f / den : 0.f;
+                    f32x4c o = {0.f, 0.f, 0.f, 0.f};
+                    const size_t r = (size_t)t * A.M + g_lo + traj;
+#pragma unroll
+                    for (int nt = 0; nt < CO_NT; ++nt) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            sc[nt][v] *= inv;
+                            o = __builtin_amdgcn_mfma_f32_16x16x4f32(vop[nt][v], sc[nt][v], o, 0, 0, 0);
+                        }
+                        if (TRAIN && live) {
+                            float* rA = A.trA + (((size_t)b * ELG_H + wave) * Rcap + r) * N1 + 16 * nt + 4 * hi_t;
+#pragma unroll
+                            for (int v = 0; v < 4; ++v)
+                                if (16 * nt + 4 * hi_t + v < N1) rA[v] = sc[nt][v];
+                        }
+                    }
+                    // O^T[d = 4 hi_t + v][traj = lo_t] -> this head's 16 channels of the trajectory's exchange row
+                    *reinterpret_cast<float4*>(sQ + traj * CO_QP + 16 * wave + 4 * hi_t) = make_float4(o[0], o[1], o[2], o[3]);
+                    if (TRAIN && live)
+                        *reinterpret_cast<float4*>(A.trO + ((size_t)b * Rcap + r) * ELG_E + 16 * wave + 4 * hi_t) =
+                            make_float4(o[0], o[1], o[2], o[3]);
+                }
+                __syncthreads();
+                // =============== pointer (waves 0-5: 7 node tiles x 2 trajectory tiles) || local policy (waves 6, 7) ====
+                if (wave < 6) {
+#pragma unroll 1
+                    for (int un = wave; un < (two_rt ? 2 * CO_NT : CO_NT); un += 6) {
+                        const int nt = un % CO_NT, rt = un / CO_NT;
+                        const int traj = 16 * rt + lo_t;
+                        const float* orow = sQ + traj * CO_QP + hi_t;
+                        const float* pop = sP + nt * 32 * 64 + lane_t;
+                        const float4 pb4 = *reinterpret_cast<const float4*>(sPb + 16 * nt + 4 * hi_t);
+                        f32x4c a0 = {pb4.x, pb4.y, pb4.z, pb4.w}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int s4 = 0; s4 < 32; s4 += 2) {
+                            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pop[s4 * 64], orow[4 * s4], a0, 0, 0, 0);
+                            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pop[(s4 + 1) * 64], orow[4 * s4 + 4], a1, 0, 0, 0);
+                        }
+                        *reinterpret_cast<float4*>(sSc + traj * CO_SP + 16 * nt + 4 * hi_t) =
+                            make_float4(a0[0] + a1[0], a0[1] + a1[1], a0[2] + a1[2], a0[3] + a1[3]);
+                    }
+                } else if (A.has_local && (wave == 6 || two_rt)) {
+                    // wave 6: trajectories 0-15, wave 7: trajectories 16-31
+                    co_local16(sT, la, sX + (wave - 6) * 16 * CO_XP, lo_t, hi_t);
+                }
+                __syncthreads();
+            }
+            // =============== owners: finish this step, advance, prepare the next ===============
+            int any_left = 0;
+            for (int q = wave; q < ntraj; q += 8) {
+                Traj<2> st;
+                co_load_state(sState + 16 * q, st, lane_t);
+                const int m = g_lo + q;
+                const size_t bm = (size_t)b * A.M + m;
+                const size_t r = (size_t)t * A.M + m;
+                if (!st.fin) {
+                    int fsel = 0;
+                    if (A.forced && t < A.Tforced) fsel = __builtin_amdgcn_readfirstlane(A.forced[bm * A.Tforced + t]);
+                    int sel;
+                    float pr = 1.0f;
+                    if (!decode_step) {
+                        if (A.mode == ELG_MODE_FORCED) sel = fsel;
+                        else sel = (!TSP && t == 0) ? 0 : __builtin_amdgcn_readfirstlane(A.starts[m]);
+                    } else {
+                        unsigned long long mk[2];
+                        {
+                            const unsigned long long x0 = sMask[2 * q], x1 = sMask[2 * q + 1];
+                            mk[0] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(x0 >> 32)) << 32) |
+                                    (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)x0);
+                            mk[1] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(x1 >> 32)) << 32) |
+                                    (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)x1);
+                        }
+                        float addval = 0.f;
+                        int snid = -1;
+                        if (lane_t < ELG_SLOT_STRIDE) {
+                            const float* X = sX + q * CO_XP;
+                            const int code = reinterpret_cast<const int*>(X)[CO_XS + lane_t];
+                            snid = (code == -2) ? 0 : code;
+                            addval = X[CO_XPEN + lane_t] + X[CO_XU + lane_t] * A.inv_ens;
+                        }
+                        float s[2];
+                        s[0] = (lane_t < N1) ? sSc[q * CO_SP + lane_t] : 0.f;
+                        s[1] = (lane_t + 64 < N1) ? sSc[q * CO_SP + 64 + lane_t] : 0.f;
+                        float uni = 0.f;
+                        if (A.mode == ELG_MODE_SAMPLE)
+                            uni = A.uniforms ? A.uniforms[bm * A.Tmax + t] : philox_uniform(A.seed, (unsigned)bm, (unsigned)t);
+                        float* frow = (A.full_probs && t < A.dump_T) ? A.full_probs + (bm * A.dump_T + t) * N1 : nullptr;
+                        const FwdOut o = finish_step<2, TSP, TRAIN>(A, N1, lane_t, sb, mk, s, snid, addval, fsel, uni, frow,
+                                                                    (size_t)b, r, Rcap);
+                        sel = __builtin_amdgcn_readfirstlane(o.sel);
+                        pr = i2f(__builtin_amdgcn_readfirstlane(f2i(o.p)));
+                    }
+                    if (lane_t == 0) {
+                        if (A.actions) A.actions[bm * A.Tmax + t] = sel;
+                        if (A.probs) A.probs[((size_t)b * A.Tmax + t) * A.M + m] = pr;
+                    }
+                    env_update<2, TSP>(st, I, N1, sel);
+                }
+                // the step this trajectory decodes next (t + 1): its mask and query, or an inert row
+                const bool next_decodes = !st.fin && (t + 1 < A.Tmax) && (TSP ? (t + 1 >= 1) : (t + 1 >= 2));
+                co_prepare<TSP, TRAIN>(A, I, st, N1, lane_t, next_decodes, sMask + 2 * q, sQ + q * CO_QP, sX + q * CO_XP, sb,
+                                       (size_t)b, (size_t)(t + 1) * A.M + m, Rcap);
+                co_store_state<TSP>(sState + 16 * q, st, lane_t);
+                any_left |= st.fin ? 0 : 1;
+            }
+            ELG_CO_LOAD_KV()                                         // next step's glimpse operands, in flight over the barrier
+            if (!__syncthreads_or(any_left)) break;                  // also orders the exchange rows for the next step
+        }
+        // ---- results of the group
+        for (int q = wave; q < ntraj; q += 8) {
+            Traj<2> st;
+            co_load_state(sState + 16 * q, st, lane);
+            const size_t bm = (size_t)b * A.M + g_lo + q;
+            if (lane == 0) {
+                if (A.reward) A.reward[bm] = -st.len;
+                if (A.tlen) A.tlen[bm] = st.cnt;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <bool TSP, bool TRAIN>
+static int launch_fwd_coop(const elg_rollout_args& A, hipStream_t stream) {
+    const size_t lds = ((size_t)CO_MAXTR * CO_QP + (size_t)CO_MAXTR * CO_SP + 4 * CO_MAXTR + 16 * CO_MAXTR +
+                        ((A.N1 + 3) & ~3) + ((2 * A.N1 + 3) & ~3) + (size_t)CO_MAXTR * CO_XP + CL_SIZE + CO_NT * 32 * 64 + 16 * CO_NT +
+                        8 * SbSize<2>::value) * 4 + 64;
+    auto kern = rollout_fwd_coop_kernel<TSP, TRAIN>;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        (void)hipGetLastError();
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(ELG_ELAUNCH, std::string("coop rollout: hipFuncSetAttribute: ") + hipGetErrorString(e));
+        attr_lds = lds;
+    }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3(A.B * A.tiles), dim3(512), lds, stream, A);
+    return launch_status("rollout_fwd_coop");
+}
+
+// =============================================================================================
 // Node-tiled rollout kernel for large instances (N1 > 128: TSP-500, VRPLIB up to 1000 nodes).
 // K / V / PK do not fit LDS, so the workgroup walks them in tiles of TR rows: a tile is staged ONCE per
 // step and consumed by all WAVES trajectories of the workgroup (they advance in lockstep), instead of every
@@ -769,6 +1302,15 @@ static int dispatch_fwd(const elg_rollout_args& A, hipStream_t stream) {
     if (lds && A.N1 > 104) return fail(ELG_EINVAL, "lds_stage needs N1 <= 104");
     if (A.waves != 8 && A.waves != 9 && A.waves != 13) return fail(ELG_EINVAL, "waves must be 8, 9 or 13");
 #define ELG_GO(NCHV, L, W) return launch_fwd<NCHV, TSP, L, W>(A, stream)
+    if (lds && A.waves == 8 && A.N1 >= 4 && A.N1 <= 16 * CO_NT && !A.use_state && A.do_decode && A.do_update &&
+        A.max_steps <= 0 && !(A.debug_skip & 0xB)) {   // bits 4,5: coop-kernel ablations
+        // fused rollout at the training scale: lockstep trajectories, tables as MFMA operands in registers
+        if (A.trA) {
+            if (!A.trPC || !A.trCsel || !A.trQ || !A.trO) return fail(ELG_EINVAL, "rollout: incomplete training rows");
+            return launch_fwd_coop<TSP, true>(A, stream);
+        }
+        return launch_fwd_coop<TSP, false>(A, stream);
+    }
     if (A.trA) {        // training forward: saves the backward rows; built for N1 <= 128, 8 waves
         if (!A.trPC || !A.trCsel || !A.trQ || !A.trO) return fail(ELG_EINVAL, "rollout: incomplete training rows");
         if (A.use_state) return fail(ELG_EINVAL, "rollout: training rows need the fused rollout");

@@ -85,7 +85,8 @@ typedef struct elg_rollout_args {
     float clip;             /* model_params.logit_clipping                                      */
     float inv_ens;          /* 1 / ensemble_size                                                */
     int32_t debug_skip;     /* diagnostics only (0 in production): bit0 skip glimpse, bit1 skip pointer,
-                               bit2 run N1 > 128 through the untiled kernel */
+                               bit2 run N1 > 128 through the untiled kernel,
+                               bit3 run N1 <= 112 through the one-wavefront-per-trajectory kernel */
     uint64_t seed;          /* sampling seed (Philox key)                                       */
     const float* Kmat;      /* (B,N1,128) decoder.Wk enc                                        */
     const float* Vmat;      /* (B,N1,128) decoder.Wv enc                                        */
