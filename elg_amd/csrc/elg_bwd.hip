@@ -575,9 +575,9 @@ static int dispatch_bwd(const elg_bwd_args& BA, hipStream_t stream) {
 //     dQ_h = dS K_h                          contraction over nodes
 //     dK_h += dS^T Q_h ,  dV_h += a^T dO_h   contractions over rows, accumulated in registers
 // The node contraction wants dS with the ROW on the lane (B operand), the row contractions want the NODE on the
-// lane (A operand); instead of transposing 16 x 112 values through LDS per tile, dA is formed in both
-// orientations (dO V^T and V dO^T: 4 extra MFMAs per 16 nodes) and the weights a are loaded in both layouts
-// (the second read hits L1/L2).  Operand maps (lane l, lo = l & 15, hi = l >> 4):
+// lane (A operand): each 16 x 16 tile of dS is transposed once through per-wave LDS (ds_write_b128 + 4 ds_read_b32,
+// 20-float pitch, conflict-free); the weights a are read from HBM exactly once.  Operand maps (lane l, lo = l & 15,
+// hi = l >> 4):
 //     A[i = lo][k = hi]   B[k = hi][j = lo]   D[i = 4 hi + reg][j = lo]
 // and a k-slot may stand for any node / row as long as both operands agree (node 16 nt + 4 hi + v for
 // the dQ product, row 4 hi + v for dK / dV), which is what lets D tiles feed the next MFMA directly.
@@ -604,6 +604,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float* sRed = lds + NT * 256;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lo = lane & 15, hi = lane >> 4;
+    float* sTr = lds + NT * 256 + 4 * 2 * NT * 256 + wave * (2 * 320);    // two 16 x 16 transpose tiles (pitch 20)
     const int bh = blockIdx.y, b = bh >> 3, h = bh & 7;
     const int split = blockIdx.x;
 
@@ -636,45 +637,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int t_lo = split * per, t_hi = min(ntile, t_lo + per);
     const float* Abh = rowA + (size_t)bh * rowA_rows * N1;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    for (int tile = t_lo + wave_u; tile < t_hi; tile += 4) {
+    // ---- tile loads.  No load is guarded: the compiler turns `ok ? load : 0` (and any if / else around loads) into
+    // branches with their own vmcnt(0) waits, which serialises the ~45 loads of a tile (27 us per tile instead of one
+    // memory latency).  Rows past R are clamped to the last valid row (finite duplicates): they meet zeroed Q / dO
+    // operands in dK / dV and an unstored dQ column.  Q / dO rows past R must be exact zeros: 0/1 mask multiply.
+    // The loads of tile i + 1 are issued before tile i is consumed (software prefetch, 44 registers).
+#define ELG_GB_LOAD(TILE, A1, DOA, OA, DOB, QB)                                                                   \
+    {                                                                                                             \
+        const int r0_ = (TILE) << 4;                                                                              \
+        const float* __restrict__ At = Abh + (size_t)r0_ * N1;                                                    \
+        const int rleft_ = R - 1 - r0_;                                                                           \
+        _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                                           \
+            const unsigned off1 = (unsigned)(min(4 * hi + v, rleft_) * N1);                                       \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) A1[nt][v] = At[off1 + gl[nt]];                      \
+        }                                                                                                         \
+        const float* __restrict__ dOt = dO + ((size_t)b * R + r0_) * ELG_E + h * 16;                              \
+        const float* __restrict__ Ot = rowO + ((size_t)b * rowO_rows + r0_) * ELG_E + h * 16;                     \
+        const float* __restrict__ Qt = rowQ + ((size_t)b * rowQ_rows + r0_) * ELG_E + h * 16;                     \
+        const unsigned offA = (unsigned)(min(lo, rleft_) * ELG_E + hi);                                           \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) { DOA[kk] = dOt[offA + 4 * kk]; OA[kk] = Ot[offA + 4 * kk]; } \
+        _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                                           \
+            const int rr = 4 * hi + v;                                                                            \
+            const unsigned offB = (unsigned)(min(rr, rleft_) * ELG_E + lo);                                       \
+            const float mk = (rr <= rleft_) ? 1.f : 0.f;                                                          \
+            DOB[v] = dOt[offB] * mk;                                                                              \
+            QB[v] = Qt[offB] * mk;                                                                                \
+        }                                                                                                         \
+    }
+    float a1[NT][4], doA[4], oA[4], doB[4], qB[4];
+    const int tile0 = t_lo + wave_u;
+    if (tile0 < t_hi) ELG_GB_LOAD(tile0, a1, doA, oA, doB, qB)
+    for (int tile = tile0; tile < t_hi; tile += 4) {
         const int r0 = tile << 4;                                  // wave-uniform
         const int rT = r0 + lo;                                    // row of this lane in the row-on-lane layout
-        // ---- weights a in both layouts.  No load is guarded: the compiler turns `ok ? load : 0` (and any
-        // if / else around loads) into branches with their own vmcnt(0) waits, which serialises the ~40 loads
-        // of a tile (27 us per tile instead of one memory latency).  Rows past R are clamped to the last valid
-        // row (finite duplicates): they meet zeroed Q / dO operands in dK / dV and an unstored dQ column.
-        const float* __restrict__ At = Abh + (size_t)r0 * N1;
-        const int rleft = R - 1 - r0;                              // last valid row of the tile, relative
-        unsigned off1[4];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) off1[v] = (unsigned)(min(4 * hi + v, rleft) * N1);
-        const unsigned offT = (unsigned)(min(lo, rleft) * N1);
-        float a1[NT][4], aT[NT][4];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) a1[nt][v] = At[off1[v] + gl[nt]];          // row 4 hi + v, position lo
-            const f4u t = *reinterpret_cast<const f4u*>(At + (offT + (unsigned)grp_start(nt, hi, N1)));
-            aT[nt][0] = t.x; aT[nt][1] = t.y; aT[nt][2] = t.z; aT[nt][3] = t.w;   // row lo, positions 4 hi + v
-        }
-        // ---- the 16-wide operands of the tile (Q / dO rows past R must be exact zeros: multiply by a 0/1 mask)
-        const float* __restrict__ dOt = dO + ((size_t)b * R + r0) * ELG_E + h * 16;
-        const float* __restrict__ Ot = rowO + ((size_t)b * rowO_rows + r0) * ELG_E + h * 16;
-        const float* __restrict__ Qt = rowQ + ((size_t)b * rowQ_rows + r0) * ELG_E + h * 16;
-        float doA[4], oA[4], doB[4], qB[4];
-        const unsigned offA = (unsigned)(min(lo, rleft) * ELG_E + hi);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            doA[kk] = dOt[offA + 4 * kk];
-            oA[kk] = Ot[offA + 4 * kk];
-        }
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int rr = 4 * hi + v;
-            const unsigned offB = (unsigned)(min(rr, rleft) * ELG_E + lo);
-            const float mk = (rr <= rleft) ? 1.f : 0.f;
-            doB[v] = dOt[offB] * mk;
-            qB[v] = Qt[offB] * mk;
+        float a1n[NT][4], doAn[4], oAn[4], doBn[4], qBn[4];
+        {
+            const int tn = min(tile + 4, t_hi - 1);                // the last prefetch re-reads a valid tile, unused
+            ELG_GB_LOAD(tn, a1n, doAn, oAn, doBn, qBn)
         }
         // <dO_h, O_h> per row: partial over this lane's 4 channels, summed over the 4 lane groups
         float doto = doA[0] * oA[0];
@@ -687,27 +686,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         f32x4 dq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            f32x4 dA = {0.f, 0.f, 0.f, 0.f}, dAT = {0.f, 0.f, 0.f, 0.f};
+            f32x4 dA = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                dA = __builtin_amdgcn_mfma_f32_16x16x4f32(doA[kk], vop[nt][kk], dA, 0, 0, 0);
-                dAT = __builtin_amdgcn_mfma_f32_16x16x4f32(vop[nt][kk], doA[kk], dAT, 0, 0, 0);
-            }
+            for (int kk = 0; kk < 4; ++kk) dA = __builtin_amdgcn_mfma_f32_16x16x4f32(doA[kk], vop[nt][kk], dA, 0, 0, 0);
+            float ds1[4];
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const float ds1 = 0.25f * a1[nt][v] * (dA[v] - dv[v]);        // position lo, row 4 hi + v
-                dKacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds1, qB[v], dKacc[nt], 0, 0, 0);
+                ds1[v] = 0.25f * a1[nt][v] * (dA[v] - dv[v]);                 // position lo, row 4 hi + v
+                dKacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds1[v], qB[v], dKacc[nt], 0, 0, 0);
                 dVacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[nt][v], doB[v], dVacc[nt], 0, 0, 0);
             }
+            // dS with the row on the lane (the B operand of dQ^T = K^T dS^T) is the 16 x 16 transpose of the tile just
+            // formed: through per-wave LDS (one ds_write_b128 + four ds_read_b32).  Earlier versions re-read the
+            // weights in the second layout (doubled the HBM traffic: PMC 6.7 GB for 3.3 GB of weights) and formed
+            // dA a second time (28 more MFMAs per tile).
+            // (software-pipelined by one tile: the transposed tile nt - 1 is read back and consumed while tile nt's
+            // products issue, so the LDS round trip is off the MFMA dependency chain)
+            *reinterpret_cast<float4*>(sTr + (nt & 1) * 320 + lo * 20 + 4 * hi) = make_float4(ds1[0], ds1[1], ds1[2], ds1[3]);
+            wave_lds_fence();
+            if (nt > 0) {
+                const float* pb = sTr + ((nt - 1) & 1) * 320;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const float ds2 = 0.25f * aT[nt][v] * (dAT[v] - doto);        // position 4 hi + v, row lo
-                dq = __builtin_amdgcn_mfma_f32_16x16x4f32(sK[(nt * 4 + v) * 64 + lane], ds2, dq, 0, 0, 0);
+                for (int v = 0; v < 4; ++v)
+                    dq = __builtin_amdgcn_mfma_f32_16x16x4f32(sK[((nt - 1) * 4 + v) * 64 + lane], pb[(4 * hi + v) * 20 + lo], dq, 0, 0, 0);
             }
         }
+        {
+            const float* pb = sTr + ((NT - 1) & 1) * 320;
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                dq = __builtin_amdgcn_mfma_f32_16x16x4f32(sK[((NT - 1) * 4 + v) * 64 + lane], pb[(4 * hi + v) * 20 + lo], dq, 0, 0, 0);
+        }
+        wave_lds_fence();
         if (rT < R) *reinterpret_cast<float4*>(dQ + ((size_t)b * R + rT) * ELG_E + h * 16 + 4 * hi) =
                         make_float4(dq[0], dq[1], dq[2], dq[3]);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) a1[nt][v] = a1n[nt][v];
+            doA[v] = doAn[v]; oA[v] = oAn[v]; doB[v] = doBn[v]; qB[v] = qBn[v];
+        }
     }
+#undef ELG_GB_LOAD
     // ---- sum the four waves' dK_h / dV_h and write this split's partial (B,N1,128) image.
     // D rows are positions 4 hi + v of chunk nt; position -> node, owners only.
     float* my = sRed + (size_t)wave * (2 * NT * 256);
@@ -737,7 +757,7 @@ template <int NT>
 static int launch_glimpse_bwd_mfma(const float* rowA, const float* dO, const float* rowO, const float* rowQ,
                                    const float* Kmat, const float* Vmat, float* dQ, float* dKp, float* dVp, int B,
                                    int R, int N1, size_t ra, size_t ro, size_t rq, int splits, hipStream_t stream) {
-    const size_t lds = (size_t)(NT * 256 + 4 * 2 * NT * 256) * sizeof(float);
+    const size_t lds = (size_t)(NT * 256 + 4 * 2 * NT * 256 + 4 * 2 * 320) * sizeof(float);
     auto kern = glimpse_bwd_mfma_kernel<NT>;
     static bool attr_done = false;
     if (!attr_done && lds > 65536) {

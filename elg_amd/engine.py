@@ -508,7 +508,7 @@ class _ChosenProbs(torch.autograd.Function):
         dQ = torch.empty(B, R, E, device=dev)
         if N1 <= 128 and os.environ.get("ELG_FUSED_GLIMPSE_BWD", "1") != "0":
             # one MFMA launch: dS stays in registers, dQ / dK / dV come out directly
-            splits = max(1, min(8, 512 // (B * H)))
+            splits = max(1, min(8, 1024 // (B * H)))
             dKp = torch.empty(splits, B, N1, E, device=dev)
             dVp = torch.empty(splits, B, N1, E, device=dev)
             L.check(L.lib().elg_glimpse_bwd_fused(_ptr(rowA), _ptr(dO), _ptr(rowO), _ptr(rowQ), _ptr(Kt), _ptr(Vt),

@@ -2,7 +2,7 @@
 import sqlite3, sys, collections
 c = sqlite3.connect(sys.argv[1])
 rows = c.execute("select name,start,end,queue_id from kernels order by start").fetchall()
-idx = [i for i, r in enumerate(rows) if 'rollout_fwd_kernel' in r[0]]
+idx = [i for i, r in enumerate(rows) if 'rollout_fwd' in r[0]]
 i0, i1 = idx[-2], idx[-1]
 t0 = rows[i0][1]
 print("step span ms", (rows[i1][1] - t0) / 1e6, "kernels", i1 - i0)

@@ -22,5 +22,5 @@ for splits in (1, 2, 4):
     for _ in range(10): run()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
-    flops = B * 8 * (R / 16) * 140 * 2048
+    flops = B * 8 * (R / 16) * 112 * 2048
     print(f"splits={splits}: {ms:.3f} ms  ({flops/ms/1e9:.1f} TFLOP/s MFMA, A read {B*8*R*N1*4/ms/1e6:.0f} GB/s)", flush=True)
