@@ -8,8 +8,8 @@ random-init weights.
         bench.py --gpus N --steps K --warmup W
 
 One "step" = generate batch -> H2D -> neighbour tables -> encoder -> sampled POMO rollout (one persistent HIP
-launch) -> loss -> backward (replay kernels + dense contractions + encoder autograd) -> [RCCL gradient
-all-reduce] -> Adam.  Rank 0 prints ONE JSON line."""
+launch) -> loss kernel -> backward (row prep, MFMA glimpse / local-policy backward kernels, three batched GEMMs,
+encoder autograd) -> [RCCL all-reduce of the packed gradient] -> one-launch Adam.  Rank 0 prints ONE JSON line."""
 from __future__ import annotations
 
 import argparse
@@ -162,7 +162,7 @@ def main():
             "config": {"workload": "CVRP-100 batch=64/GPU pomo=100 joint (local policy on), BASELINE configs[1]",
                        "global_batch": LOCAL_BATCH * world, "pomo": POMO, "problem_size": N_NODES,
                        "parallelism": f"dp{world}"},
-            "roofline": {"kernel": "rollout_fwd_kernel (persistent decode: all steps of all trajectories)",
+            "roofline": {"kernel": "rollout_fwd_coop_kernel (persistent decode: all steps of all trajectories)",
                          "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(bytes_launch),
