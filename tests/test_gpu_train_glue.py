@@ -139,3 +139,34 @@ def test_adam_handles_missing_gradients():
     (p[0] * 2).sum().backward()
     opt.step()
     assert torch.equal(p[1].detach(), w1) and opt.step_count == 1
+
+
+def test_grad_bucket_uses_the_optimizer_buffer(monkeypatch):
+    """Data-parallel path of bench.py / train.py: the all-reduce runs on the optimiser's packed gradient buffer and
+    1/world is folded into the Adam kernel.  Two ranks with identical gradients (all_reduce emulated as x2) must
+    give exactly the single-rank update."""
+    import torch.distributed as dist
+    from elg_amd import parallel
+    from elg_amd.optim import Adam
+    torch.manual_seed(3)
+    shapes = [(64, 32), (32,), (5, 3)]
+    pa = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa, ob = Adam(pa, lr=1e-3, weight_decay=1e-6), Adam(pb, lr=1e-3, weight_decay=1e-6)
+    bucket = parallel.GradBucket(pa, oa)
+    assert bucket.flat.data_ptr() == oa.grad_flat.data_ptr()
+    calls = []
+
+    def fake_all_reduce(t, op=None):
+        calls.append(t.data_ptr())
+        t.mul_(2.0)                                    # sum over two identical ranks
+    monkeypatch.setattr(dist, "all_reduce", fake_all_reduce)
+    gs = [torch.randn(s, device=DEV) for s in shapes]
+    for ps, opt in ((pa, oa), (pb, ob)):
+        opt.zero_grad()
+        sum((p * g).sum() for p, g in zip(ps, gs)).backward()
+    bucket.allreduce(2)
+    assert calls == [oa.grad_flat.data_ptr()] and oa.grad_scale == 0.5
+    oa.step(); ob.step()
+    for x, y in zip(pa, pb):
+        assert torch.equal(x.detach(), y.detach())
