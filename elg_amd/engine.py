@@ -593,3 +593,37 @@ def pomo_loss(probs: torch.Tensor, rewards: torch.Tensor, scale_norm: bool = Tru
     (reference CVRP/train.py:112-121; guard_zero = the TSP variant's batch-wide zero-normaliser check)."""
     _need_cuda(probs, "probs")
     return _PomoLoss.apply(probs.float(), rewards, bool(scale_norm), bool(guard_zero))
+
+
+# ----------------------------------------------------------------------------------------------
+# residual add + instance norm (encoder, reference models.py:506-527)
+# ----------------------------------------------------------------------------------------------
+class _AddInstNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, gamma, beta, eps):
+        a, b = a.contiguous(), b.contiguous()
+        B, N, Cn = a.shape
+        out = torch.empty_like(a)
+        xhat = torch.empty_like(a)
+        rstd = torch.empty(B, Cn, device=a.device)
+        L.check(L.lib().elg_add_instnorm_fwd(_ptr(a), _ptr(b), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(xhat), _ptr(rstd),
+                                             B, N, Cn, float(eps), _stream()), "elg_add_instnorm_fwd")
+        ctx.save_for_backward(xhat, rstd, gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xhat, rstd, gamma = ctx.saved_tensors
+        dout = dout.contiguous()
+        B, N, Cn = xhat.shape
+        ds = torch.empty_like(xhat)
+        dgb = torch.zeros(2, Cn, device=xhat.device)
+        L.check(L.lib().elg_add_instnorm_bwd(_ptr(dout), _ptr(xhat), _ptr(rstd), _ptr(gamma), _ptr(ds), _ptr(dgb[0]),
+                                             _ptr(dgb[1]), B, N, Cn, _stream()), "elg_add_instnorm_bwd")
+        return ds, ds, dgb[0], dgb[1], None
+
+
+def add_instance_norm(a: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5):
+    """InstanceNorm1d(affine) of (a + b) over the node axis, (B,N,C) in and out, one HIP launch each way."""
+    _need_cuda(a, "a")
+    return _AddInstNorm.apply(a.float(), b.float(), gamma, beta, eps)

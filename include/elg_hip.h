@@ -224,6 +224,15 @@ int elg_adam_step(float* param, float* const* param_table, const int64_t* offset
                   float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int64_t step, float grad_scale, void* stream);
 
+/* Residual add + instance normalisation over the node axis (reference CVRP/models.py:506-527:
+ * nn.InstanceNorm1d(C, affine=True, eps) on (a + b) viewed as (B, C, N)).  a, b, out, xhat, dout, ds: (B,N,C) f32,
+ * b may be NULL; rstd: (B,C); gamma, beta, dgamma, dbeta: (C).  Forward saves xhat / rstd for the backward;
+ * backward returns ds = d(a + b) and ACCUMULATES dgamma / dbeta (caller zeroes).  C multiple of 32. */
+int elg_add_instnorm_fwd(const float* a, const float* b, const float* gamma, const float* beta, float* out,
+                         float* xhat, float* rstd, int B, int N, int C, float eps, void* stream);
+int elg_add_instnorm_bwd(const float* dout, const float* xhat, const float* rstd, const float* gamma, float* ds,
+                         float* dgamma, float* dbeta, int B, int N, int C, void* stream);
+
 /* fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32, exact f32) for the encoder's nn.Linear layers and
  * their backward (reference CVRP/models.py:240-269,550-561):
  *   C[M,N] (+)= op(A)[M,K] op(B)[K,N] (+ bias[N]) (ReLU);  transA: A stored KxM;  transB: B stored NxK.
