@@ -80,7 +80,7 @@ def lib() -> C.CDLL:
         L.elg_rollout_bwd.argtypes = [C.POINTER(BwdArgs), f]
         L.elg_glimpse_rows_bwd.argtypes = [f, f, f, f, f, f, f, i, i, i, C.c_int64, C.c_int64, f]
         L.elg_glimpse_bwd_fused.argtypes = [f, f, f, f, f, f, f, f, f, i, i, i, C.c_int64, C.c_int64, C.c_int64, i, f]
-        L.elg_gemm_f32.argtypes = [f, f, f, f, i, i, i, i, i, i, i, i, i, i, f]
+        L.elg_gemm_f32.argtypes = [f, f, f, f, i, i, i, i, i, i, i, i, i, i, f, f]
         i64, fl = C.c_int64, C.c_float
         L.elg_pomo_loss.argtypes = [f, f, i, i, i, i64, i64, f, f, f, f, f, f]
         L.elg_rows_prep.argtypes = [f, f, f, f, f, f, f, f, f, f, f, f, i, i, i, i, i, i64, i, fl, f]

@@ -71,7 +71,7 @@ template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                        float* __restrict__ C, const float* __restrict__ bias,
                                                        int M, int N, int K, int lda, int ldb, int ldc, int relu,
-                                                       int k_per_split) {
+                                                       int k_per_split, float* __restrict__ a_rowsum) {
     __shared__ __attribute__((aligned(16))) float sA[BK * LDT];
     __shared__ __attribute__((aligned(16))) float sB[BK * LDT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -81,12 +81,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // optional: row sums of op(A) over this split's k range (= the bias gradient when C = dY^T X), taken from the
+    // staged tiles by the workgroups of the first column tile
+    const bool do_sum = a_rowsum != nullptr && blockIdx.x == 0;
+    float rsum = 0.f;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         // op(A)[m][k]: !TA -> A stored (M x K) ; TA -> A stored (K x M)
         stage_tile<TA>(A, lda, m0, k0, M, kend, sA, tid);
         // op(B)[k][n]: !TB -> B stored (K x N) = "k-major rows" -> the transposed-source path; TB -> (N x K)
         stage_tile<!TB>(B, ldb, n0, k0, N, kend, sB, tid);
         __syncthreads();
+        if (do_sum && tid < BM) {
+#pragma unroll 8
+            for (int kk = 0; kk < BK; ++kk) rsum += sA[kk * LDT + tid];
+        }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const float a = sA[(kk + (lane >> 5)) * LDT + wm + (lane & 31)];
@@ -95,6 +103,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         }
         __syncthreads();
     }
+    if (do_sum && tid < BM && m0 + tid < M) atomicAdd(a_rowsum + m0 + tid, rsum);
     // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     const int col = n0 + wn + (lane & 31);
     const float bv = (bias && col < N && blockIdx.z == 0) ? bias[col] : 0.f;
@@ -117,7 +126,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 using namespace elg;
 
 extern "C" int elg_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
-                            int lda, int ldb, int ldc, int transA, int transB, int relu, int split_k, void* stream) {
+                            int lda, int ldb, int ldc, int transA, int transB, int relu, int split_k, float* a_rowsum,
+                            void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) return fail(ELG_EINVAL, "gemm: empty problem");
     if (split_k < 1) split_k = 1;
     if (split_k > 1 && relu) return fail(ELG_EINVAL, "gemm: ReLU epilogue needs split_k == 1");
@@ -129,9 +139,9 @@ extern "C" int elg_gemm_f32(const float* A, const float* B, float* C, const floa
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, splits), block(256);
     hipStream_t s = (hipStream_t)stream;
     (void)hipGetLastError();
-    if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, relu, kps);
-    else if (!transA && transB) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, relu, kps);
-    else if (transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, relu, kps);
-    else hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, relu, kps);
+    if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, relu, kps, a_rowsum);
+    else if (!transA && transB) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, relu, kps, a_rowsum);
+    else if (transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, relu, kps, a_rowsum);
+    else hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, relu, kps, a_rowsum);
     return launch_status("gemm_f32");
 }

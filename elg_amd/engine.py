@@ -127,7 +127,7 @@ def route_length(xy: torch.Tensor, tour: torch.Tensor, rounding: bool = False) -
 # fp32 MFMA GEMM (encoder layers)
 # ----------------------------------------------------------------------------------------------
 def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, bias=None, relu=False, split_k=1,
-         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+         out: Optional[torch.Tensor] = None, a_rowsum: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M,N] (+)= op(a) op(b) (+bias)(ReLU) through elg_gemm_f32 (v_mfma_f32_32x32x2_f32).  2-D fp32 inputs."""
     _need_cuda(a, "a")
     assert a.dim() == 2 and b.dim() == 2 and a.dtype == torch.float32 and b.dtype == torch.float32
@@ -138,7 +138,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, bias
     if out is None:
         out = torch.zeros(M, N, device=a.device) if split_k > 1 else torch.empty(M, N, device=a.device)
     L.check(L.lib().elg_gemm_f32(_ptr(a), _ptr(b), _ptr(out), _ptr(bias), M, N, K, a.shape[1], b.shape[1], N,
-                                 int(trans_a), int(trans_b), int(relu), split_k, _stream()), "elg_gemm_f32")
+                                 int(trans_a), int(trans_b), int(relu), split_k, _ptr(a_rowsum), _stream()),
+            "elg_gemm_f32")
     return out
 
 
@@ -159,9 +160,45 @@ class _LinearFn(torch.autograd.Function):
         x2, W = ctx.saved_tensors
         dy = dy.contiguous()
         dx = dy @ W if ctx.needs_input_grad[0] else None
-        dW = gemm(dy, x2, trans_a=True, split_k=max(1, min(64, x2.shape[0] // 128)))
-        db = dy.sum(dim=0) if ctx.has_bias else None
+        split = max(1, min(64, x2.shape[0] // 128))
+        # dW and (bias: its row sums, from the same staged tiles) in one zero-filled buffer and one launch
+        buf = torch.zeros(W.shape[0] * (W.shape[1] + 1), device=dy.device)
+        dW = buf[:W.numel()].view_as(W)
+        db = buf[W.numel():] if ctx.has_bias else None
+        gemm(dy, x2, trans_a=True, split_k=split, out=dW, a_rowsum=db)
         return dx, dW, db
+
+
+class _QKVFn(torch.autograd.Function):
+    """The three bias-free projections of an attention layer (reference models.py:546-552) as one GEMM each way:
+    y = x [Wq; Wk; Wv]^T forward, dX = dY W and dW = dY^T X (split-K MFMA) backward."""
+
+    @staticmethod
+    def forward(ctx, x2, Wq, Wk, Wv):
+        W = torch.cat((Wq, Wk, Wv), dim=0)
+        ctx.save_for_backward(x2, W)
+        ctx.sizes = (Wq.shape[0], Wk.shape[0], Wv.shape[0])
+        y = x2 @ W.t()
+        return torch.split(y, ctx.sizes, dim=1)
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        x2, W = ctx.saved_tensors
+        dy = torch.cat((dq, dk, dv), dim=1)
+        dx = dy @ W if ctx.needs_input_grad[0] else None
+        dW = gemm(dy, x2, trans_a=True, split_k=max(1, min(64, x2.shape[0] // 128)))
+        gq, gk, gv = torch.split(dW, ctx.sizes, dim=0)
+        return dx, gq, gk, gv
+
+
+def qkv_linear(x: torch.Tensor, Wq: torch.Tensor, Wk: torch.Tensor, Wv: torch.Tensor):
+    """(x Wq^T, x Wk^T, x Wv^T) with shared-input fusion (GPU tensors; falls back to three F.linear otherwise)."""
+    if not _MFMA_DW or not x.is_cuda or not torch.is_grad_enabled():
+        Fn = torch.nn.functional.linear
+        return Fn(x, Wq), Fn(x, Wk), Fn(x, Wv)
+    lead = x.shape[:-1]
+    q, k, v = _QKVFn.apply(x.reshape(-1, x.shape[-1]), Wq, Wk, Wv)
+    return q.reshape(*lead, -1), k.reshape(*lead, -1), v.reshape(*lead, -1)
 
 
 def linear(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -236,9 +236,11 @@ int elg_add_instnorm_bwd(const float* dout, const float* xhat, const float* rstd
 /* fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32, exact f32) for the encoder's nn.Linear layers and
  * their backward (reference CVRP/models.py:240-269,550-561):
  *   C[M,N] (+)= op(A)[M,K] op(B)[K,N] (+ bias[N]) (ReLU);  transA: A stored KxM;  transB: B stored NxK.
- * split_k > 1 accumulates with f32 atomics into a caller-zeroed C (weight gradients, K = batch*nodes). */
+ * split_k > 1 accumulates with f32 atomics into a caller-zeroed C (weight gradients, K = batch*nodes).
+ * a_rowsum (M floats, caller-zeroed, may be NULL): += sum_k op(A)[m][k] -- the bias gradient when C = dY^T X. */
 int elg_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
-                 int lda, int ldb, int ldc, int transA, int transB, int relu, int split_k, void* stream);
+                 int lda, int ldb, int ldc, int transA, int transB, int relu, int split_k, float* a_rowsum,
+                 void* stream);
 
 #ifdef __cplusplus
 }

@@ -65,3 +65,33 @@ def test_linear_autograd_matches_torch():
     np.testing.assert_allclose(gx.cpu().numpy(), rx.cpu().numpy(), rtol=1e-3, atol=1e-3)
     np.testing.assert_allclose(gW.cpu().numpy(), rW.cpu().numpy(), rtol=1e-3, atol=2e-2)
     np.testing.assert_allclose(gb.cpu().numpy(), rb.cpu().numpy(), rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize("rows,out,inp,sk", [(6464, 512, 128, 50), (6464, 128, 512, 25), (333, 70, 36, 3), (64, 64, 32, 1)])
+def test_gemm_row_sums_give_the_bias_gradient(rows, out, inp, sk):
+    """a_rowsum: the sums of op(A)'s rows come out of the same staged tiles (db of dW = dY^T X)."""
+    from elg_amd import engine as eng
+    torch.manual_seed(4)
+    dy, x = torch.randn(rows, out, device=DEV), torch.randn(rows, inp, device=DEV)
+    if out % 4 or inp % 4:
+        dy, x = dy[:, :out - out % 4].contiguous(), x[:, :inp - inp % 4].contiguous()
+    db = torch.zeros(dy.shape[1], device=DEV)
+    dW = eng.gemm(dy, x, trans_a=True, split_k=sk, a_rowsum=db)
+    np.testing.assert_allclose(dW.cpu().numpy(), (dy.double().t() @ x.double()).cpu().numpy(), rtol=1e-3, atol=5e-3)
+    np.testing.assert_allclose(db.cpu().numpy(), dy.double().sum(0).cpu().numpy(), rtol=1e-4, atol=2e-3)
+
+
+def test_qkv_linear_matches_three_linears():
+    from elg_amd import engine as eng
+    torch.manual_seed(5)
+    x = torch.randn(64, 101, 128, device=DEV, requires_grad=True)
+    Ws = [torch.randn(128, 128, device=DEV, requires_grad=True) for _ in range(3)]
+    gs = [torch.randn(64, 101, 128, device=DEV) for _ in range(3)]
+    outs = eng.qkv_linear(x, *Ws)
+    refs = [torch.nn.functional.linear(x, W) for W in Ws]
+    for o, r in zip(outs, refs):
+        np.testing.assert_allclose(o.detach().cpu().numpy(), r.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    got = torch.autograd.grad(sum((o * g).sum() for o, g in zip(outs, gs)), [x] + Ws)
+    ref = torch.autograd.grad(sum((o * g).sum() for o, g in zip(refs, gs)), [x] + Ws)
+    for a, b in zip(got, ref):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-3, atol=2e-3 * b.abs().max().item())
