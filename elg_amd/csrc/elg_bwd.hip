@@ -557,8 +557,8 @@ template <bool TSP>
 static int dispatch_bwd(const elg_bwd_args& BA, hipStream_t stream) {
     const elg_rollout_args& A = BA.fwd;
     const int nch = (A.N1 + 63) / 64;
-    const bool lds = A.lds_stage != 0;
-    if (lds && A.N1 > 104) return fail(ELG_EINVAL, "lds_stage needs N1 <= 104");
+    if (A.lds_stage && A.N1 > 112) return fail(ELG_EINVAL, "lds_stage needs N1 <= 112");
+    const bool lds = A.lds_stage != 0 && A.N1 <= 104;          // 105..112: tables from L2 (see dispatch_fwd)
     if (nch == 1) { if (lds) return launch_bwd<1, TSP, true, 8>(BA, stream); return launch_bwd<1, TSP, false, 8>(BA, stream); }
     if (nch == 2) { if (lds) return launch_bwd<2, TSP, true, 8>(BA, stream); return launch_bwd<2, TSP, false, 8>(BA, stream); }
     if (lds) return fail(ELG_EINVAL, "lds_stage needs N1 <= 104");

@@ -1298,11 +1298,13 @@ static int launch_fwd(const elg_rollout_args& A, hipStream_t stream) {
 template <bool TSP>
 static int dispatch_fwd(const elg_rollout_args& A, hipStream_t stream) {
     const int nch = (A.N1 + 63) / 64;
-    const bool lds = A.lds_stage != 0;
-    if (lds && A.N1 > 104) return fail(ELG_EINVAL, "lds_stage needs N1 <= 104");
+    if (A.lds_stage && A.N1 > 16 * CO_NT) return fail(ELG_EINVAL, "lds_stage needs N1 <= 112");
     if (A.waves != 8 && A.waves != 9 && A.waves != 13) return fail(ELG_EINVAL, "waves must be 8, 9 or 13");
+    // lds_stage = "keep the instance's tables on chip": MFMA operand images (cooperative kernel, N1 <= 112) or the
+    // LDS copies of the one-wavefront-per-trajectory kernel (N1 <= 104; 105..112 fall back to its L2 variant)
+    const bool lds = A.lds_stage != 0 && A.N1 <= 104;
 #define ELG_GO(NCHV, L, W) return launch_fwd<NCHV, TSP, L, W>(A, stream)
-    if (lds && A.waves == 8 && A.N1 >= 4 && A.N1 <= 16 * CO_NT && !A.use_state && A.do_decode && A.do_update &&
+    if (A.lds_stage && A.waves == 8 && A.N1 >= 4 && A.N1 <= 16 * CO_NT && !A.use_state && A.do_decode && A.do_update &&
         A.max_steps <= 0 && !(A.debug_skip & 0xB)) {   // bits 4,5: coop-kernel ablations
         // fused rollout at the training scale: lockstep trajectories, tables as MFMA operands in registers
         if (A.trA) {

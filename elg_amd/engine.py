@@ -143,6 +143,16 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, bias
     return out
 
 
+_DW_WGS = int(os.environ.get("ELG_DW_WGS", "512"))
+
+
+def _dw_split(out_f: int, in_f: int, rows: int) -> int:
+    """split-K factor of a weight-gradient GEMM: enough workgroups to fill the 256 CUs, no more -- every split adds
+    one f32 atomic per output element."""
+    tiles = ((out_f + 63) // 64) * ((in_f + 63) // 64)
+    return max(1, min(64, rows // 128, max(4, _DW_WGS // tiles)))
+
+
 class _LinearFn(torch.autograd.Function):
     """y = x W^T (+ b) with x (rows, in), W (out, in).  Forward and dX are plain library GEMMs (hipBLASLt is
     already at ~6 us for these shapes); the weight gradient dW = dY^T X reduces over rows = batch*nodes (6464),
@@ -160,7 +170,7 @@ class _LinearFn(torch.autograd.Function):
         x2, W = ctx.saved_tensors
         dy = dy.contiguous()
         dx = dy @ W if ctx.needs_input_grad[0] else None
-        split = max(1, min(64, x2.shape[0] // 128))
+        split = _dw_split(W.shape[0], W.shape[1], x2.shape[0])
         # dW and (bias: its row sums, from the same staged tiles) in one zero-filled buffer and one launch
         buf = torch.zeros(W.shape[0] * (W.shape[1] + 1), device=dy.device)
         dW = buf[:W.numel()].view_as(W)
@@ -186,7 +196,7 @@ class _QKVFn(torch.autograd.Function):
         x2, W = ctx.saved_tensors
         dy = torch.cat((dq, dk, dv), dim=1)
         dx = dy @ W if ctx.needs_input_grad[0] else None
-        dW = gemm(dy, x2, trans_a=True, split_k=max(1, min(64, x2.shape[0] // 128)))
+        dW = gemm(dy, x2, trans_a=True, split_k=_dw_split(W.shape[0], W.shape[1], x2.shape[0]))
         gq, gk, gv = torch.split(dW, ctx.sizes, dim=0)
         return dx, gq, gk, gv
 
@@ -324,7 +334,7 @@ class Policy:
 def launch_geometry(B: int, M: int, N1: int):
     """(waves, tiles, lds_stage).  256 CUs, one workgroup per CU when K/V/PK are staged in LDS:
     aim for ~256 workgroups of 8 waves (2 per SIMD, 256-VGPR budget: no spills)."""
-    lds = 1 if N1 <= 104 else 0
+    lds = 1 if N1 <= 112 else 0          # tables on chip: cooperative MFMA kernel (fused rollouts), LDS copies otherwise
     waves = 8
     n_cu = 256
     tiles = max(1, min(M, (n_cu + B - 1) // B))
