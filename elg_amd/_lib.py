@@ -34,7 +34,7 @@ class RolloutArgs(C.Structure):
         ("st_cur", _vp), ("st_cnt", _vp), ("st_fin", _vp), ("st_first", _vp), ("st_load", _vp), ("st_len", _vp),
         ("st_vis", _vp),
         ("actions", _vp), ("probs", _vp), ("reward", _vp), ("tlen", _vp), ("full_probs", _vp),
-        ("trA", _vp), ("trPC", _vp), ("trCsel", _vp), ("trQ", _vp), ("trO", _vp), ("trLoad", _vp), ("trSlot", _vp), ("trF", _vp),
+        ("trA", _vp), ("trPC", _vp), ("trCsel", _vp), ("trQ", _vp), ("trO", _vp), ("trLoad", _vp), ("trSlot", _vp), ("trF", _vp), ("trMask", _vp),
     ]
 
 
@@ -79,7 +79,7 @@ def lib() -> C.CDLL:
         L.elg_rollout_fwd.argtypes = [C.POINTER(RolloutArgs), f]
         L.elg_rollout_bwd.argtypes = [C.POINTER(BwdArgs), f]
         L.elg_glimpse_rows_bwd.argtypes = [f, f, f, f, f, f, f, i, i, i, C.c_int64, C.c_int64, f]
-        L.elg_glimpse_bwd_fused.argtypes = [f, f, f, f, f, f, f, f, f, i, i, i, C.c_int64, C.c_int64, C.c_int64, i, f]
+        L.elg_glimpse_bwd_fused.argtypes = [f, f, f, f, f, f, f, f, f, f, i, i, i, C.c_int64, C.c_int64, C.c_int64, i, f]
         L.elg_gemm_f32.argtypes = [f, f, f, f, i, i, i, i, i, i, i, i, i, i, f, f]
         i64, fl = C.c_int64, C.c_float
         L.elg_pomo_loss.argtypes = [f, f, i, i, i, i64, i64, f, f, f, f, f, f]

@@ -592,9 +592,13 @@ struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
 // node < the group's natural start) get a zero K operand and their dK / dV rows are not stored.
 __device__ __forceinline__ int grp_start(int nt, int q, int N1) { return min(16 * nt + 4 * q, N1 - 4); }
 
-template <int NT>
+// RECOMP: the weights a are not read (3.3 GB at the bench shape, written by the forward and read here) but recomputed
+// per tile from the saved query rows and the rows' feasibility mask words: S = q_h K_h^T / 4 (28 more MFMAs per tile),
+// masked softmax over the row's nodes (16-lane DPP reductions).
+template <int NT, bool RECOMP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void glimpse_bwd_mfma_kernel(
-    const float* __restrict__ rowA, const float* __restrict__ dO, const float* __restrict__ rowO,
+    const float* __restrict__ rowA, const unsigned long long* __restrict__ rowMask, const float* __restrict__ dO,
+    const float* __restrict__ rowO,
     const float* __restrict__ rowQ, const float* __restrict__ Kmat, const float* __restrict__ Vmat,
     float* __restrict__ dQ, float* __restrict__ dKp, float* __restrict__ dVp, int B, int R, int N1,
     size_t rowA_rows, size_t rowO_rows, size_t rowQ_rows, int splits) {
@@ -605,6 +609,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lo = lane & 15, hi = lane >> 4;
     float* sTr = lds + NT * 256 + 4 * 2 * NT * 256 + wave * (2 * 320);    // two 16 x 16 transpose tiles (pitch 20)
+    float* sK2 = lds + NT * 256 + 4 * 2 * NT * 256 + 4 * 2 * 320;          // RECOMP: K as the B operand of q K^T
     const int bh = blockIdx.y, b = bh >> 3, h = bh & 7;
     const int split = blockIdx.x;
 
@@ -626,8 +631,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const bool own = g >= 16 * nt + 4 * hi;
         const float x = Kmat[((size_t)b * N1 + g) * ELG_E + h * 16 + lo];
         sK[e * 64 + lane] = own ? x : 0.f;
+        if (RECOMP) {      // entry (nt, kk): K[node of position lo][4 kk + hi]
+            const int g2 = grp_start(nt, lo >> 2, N1) + (lo & 3);
+            sK2[e * 64 + lane] = Kmat[((size_t)b * N1 + g2) * ELG_E + h * 16 + 4 * v + hi];
+        }
     }
     __syncthreads();
+    bool own_lo[NT];                                               // position lo of chunk nt is the node's first visit
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) own_lo[nt] = (int)gl[nt] >= 16 * nt + 4 * (lo >> 2);
     f32x4 dKacc[NT], dVacc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { dKacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dVacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -642,14 +654,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // memory latency).  Rows past R are clamped to the last valid row (finite duplicates): they meet zeroed Q / dO
     // operands in dK / dV and an unstored dQ column.  Q / dO rows past R must be exact zeros: 0/1 mask multiply.
     // The loads of tile i + 1 are issued before tile i is consumed (software prefetch, 44 registers).
-#define ELG_GB_LOAD(TILE, A1, DOA, OA, DOB, QB)                                                                   \
+#define ELG_GB_LOAD(TILE, A1, DOA, OA, DOB, QB, QA, MW)                                                           \
     {                                                                                                             \
         const int r0_ = (TILE) << 4;                                                                              \
-        const float* __restrict__ At = Abh + (size_t)r0_ * N1;                                                    \
         const int rleft_ = R - 1 - r0_;                                                                           \
-        _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                                           \
-            const unsigned off1 = (unsigned)(min(4 * hi + v, rleft_) * N1);                                       \
-            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) A1[nt][v] = At[off1 + gl[nt]];                      \
+        if (!RECOMP) {                                                                                            \
+            const float* __restrict__ At = Abh + (size_t)r0_ * N1;                                                \
+            _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                                       \
+                const unsigned off1 = (unsigned)(min(4 * hi + v, rleft_) * N1);                                   \
+                _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) A1[nt][v] = At[off1 + gl[nt]];                  \
+            }                                                                                                     \
+        } else {                                                                                                  \
+            const unsigned long long* __restrict__ Mt = rowMask + ((size_t)b * rowQ_rows + r0_) * 2;              \
+            _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                                       \
+                const unsigned offm = (unsigned)(min(4 * hi + v, rleft_) * 2);                                    \
+                MW[v][0] = Mt[offm]; MW[v][1] = Mt[offm + 1];                                                     \
+            }                                                                                                     \
+            const float* __restrict__ Qa = rowQ + ((size_t)b * rowQ_rows + r0_) * ELG_E + h * 16;                 \
+            const unsigned offq = (unsigned)(min(lo, rleft_) * ELG_E + hi);                                       \
+            _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) QA[kk] = Qa[offq + 4 * kk];                          \
         }                                                                                                         \
         const float* __restrict__ dOt = dO + ((size_t)b * R + r0_) * ELG_E + h * 16;                              \
         const float* __restrict__ Ot = rowO + ((size_t)b * rowO_rows + r0_) * ELG_E + h * 16;                     \
@@ -664,16 +687,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             QB[v] = Qt[offB] * mk;                                                                                \
         }                                                                                                         \
     }
-    float a1[NT][4], doA[4], oA[4], doB[4], qB[4];
+    float a1[NT][4], doA[4], oA[4], doB[4], qB[4], qA[4];
+    unsigned long long mw[4][2];
     const int tile0 = t_lo + wave_u;
-    if (tile0 < t_hi) ELG_GB_LOAD(tile0, a1, doA, oA, doB, qB)
+    if (tile0 < t_hi) ELG_GB_LOAD(tile0, a1, doA, oA, doB, qB, qA, mw)
     for (int tile = tile0; tile < t_hi; tile += 4) {
         const int r0 = tile << 4;                                  // wave-uniform
         const int rT = r0 + lo;                                    // row of this lane in the row-on-lane layout
-        float a1n[NT][4], doAn[4], oAn[4], doBn[4], qBn[4];
+        float a1n[NT][4], doAn[4], oAn[4], doBn[4], qBn[4], qAn[4];
+        unsigned long long mwn[4][2];
         {
             const int tn = min(tile + 4, t_hi - 1);                // the last prefetch re-reads a valid tile, unused
-            ELG_GB_LOAD(tn, a1n, doAn, oAn, doBn, qBn)
+            ELG_GB_LOAD(tn, a1n, doAn, oAn, doBn, qBn, qAn, mwn)
+        }
+        if (RECOMP) {
+            // a_h[row 4 hi + v][position lo] = softmax over the row's open nodes of q_h . K_h[node] / 4
+            float mx[4] = {ELG_NEG_INF, ELG_NEG_INF, ELG_NEG_INF, ELG_NEG_INF};
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 S = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    S = __builtin_amdgcn_mfma_f32_16x16x4f32(qA[kk], sK2[(nt * 4 + kk) * 64 + lane], S, 0, 0, 0);
+                const unsigned node = gl[nt];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const unsigned long long w = (node < 64u) ? mw[v][0] : mw[v][1];
+                    const bool closed = !own_lo[nt] || ((w >> (node & 63u)) & 1ull);
+                    const float x = closed ? ELG_NEG_INF : S[v] * 0.25f;
+                    a1[nt][v] = x;
+                    mx[v] = fmaxf(mx[v], x);
+                }
+            }
+            float den[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { mx[v] = row16_max(mx[v]); den[v] = 0.f; }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float e = (a1[nt][v] > ELG_NEG_INF) ? __expf(a1[nt][v] - mx[v]) : 0.f;
+                    a1[nt][v] = e;
+                    den[v] += e;
+                }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { den[v] = row16_sum(den[v]); den[v] = den[v] > 0.f ? 1.0f / den[v] : 0.f; }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) a1[nt][v] *= den[v];
         }
         // <dO_h, O_h> per row: partial over this lane's 4 channels, summed over the 4 lane groups
         float doto = doA[0] * oA[0];
@@ -725,6 +787,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) a1[nt][v] = a1n[nt][v];
             doA[v] = doAn[v]; oA[v] = oAn[v]; doB[v] = doBn[v]; qB[v] = qBn[v];
+            qA[v] = qAn[v]; mw[v][0] = mwn[v][0]; mw[v][1] = mwn[v][1];
         }
     }
 #undef ELG_GB_LOAD
@@ -753,12 +816,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-template <int NT>
-static int launch_glimpse_bwd_mfma(const float* rowA, const float* dO, const float* rowO, const float* rowQ,
-                                   const float* Kmat, const float* Vmat, float* dQ, float* dKp, float* dVp, int B,
-                                   int R, int N1, size_t ra, size_t ro, size_t rq, int splits, hipStream_t stream) {
-    const size_t lds = (size_t)(NT * 256 + 4 * 2 * NT * 256 + 4 * 2 * 320) * sizeof(float);
-    auto kern = glimpse_bwd_mfma_kernel<NT>;
+template <int NT, bool RECOMP>
+static int launch_glimpse_bwd_mfma(const float* rowA, const unsigned long long* rowMask, const float* dO, const float* rowO,
+                                   const float* rowQ, const float* Kmat, const float* Vmat, float* dQ, float* dKp,
+                                   float* dVp, int B, int R, int N1, size_t ra, size_t ro, size_t rq, int splits,
+                                   hipStream_t stream) {
+    const size_t lds = (size_t)(NT * 256 + 4 * 2 * NT * 256 + 4 * 2 * 320 + (RECOMP ? NT * 256 : 0)) * sizeof(float);
+    auto kern = glimpse_bwd_mfma_kernel<NT, RECOMP>;
     static bool attr_done = false;
     if (!attr_done && lds > 65536) {
         (void)hipGetLastError();
@@ -768,8 +832,8 @@ static int launch_glimpse_bwd_mfma(const float* rowA, const float* dO, const flo
         attr_done = true;
     }
     (void)hipGetLastError();
-    hipLaunchKernelGGL(kern, dim3(splits, B * 8), dim3(256), lds, stream, rowA, dO, rowO, rowQ, Kmat, Vmat, dQ, dKp,
-                       dVp, B, R, N1, ra, ro, rq, splits);
+    hipLaunchKernelGGL(kern, dim3(splits, B * 8), dim3(256), lds, stream, rowA, rowMask, dO, rowO, rowQ, Kmat, Vmat, dQ,
+                       dKp, dVp, B, R, N1, ra, ro, rq, splits);
     return launch_status("glimpse_bwd_fused");
 }
 
@@ -777,21 +841,30 @@ static int launch_glimpse_bwd_mfma(const float* rowA, const float* dO, const flo
 
 using namespace elg;
 
-extern "C" int elg_glimpse_bwd_fused(const float* rowA, const float* dO, const float* rowO, const float* rowQ,
-                                     const float* Kmat, const float* Vmat, float* dQ, float* dK_part, float* dV_part,
-                                     int B, int R, int N1, int64_t rowA_rows, int64_t rowO_rows, int64_t rowQ_rows,
-                                     int splits, void* stream) {
-    if (rowA_rows < R || rowO_rows < R || rowQ_rows < R) return fail(ELG_EINVAL, "glimpse_bwd_fused: row strides smaller than R");
+extern "C" int elg_glimpse_bwd_fused(const float* rowA, const uint64_t* rowMask, const float* dO, const float* rowO,
+                                     const float* rowQ, const float* Kmat, const float* Vmat, float* dQ, float* dK_part,
+                                     float* dV_part, int B, int R, int N1, int64_t rowA_rows, int64_t rowO_rows,
+                                     int64_t rowQ_rows, int splits, void* stream) {
+    if ((!rowMask && rowA_rows < R) || rowO_rows < R || rowQ_rows < R)
+        return fail(ELG_EINVAL, "glimpse_bwd_fused: row strides smaller than R");
+    if (!rowA && !rowMask) return fail(ELG_EINVAL, "glimpse_bwd_fused: neither weights nor mask rows given");
     if (B <= 0 || R <= 0 || N1 < 4 || splits <= 0) return fail(ELG_EINVAL, "glimpse_bwd_fused: bad sizes");
     if (N1 > 128) return fail(ELG_ENOTIMPL, "glimpse_bwd_fused: N1 > 128 not built (use elg_glimpse_rows_bwd)");
     hipStream_t s = (hipStream_t)stream;
     const int nt = (N1 + 15) / 16;
-#define ELG_GB(NT) return launch_glimpse_bwd_mfma<NT>(rowA, dO, rowO, rowQ, Kmat, Vmat, dQ, dK_part, dV_part, B, R, N1, \
-                                                      (size_t)rowA_rows, (size_t)rowO_rows, (size_t)rowQ_rows, splits, s)
-    if (nt <= 2) ELG_GB(2);
-    if (nt <= 4) ELG_GB(4);
-    if (nt <= 7) ELG_GB(7);
-    ELG_GB(8);
+    const unsigned long long* mk = reinterpret_cast<const unsigned long long*>(rowMask);
+#define ELG_GB(NT)                                                                                                       \
+    {                                                                                                                    \
+        if (mk) return launch_glimpse_bwd_mfma<NT, true>(rowA, mk, dO, rowO, rowQ, Kmat, Vmat, dQ, dK_part, dV_part, B,  \
+                                                         R, N1, (size_t)rowA_rows, (size_t)rowO_rows, (size_t)rowQ_rows, \
+                                                         splits, s);                                                     \
+        return launch_glimpse_bwd_mfma<NT, false>(rowA, mk, dO, rowO, rowQ, Kmat, Vmat, dQ, dK_part, dV_part, B, R, N1,  \
+                                                  (size_t)rowA_rows, (size_t)rowO_rows, (size_t)rowQ_rows, splits, s);   \
+    }
+    if (nt <= 2) ELG_GB(2)
+    if (nt <= 4) ELG_GB(4)
+    if (nt <= 7) ELG_GB(7)
+    ELG_GB(8)
 #undef ELG_GB
 }
 

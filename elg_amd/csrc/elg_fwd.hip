@@ -679,6 +679,7 @@ __device__ __forceinline__ void co_prepare(const elg_rollout_args& A, const Inst
         }
         if (TRAIN && lane < 32) *reinterpret_cast<float4*>(A.trQ + (b * Rcap + r) * ELG_E + cb) = q4;
         if (TRAIN && lane == 0 && A.trLoad) A.trLoad[b * Rcap + r] = st.load;
+        if (TRAIN && lane == 0 && A.trMask) { A.trMask[(b * Rcap + r) * 2] = mk[0]; A.trMask[(b * Rcap + r) * 2 + 1] = mk[1]; }
         if (A.has_penalty || A.has_local) {
             const Slots S = slot_setup<2, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb);
             ssave = (S.smask && S.snid >= 0) ? -2 : S.snid;           // -2: present but masked (CVRP depot slot)
@@ -864,7 +865,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                             sc[nt][v] *= inv;
                             o = __builtin_amdgcn_mfma_f32_16x16x4f32(vop[nt][v], sc[nt][v], o, 0, 0, 0);
                         }
-                        if (TRAIN && live) {
+                        if (TRAIN && live && A.trA) {
                             float* rA = A.trA + (((size_t)b * ELG_H + wave) * Rcap + r) * N1 + 16 * nt + 4 * hi_t;
                             if (16 * nt + 4 * hi_t + 3 < N1) {          // whole group inside the row: one 16-byte store
                                 f4s t4; t4.x = sc[nt][0]; t4.y = sc[nt][1]; t4.z = sc[nt][2]; t4.w = sc[nt][3];
@@ -1313,12 +1314,13 @@ static int dispatch_fwd(const elg_rollout_args& A, hipStream_t stream) {
     if (A.lds_stage && A.waves == 8 && A.N1 >= 4 && A.N1 <= 16 * CO_NT && !A.use_state && A.do_decode && A.do_update &&
         A.max_steps <= 0 && !(A.debug_skip & 0xB)) {   // bits 4,5: coop-kernel ablations
         // fused rollout at the training scale: lockstep trajectories, tables as MFMA operands in registers
-        if (A.trA) {
+        if (A.trA || A.trMask) {        // training forward (glimpse weights saved, or recomputed from the mask rows)
             if (!A.trPC || !A.trCsel || !A.trQ || !A.trO) return fail(ELG_EINVAL, "rollout: incomplete training rows");
             return launch_fwd_coop<TSP, true>(A, stream);
         }
         return launch_fwd_coop<TSP, false>(A, stream);
     }
+    if (A.trMask && !A.trA) return fail(ELG_EINVAL, "rollout: this kernel needs trA (mask-only rows: cooperative kernel)");
     if (A.trA) {        // training forward: saves the backward rows; built for N1 <= 128, 8 waves
         if (!A.trPC || !A.trCsel || !A.trQ || !A.trO) return fail(ELG_EINVAL, "rollout: incomplete training rows");
         if (A.use_state) return fail(ELG_EINVAL, "rollout: training rows need the fused rollout");

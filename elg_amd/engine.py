@@ -375,7 +375,9 @@ class TrainRows:
     def __init__(self, B, M, N1, Tcap, dev):
         Rcap = Tcap * M
         self.B, self.M, self.N1, self.Tcap, self.Rcap = B, M, N1, Tcap, Rcap
-        self.A = torch.empty(B, H, Rcap, N1, device=dev)
+        self._A = None                          # glimpse weights: only for forwards that cannot save mask rows
+        self.Mask = torch.zeros(B, Rcap, 2, device=dev, dtype=torch.int64)    # feasibility mask words per row
+        self.use_mask = False                   # set by the forward that filled the rows
         self.PC = torch.empty(B, Rcap, N1, device=dev)
         self.Csel = torch.empty(B, Rcap, device=dev)
         self.Q = torch.empty(B, Rcap, E, device=dev)
@@ -385,7 +387,7 @@ class TrainRows:
         self.F = torch.empty(B, Rcap, 3, 48, device=dev)
         # zero ONCE: afterwards every value ever written is finite, and the backward multiplies the rows of
         # undecoded steps (first moves, finished trajectories) by an exactly-zero weight, so stale rows are inert
-        for t in (self.A, self.PC, self.Csel, self.Q, self.O, self.Load, self.F):
+        for t in (self.PC, self.Csel, self.Q, self.O, self.Load, self.F):
             t.zero_()
         self.Slot.fill_(-1)
         self.gen = 0
@@ -397,6 +399,12 @@ class TrainRows:
         if ws is None:
             ws = cls._cache[key] = TrainRows(B, M, N1, Tcap, dev)
         return ws
+
+    @property
+    def A(self):
+        if self._A is None:
+            self._A = torch.zeros(self.B, H, self.Rcap, self.N1, device=self.PC.device)
+        return self._A
 
     def prepare(self):
         self.gen += 1
@@ -444,7 +452,15 @@ def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mo
     if train and N1 <= 128:
         rows = TrainRows.get(B, M, N1, Tcap, dev)
         rows.prepare()
-        a.trA, a.trPC, a.trCsel, a.trQ, a.trO = _ptr(rows.A), _ptr(rows.PC), _ptr(rows.Csel), _ptr(rows.Q), _ptr(rows.O)
+        # ELG_SAVE_GLIMPSE=0: the cooperative kernel (what dispatch_fwd picks for this launch shape) saves only the rows'
+        # 128-bit mask words and the backward recomputes the glimpse weights from q, K and the mask -- 4.2 GB less
+        # workspace and 3.3 GB less written + read per step, but measured 5 % slower end to end at the bench shape (the
+        # forward's stores are asynchronous, the backward kernel is MFMA/VALU bound: +28 MFMAs and a softmax per tile)
+        rows.use_mask = bool(a.lds_stage and a.waves == 8 and 4 <= N1 <= 112 and not (debug & 0xB)
+                             and os.environ.get("ELG_SAVE_GLIMPSE", "1") == "0")
+        a.trA = None if rows.use_mask else _ptr(rows.A)
+        a.trMask = _ptr(rows.Mask) if rows.use_mask else None
+        a.trPC, a.trCsel, a.trQ, a.trO = _ptr(rows.PC), _ptr(rows.Csel), _ptr(rows.Q), _ptr(rows.O)
         a.trLoad, a.trSlot, a.trF = _ptr(rows.Load), _ptr(rows.Slot), _ptr(rows.F)
     L.check(L.lib().elg_rollout_fwd(C.byref(a), _stream()), "elg_rollout_fwd")
     res = RolloutResult(actions, probs, reward, tlen, full)
@@ -500,7 +516,8 @@ class _ChosenProbs(torch.autograd.Function):
         ba.gloc = _ptr(gloc)
         if use_saved:
             # rows saved by the training forward (time-major r = t*M + m): no glimpse replay needed
-            rowA, rowO_rows = rows.A, rows.Rcap
+            rowA, rowO_rows = (None if rows.use_mask else rows.A), rows.Rcap
+            rowMask = rows.Mask if rows.use_mask else None
             rowO, rowQ = rows.O, rows.Q[:, :R]
             t0 = 1 if prob.kind == L.PROBLEM_TSP else 2
             # one launch: row weights (decoded steps only), d loss / d score rows, local-policy cotangents and
@@ -529,7 +546,7 @@ class _ChosenProbs(torch.autograd.Function):
                     L.check(L.lib().elg_rollout_bwd(C.byref(ba), _stream()), "elg_rollout_bwd(local)")
                 join_side = side
             rowA_rows = rows.Rcap
-            rowA_v = rows.A[:, :, :R]
+            rowA_v = None if rows.use_mask else rows.A[:, :, :R]
             rowO_v = rows.O[:, :R]
         else:
             rowA = torch.empty(B, H, R, N1, device=dev)
@@ -544,6 +561,7 @@ class _ChosenProbs(torch.autograd.Function):
             L.check(L.lib().elg_rollout_bwd(C.byref(ba), _stream()), "elg_rollout_bwd")
             rowA_rows = rowO_rows = R
             rowA_v, rowO_v = rowA, rowO
+            rowMask = None
             # the query of decode step t was gathered at cur = action[t-1] (and first = action[0] for TSP)
             prev = torch.cat([torch.zeros(B, M, 1, dtype=torch.long, device=dev), fl[:, :, :-1]], dim=2).reshape(B, R)
             first = fl[:, :, :1].expand(B, M, T).reshape(B, R) if hasQ2 else None
@@ -553,12 +571,12 @@ class _ChosenProbs(torch.autograd.Function):
             return x.view(B, x.shape[1], H, DK).permute(0, 2, 1, 3)
         dO = torch.bmm(rowDL, PKt)                                  # (B,R,128)   d o = d s . PK
         dQ = torch.empty(B, R, E, device=dev)
-        if N1 <= 128 and os.environ.get("ELG_FUSED_GLIMPSE_BWD", "1") != "0":
+        if N1 <= 128 and (rowMask is not None or os.environ.get("ELG_FUSED_GLIMPSE_BWD", "1") != "0"):
             # one MFMA launch: dS stays in registers, dQ / dK / dV come out directly
             splits = max(1, min(8, 1024 // (B * H)))
             dKp = torch.empty(splits, B, N1, E, device=dev)
             dVp = torch.empty(splits, B, N1, E, device=dev)
-            L.check(L.lib().elg_glimpse_bwd_fused(_ptr(rowA), _ptr(dO), _ptr(rowO), _ptr(rowQ), _ptr(Kt), _ptr(Vt),
+            L.check(L.lib().elg_glimpse_bwd_fused(_ptr(rowA), _ptr(rowMask), _ptr(dO), _ptr(rowO), _ptr(rowQ), _ptr(Kt), _ptr(Vt),
                                                   _ptr(dQ), _ptr(dKp), _ptr(dVp), B, R, N1, rowA_rows, rowO_rows,
                                                   rowQ.stride(0) // E, splits, _stream()), "elg_glimpse_bwd_fused")
             dK = dKp[0] if splits == 1 else dKp.sum(0)

@@ -127,6 +127,8 @@ typedef struct elg_rollout_args {
     float* trLoad;          /* (B,Rcap)       load at the step (CVRP)                           */
     int32_t* trSlot;        /* (B,Rcap,48)    node of every k-NN slot (-1: none, -2: depot slot, masked) */
     float* trF;             /* (B,Rcap,3,48)  local-policy features of every slot (NULL: not saved)   */
+    uint64_t* trMask;       /* (B,Rcap,2)     feasibility mask words of the row (bit n = node n closed); with it the
+                               cooperative kernel (N1 <= 112) may skip trA: the backward recomputes a_h from q, K   */
 } elg_rollout_args;
 
 /* POMO construction: CVRPEnv.reset/step + CVRPModel.one_step_rollout + utils.rollout fused into one
@@ -186,11 +188,12 @@ int elg_glimpse_rows_bwd(const float* rowA, const float* dO, const float* rowO, 
  *     dK_h = sum_r dS^T Q_h,  dV_h = sum_r a^T dO_h.
  * rowA (B,8,rowA_rows,N1); dO, dQ (B,R,128); rowO (B,rowO_rows,128); rowQ (B,rowQ_rows,128); Kmat, Vmat (B,N1,128);
  * dK_part, dV_part (splits,B,N1,128): partial sums over `splits` contiguous row ranges (the caller adds them).
- * N1 <= 128. */
-int elg_glimpse_bwd_fused(const float* rowA, const float* dO, const float* rowO, const float* rowQ,
-                          const float* Kmat, const float* Vmat, float* dQ, float* dK_part, float* dV_part,
-                          int B, int R, int N1, int64_t rowA_rows, int64_t rowO_rows, int64_t rowQ_rows,
-                          int splits, void* stream);
+ * rowMask (B,rowQ_rows,2) non-NULL: the weights a are not read but recomputed, a_h = softmax(q_h K_h^T / 4 + mask)
+ * (rowA may then be NULL; N1 <= 128 nodes = two 64-bit mask words per row).  N1 <= 128. */
+int elg_glimpse_bwd_fused(const float* rowA, const uint64_t* rowMask, const float* dO, const float* rowO,
+                          const float* rowQ, const float* Kmat, const float* Vmat, float* dQ, float* dK_part,
+                          float* dV_part, int B, int R, int N1, int64_t rowA_rows, int64_t rowO_rows,
+                          int64_t rowQ_rows, int splits, void* stream);
 
 /* ---- training-step glue (one launch each instead of chains of framework kernels) ----------------------------
  * REINFORCE / POMO loss with the shared baseline (reference CVRP/train.py:112-121, TSP/train.py:107-118):

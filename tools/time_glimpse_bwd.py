@@ -10,10 +10,12 @@ A = torch.softmax(torch.randn(B, 8, Rcap, N1, device=dev), -1)
 K = torch.randn(B, N1, E, device=dev); V = torch.randn(B, N1, E, device=dev)
 Q = torch.randn(B, Rcap, E, device=dev); O = torch.randn(B, Rcap, E, device=dev); dO = torch.randn(B, R, E, device=dev)
 dQ = torch.empty(B, R, E, device=dev)
+RECOMP = len(sys.argv) > 2
+MASK = (torch.rand(B, Rcap, 2, device=dev) * 2**62).long()
 for splits in (1, 2, 4):
     dKp = torch.empty(splits, B, N1, E, device=dev); dVp = torch.empty(splits, B, N1, E, device=dev)
     def run():
-        L.check(L.lib().elg_glimpse_bwd_fused(eng._ptr(A), eng._ptr(dO), eng._ptr(O), eng._ptr(Q), eng._ptr(K), eng._ptr(V),
+        L.check(L.lib().elg_glimpse_bwd_fused(eng._ptr(A) if not RECOMP else None, eng._ptr(MASK) if RECOMP else None, eng._ptr(dO), eng._ptr(O), eng._ptr(Q), eng._ptr(K), eng._ptr(V),
                                               eng._ptr(dQ), eng._ptr(dKp), eng._ptr(dVp), B, R, N1, Rcap, Rcap, Rcap, splits,
                                               eng._stream()), "fused")
     for _ in range(3): run()
