@@ -50,7 +50,7 @@ class BwdArgs(C.Structure):
 EXPORTS = ["elg_version", "elg_last_error", "elg_aug8", "elg_dist_matrix", "elg_nbr_tables", "elg_route_length",
            "elg_rollout_fwd", "elg_rollout_bwd", "elg_glimpse_rows_bwd", "elg_glimpse_bwd_fused", "elg_gemm_f32",
            "elg_pomo_loss", "elg_rows_prep", "elg_adam_step", "elg_local_bwd_rows",
-           "elg_add_instnorm_fwd", "elg_add_instnorm_bwd"]
+           "elg_add_instnorm_fwd", "elg_add_instnorm_bwd", "elg_rows_segsum"]
 
 _lib = None
 
@@ -83,7 +83,8 @@ def lib() -> C.CDLL:
         L.elg_gemm_f32.argtypes = [f, f, f, f, i, i, i, i, i, i, i, i, i, i, f, f]
         i64, fl = C.c_int64, C.c_float
         L.elg_pomo_loss.argtypes = [f, f, i, i, i, i64, i64, f, f, f, f, f, f]
-        L.elg_rows_prep.argtypes = [f, f, f, f, f, f, f, f, f, f, f, f, i, i, i, i, i, i64, i, fl, f]
+        L.elg_rows_prep.argtypes = [f, f, f, f, f, f, f, f, f, f, f, f, f, f, i, i, i, i, i, i64, i, fl, f]
+        L.elg_rows_segsum.argtypes = [f, f, f, f, i, i, i, i, i64, i, f]
         L.elg_add_instnorm_fwd.argtypes = [f, f, f, f, f, f, f, i, i, i, fl, f]
         L.elg_add_instnorm_bwd.argtypes = [f, f, f, f, f, f, f, i, i, i, f]
         L.elg_local_bwd_rows.argtypes = [f, f, f, f, f, i, i, i64, i, f]
@@ -91,7 +92,7 @@ def lib() -> C.CDLL:
         for n in ("elg_aug8", "elg_dist_matrix", "elg_nbr_tables", "elg_route_length", "elg_rollout_fwd",
                   "elg_rollout_bwd", "elg_glimpse_rows_bwd", "elg_glimpse_bwd_fused", "elg_gemm_f32",
                   "elg_pomo_loss", "elg_rows_prep", "elg_adam_step", "elg_local_bwd_rows",
-                  "elg_add_instnorm_fwd", "elg_add_instnorm_bwd"):
+                  "elg_add_instnorm_fwd", "elg_add_instnorm_bwd", "elg_rows_segsum"):
             getattr(L, n).restype = C.c_int
         _lib = L
     return _lib

@@ -212,11 +212,20 @@ int elg_pomo_loss(const float* probs, const float* reward, int B, int T, int M, 
  * gprob, pval (B,T,M) dense; tlen (B,M); actions (B,M,Tcap_actions); PC (B,Rcap,N1); Csel (B,Rcap); Slot (B,Rcap,48);
  * outputs dense over R = T*M rows.  rowDU / onehot_* may be NULL.  If `load` (B,Rcap: vehicle load of the row, CVRP)
  * is given, onehot_prev is (B,R,N1+1) and its last column holds the load, so that onehot_prev^T dQ also produces
- * d wl (the load column of Wq_last) in row N1. */
+ * d wl (the load column of Wq_last) in row N1.  idx_prev / idx_first (B,R) int32, may be NULL: the same node indices
+ * as plain integers, for elg_rows_segsum (which needs no one-hot matrix). */
 int elg_rows_prep(const float* gprob, const float* pval, const int32_t* tlen, const int32_t* actions,
                   const float* PC, const float* Csel, const int32_t* Slot, const float* load, float* rowDL,
-                  float* rowDU, float* onehot_prev, float* onehot_first, int B, int T, int M, int N1, int Tcap_actions,
+                  float* rowDU, float* onehot_prev, float* onehot_first, int32_t* idx_prev, int32_t* idx_first,
+                  int B, int T, int M, int N1, int Tcap_actions,
                   int64_t Rcap, int first_decode_step, float inv_ens, void* stream);
+
+/* out_part[s, b, n, :] = sum over the rows r (in row split s) of instance b with idx[b, r] == n of X[b, r, :]; if
+ * wrow >= 0, row wrow instead holds sum_r w[b, r] X[b, r, :].  X (B,R,128), idx (B,R), w (B,w_stride), out_part
+ * (splits,B,NO,128), NO <= 128.  This is onehot^T X (the query-gather backward, models.py:330-333 / the load column
+ * of Wq_last) with the one-hot operand built in registers. */
+int elg_rows_segsum(const float* X, const int32_t* idx, const float* w, float* out_part, int B, int R, int NO, int wrow,
+                    int64_t w_stride, int splits, void* stream);
 
 /* torch.optim.Adam update (L2 weight decay added to the gradient, bias correction; reference train.py:101) over n
  * floats in one launch.  grad / exp_avg / exp_avg_sq are flat.  Parameters: either flat (`param`), or left in place

@@ -71,8 +71,10 @@ def test_rows_prep_matches_torch(tsp):
     Load = torch.rand(B, Rcap, generator=g).to(DEV)
     ohP = torch.full((B, R, N1 + (0 if tsp else 1)), float("nan"), device=DEV)
     ohF = torch.full((B, R, N1), float("nan"), device=DEV) if tsp else None
+    ixP = torch.full((B, R), -7, device=DEV, dtype=torch.int32)
+    ixF = torch.full((B, R), -7, device=DEV, dtype=torch.int32) if tsp else None
     L.check(L.lib().elg_rows_prep(eng._ptr(gp), eng._ptr(pv), eng._ptr(tlen), eng._ptr(acts), eng._ptr(PC), eng._ptr(Csel),
-                                  eng._ptr(Slot), eng._ptr(Load) if not tsp else None, eng._ptr(rowDL), eng._ptr(rowDU), eng._ptr(ohP), eng._ptr(ohF),
+                                  eng._ptr(Slot), eng._ptr(Load) if not tsp else None, eng._ptr(rowDL), eng._ptr(rowDU), eng._ptr(ohP), eng._ptr(ohF), eng._ptr(ixP), eng._ptr(ixF),
                                   B, T, M, N1, Tcap, Rcap, t0, inv, eng._stream()), "rows_prep")
     # the torch chain this kernel replaces (engine._ChosenProbs.backward before the fusion)
     fl = acts[:, :, :T].long()
@@ -89,11 +91,13 @@ def test_rows_prep_matches_torch(tsp):
     np.testing.assert_allclose(rowDL.cpu().numpy(), ref.cpu().numpy(), rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(rowDU.cpu().numpy(), refU.cpu().numpy(), rtol=1e-6, atol=1e-7)
     assert torch.equal(ohP[:, :, :N1], refP)
+    assert torch.equal(ixP.long(), prev)
     if not tsp:
         assert torch.equal(ohP[:, :, N1], Load[:, :R])
     if tsp:
         first = fl[:, :, 0][:, None, :].expand(B, T, M).reshape(B, R)
         assert torch.equal(ohF, torch.zeros(B, R, N1, device=DEV).scatter_(2, first[:, :, None], 1.0))
+        assert torch.equal(ixF.long(), first)
 
 
 def test_adam_matches_torch_and_checkpoints():
@@ -191,3 +195,27 @@ def test_add_instance_norm_matches_torch(B, N, C):
     gg = torch.autograd.grad((got * w).sum(), [a, b, norm.weight, norm.bias])
     for x, y in zip(gg, gr):
         np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=0, atol=1e-5 * max(1.0, y.abs().max().item()))
+
+
+@pytest.mark.parametrize("B,R,NO,wrow,splits", [(3, 203, 102, 101, 2), (2, 37, 21, -1, 1), (1, 1000, 128, -1, 4), (2, 64, 52, 51, 3)])
+def test_rows_segsum_is_onehot_transpose_times_x(B, R, NO, wrow, splits):
+    """elg_rows_segsum = the one-hot GEMM of the query-gather backward (fp64 reference; exact zeros for untouched nodes)."""
+    from elg_amd import _lib as L, engine as eng
+    g = torch.Generator().manual_seed(R)
+    X = torch.randn(B, R, 128, generator=g).to(DEV)
+    nn = NO - (1 if wrow >= 0 else 0)
+    idx = torch.randint(0, max(1, nn - 3), (B, R), generator=g, dtype=torch.int32).to(DEV)      # last nodes never hit
+    Rcap = R + 5
+    w = torch.randn(B, Rcap, generator=g).to(DEV)
+    part = torch.full((splits, B, NO, 128), float("nan"), device=DEV)
+    L.check(L.lib().elg_rows_segsum(eng._ptr(X), eng._ptr(idx), eng._ptr(w) if wrow >= 0 else None, eng._ptr(part), B, R, NO,
+                                    wrow, Rcap, splits, eng._stream()), "segsum")
+    got = part.sum(0).cpu().double()
+    oh = torch.zeros(B, R, NO, dtype=torch.float64, device=DEV).scatter_(2, idx.long()[:, :, None], 1.0)
+    if wrow >= 0:
+        oh[:, :, wrow] = w[:, :R].double()
+    ref = torch.bmm(oh.transpose(1, 2), X.double()).cpu()
+    assert torch.isfinite(got).all()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=2e-5 * ref.abs().max().item())
+    if nn >= 4:
+        assert (got[:, nn - 2] == 0).all()
