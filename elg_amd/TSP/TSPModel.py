@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 import random
 
 import torch
@@ -12,6 +13,22 @@ from elg_amd import engine as eng
 from elg_amd.TSP.models import TSP_Decoder, TSP_Encoder
 
 
+class _EncodeAndFold(nn.Module):
+    """encoder + table folds as one static-shape callable (two hipGraphs per training step, see CVRPModel)."""
+
+    def __init__(self, encoder, decoder):
+        super().__init__()
+        self.encoder, self.decoder = encoder, decoder
+
+    def forward(self, problems):
+        enc = self.encoder(problems)
+        t, loc = self.decoder.fold(enc)
+        outs = [enc, t["K"], t["V"], t["PK"], t["pb"], t["Q1"], t["Q2"]]
+        if loc is not None:
+            outs.append(loc)
+        return tuple(outs)
+
+
 class TSPModel(nn.Module):
     def __init__(self, **model_params):
         super().__init__()
@@ -19,9 +36,35 @@ class TSPModel(nn.Module):
         self.encoder = TSP_Encoder(**model_params)
         self.decoder = TSP_Decoder(**model_params)
         self.encoded_nodes = None
+        self.__dict__["_graphs"] = {}
+        self.use_graphs = os.environ.get("ELG_HIPGRAPH", "1") != "0"
+
+    def _graphed(self, problems):
+        key = (tuple(problems.shape), str(problems.device), tuple(id(p) for p in self.parameters()))
+        g = self._graphs.get(key)
+        if g is None:
+            try:
+                g = torch.cuda.make_graphed_callables(_EncodeAndFold(self.encoder, self.decoder),
+                                                      (problems.detach().clone(),))
+            except Exception as e:          # capture is an optimisation only: eager PyTorch is the same math
+                print(f"[elg_amd] hipGraph capture of the encoder failed ({type(e).__name__}: {e}); running eager")
+                g = False
+            self._graphs.clear()
+            self._graphs[key] = g
+        return g
 
     def pre_forward(self, reset_state):
-        self.encoded_nodes = self.encoder(reset_state.problems)
+        problems = reset_state.problems
+        g = None
+        if self.use_graphs and self.training and torch.is_grad_enabled() and problems.is_cuda:
+            g = self._graphed(problems)
+        if g:
+            outs = g(problems.contiguous())
+            self.encoded_nodes = outs[0]
+            tables = dict(K=outs[1], V=outs[2], PK=outs[3], pb=outs[4], Q1=outs[5], Q2=outs[6], wl=None)
+            self.decoder.set_tables(self.encoded_nodes, tables, outs[7] if len(outs) > 7 else None)
+            return
+        self.encoded_nodes = self.encoder(problems)
         self.decoder.set_kv(self.encoded_nodes)
 
     @staticmethod

@@ -72,8 +72,8 @@ class TSP_Decoder(nn.Module):
         self.local_policy_0 = local_policy_att(mp).to(device)
         self.local = True
 
-    def set_kv(self, encoded_nodes):
-        """reference TSP/models.py:231-241 (+ set_q1 :236-241 folded into the Q2 table)."""
+    def fold(self, encoded_nodes):
+        """(tables, loc): decoder / local-policy weights folded for the HIP kernels (engine.fold_*)."""
         mp = self.model_params
         dec = {"Wq_first.weight": self.Wq_first.weight, "Wq_last.weight": self.Wq_last.weight,
                "Wk.weight": self.Wk.weight, "Wv.weight": self.Wv.weight,
@@ -81,9 +81,18 @@ class TSP_Decoder(nn.Module):
                "multi_head_combine.bias": self.multi_head_combine.bias}
         tables = eng.fold_decoder_tables(dec, encoded_nodes, L.PROBLEM_TSP)
         has_local = bool(mp['ensemble'] and self.local)
-        K = int(mp['local_size'][0])
-        loc = self.local_policy_0.folded_tables(K) if has_local else None
-        self.policy = eng.Policy(tables, loc, K, float(mp['xi']), float(mp['logit_clipping']), 1.0, has_local,
-                                 bool(mp['distance_penalty']))
+        loc = self.local_policy_0.folded_tables(int(mp['local_size'][0])) if has_local else None
+        return tables, loc
+
+    def set_tables(self, encoded_nodes, tables, loc):
+        mp = self.model_params
+        has_local = bool(mp['ensemble'] and self.local)
+        self.policy = eng.Policy(tables, loc, int(mp['local_size'][0]), float(mp['xi']), float(mp['logit_clipping']), 1.0,
+                                 has_local, bool(mp['distance_penalty']))
         self.k, self.v = tables["K"], tables["V"]
         self.single_head_key = encoded_nodes.transpose(1, 2)
+
+    def set_kv(self, encoded_nodes):
+        """reference TSP/models.py:231-241 (+ set_q1 :236-241 folded into the Q2 table)."""
+        tables, loc = self.fold(encoded_nodes)
+        self.set_tables(encoded_nodes, tables, loc)
