@@ -1,0 +1,132 @@
+"""BASELINE.json's full sizes through size-independent properties (the oracle only replays small cases in seconds):
+CVRP-100 batch 64 pomo 100 (configs[1], the bench workload), TSP-500 batch 16 pomo 500 (configs[3]) and a VRPLIB-sized
+instance.  Properties: every tour feasible (each customer once, capacity never exceeded -- the reference's own
+check_feasible on EVERY instance), reward = closed-tour length of the recorded actions (route-length kernel and the
+oracle's formula), probabilities in (0, 1], step counts consistent with the action rows, same seed -> same tours,
+sampled tours replayed teacher-forced give the same probabilities, the saved training rows are finite and complete."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import elg_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cvrp_model(mp, seed):
+    from elg_amd.CVRP.CVRPModel import CVRPModel
+    m = CVRPModel(**mp)
+    m.decoder.add_local_policy("cpu")
+    w = gu.golden_weights("cvrp", seed, mp, True, 1.0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    return m.to(DEV)
+
+
+def test_cvrp100_bench_shape_properties():
+    from elg_amd import _lib as L, engine as eng
+    from elg_amd.CVRP.CVRPEnv import CVRPEnv
+    from elg_amd.CVRP.generate_data import generate_vrp_data
+    torch.manual_seed(7)
+    B, N, M = 64, 100, 100
+    mp = dict(gu.CVRP_MODEL_PARAMS)
+    model = _cvrp_model(mp, 12).eval()
+    env = CVRPEnv(M, DEV)
+    batch = generate_vrp_data(B, N, dict(data_type="uniform"))
+    env.load_random_problems(batch)
+    rs, _, _ = env.reset()
+    with torch.no_grad():
+        model.pre_forward(rs)
+    pol, prob = model.decoder.policy, env.problem
+    starts = torch.randperm(N)[:M]
+    res = eng.rollout_forward(prob, pol, M, starts, L.MODE_SAMPLE, seed=99, train=True)
+    T = int(res.tlen.max().item())
+    acts = res.actions[:, :, :T].cpu().long()
+    tl = res.tlen.cpu()
+    dem = env.depot_node_demand.cpu().numpy()
+    for b in range(B):                                                  # the reference's feasibility check, every instance
+        orc.check_feasible(acts[b].numpy(), dem[b, 1:])
+    # finished trajectories stay at the depot with probability 1; unfinished rows end exactly at tlen
+    tt = torch.arange(T)[None, None, :]
+    assert (acts[tt.expand(B, M, T) >= tl[:, :, None]] == 0).all()
+    p = res.probs[:, :T].cpu()
+    assert ((p > 0) & (p <= 1.0 + 1e-6)).all()
+    assert (p.permute(0, 2, 1)[tt.expand(B, M, T) >= tl[:, :, None]] == 1).all()
+    # reward = -closed tour length: route-length kernel and the oracle's formula
+    xy = env.depot_node_xy
+    np.testing.assert_allclose(-res.reward.cpu().numpy(), eng.route_length(xy, res.actions[:, :, :T].long()).cpu().numpy(), rtol=2e-6)
+    np.testing.assert_allclose(-res.reward[:4].cpu().numpy(), orc.route_length(xy[:4].cpu(), acts[:4]).numpy(), rtol=1e-5)
+    # same seed -> same tours; teacher-forced replay of the sampled tours -> same probabilities
+    res2 = eng.rollout_forward(prob, pol, M, starts, L.MODE_SAMPLE, seed=99)
+    assert torch.equal(res.actions, res2.actions) and torch.equal(res.tlen, res2.tlen)
+    res3 = eng.rollout_forward(prob, pol, M, starts, L.MODE_FORCED, forced=res.actions[:, :, :T].contiguous())
+    np.testing.assert_allclose(res3.probs[:, :T].cpu().numpy(), p.numpy(), rtol=1e-6)
+    # saved training rows: finite everywhere, softmax Jacobian rows sum to ~0 weight outside the open nodes
+    rows = res.rows
+    R = T * M
+    for name in ("A", "PC", "Csel", "Q", "O", "Load", "F"):
+        assert torch.isfinite(getattr(rows, name)[:, ..., :R, :] if name == "A" else getattr(rows, name)[:, :R]).all(), name
+    valid = ((torch.arange(T, device=DEV)[None, :, None] >= 2) & (torch.arange(T, device=DEV)[None, :, None] < res.tlen[:, None, :])).reshape(B, R)
+    A = rows.A[:, :, :R]                                                # glimpse weights: rows of decoded steps sum to 1 per head
+    s = A.sum(-1)[valid[:, None, :].expand(B, 8, R)]
+    assert torch.allclose(s, torch.ones_like(s), atol=1e-5)
+
+
+def test_tsp500_properties():
+    from elg_amd import _lib as L, engine as eng
+    from elg_amd.TSP.TSPEnv import TSPEnv
+    from elg_amd.TSP.TSPModel import TSPModel
+    torch.manual_seed(3)
+    B, N = 16, 500
+    mp = dict(gu.TSP_MODEL_PARAMS)
+    model = TSPModel(**mp)
+    model.decoder.add_local_policy("cpu")
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in gu.golden_weights("tsp", 2, mp, True, 1.0).items()})
+    model.to(DEV).eval()
+    env = TSPEnv(N, DEV)
+    env.load_random_problems(torch.rand(B, N, 2))
+    rs, _, _ = env.reset()
+    with torch.no_grad():
+        model.pre_forward(rs)
+    pol, prob = model.decoder.policy, env.problem
+    starts = torch.randperm(N)
+    res = eng.rollout_forward(prob, pol, N, starts, L.MODE_SAMPLE, seed=4)
+    assert (res.tlen.cpu() == N).all()
+    acts = res.actions.cpu().long()
+    assert (np.sort(acts.numpy(), -1) == np.arange(N)).all()            # every tour is a permutation of the nodes
+    assert torch.equal(acts[0, :, 0], starts)
+    p = res.probs.cpu()
+    assert ((p > 0) & (p <= 1.0 + 1e-6)).all() and (p[:, 0] == 1).all() and (p[:, -1] > 0.999999).all()   # last node is forced
+    xy = env.problems
+    np.testing.assert_allclose(-res.reward.cpu().numpy(), eng.route_length(xy, acts.to(DEV)).cpu().numpy(), rtol=3e-6)
+    np.testing.assert_allclose(-res.reward[:2].cpu().numpy(), orc.route_length(xy[:2].cpu(), acts[:2]).numpy(), rtol=2e-5)
+    res2 = eng.rollout_forward(prob, pol, N, starts, L.MODE_FORCED, forced=res.actions)
+    np.testing.assert_allclose(res2.probs.cpu().numpy(), p.numpy(), rtol=1e-6)
+    g1 = eng.rollout_forward(prob, pol, N, starts, L.MODE_GREEDY)
+    g2 = eng.rollout_forward(prob, pol, N, starts, L.MODE_GREEDY)
+    assert torch.equal(g1.actions, g2.actions)
+
+
+def test_vrplib_n1001_properties():
+    """X-n1001-k43 with 8-fold augmentation, pomo 1000 (configs[4] upper end): feasible integer-cost tours never below
+    the best-known solution."""
+    import os
+    from elg_amd import vrplib_io
+    from elg_amd.CVRP.CVRPEnv import CVRPEnv
+    from elg_amd.CVRP.utils import rollout
+    mp = dict(gu.CVRP_MODEL_PARAMS)
+    model = _cvrp_model(mp, 17).eval()
+    inst = vrplib_io.read_instance(os.path.join(gu.GOLDEN_DIR, "vrplib", "X", "X-n1001-k43.vrp"))
+    sol = vrplib_io.read_solution(os.path.join(gu.GOLDEN_DIR, "vrplib", "X", "X-n1001-k43.sol"))
+    env = CVRPEnv(1000, DEV)
+    env.load_vrplib_problem(inst, aug_factor=8)
+    rs, _, _ = env.reset()
+    with torch.no_grad():
+        model.pre_forward(rs)
+        acts, _, rew = rollout(model, env, 'greedy')
+    cost = -rew
+    assert torch.equal(cost, cost.round()) and float(cost.min()) >= sol["cost"]
+    dem = env.depot_node_demand.cpu().numpy()
+    for b in (0, 7):
+        orc.check_feasible(acts[b, ::97].cpu().numpy(), dem[b, 1:])
