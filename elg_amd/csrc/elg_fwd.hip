@@ -473,13 +473,13 @@ static int launch_fwd_impl(const elg_rollout_args& A, hipStream_t stream) {
 // REGISTERS: wave h keeps K_h and V_h (its head's 16 channels of every node: 56 VGPRs) and wave w < 7 keeps the
 // 16-node slice w of PK (32 VGPRs).  LDS only carries the per-step exchange: queries in, glimpse outputs back,
 // pointer scores out.  Per step:
-//   owners   (wave w owns trajectories w, w+8, w+16, w+24): mask, query q -> LDS
+//   owners   (wave w owns trajectories 4 w .. 4 w + 3): mask, query q, k-NN slots -> LDS
 //   glimpse  (wave h = head h): S^T[n][traj] = K_h[n] . q_h[traj] for 2 x 7 tiles, softmax over n (registers +
 //            two cross-quarter shuffles), O^T[d][traj] = sum_n V_h[n][d] P^T[n][traj]; the D tile of the first
 //            product is the B operand of the second (node on the k-slot), nothing is transposed
 //   pointer  (wave w < 7 = node tile w): s^T[n][traj] = sum_c PK[n][c] o[traj][c] + pb[n] -> LDS
-//   owners:  k-NN slots, local policy, clip/softmax/choice, env update (the per-trajectory code of the other
-//            kernel, unchanged), then the next step's mask and query.
+//   owners:  clip / mask / softmax / choice of the wave's four trajectories at once (16 lanes per trajectory,
+//            DPP row reductions and scans), then per trajectory the env update and the next step's mask, query, slots.
 // Trajectory state lives in LDS between phases (12 dwords), wave-uniform in SGPRs while a wave works on it.
 // =============================================================================================
 constexpr int CO_QP = 132;      // pitch of the query / glimpse-output exchange rows (conflict-free column reads)
@@ -703,6 +703,138 @@ __device__ __forceinline__ void co_prepare(const elg_rollout_args& A, const Inst
     }
 }
 
+// 16-lane (DPP row) integer min / max all-reduce
+__device__ __forceinline__ int row16_min_i(int v) {
+    v = min(v, f2i(quad_xor1(i2f(v)))); v = min(v, f2i(quad_xor2(i2f(v))));
+    v = min(v, f2i(dpp<0x141>(i2f(v)))); v = min(v, f2i(dpp<0x140>(i2f(v))));
+    return v;
+}
+__device__ __forceinline__ int row16_max_i(int v) {
+    v = max(v, f2i(quad_xor1(i2f(v)))); v = max(v, f2i(quad_xor2(i2f(v))));
+    v = max(v, f2i(dpp<0x141>(i2f(v)))); v = max(v, f2i(dpp<0x140>(i2f(v))));
+    return v;
+}
+
+// Clip / mask / softmax / choice (models.py:405-420, CVRPModel.py:53-70) of the FOUR trajectories a wave owns at
+// once: 16 lanes per trajectory (row tq = lane >> 4), node n = lo + 16 k in register k (7 registers cover 112
+// nodes).  Softmax reductions are 16-lane DPP row reductions, the inverse-CDF sample a DPP row scan per register
+// chunk (node order = k-major), the arg-max a (value desc, node asc) row reduction.  One pass of ~250 VALU
+// instructions for four trajectories instead of ~400 per trajectory with a whole wavefront each.
+// Results (chosen node, its probability) go to dwords 12 / 13 of the trajectory's state block.
+template <bool TSP, bool TRAIN>
+__device__ __forceinline__ void co_finish4(const elg_rollout_args& A, int N1, int lane, int wave, int ntraj, int t, int g_lo,
+                                           size_t b, size_t Rcap, float* sSc, const unsigned long long* sMask,
+                                           const float* sX, int* sState) {
+    constexpr int NK = CO_NT;
+    const int tq = lane >> 4, lo = lane & 15;
+    const int q = 4 * wave + tq;
+    const float dflt = A.has_penalty ? A.xi : 0.f;
+    // ---- slot terms (penalty + local policy) scattered into the score rows: one trajectory per pass, lane = slot
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int qq = 4 * wave + i;
+        if (qq < ntraj && lane < ELG_SLOT_STRIDE) {
+            const float* X = sX + qq * CO_XP;
+            const int code = reinterpret_cast<const int*>(X)[CO_XS + lane];
+            const int snid = (code == -2) ? 0 : code;
+            if (snid >= 0) sSc[qq * CO_SP + snid] += X[CO_XPEN + lane] + X[CO_XU + lane] * A.inv_ens - dflt;
+        }
+    }
+    wave_lds_fence();
+    const bool act = q < ntraj && sState[16 * q + 3] == 0;           // decoding this step (row-uniform)
+    const unsigned long long w0 = sMask[2 * q], w1 = sMask[2 * q + 1];
+    const int m = g_lo + q;
+    const size_t bm = b * A.M + m;
+    const size_t r = (size_t)t * A.M + m;
+    float e[NK], th[NK];
+    float mx = ELG_NEG_INF;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int n = lo + 16 * k;
+        const unsigned long long w = (k < 4) ? w0 : w1;
+        const bool masked = (n >= N1) || ((w >> (n & 63)) & 1ull);
+        float x = ELG_NEG_INF;
+        th[k] = 0.f;
+        if (!masked) { th[k] = fast_tanh(sSc[q * CO_SP + n] + dflt); x = A.clip * th[k]; }
+        e[k] = x;
+        mx = fmaxf(mx, x);
+    }
+    mx = row16_max(mx);
+    float part = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        e[k] = (e[k] > ELG_NEG_INF) ? __expf(e[k] - mx) : 0.f;
+        part += e[k];
+    }
+    const float tot = row16_sum(part);
+    const float inv = tot > 0.f ? 1.0f / tot : 0.f;
+    if (A.full_probs && t < A.dump_T && act) {
+        float* frow = A.full_probs + (bm * A.dump_T + t) * N1;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) if (lo + 16 * k < N1) frow[lo + 16 * k] = e[k] * inv;
+    }
+    // ---- choose
+    int sel = 0;
+    if (A.mode == ELG_MODE_FORCED) {
+        sel = (act && A.forced && t < A.Tforced) ? A.forced[bm * A.Tforced + t] : 0;
+    } else if (A.mode == ELG_MODE_GREEDY) {
+        float bv = -1.f;
+        int bn = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const float pv = e[k] * inv;
+            if (lo + 16 * k < N1 && pv > bv) { bv = pv; bn = lo + 16 * k; }
+        }
+#pragma unroll
+        for (int mm = 1; mm < 16; mm <<= 1) {                        // stays inside the 16-lane row
+            const float ov = shfl_xor(bv, mm);
+            const int on = shfl_xor(bn, mm);
+            if (ov > bv || (ov == bv && on < bn)) { bv = ov; bn = on; }
+        }
+        sel = bn;
+    } else {
+        float uni = 0.f;
+        if (act) uni = A.uniforms ? A.uniforms[bm * A.Tmax + t] : philox_uniform(A.seed, (unsigned)bm, (unsigned)t);
+        const float target = uni * tot;
+        float run = 0.f;
+        int found = 0x7fffffff, lastpos = -1;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            float c = e[k];
+            c += dpp<0x111>(c); c += dpp<0x112>(c); c += dpp<0x114>(c); c += dpp<0x118>(c);   // row inclusive scan
+            c += run;
+            run += row16_sum(e[k]);
+            const int n = lo + 16 * k;
+            if (e[k] > 0.f) {
+                lastpos = n;                                          // k ascending: the lane's largest open node
+                if (c > target && found == 0x7fffffff) found = n;
+            }
+        }
+        found = row16_min_i(found);
+        lastpos = row16_max_i(lastpos);
+        sel = (found != 0x7fffffff) ? found : max(lastpos, 0);
+    }
+    // probability (and clip Jacobian) of the chosen node: held by lane (sel & 15), register sel >> 4
+    const bool mine = (sel & 15) == lo;
+    float pe = 0.f, pj = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+        if (mine && (sel >> 4) == k) { pe = e[k] * inv; pj = A.clip * (1.f - th[k] * th[k]); }
+    pe = row16_sum(pe);
+    if (TRAIN) {
+        pj = row16_sum(pj);
+        if (act) {
+            float* rPC = A.trPC + (b * Rcap + r) * N1;
+#pragma unroll
+            for (int k = 0; k < NK; ++k)
+                if (lo + 16 * k < N1) rPC[lo + 16 * k] = e[k] * inv * (A.clip * (1.f - th[k] * th[k]));
+            if (lo == 0) A.trCsel[b * Rcap + r] = pj;
+        }
+    }
+    if (act && lo == 0) { sState[16 * q + 12] = sel; sState[16 * q + 13] = f2i(pe); }
+    wave_lds_fence();
+}
+
 template <bool TSP, bool TRAIN>
 __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout_args A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -907,7 +1039,13 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
             }
             // =============== owners: finish this step, advance, prepare the next ===============
             int any_left = 0;
-            for (int q = wave; q < ntraj; q += 8) {
+            const bool batched = !(A.debug_skip & 32);                  // bit 5: per-trajectory finish_step (A/B)
+            if (decode_step && batched)
+                co_finish4<TSP, TRAIN>(A, N1, lane_t, wave, ntraj, t, g_lo, (size_t)b, Rcap, sSc, sMask, sX, sState);
+#pragma unroll 1
+            for (int qi = 0; qi < 4; ++qi) {
+                const int q = 4 * wave + qi;                            // wave w owns trajectories 4 w .. 4 w + 3
+                if (q >= ntraj) break;
                 Traj<2> st;
                 co_load_state(sState + 16 * q, st, lane_t);
                 const int m = g_lo + q;
@@ -921,6 +1059,9 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                     if (!decode_step) {
                         if (A.mode == ELG_MODE_FORCED) sel = fsel;
                         else sel = (!TSP && t == 0) ? 0 : __builtin_amdgcn_readfirstlane(A.starts[m]);
+                    } else if (batched) {
+                        sel = __builtin_amdgcn_readfirstlane(sState[16 * q + 12]);
+                        pr = i2f(__builtin_amdgcn_readfirstlane(sState[16 * q + 13]));
                     } else {
                         unsigned long long mk[2];
                         {
@@ -967,7 +1108,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
             if (!__syncthreads_or(any_left)) break;                  // also orders the exchange rows for the next step
         }
         // ---- results of the group
-        for (int q = wave; q < ntraj; q += 8) {
+        for (int q = 4 * wave; q < min(ntraj, 4 * wave + 4); ++q) {
             Traj<2> st;
             co_load_state(sState + 16 * q, st, lane);
             const size_t bm = (size_t)b * A.M + g_lo + q;
@@ -1309,7 +1450,7 @@ static int dispatch_fwd(const elg_rollout_args& A, hipStream_t stream) {
     const bool lds = A.lds_stage != 0 && A.N1 <= 104;
 #define ELG_GO(NCHV, L, W) return launch_fwd<NCHV, TSP, L, W>(A, stream)
     if (A.lds_stage && A.waves == 8 && A.N1 >= 4 && A.N1 <= 16 * CO_NT && !A.use_state && A.do_decode && A.do_update &&
-        A.max_steps <= 0 && !(A.debug_skip & 0xB)) {   // bits 4,5: coop-kernel ablations
+        A.max_steps <= 0 && !(A.debug_skip & 0xB)) {   // bits 4, 5: coop-kernel ablations / variants
         // fused rollout at the training scale: lockstep trajectories, tables as MFMA operands in registers
         if (A.trA || A.trMask) {        // training forward (glimpse weights saved, or recomputed from the mask rows)
             if (!A.trPC || !A.trCsel || !A.trQ || !A.trO) return fail(ELG_EINVAL, "rollout: incomplete training rows");
