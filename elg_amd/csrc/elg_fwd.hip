@@ -478,8 +478,9 @@ static int launch_fwd_impl(const elg_rollout_args& A, hipStream_t stream) {
 //            two cross-quarter shuffles), O^T[d][traj] = sum_n V_h[n][d] P^T[n][traj]; the D tile of the first
 //            product is the B operand of the second (node on the k-slot), nothing is transposed
 //   pointer  (wave w < 7 = node tile w): s^T[n][traj] = sum_c PK[n][c] o[traj][c] + pb[n] -> LDS
-//   owners:  clip / mask / softmax / choice of the wave's four trajectories at once (16 lanes per trajectory,
-//            DPP row reductions and scans), then per trajectory the env update and the next step's mask, query, slots.
+//   owners:  the wave's four trajectories side by side, 16 lanes each (state in the row's registers): clip / mask /
+//            softmax / choice (DPP row reductions and scans), environment transition, then the next step's mask
+//            words (row slices of ballots), query row and k-NN slots (rank = DPP row scan over the sorted neighbours).
 // Trajectory state lives in LDS between phases (12 dwords), wave-uniform in SGPRs while a wave works on it.
 // =============================================================================================
 constexpr int CO_QP = 132;      // pitch of the query / glimpse-output exchange rows (conflict-free column reads)
@@ -724,7 +725,7 @@ __device__ __forceinline__ int row16_max_i(int v) {
 template <bool TSP, bool TRAIN>
 __device__ __forceinline__ void co_finish4(const elg_rollout_args& A, int N1, int lane, int wave, int ntraj, int t, int g_lo,
                                            size_t b, size_t Rcap, float* sSc, const unsigned long long* sMask,
-                                           const float* sX, int* sState) {
+                                           const float* sX, int* sState, int fin_row, int& sel_out, float& p_out) {
     constexpr int NK = CO_NT;
     const int tq = lane >> 4, lo = lane & 15;
     const int q = 4 * wave + tq;
@@ -741,7 +742,7 @@ __device__ __forceinline__ void co_finish4(const elg_rollout_args& A, int N1, in
         }
     }
     wave_lds_fence();
-    const bool act = q < ntraj && sState[16 * q + 3] == 0;           // decoding this step (row-uniform)
+    const bool act = q < ntraj && (fin_row >= 0 ? fin_row == 0 : sState[16 * q + 3] == 0);   // decoding this step (row-uniform)
     const unsigned long long w0 = sMask[2 * q], w1 = sMask[2 * q + 1];
     const int m = g_lo + q;
     const size_t bm = b * A.M + m;
@@ -832,6 +833,168 @@ __device__ __forceinline__ void co_finish4(const elg_rollout_args& A, int N1, in
         }
     }
     if (act && lo == 0) { sState[16 * q + 12] = sel; sState[16 * q + 13] = f2i(pe); }
+    wave_lds_fence();
+    sel_out = sel;
+    p_out = pe;
+}
+
+// State of the trajectory a 16-lane row works on (identical in the row's lanes, different between rows).
+struct CoRow {
+    int cur, first, cnt, fin;
+    float load, len, cx, cy;
+    unsigned long long v0, v1;
+};
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true); }
+
+// Environment transition (CVRPEnv.py:195-232, TSPEnv.py:108-124; same roundings as env_update()) and the next step's
+// mask / query / k-NN slots (build_mask(), slot_setup()) for the wave's four trajectories at once, 16 lanes per trajectory.
+template <bool TSP, bool TRAIN>
+__device__ __forceinline__ void co_advance4(const elg_rollout_args& A, const Inst& I, int N1, int lane, int wave, int ntraj,
+                                            int t, int g_lo, size_t b, size_t Rcap, CoRow& st, int sel, bool active,
+                                            unsigned long long* sMask, float* sQ, float* sX) {
+    const int tq = lane >> 4, lo = lane & 15;
+    const int q = 4 * wave + tq;
+    const int m = g_lo + q;
+    // ---------------- transition
+    if (active) {
+        const float sx = I.xy[2 * sel], sy = I.xy[2 * sel + 1];
+        if (st.cnt > 0) st.len += dist2d(st.cx, st.cy, sx, sy);
+        st.cx = sx; st.cy = sy;
+        if (TSP) { if (st.cnt == 0) st.first = sel; }
+        else st.load = (sel == 0) ? 1.0f : __fsub_rn(st.load, I.dem[sel]);
+        if (sel < 64) st.v0 |= 1ull << sel; else st.v1 |= 1ull << (sel - 64);
+        if (!TSP) { if (sel == 0) st.v0 |= 1ull; else st.v0 &= ~1ull; }
+        st.cur = sel;
+        st.cnt += 1;
+        if (TSP) {
+            if (st.cnt == N1) {
+                st.len += dist2d(sx, sy, I.xy[2 * st.first], I.xy[2 * st.first + 1]);
+                st.fin = 1;
+            }
+        } else {
+            const unsigned long long f0 = N1 >= 64 ? ~0ull : ((1ull << N1) - 1ull);
+            const unsigned long long f1 = N1 <= 64 ? 0ull : (N1 >= 128 ? ~0ull : ((1ull << (N1 - 64)) - 1ull));
+            if ((st.v0 & f0) == f0 && (st.v1 & f1) == f1) st.fin = 1;
+        }
+    }
+    // ---------------- the step decoded next (t + 1): mask words
+    const bool nxt = q < ntraj && !st.fin && (t + 1 < A.Tmax) && (TSP ? (t + 1 >= 1) : (t + 1 >= 2));
+    const size_t r1 = (size_t)(t + 1) * A.M + m;
+    const float lim = __fadd_rn(st.load, 1e-6f);
+    unsigned long long w0 = 0ull, w1 = 0ull;
+#pragma unroll
+    for (int k = 0; k < CO_NT; ++k) {
+        const int n = lo + 16 * k;
+        bool mm = true;
+        if (n < N1 && nxt) {
+            mm = ((k < 4 ? st.v0 : st.v1) >> (n & 63)) & 1ull;
+            if (!TSP) {
+                mm = mm || (lim < I.dem[n]);
+                if (n == 0 && st.fin) mm = false;
+            }
+        }
+        const unsigned long long bal = __ballot(mm);
+        const unsigned long long rowbits = (bal >> (16 * tq)) & 0xFFFFull;
+        if (k < 4) w0 |= rowbits << (16 * (k & 3)); else w1 |= rowbits << (16 * (k & 3));
+    }
+    if (N1 <= 64) w1 = ~0ull;                                           // nodes past N1 are closed, as in build_mask()
+    else w1 |= 0xFFFF000000000000ull;                                   // (nodes 112..127)
+    if (lo == 0) {
+        sMask[2 * q] = w0; sMask[2 * q + 1] = w1;
+        if (TRAIN && nxt && A.trMask) { A.trMask[(b * Rcap + r1) * 2] = w0; A.trMask[(b * Rcap + r1) * 2 + 1] = w1; }
+        if (TRAIN && nxt && A.trLoad) A.trLoad[b * Rcap + r1] = st.load;
+    }
+    // ---------------- query row: 8 channels per lane
+    {
+        const float* q1 = I.Q1 + (size_t)st.cur * ELG_E + 8 * lo;
+        float4 a = *reinterpret_cast<const float4*>(q1), c = *reinterpret_cast<const float4*>(q1 + 4);
+        if (TSP) {
+            const float* q2 = I.Q2 + (size_t)st.first * ELG_E + 8 * lo;
+            const float4 a2 = *reinterpret_cast<const float4*>(q2), c2 = *reinterpret_cast<const float4*>(q2 + 4);
+            a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w; c.x += c2.x; c.y += c2.y; c.z += c2.z; c.w += c2.w;
+        } else {
+            const float4 wa = *reinterpret_cast<const float4*>(I.wl + 8 * lo), wc = *reinterpret_cast<const float4*>(I.wl + 8 * lo + 4);
+            a.x = fmaf(st.load, wa.x, a.x); a.y = fmaf(st.load, wa.y, a.y); a.z = fmaf(st.load, wa.z, a.z); a.w = fmaf(st.load, wa.w, a.w);
+            c.x = fmaf(st.load, wc.x, c.x); c.y = fmaf(st.load, wc.y, c.y); c.z = fmaf(st.load, wc.z, c.z); c.w = fmaf(st.load, wc.w, c.w);
+        }
+        if (!nxt) { a = make_float4(0.f, 0.f, 0.f, 0.f); c = a; }
+        *reinterpret_cast<float4*>(sQ + q * CO_QP + 8 * lo) = a;
+        *reinterpret_cast<float4*>(sQ + q * CO_QP + 8 * lo + 4) = c;
+        if (TRAIN && nxt) {
+            *reinterpret_cast<float4*>(A.trQ + (b * Rcap + r1) * ELG_E + 8 * lo) = a;
+            *reinterpret_cast<float4*>(A.trQ + (b * Rcap + r1) * ELG_E + 8 * lo + 4) = c;
+        }
+    }
+    // ---------------- k-NN slots: first K open customers of cur's sorted neighbour row, rank = row scan
+    constexpr int S0 = TSP ? 0 : 1;
+    float* X = sX + q * CO_XP;
+    int* Xi = reinterpret_cast<int*>(X);
+    int kk = 0;
+    if (A.has_penalty || A.has_local) {
+        int found = 0;
+        const size_t row = (size_t)st.cur * N1;
+#pragma unroll
+        for (int k = 0; k < CO_NT; ++k) {
+            const int i = lo + 16 * k;
+            const bool valid = i < N1 && nxt;
+            const int ic = min(i, N1 - 1);
+            const int nid = I.nidx[row + ic];
+            const float nd = I.ndist[row + ic], nth = I.ntheta[row + ic];
+            bool cand = valid && !(((nid < 64 ? w0 : w1) >> (nid & 63)) & 1ull);
+            if (!TSP) cand = cand && (nid != 0);
+            const int cI = cand ? 1 : 0;
+            int inc = cI;
+            inc += dpp_i<0x111>(inc); inc += dpp_i<0x112>(inc); inc += dpp_i<0x114>(inc); inc += dpp_i<0x118>(inc);
+            const int rank = found + inc - cI;
+            if (cand && rank < A.K) {
+                X[CO_XF + S0 + rank] = nd;
+                X[CO_XF + ELG_SLOT_STRIDE + S0 + rank] = nth;
+                Xi[CO_XS + S0 + rank] = nid;
+            }
+            found += __shfl(inc, (lane & 48) | 15, ELG_WAVE);          // row total = the scan's value in lane 15 of the row
+        }
+        kk = min(found, A.K);
+    }
+    wave_lds_fence();
+    const float dmax = (kk > 0) ? X[CO_XF + S0 + kk - 1] : 0.f;
+    wave_lds_fence();
+    const float nf = dmax + 1e-6f;
+    const bool depot_closed = w0 & 1ull;
+#pragma unroll
+    for (int c3 = 0; c3 < 3; ++c3) {
+        const int j = lo + 16 * c3;
+        const bool cust = nxt && (j >= S0) && (j < S0 + kk);
+        float sd = 0.f, sth = 0.f;
+        int snid = -1;
+        if (cust) { sd = X[CO_XF + j]; sth = X[CO_XF + ELG_SLOT_STRIDE + j]; snid = Xi[CO_XS + j]; }
+        if (!TSP && j == 0 && nxt && (A.has_penalty || A.has_local)) snid = 0;          // depot slot
+        float pen = 0.f;
+        if (A.has_penalty && cust) {
+            if (TSP) pen = -(sd / (dmax + 1e-6f));
+            else pen = (dmax != 0.f) ? -(sd / dmax) : -sd;
+        }
+        float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+        if (cust) {
+            f0 = sd / nf;
+            f1 = sth;
+            if (!TSP) f2 = I.dem[snid] / st.load;
+        }
+        bool smask = !cust;
+        if (!TSP && j == 0) smask = depot_closed;
+        const int ssave = (smask && snid >= 0) ? -2 : snid;
+        X[CO_XF + j] = f0; X[CO_XF + ELG_SLOT_STRIDE + j] = f1; X[CO_XF + 2 * ELG_SLOT_STRIDE + j] = f2;
+        Xi[CO_XS + j] = ssave;
+        X[CO_XPEN + j] = pen;
+        X[CO_XU + j] = 0.f;
+        if (TRAIN && nxt && A.trSlot) {
+            A.trSlot[(b * Rcap + r1) * ELG_SLOT_STRIDE + j] = ssave;
+            if (A.trF) {
+                float* fr = A.trF + (b * Rcap + r1) * (3 * ELG_SLOT_STRIDE) + j;
+                fr[0] = f0; fr[ELG_SLOT_STRIDE] = f1; fr[2 * ELG_SLOT_STRIDE] = f2;
+            }
+        }
+    }
     wave_lds_fence();
 }
 
@@ -928,6 +1091,9 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
         }
         __syncthreads();
         const int step_cap = TSP ? N1 : 2 * N1 + 2;
+        CoRow row;                                                  // batched owners: the row's trajectory (registers)
+        row.cur = 0; row.first = 0; row.cnt = 0; row.fin = (4 * wave + (lane >> 4) < ntraj) ? 0 : 1;
+        row.load = 1.0f; row.len = 0.f; row.cx = 0.f; row.cy = 0.f; row.v0 = 0ull; row.v1 = 0ull;
         float kop[CO_NT][4], vop[CO_NT][4];                         // (re)loaded at the end of every owners' phase
 #pragma unroll
         for (int nt = 0; nt < CO_NT; ++nt)
@@ -1040,8 +1206,34 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
             // =============== owners: finish this step, advance, prepare the next ===============
             int any_left = 0;
             const bool batched = !(A.debug_skip & 32);                  // bit 5: per-trajectory finish_step (A/B)
+            const bool all4 = !(A.debug_skip & 96);                     // bit 6: batched choice, per-trajectory advance (A/B)
+            if (all4) {
+                // the wave's four trajectories side by side, 16 lanes each: choice, transition, next step's inputs
+                const int q4 = 4 * wave + (lane_t >> 4);
+                const int m4 = g_lo + min(q4, ntraj - 1);
+                const size_t bm4 = (size_t)b * A.M + m4;
+                const bool active = q4 < ntraj && !row.fin;
+                int sel = 0;
+                float pr = 1.0f;
+                if (decode_step) {
+                    co_finish4<TSP, TRAIN>(A, N1, lane_t, wave, ntraj, t, g_lo, (size_t)b, Rcap, sSc, sMask, sX, sState,
+                                           q4 < ntraj ? row.fin : 1, sel, pr);
+                } else if (A.mode == ELG_MODE_FORCED) {
+                    sel = (A.forced && t < A.Tforced) ? A.forced[bm4 * A.Tforced + t] : 0;
+                } else {
+                    sel = (!TSP && t == 0) ? 0 : A.starts[m4];
+                }
+                if (active && (lane_t & 15) == 0) {
+                    if (A.actions) A.actions[bm4 * A.Tmax + t] = sel;
+                    if (A.probs) A.probs[((size_t)b * A.Tmax + t) * A.M + m4] = pr;
+                }
+                co_advance4<TSP, TRAIN>(A, I, N1, lane_t, wave, ntraj, t, g_lo, (size_t)b, Rcap, row, sel, active, sMask, sQ, sX);
+                any_left = (q4 < ntraj && !row.fin) ? 1 : 0;
+            } else {
+            int dsel = 0;
+            float dpr = 1.0f;
             if (decode_step && batched)
-                co_finish4<TSP, TRAIN>(A, N1, lane_t, wave, ntraj, t, g_lo, (size_t)b, Rcap, sSc, sMask, sX, sState);
+                co_finish4<TSP, TRAIN>(A, N1, lane_t, wave, ntraj, t, g_lo, (size_t)b, Rcap, sSc, sMask, sX, sState, -1, dsel, dpr);
 #pragma unroll 1
             for (int qi = 0; qi < 4; ++qi) {
                 const int q = 4 * wave + qi;                            // wave w owns trajectories 4 w .. 4 w + 3
@@ -1104,10 +1296,19 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                 co_store_state<TSP>(sState + 16 * q, st, lane_t);
                 any_left |= st.fin ? 0 : 1;
             }
+            }
             ELG_CO_LOAD_KV()                                         // next step's glimpse operands, in flight over the barrier
             if (!__syncthreads_or(any_left)) break;                  // also orders the exchange rows for the next step
         }
         // ---- results of the group
+        if (!(A.debug_skip & 96)) {
+            const int q4 = 4 * wave + (lane >> 4);
+            if (q4 < ntraj && (lane & 15) == 0) {
+                const size_t bm = (size_t)b * A.M + g_lo + q4;
+                if (A.reward) A.reward[bm] = -row.len;
+                if (A.tlen) A.tlen[bm] = row.cnt;
+            }
+        } else
         for (int q = 4 * wave; q < min(ntraj, 4 * wave + 4); ++q) {
             Traj<2> st;
             co_load_state(sState + 16 * q, st, lane);

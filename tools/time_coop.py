@@ -27,6 +27,8 @@ run("per-wave kernel, full", pol, debug=8)
 run("per-wave kernel, full, train", pol, debug=8, train=True)
 run("coop, full", pol)
 run("coop, full, train", pol, train=True)
+run("coop, batched choice, per-trajectory advance", pol, debug=64)
+run("coop, batched choice, per-trajectory advance, train", pol, debug=64, train=True)
 run("coop, per-trajectory finish", pol, debug=32)
 run("coop, per-trajectory finish, train", pol, debug=32, train=True)
 run("coop, no MFMA phases", pol, debug=16)
