@@ -57,13 +57,12 @@ def check_feasible(pi, demand):
     ok = (srt[:, -n:] == torch.arange(1, n + 1, device=pi.device)[None]).all() and (srt[:, :-n] == 0).all()
     assert ok, "Invalid tour"
     d = torch.cat((torch.full((1, 1), -1.0, device=demand.device), demand), 1).expand(multi, n + 1).gather(1, pi)
-    # running load with reset at the depot == running sum minus its running minimum prefix (clamped at 0)
-    used = torch.zeros(multi, device=pi.device)
-    worst = torch.zeros(multi, device=pi.device)
-    for i in range(pi.size(1)):
-        used = (used + d[:, i]).clamp_(min=0)
-        worst = torch.maximum(worst, used)
-    assert (worst <= 1 + 1e-4).all(), "Used more than capacity"
+    # the reference's scan `used = max(0, used + d_i)` (depot demand -1 = reset) in closed form: a running sum
+    # reflected at zero equals the running sum minus its running minimum (clamped at 0) -- three kernels instead of
+    # two per tour position (~240 launches between the rollout and its backward)
+    S = d.cumsum(dim=1)
+    used = S - torch.cummin(S, dim=1).values.clamp(max=0.0)
+    assert (used.max(dim=1).values <= 1 + 1e-4).all(), "Used more than capacity"
 
 
 def seed_everything(seed=2022):
