@@ -93,8 +93,7 @@ class EncoderLayer(nn.Module):
         def heads(t):
             return t.view(B, n, h, -1).transpose(1, 2)
         q, k, v = eng.qkv_linear(x, self.Wq.weight, self.Wk.weight, self.Wv.weight)      # one GEMM, shared input
-        att = F.scaled_dot_product_attention(heads(q), heads(k), heads(v))
-        att = att.transpose(1, 2).reshape(B, n, -1)
+        att = eng.self_attention(q, k, v)                          # SDPA forward, MFMA attention backward
         o1 = self.add_n_normalization_1(x, self.multi_head_combine(att))
         return self.add_n_normalization_2(o1, self.feed_forward(o1))
 

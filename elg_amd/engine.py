@@ -718,3 +718,56 @@ def add_instance_norm(a: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, bet
     """InstanceNorm1d(affine) of (a + b) over the node axis, (B,N,C) in and out, one HIP launch each way."""
     _need_cuda(a, "a")
     return _AddInstNorm.apply(a.float(), b.float(), gamma, beta, eps)
+
+
+# ----------------------------------------------------------------------------------------------
+# encoder self-attention (reference models.py:455-503) with the MFMA attention backward
+# ----------------------------------------------------------------------------------------------
+_ZMASK = {}
+
+
+class _SelfAttention(torch.autograd.Function):
+    """softmax(q k^T / 4) v over the nodes of an instance, 8 heads x 16 (channel = head * 16 + d).  Forward: the
+    library SDPA kernel.  Backward: csrc/elg_bwd.hip::glimpse_bwd_mfma_kernel in its recompute mode -- the same
+    attention backward the decoder's glimpse uses (rows = the instance's own nodes, nothing masked): one launch for
+    dq, dk, dv instead of the library's 59 us kernel."""
+
+    @staticmethod
+    def forward(ctx, q, k, v):
+        B, n, _ = q.shape
+
+        def heads(t):
+            return t.view(B, n, H, DK).transpose(1, 2)
+        out = torch.nn.functional.scaled_dot_product_attention(heads(q), heads(k), heads(v))
+        out = out.transpose(1, 2).reshape(B, n, E)
+        ctx.save_for_backward(q, k, v, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out = ctx.saved_tensors
+        B, n, _ = q.shape
+        dev = q.device
+        q, k, v, dout = q.contiguous(), k.contiguous(), v.contiguous(), dout.contiguous()
+        key = (B, n, str(dev))
+        zm = _ZMASK.get(key)
+        if zm is None:
+            zm = _ZMASK[key] = torch.zeros(B, n, 2, device=dev, dtype=torch.int64)      # every node open
+        dq = torch.empty(B, n, E, device=dev)
+        dkv = torch.empty(2, 1, B, n, E, device=dev)
+        L.check(L.lib().elg_glimpse_bwd_fused(None, _ptr(zm), _ptr(dout), _ptr(out), _ptr(q), _ptr(k), _ptr(v), _ptr(dq),
+                                              _ptr(dkv[0]), _ptr(dkv[1]), B, n, n, 0, n, n, 1, _stream()),
+                "elg_glimpse_bwd_fused(encoder)")
+        return dq, dkv[0, 0], dkv[1, 0]
+
+
+def self_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """(B,n,128) x3 -> (B,n,128): multi-head self-attention of the encoder layers (4 <= n <= 128 on the MFMA path)."""
+    B, n, e = q.shape
+    if (q.is_cuda and torch.is_grad_enabled() and e == E and 4 <= n <= 128
+            and os.environ.get("ELG_MFMA_ATTN_BWD", "0") == "1"):      # measured neutral at n = 101 (7 row tiles): off
+        return _SelfAttention.apply(q, k, v)
+    def heads(t):
+        return t.view(B, n, H, -1).transpose(1, 2)
+    att = torch.nn.functional.scaled_dot_product_attention(heads(q), heads(k), heads(v))
+    return att.transpose(1, 2).reshape(B, n, -1)

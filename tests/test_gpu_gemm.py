@@ -95,3 +95,23 @@ def test_qkv_linear_matches_three_linears():
     ref = torch.autograd.grad(sum((o * g).sum() for o, g in zip(refs, gs)), [x] + Ws)
     for a, b in zip(got, ref):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-3, atol=2e-3 * b.abs().max().item())
+
+
+@pytest.mark.parametrize("B,n", [(64, 101), (3, 21), (2, 128), (1, 77)])
+def test_self_attention_backward_matches_sdpa(B, n, monkeypatch):
+    """engine.self_attention: library SDPA forward, MFMA attention backward (the decoder's glimpse backward kernel in its
+    recompute mode) against autograd through F.scaled_dot_product_attention."""
+    from elg_amd import engine as eng
+    import torch.nn.functional as F
+    monkeypatch.setenv("ELG_MFMA_ATTN_BWD", "1")
+    torch.manual_seed(n)
+    q, k, v = [torch.randn(B, n, 128, device=DEV, requires_grad=True) for _ in range(3)]
+    g = torch.randn(B, n, 128, device=DEV)
+    heads = lambda t: t.view(B, n, 8, 16).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(heads(q.double()), heads(k.double()), heads(v.double())).transpose(1, 2).reshape(B, n, 128)
+    out = eng.self_attention(q, k, v)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    gr = torch.autograd.grad((ref * g.double()).sum(), [q, k, v])
+    gg = torch.autograd.grad((out * g).sum(), [q, k, v])
+    for a, b in zip(gg, gr):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=3e-5 * b.abs().max().item())
