@@ -105,38 +105,51 @@ __global__ __launch_bounds__(256) void local_bwd_rows_kernel(const float* __rest
     const int tiles_per_b = (R + 15) >> 4;
     const long long ntiles = (long long)B * tiles_per_b;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    for (long long tile = (long long)blockIdx.x * 4 + wave_u; tile < ntiles; tile += (long long)gridDim.x * 4) {
+    // tile loads (cotangents, slot codes, slot features of row lo; rows past R are clamped and get du = 0, so they
+    // contribute nothing); the loads of the wave's next tile are issued before the current one is consumed
+#define ELG_LB_LOAD(TILE, DU, SL, FF)                                                                              \
+    {                                                                                                              \
+        const int b_ = (int)((TILE) / tiles_per_b);                                                                \
+        const int row0_ = (int)((TILE) % tiles_per_b) << 4;                                                        \
+        const int rl_ = min(lo, R - 1 - row0_);                                                                    \
+        const float live_ = (lo <= R - 1 - row0_) ? 1.f : 0.f;                                                     \
+        const float* duRow = rowDU + ((size_t)b_ * R + row0_ + rl_) * ELG_SLOT_STRIDE + 4 * hi;                    \
+        const size_t src_ = (size_t)b_ * Rcap + row0_ + rl_;                                                       \
+        const int* slRow = trSlot + src_ * ELG_SLOT_STRIDE + 4 * hi;                                               \
+        const float* fRow = trF + src_ * (3 * ELG_SLOT_STRIDE) + 4 * hi;                                           \
+        _Pragma("unroll") for (int jt = 0; jt < JT; ++jt) {                                                        \
+            const float4 t = *reinterpret_cast<const float4*>(duRow + 16 * jt);                                    \
+            DU[jt] = f32x4{t.x * live_, t.y * live_, t.z * live_, t.w * live_};                                    \
+            SL[jt] = *reinterpret_cast<const int4*>(slRow + 16 * jt);                                              \
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                                        \
+                const float4 u = *reinterpret_cast<const float4*>(fRow + k * ELG_SLOT_STRIDE + 16 * jt);           \
+                FF[k][jt] = f32x4{u.x, u.y, u.z, u.w};                                                             \
+            }                                                                                                      \
+        }                                                                                                          \
+    }
+    const long long tstride = (long long)gridDim.x * 4;
+    const long long tile0 = (long long)blockIdx.x * 4 + wave_u;
+    f32x4 du1[JT], f1[3][JT];
+    int4 sl1[JT];
+    if (tile0 < ntiles) ELG_LB_LOAD(tile0, du1, sl1, f1)
+    for (long long tile = tile0; tile < ntiles; tile += tstride) {
         const int b = (int)(tile / tiles_per_b);
         const int row0 = (int)(tile % tiles_per_b) << 4;
         const int rleft = R - 1 - row0;                          // last valid row of the tile, relative (>= 0)
-        // ---- L1 loads: row lo (clamped; rows past R get du = 0 and so contribute nothing)
-        const int rl = min(lo, rleft);
-        const float live = (lo <= rleft) ? 1.f : 0.f;
-        const float* duRow = rowDU + ((size_t)b * R + row0 + rl) * ELG_SLOT_STRIDE + 4 * hi;
-        f32x4 du1[JT];
-        bool any = false;
-#pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
-            const float4 t = *reinterpret_cast<const float4*>(duRow + 16 * jt);
-            du1[jt] = f32x4{t.x * live, t.y * live, t.z * live, t.w * live};
-            any = any || du1[jt][0] != 0.f || du1[jt][1] != 0.f || du1[jt][2] != 0.f || du1[jt][3] != 0.f;
+        f32x4 du1n[JT], f1n[3][JT];
+        int4 sl1n[JT];
+        {
+            const long long tn = (tile + tstride < ntiles) ? tile + tstride : tile;      // last prefetch: a valid re-read
+            ELG_LB_LOAD(tn, du1n, sl1n, f1n)
         }
-        if (!__ballot(any)) continue;                            // first moves / finished trajectories / padding
-        const size_t src = (size_t)b * Rcap + row0 + rl;
-        const int* slRow = trSlot + src * ELG_SLOT_STRIDE + 4 * hi;
-        const float* fRow = trF + src * (3 * ELG_SLOT_STRIDE) + 4 * hi;
-        f32x4 f1[3][JT];
+        bool any = false;
         bool msk[JT][4];
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
-            const int4 sl = *reinterpret_cast<const int4*>(slRow + 16 * jt);
-            msk[jt][0] = sl.x < 0; msk[jt][1] = sl.y < 0; msk[jt][2] = sl.z < 0; msk[jt][3] = sl.w < 0;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float4 t = *reinterpret_cast<const float4*>(fRow + k * ELG_SLOT_STRIDE + 16 * jt);
-                f1[k][jt] = f32x4{t.x, t.y, t.z, t.w};
-            }
+            any = any || du1[jt][0] != 0.f || du1[jt][1] != 0.f || du1[jt][2] != 0.f || du1[jt][3] != 0.f;
+            msk[jt][0] = sl1[jt].x < 0; msk[jt][1] = sl1[jt].y < 0; msk[jt][2] = sl1[jt].z < 0; msk[jt][3] = sl1[jt].w < 0;
         }
+        if (__ballot(any)) {                                     // else: first moves / finished trajectories / padding
         // ---- forward recompute: attention weights, F, o', g'   (L1)
         f32x4 al[ELG_LH][JT];
         float F[ELG_LH][3];
@@ -367,7 +380,15 @@ __global__ __launch_bounds__(256) void local_bwd_rows_kernel(const float* __rest
             }
             aLbc[dt] += (dg2[dt][0] + dg2[dt][1]) + (dg2[dt][2] + dg2[dt][3]);  // column d = 16 dt + lo, rows 4 hi + v
         }
+        }                                                        // if (any)
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            du1[jt] = du1n[jt]; sl1[jt] = sl1n[jt];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) f1[k][jt] = f1n[k][jt];
+        }
     }
+#undef ELG_LB_LOAD
 
     // ---- fold this wave's accumulators into the workgroup's image of the table gradient, then one flush
 #pragma unroll
