@@ -1,18 +1,16 @@
-"""Greedy evaluation on a pickled TSP test set with x8 augmentation -- the reference's `python test.py`
-(gaocrr/ELG TSP/test.py)."""
+"""`python test.py` of the reference (gaocrr/ELG TSP/test.py): greedy tour length of a pickled TSP test set with and
+without 8-fold augmentation.  The evaluation loop lives in elg_amd/evaluate.py."""
 from __future__ import annotations
 
 import os
 import sys
-import time
 
-import torch
-import yaml
 from torch.utils.data import DataLoader
 
 if __package__ in (None, ""):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
+from elg_amd import evaluate as ev
 from elg_amd.TSP.TSPEnv import TSPEnv
 from elg_amd.TSP.TSPModel import TSPModel
 from elg_amd.TSP.generate_data import TSPDataset
@@ -20,38 +18,13 @@ from elg_amd.TSP.utils import rollout
 
 
 def test(dataloader, model, env, aug_factor):
-    model.eval()
-    model.requires_grad_(False)
-    aug_total, plain_total, batches = 0.0, 0.0, 0
-    start = time.time()
-    for batch in dataloader:
-        env.load_random_problems(batch, aug_factor)
-        reset_state, _, _ = env.reset()
-        with torch.no_grad():
-            model.pre_forward(reset_state)
-            _, _, rewards = rollout(model=model, env=env, eval_type='greedy')
-        best_pomo = rewards.reshape(aug_factor, batch.shape[0], env.pomo_size).max(dim=2)[0]
-        plain_total += float(-best_pomo[0].float().mean())
-        aug_total += float(-best_pomo.max(dim=0)[0].float().mean())
-        batches += 1
-    torch.cuda.synchronize()
-    elapsed = time.time() - start
-    print("Aug cost: {:.4f}".format(aug_total / batches))
-    print("no aug Avg cost: {:.4f}, Wall-clock time: {:.2f}s".format(plain_total / batches, elapsed))
-    return aug_total / batches, plain_total / batches
+    """-> (augmented cost, plain cost), averaged over the loader's instances."""
+    return ev.evaluate_loader(dataloader, model, env, aug_factor, rollout, lambda batch: batch.shape[0])
 
 
 if __name__ == "__main__":
-    with open('config.yml', 'r', encoding='utf-8') as fh:
-        config = yaml.load(fh.read(), Loader=yaml.FullLoader)
-    device = "cuda:{}".format(config['cuda_device_num'])
-    p = config['params']
-    model = TSPModel(**config['model_params'])
-    if config['model_params']['ensemble']:
-        model.decoder.add_local_policy(device)
-    if config['load_checkpoint']:
-        model.load_state_dict(torch.load(config['load_checkpoint'], map_location=device)['model_state_dict'])
-    model.to(device)
-    data = TSPDataset(config['test_filename'], num_samples=p['test_size'])
-    env = TSPEnv(multi_width=p['multiple_width'], device=device)
-    test(DataLoader(data, batch_size=p['test_batch_size']), model, env, p['aug_factor'])
+    cfg, device = ev.load_run_config()
+    run = cfg['params']
+    net = ev.build_model(TSPModel, cfg, device)
+    loader = DataLoader(TSPDataset(cfg['test_filename'], num_samples=run['test_size']), batch_size=run['test_batch_size'])
+    test(loader, net, TSPEnv(multi_width=run['multiple_width'], device=device), run['aug_factor'])
