@@ -124,3 +124,15 @@ def test_generate_data_and_vrplib_reader():
     assert a["capacity"] == b["capacity"] == 206 and list(a["depot"]) == [0]
     s = vrplib_io.read_solution(p + ".sol")
     assert s["cost"] == 27591 and len(s["routes"]) == 26
+
+
+def test_best_costs_of_the_test_entry_points():
+    """elg_amd.evaluate.best_costs: best over POMO, then best over the augmentations (reference test.py:30-41)."""
+    import torch
+    from elg_amd import evaluate as ev
+    torch.manual_seed(0)
+    rewards = -torch.rand(8 * 5, 7) * 10
+    plain, aug = ev.best_costs(rewards, 8, 5)
+    per_aug = rewards.reshape(8, 5, 7).max(dim=2)[0]
+    assert torch.equal(plain, -per_aug[0]) and torch.equal(aug, -per_aug.max(dim=0)[0])
+    assert (aug <= plain).all()
