@@ -33,13 +33,7 @@ def softmax(x):
 
 def pomo_loss(probs, rewards, scale_norm=True):
     """reference train.py:112-121: shared baseline = mean reward over the POMO trajectories of an instance."""
-    if probs.is_cuda:
-        return eng.pomo_loss(probs, rewards, scale_norm)           # fused HIP kernel (csrc/elg_train.hip)
-    advantage = rewards - rewards.mean(dim=1)[:, None]              # host tensors (unit tests of the formula)
-    J = -advantage * probs.log().sum(dim=1)
-    if scale_norm:
-        J = J / advantage.max(dim=1)[0][:, None]
-    return J.mean()
+    return eng.pomo_loss(probs, rewards, scale_norm)     # csrc/elg_train.hip; GPU tensors only (no CPU path)
 
 
 def train_step(model, env, optimizer, batch, scale_norm=True, bucket=None, world=1, check=True):

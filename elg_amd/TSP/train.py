@@ -24,15 +24,7 @@ from elg_amd.TSP.utils import Logger, check_feasible, rollout, seed_everything
 
 def pomo_loss(probs, rewards, scale_norm=True):
     """reference TSP/train.py:107-118 (scale only when no instance has a zero normaliser)."""
-    if probs.is_cuda:
-        return eng.pomo_loss(probs, rewards, scale_norm, guard_zero=True)   # fused HIP kernel (csrc/elg_train.hip)
-    advantage = rewards - rewards.mean(dim=1)[:, None]              # host tensors (unit tests of the formula)
-    J = -advantage * probs.log().sum(dim=1)
-    if scale_norm:
-        norm_fac = advantage.max(dim=1)[0][:, None]
-        if bool((norm_fac != 0.).all()):
-            J = J / norm_fac
-    return J.mean()
+    return eng.pomo_loss(probs, rewards, scale_norm, guard_zero=True)     # csrc/elg_train.hip; GPU tensors only (no CPU path)
 
 
 def train_step(model, env, optimizer, batch, scale_norm=True, bucket=None, world=1):
