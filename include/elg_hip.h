@@ -77,9 +77,10 @@ typedef struct elg_rollout_args {
     int32_t do_decode;      /* 0: env update only with forced actions (CVRPEnv.step)            */
     int32_t do_update;      /* 0: decode only (CVRPModel.one_step_rollout)                      */
     int32_t use_state;      /* 1: load/store the st_* arrays (step-wise protocol)               */
-    int32_t waves;          /* wavefronts per workgroup: 8 or 13                                */
+    int32_t waves;          /* wavefronts per workgroup: 8 (9 / 13: per-wavefront kernel experiments) */
     int32_t tiles;          /* workgroups per instance                                          */
-    int32_t lds_stage;      /* 1: K/V/PK of the instance staged in LDS (N1 <= 104)              */
+    int32_t lds_stage;      /* 1: keep the instance's tables on chip (N1 <= 112): fused rollouts run the
+                               cooperative lockstep MFMA kernel, step-wise calls the LDS-staged kernel   */
     int32_t dump_T;         /* time extent of full_probs (0 = no dump)                          */
     float xi;               /* model_params.xi                                                  */
     float clip;             /* model_params.logit_clipping                                      */
