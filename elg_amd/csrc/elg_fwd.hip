@@ -1,5 +1,10 @@
-// Forward POMO construction kernel (persistent: one launch runs every trajectory of the batch to
-// completion) + the small per-batch kernels (neighbour tables, distance matrix, aug8, route length).
+// Forward POMO construction kernels (persistent: one launch runs every trajectory of the batch to completion)
+// + the small per-batch kernels (neighbour tables, distance matrix, aug8, route length).
+//   rollout_fwd_coop_kernel   N1 <= 112: lockstep trajectories, glimpse / pointer / local policy on fp32 MFMA,
+//                             clip / softmax / choice / transition / k-NN for four trajectories per wave
+//   rollout_fwd_tiled_kernel  N1 > 128: K / V / PK walked in LDS tiles shared by 8 lockstep trajectories
+//   rollout_fwd_kernel        one wavefront per trajectory: the step-wise protocol (CVRPEnv.step, one_step_rollout),
+//                             explicit geometries, A/B reference
 //
 // Replaces, for gaocrr/ELG: CVRP/utils.py:7-29 (rollout loop), CVRPEnv.py:152-318 (reset / step /
 // get_cur_feature / _get_reward), CVRPModel.py:36-75 (one_step_rollout), models.py:51-175,322-423
