@@ -270,3 +270,40 @@ def test_dataset_eval_with_augmentation():
             _, _, r = rollout(model, env, 'greedy')
         tot += float(-r.reshape(8, 4, 100).max(dim=2)[0][0].mean())
     assert abs(tot / 2 - plain) < 1e-4
+
+
+def test_global_only_then_joint_training_steps():
+    """The reference trains the global policy alone for the first T steps and attaches the local policy afterwards
+    (train.py:93-96): both regimes, and the switch (new optimizer over the grown parameter list), step without the
+    other's tables; TSP likewise."""
+    import yaml
+    from elg_amd.CVRP.CVRPEnv import CVRPEnv
+    from elg_amd.CVRP.CVRPModel import CVRPModel
+    from elg_amd.CVRP.generate_data import generate_vrp_data
+    from elg_amd.CVRP.train import train_step
+    from elg_amd.TSP.TSPEnv import TSPEnv
+    from elg_amd.TSP.TSPModel import TSPModel
+    from elg_amd.TSP.train import train_step as tsp_step
+    from elg_amd.optim import Adam
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "elg_amd", "CVRP", "config.yml")))
+    torch.manual_seed(0)
+    m = CVRPModel(**cfg["model_params"]).to(DEV).train()
+    env = CVRPEnv(50, DEV)
+    opt = Adam(m.parameters(), lr=1e-4, weight_decay=1e-6)
+    w0 = m.decoder.Wq_last.weight.detach().clone()
+    dist = dict(cfg["distribution"], data_type="uniform")
+    for _ in range(2):
+        J, _ = train_step(m, env, opt, generate_vrp_data(16, 50, dist), True)
+    assert torch.isfinite(J) and not torch.equal(w0, m.decoder.Wq_last.weight.detach())
+    m.decoder.add_local_policy(DEV)
+    opt = Adam(m.parameters(), lr=1e-4, weight_decay=1e-6)
+    l0 = m.decoder.local_policies[0].Wq.weight.detach().clone()
+    J2, _ = train_step(m, env, opt, generate_vrp_data(16, 50, dist), True)
+    assert torch.isfinite(J2) and not torch.equal(l0, m.decoder.local_policies[0].Wq.weight.detach())
+    tcfg = yaml.safe_load(open(os.path.join(root, "elg_amd", "TSP", "config.yml")))
+    t = TSPModel(**tcfg["model_params"]).to(DEV).train()
+    tenv = TSPEnv(50, DEV)
+    topt = Adam(t.parameters(), lr=1e-4, weight_decay=1e-6)
+    J3, _ = tsp_step(t, tenv, topt, torch.rand(16, 50, 2), True)
+    assert torch.isfinite(J3)
