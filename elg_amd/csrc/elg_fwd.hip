@@ -1081,8 +1081,12 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
     for (int i = tid; i < 16 * CO_NT; i += 512) sPb[i] = (i < N1) ? I.pb[i] : 0.f;
     __syncthreads();
 
-    for (int g_lo = m_lo; g_lo < m_hi; g_lo += CO_MAXTR) {           // groups of <= 32 lockstep trajectories
-        const int ntraj = min(CO_MAXTR, m_hi - g_lo);
+    // groups of <= 32 lockstep trajectories, evenly sized (100 trajectories = 4 x 25, not 3 x 32 + 4: a group of 4 costs
+    // as many barriers per step as a group of 32)
+    const int n_groups = (m_hi - m_lo + CO_MAXTR - 1) / CO_MAXTR;
+    const int g_size = n_groups > 0 ? (m_hi - m_lo + n_groups - 1) / n_groups : CO_MAXTR;
+    for (int g_lo = m_lo; g_lo < m_hi; g_lo += g_size) {
+        const int ntraj = min(g_size, m_hi - g_lo);
         const bool two_rt = ntraj > 16;
         // ---- reset: every trajectory at the depot / nowhere, step 0 (nothing to decode at t = 0)
         for (int q = wave; q < CO_MAXTR; q += 8) {
