@@ -69,6 +69,9 @@ if __name__ == "__main__":
     with open('config.yml', 'r', encoding='utf-8') as fh:
         config = yaml.load(fh.read(), Loader=yaml.FullLoader)
     rank, world, local = parallel.init_distributed()
+    if config['training'] not in ('joint', 'only_global'):
+        # the reference's own entry point names a class it never defines for this mode (train.py:199-200)
+        raise NotImplementedError("training: {} is not built (the reference's 'only_local_att' model class does not exist either)".format(config['training']))
     p = config['params']
     device = "cuda:{}".format(local if world > 1 else config['cuda_device_num'])
     seed_everything(config['seed'] + rank)
