@@ -771,3 +771,22 @@ def self_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.T
         return t.view(B, n, H, -1).transpose(1, 2)
     att = torch.nn.functional.scaled_dot_product_attention(heads(q), heads(k), heads(v))
     return att.transpose(1, 2).reshape(B, n, -1)
+
+
+# ----------------------------------------------------------------------------------------------
+# orderly shutdown: drop the cached device / pinned buffers, events and the side stream while the HIP runtime is
+# still alive (module globals are otherwise destroyed in arbitrary order at interpreter exit)
+# ----------------------------------------------------------------------------------------------
+def _teardown():
+    try:
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.synchronize()
+    except Exception:
+        pass
+    for cache in (_PINNED, TrainRows._cache, _ZMASK, _SIDE):
+        cache.clear()
+
+
+import atexit  # noqa: E402
+
+atexit.register(_teardown)
