@@ -5,6 +5,7 @@ construction into one persistent launch."""
 from __future__ import annotations
 
 import ctypes as C
+import gc
 import os
 import random
 
@@ -49,6 +50,11 @@ class CVRPModel(nn.Module):
                tuple(id(p) for p in self.parameters()))
         g = self._graphs.get(key)
         if g is None:
+            # retire the previous graph set at a quiescent point: destroying graph executables while another graph
+            # is being launched (e.g. from the autograd thread) is not safe in the HIP runtime
+            torch.cuda.synchronize()
+            self._graphs.clear()
+            gc.collect()
             try:
                 mod = _EncodeAndFold(self.encoder, self.decoder)
                 g = torch.cuda.make_graphed_callables(mod, (depot_xy.detach().clone(), node_xy_demand.detach().clone()))

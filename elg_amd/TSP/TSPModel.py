@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import gc
 import os
 import random
 
@@ -43,6 +44,11 @@ class TSPModel(nn.Module):
         key = (tuple(problems.shape), str(problems.device), tuple(id(p) for p in self.parameters()))
         g = self._graphs.get(key)
         if g is None:
+            # retire the previous graph set at a quiescent point: destroying graph executables while another graph
+            # is being launched (e.g. from the autograd thread) is not safe in the HIP runtime
+            torch.cuda.synchronize()
+            self._graphs.clear()
+            gc.collect()
             try:
                 g = torch.cuda.make_graphed_callables(_EncodeAndFold(self.encoder, self.decoder),
                                                       (problems.detach().clone(),))
