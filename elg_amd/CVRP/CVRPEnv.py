@@ -24,6 +24,8 @@ class Reset_State:
     node_xy: torch.Tensor = None         # (batch, problem, 2)
     node_demand: torch.Tensor = None     # (batch, problem)
     dist: torch.Tensor = None            # (batch, problem+1, problem+1)
+    _xy: torch.Tensor = None             # (batch, problem+1, 2)   depot + customers, as the encoder kernel reads them
+    _demand: torch.Tensor = None         # (batch, problem+1)      demand[:, 0] = 0
 
 
 @dataclass
@@ -67,6 +69,7 @@ class CVRPEnv:
         self.reset_state.depot_xy = depot
         self.reset_state.node_xy = self.depot_node_xy[:, 1:, :]
         self.reset_state.node_demand = self.depot_node_demand[:, 1:]
+        self.reset_state._xy, self.reset_state._demand = self.depot_node_xy, self.depot_node_demand
         self.problem_size = self.depot_node_xy.shape[1] - 1
         self.problem = eng.Problem(L.PROBLEM_CVRP, self.depot_node_xy, self.depot_node_demand,
                                    eng.nbr_tables(self.depot_node_xy))

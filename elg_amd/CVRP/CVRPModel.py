@@ -5,33 +5,15 @@ construction into one persistent launch."""
 from __future__ import annotations
 
 import ctypes as C
-import gc
-import os
 import random
 
 import torch
 import torch.nn as nn
 
 from elg_amd import _lib as L
+from elg_amd import encoder as enc_host
 from elg_amd import engine as eng
 from elg_amd.CVRP.models import CVRP_Decoder, CVRP_Encoder
-
-
-class _EncodeAndFold(nn.Module):
-    """encoder + table folds as ONE static-shape callable, so that a training step can replay them (forward
-    and backward) as two hipGraphs instead of ~400 eager launches (the encoder is launch-bound at B=64)."""
-
-    def __init__(self, encoder, decoder):
-        super().__init__()
-        self.encoder, self.decoder = encoder, decoder
-
-    def forward(self, depot_xy, node_xy_demand):
-        enc = self.encoder(depot_xy, node_xy_demand)
-        t, loc = self.decoder.fold(enc)
-        outs = [enc, t["K"], t["V"], t["PK"], t["pb"], t["Q1"], t["wl"]]
-        if loc is not None:
-            outs.append(loc)
-        return tuple(outs)
 
 
 class CVRPModel(nn.Module):
@@ -41,44 +23,22 @@ class CVRPModel(nn.Module):
         self.encoder = CVRP_Encoder(**model_params)
         self.decoder = CVRP_Decoder(**model_params)
         self.encoded_nodes = None            # (batch, problem+1, embedding)
-        self.__dict__["_graphs"] = {}        # (shape, param ids) -> graphed _EncodeAndFold (not a submodule)
-        self.use_graphs = os.environ.get("ELG_HIPGRAPH", "1") != "0"
 
-    def _graphed(self, depot_xy, node_xy_demand):
-        """hipGraph-captured encoder+folds for this input shape / parameter set (training mode only)."""
-        key = (tuple(depot_xy.shape), tuple(node_xy_demand.shape), str(depot_xy.device),
-               tuple(id(p) for p in self.parameters()))
-        g = self._graphs.get(key)
-        if g is None:
-            # retire the previous graph set at a quiescent point: destroying graph executables while another graph
-            # is being launched (e.g. from the autograd thread) is not safe in the HIP runtime
-            torch.cuda.synchronize()
-            self._graphs.clear()
-            gc.collect()
-            try:
-                mod = _EncodeAndFold(self.encoder, self.decoder)
-                g = torch.cuda.make_graphed_callables(mod, (depot_xy.detach().clone(), node_xy_demand.detach().clone()))
-            except Exception as e:          # capture is an optimisation only: eager PyTorch is the same math
-                print(f"[elg_amd] hipGraph capture of the encoder failed ({type(e).__name__}: {e}); running eager")
-                g = False
-            self._graphs.clear()            # one live graph set (static buffers) at a time
-            self._graphs[key] = g
-        return g
+    def _encoder_params(self):
+        sd = dict(self.named_parameters())
+        return [sd[n] for n in enc_host.parameter_names(L.PROBLEM_CVRP, len(self.encoder.layers))]
 
     def pre_forward(self, reset_state):
-        node_xy_demand = torch.cat((reset_state.node_xy, reset_state.node_demand[:, :, None]), dim=2)
-        depot_xy = reset_state.depot_xy
-        g = None
-        if self.use_graphs and self.training and torch.is_grad_enabled() and depot_xy.is_cuda:
-            g = self._graphed(depot_xy, node_xy_demand)
-        if g:
-            outs = g(depot_xy.contiguous(), node_xy_demand.contiguous())
-            self.encoded_nodes = outs[0]
-            tables = dict(K=outs[1], V=outs[2], PK=outs[3], pb=outs[4], Q1=outs[5], wl=outs[6], Q2=None)
-            self.decoder.set_tables(self.encoded_nodes, tables, outs[7] if len(outs) > 7 else None)
-            return
-        self.encoded_nodes = self.encoder(depot_xy, node_xy_demand, reset_state.dist)
-        self.decoder.set_kv(self.encoded_nodes)
+        """reference CVRPModel.py:21-34: encoder + decoder.set_kv -- one call into libelg_hip.so (elg_encoder_fwd);
+        with autograd enabled the result carries elg_encoder_bwd as its backward."""
+        xy, demand = getattr(reset_state, "_xy", None), getattr(reset_state, "_demand", None)
+        if xy is None:          # a Reset_State that was not produced by elg_amd's CVRPEnv
+            xy = torch.cat((reset_state.depot_xy, reset_state.node_xy), dim=1)
+            demand = torch.cat((torch.zeros_like(reset_state.depot_xy[:, :, 0]), reset_state.node_demand), dim=1)
+        mp = self.model_params
+        self.encoded_nodes, tables = enc_host.encode_and_fold(L.PROBLEM_CVRP, xy, demand, self._encoder_params(),
+                                                              int(mp['encoder_layer_num']), int(mp['ff_hidden_dim']))
+        self.decoder.set_tables(self.encoded_nodes, tables, self.decoder.fold_local())
 
     @staticmethod
     def draw_starts(problem_size, multi_width):

@@ -1,26 +1,20 @@
 """Parameter containers + encoder of the CVRP policy, with the reference's module / state_dict
 names (gaocrr/ELG CVRP/models.py; key layout in SURVEY.md A.5) so checkpoints are interchangeable.
 
-Only the encoder runs as PyTorch ops here (dense batched GEMMs, once per batch); the decoder and
-the local policy never execute in Python: `CVRP_Decoder.set_kv` folds their weights into the tables
-the HIP rollout kernels consume (elg_amd/engine.py)."""
+Nothing here computes in PyTorch: the modules own the parameters (same names, shapes and
+seeded-init order as the reference), the encoder + `set_kv` run in csrc/elg_enc.hip
+(elg_encoder_fwd / elg_encoder_bwd via elg_amd/encoder.py) and the decoder / local policy inside the
+rollout kernels."""
 from __future__ import annotations
 
 import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from elg_amd import engine as eng
+from elg_amd import encoder as enc_host
 from elg_amd import _lib as L
-
-
-class Linear(nn.Linear):
-    """nn.Linear (same parameters / state_dict keys) whose weight gradient uses the split-K MFMA GEMM."""
-
-    def forward(self, x):
-        return eng.linear(x, self.weight, self.bias)
 
 
 class local_policy_att(nn.Module):
@@ -53,49 +47,35 @@ class local_policy_att(nn.Module):
 
 
 class AddAndInstanceNormalization(nn.Module):
+    """Parameters of `InstanceNorm1d(embedding_dim, affine=True)` over the node axis (reference models.py:506-527); the
+    normalisation itself is the epilogue of the combine / feed-forward GEMMs in csrc/elg_enc.hip."""
+
     def __init__(self, **model_params):
         super().__init__()
         self.norm = nn.InstanceNorm1d(model_params['embedding_dim'], affine=True, track_running_stats=False)
-
-    def forward(self, a, b):
-        # per (instance, channel) statistics over the node axis (reference models.py:506-527); one fused HIP kernel
-        # forward and one backward (csrc/elg_encoder.hip) instead of add + transposes + MIOpen batch-norm
-        return eng.add_instance_norm(a, b, self.norm.weight, self.norm.bias, self.norm.eps)
 
 
 class FeedForward(nn.Module):
     def __init__(self, **model_params):
         super().__init__()
-        self.W1 = Linear(model_params['embedding_dim'], model_params['ff_hidden_dim'])
-        self.W2 = Linear(model_params['ff_hidden_dim'], model_params['embedding_dim'])
-
-    def forward(self, x):
-        return self.W2(F.relu(self.W1(x)))
+        self.W1 = nn.Linear(model_params['embedding_dim'], model_params['ff_hidden_dim'])
+        self.W2 = nn.Linear(model_params['ff_hidden_dim'], model_params['embedding_dim'])
 
 
 class EncoderLayer(nn.Module):
+    """Parameter container with the reference's names (models.py:232-247); computed by elg_encoder_fwd / _bwd."""
+
     def __init__(self, **model_params):
         super().__init__()
         self.model_params = model_params
         e, h, d = model_params['embedding_dim'], model_params['head_num'], model_params['qkv_dim']
-        self.Wq = Linear(e, h * d, bias=False)
-        self.Wk = Linear(e, h * d, bias=False)
-        self.Wv = Linear(e, h * d, bias=False)
-        self.multi_head_combine = Linear(h * d, e)
+        self.Wq = nn.Linear(e, h * d, bias=False)
+        self.Wk = nn.Linear(e, h * d, bias=False)
+        self.Wv = nn.Linear(e, h * d, bias=False)
+        self.multi_head_combine = nn.Linear(h * d, e)
         self.add_n_normalization_1 = AddAndInstanceNormalization(**model_params)
         self.feed_forward = FeedForward(**model_params)
         self.add_n_normalization_2 = AddAndInstanceNormalization(**model_params)
-
-    def forward(self, x):
-        B, n, _ = x.shape
-        h = self.model_params['head_num']
-
-        def heads(t):
-            return t.view(B, n, h, -1).transpose(1, 2)
-        q, k, v = eng.qkv_linear(x, self.Wq.weight, self.Wk.weight, self.Wv.weight)      # one GEMM, shared input
-        att = eng.self_attention(q, k, v)                          # SDPA forward, MFMA attention backward
-        o1 = self.add_n_normalization_1(x, self.multi_head_combine(att))
-        return self.add_n_normalization_2(o1, self.feed_forward(o1))
 
 
 class CVRP_Encoder(nn.Module):
@@ -108,10 +88,16 @@ class CVRP_Encoder(nn.Module):
         self.layers = nn.ModuleList([EncoderLayer(**model_params) for _ in range(model_params['encoder_layer_num'])])
 
     def forward(self, depot_xy, node_xy_demand, dist=None):
-        out = torch.cat((self.embedding_depot(depot_xy), self.embedding_node(node_xy_demand)), dim=1)
-        for layer in self.layers:
-            out = layer(out)
-        return out
+        """reference models.py:211-229, inference only (training goes through CVRPModel.pre_forward, which also
+        produces the decoder tables and carries the backward)."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("CVRP_Encoder.forward is inference-only; train through CVRPModel.pre_forward")
+        xy = torch.cat((depot_xy, node_xy_demand[:, :, :2]), dim=1)
+        dem = torch.cat((torch.zeros_like(depot_xy[:, :, 0]), node_xy_demand[:, :, 2]), dim=1)
+        names = enc_host.parameter_names(L.PROBLEM_CVRP, len(self.layers))
+        sd = dict(self.named_parameters(prefix="encoder"))
+        params = [sd[n] for n in names if n.startswith("encoder.")]
+        return enc_host.encode_only(L.PROBLEM_CVRP, xy, dem, params, len(self.layers), self.model_params['ff_hidden_dim'])
 
 
 class CVRP_Decoder(nn.Module):
@@ -137,16 +123,11 @@ class CVRP_Decoder(nn.Module):
         self.local_policies = nn.ModuleList([local_policy_att(self.model_params, idx=i).to(device) for i in range(n)])
         self.local = True
 
-    def fold(self, encoded_nodes):
-        """(tables, loc): decoder / local-policy weights folded for the HIP kernels (engine.fold_*)."""
+    def fold_local(self):
+        """Folded local-policy tables (engine.fold_local_tables), or None without the ensemble head."""
         mp = self.model_params
-        dec = {"Wq_last.weight": self.Wq_last.weight, "Wk.weight": self.Wk.weight, "Wv.weight": self.Wv.weight,
-               "multi_head_combine.weight": self.multi_head_combine.weight,
-               "multi_head_combine.bias": self.multi_head_combine.bias}
-        tables = eng.fold_decoder_tables(dec, encoded_nodes, L.PROBLEM_CVRP)
         has_local = bool(mp['ensemble'] and self.local)
-        loc = self.local_policies[0].folded_tables(int(mp['local_size'][0]) + 1) if has_local else None
-        return tables, loc
+        return self.local_policies[0].folded_tables(int(mp['local_size'][0]) + 1) if has_local else None
 
     def set_tables(self, encoded_nodes, tables, loc):
         mp = self.model_params
@@ -158,6 +139,11 @@ class CVRP_Decoder(nn.Module):
         self.single_head_key = encoded_nodes.transpose(1, 2)
 
     def set_kv(self, encoded_nodes):
-        """reference models.py:300-308, plus the folds described in engine.fold_decoder_tables."""
-        tables, loc = self.fold(encoded_nodes)
-        self.set_tables(encoded_nodes, tables, loc)
+        """reference decoder.set_kv on given encodings (inference only; CVRPModel.pre_forward produces the same tables
+        together with the encoder and carries the backward)."""
+        if torch.is_grad_enabled() and encoded_nodes.requires_grad:
+            raise RuntimeError("set_kv is inference-only; train through CVRPModel.pre_forward")
+        sd = dict(self.named_parameters(prefix="decoder"))
+        names = [n for n in enc_host.parameter_names(L.PROBLEM_CVRP, 0) if n.startswith("decoder.")]
+        tables = enc_host.fold_only(L.PROBLEM_CVRP, encoded_nodes, [sd[n] for n in names])
+        self.set_tables(encoded_nodes, tables, self.fold_local())

@@ -2,32 +2,15 @@
 from __future__ import annotations
 
 import ctypes as C
-import gc
-import os
 import random
 
 import torch
 import torch.nn as nn
 
 from elg_amd import _lib as L
+from elg_amd import encoder as enc_host
 from elg_amd import engine as eng
 from elg_amd.TSP.models import TSP_Decoder, TSP_Encoder
-
-
-class _EncodeAndFold(nn.Module):
-    """encoder + table folds as one static-shape callable (two hipGraphs per training step, see CVRPModel)."""
-
-    def __init__(self, encoder, decoder):
-        super().__init__()
-        self.encoder, self.decoder = encoder, decoder
-
-    def forward(self, problems):
-        enc = self.encoder(problems)
-        t, loc = self.decoder.fold(enc)
-        outs = [enc, t["K"], t["V"], t["PK"], t["pb"], t["Q1"], t["Q2"]]
-        if loc is not None:
-            outs.append(loc)
-        return tuple(outs)
 
 
 class TSPModel(nn.Module):
@@ -37,41 +20,18 @@ class TSPModel(nn.Module):
         self.encoder = TSP_Encoder(**model_params)
         self.decoder = TSP_Decoder(**model_params)
         self.encoded_nodes = None
-        self.__dict__["_graphs"] = {}
-        self.use_graphs = os.environ.get("ELG_HIPGRAPH", "1") != "0"
 
-    def _graphed(self, problems):
-        key = (tuple(problems.shape), str(problems.device), tuple(id(p) for p in self.parameters()))
-        g = self._graphs.get(key)
-        if g is None:
-            # retire the previous graph set at a quiescent point: destroying graph executables while another graph
-            # is being launched (e.g. from the autograd thread) is not safe in the HIP runtime
-            torch.cuda.synchronize()
-            self._graphs.clear()
-            gc.collect()
-            try:
-                g = torch.cuda.make_graphed_callables(_EncodeAndFold(self.encoder, self.decoder),
-                                                      (problems.detach().clone(),))
-            except Exception as e:          # capture is an optimisation only: eager PyTorch is the same math
-                print(f"[elg_amd] hipGraph capture of the encoder failed ({type(e).__name__}: {e}); running eager")
-                g = False
-            self._graphs.clear()
-            self._graphs[key] = g
-        return g
+    def _encoder_params(self):
+        sd = dict(self.named_parameters())
+        return [sd[n] for n in enc_host.parameter_names(L.PROBLEM_TSP, len(self.encoder.layers))]
 
     def pre_forward(self, reset_state):
-        problems = reset_state.problems
-        g = None
-        if self.use_graphs and self.training and torch.is_grad_enabled() and problems.is_cuda:
-            g = self._graphed(problems)
-        if g:
-            outs = g(problems.contiguous())
-            self.encoded_nodes = outs[0]
-            tables = dict(K=outs[1], V=outs[2], PK=outs[3], pb=outs[4], Q1=outs[5], Q2=outs[6], wl=None)
-            self.decoder.set_tables(self.encoded_nodes, tables, outs[7] if len(outs) > 7 else None)
-            return
-        self.encoded_nodes = self.encoder(problems)
-        self.decoder.set_kv(self.encoded_nodes)
+        """reference TSPModel.py:17-24: encoder + decoder.set_kv as one call into libelg_hip.so (elg_encoder_fwd)."""
+        mp = self.model_params
+        self.encoded_nodes, tables = enc_host.encode_and_fold(L.PROBLEM_TSP, reset_state.problems, None,
+                                                              self._encoder_params(), int(mp['encoder_layer_num']),
+                                                              int(mp['ff_hidden_dim']))
+        self.decoder.set_tables(self.encoded_nodes, tables, self.decoder.fold_local())
 
     @staticmethod
     def draw_starts(problem_size, pomo_size):

@@ -4,36 +4,27 @@ from __future__ import annotations
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
+from elg_amd import encoder as enc_host
 from elg_amd import engine as eng
 from elg_amd import _lib as L
-from elg_amd.CVRP.models import AddAndInstanceNormalization, FeedForward, Linear, local_policy_att  # same definitions
+from elg_amd.CVRP.models import AddAndInstanceNormalization, FeedForward, local_policy_att  # same definitions
 
 
 class EncoderLayer(nn.Module):
+    """Parameter container with the reference's names (TSP/models.py:157-172); computed by elg_encoder_fwd / _bwd."""
+
     def __init__(self, **model_params):
         super().__init__()
         self.model_params = model_params
         e, h, d = model_params['embedding_dim'], model_params['head_num'], model_params['qkv_dim']
-        self.Wq = Linear(e, h * d, bias=False)
-        self.Wk = Linear(e, h * d, bias=False)
-        self.Wv = Linear(e, h * d, bias=False)
-        self.multi_head_combine = Linear(h * d, e)
+        self.Wq = nn.Linear(e, h * d, bias=False)
+        self.Wk = nn.Linear(e, h * d, bias=False)
+        self.Wv = nn.Linear(e, h * d, bias=False)
+        self.multi_head_combine = nn.Linear(h * d, e)
         self.addAndNormalization1 = AddAndInstanceNormalization(**model_params)
         self.feedForward = FeedForward(**model_params)
         self.addAndNormalization2 = AddAndInstanceNormalization(**model_params)
-
-    def forward(self, x):
-        B, n, _ = x.shape
-        h = self.model_params['head_num']
-
-        def heads(t):
-            return t.view(B, n, h, -1).transpose(1, 2)
-        q, k, v = eng.qkv_linear(x, self.Wq.weight, self.Wk.weight, self.Wv.weight)      # one GEMM, shared input
-        att = eng.self_attention(q, k, v)                          # SDPA forward, MFMA attention backward
-        o1 = self.addAndNormalization1(x, self.multi_head_combine(att))
-        return self.addAndNormalization2(o1, self.feedForward(o1))
 
 
 class TSP_Encoder(nn.Module):
@@ -44,10 +35,13 @@ class TSP_Encoder(nn.Module):
         self.layers = nn.ModuleList([EncoderLayer(**model_params) for _ in range(model_params['encoder_layer_num'])])
 
     def forward(self, data):
-        out = self.embedding(data)
-        for layer in self.layers:
-            out = layer(out)
-        return out
+        """reference TSP/models.py:145-154, inference only (training goes through TSPModel.pre_forward)."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("TSP_Encoder.forward is inference-only; train through TSPModel.pre_forward")
+        names = enc_host.parameter_names(L.PROBLEM_TSP, len(self.layers))
+        sd = dict(self.named_parameters(prefix="encoder"))
+        params = [sd[n] for n in names if n.startswith("encoder.")]
+        return enc_host.encode_only(L.PROBLEM_TSP, data, None, params, len(self.layers), self.model_params['ff_hidden_dim'])
 
 
 class TSP_Decoder(nn.Module):
@@ -71,17 +65,11 @@ class TSP_Decoder(nn.Module):
         self.local_policy_0 = local_policy_att(mp).to(device)
         self.local = True
 
-    def fold(self, encoded_nodes):
-        """(tables, loc): decoder / local-policy weights folded for the HIP kernels (engine.fold_*)."""
+    def fold_local(self):
+        """Folded local-policy tables (engine.fold_local_tables), or None without the ensemble head."""
         mp = self.model_params
-        dec = {"Wq_first.weight": self.Wq_first.weight, "Wq_last.weight": self.Wq_last.weight,
-               "Wk.weight": self.Wk.weight, "Wv.weight": self.Wv.weight,
-               "multi_head_combine.weight": self.multi_head_combine.weight,
-               "multi_head_combine.bias": self.multi_head_combine.bias}
-        tables = eng.fold_decoder_tables(dec, encoded_nodes, L.PROBLEM_TSP)
         has_local = bool(mp['ensemble'] and self.local)
-        loc = self.local_policy_0.folded_tables(int(mp['local_size'][0])) if has_local else None
-        return tables, loc
+        return self.local_policy_0.folded_tables(int(mp['local_size'][0])) if has_local else None
 
     def set_tables(self, encoded_nodes, tables, loc):
         mp = self.model_params
@@ -92,6 +80,11 @@ class TSP_Decoder(nn.Module):
         self.single_head_key = encoded_nodes.transpose(1, 2)
 
     def set_kv(self, encoded_nodes):
-        """reference TSP/models.py:231-241 (+ set_q1 :236-241 folded into the Q2 table)."""
-        tables, loc = self.fold(encoded_nodes)
-        self.set_tables(encoded_nodes, tables, loc)
+        """reference decoder.set_kv on given encodings (inference only; TSPModel.pre_forward produces the same tables
+        together with the encoder and carries the backward)."""
+        if torch.is_grad_enabled() and encoded_nodes.requires_grad:
+            raise RuntimeError("set_kv is inference-only; train through TSPModel.pre_forward")
+        sd = dict(self.named_parameters(prefix="decoder"))
+        names = [n for n in enc_host.parameter_names(L.PROBLEM_TSP, 0) if n.startswith("decoder.")]
+        tables = enc_host.fold_only(L.PROBLEM_TSP, encoded_nodes, [sd[n] for n in names])
+        self.set_tables(encoded_nodes, tables, self.fold_local())

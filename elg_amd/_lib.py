@@ -47,10 +47,39 @@ class BwdArgs(C.Structure):
     ]
 
 
+ENC_MAX_LAYERS = 8
+_LAYER_FIELDS = ("Wq", "Wk", "Wv", "Wc", "bc", "g1", "b1", "W1", "bf1", "W2", "bf2", "g2", "b2")
+
+
+class EncLayer(C.Structure):
+    _fields_ = [(n, _vp) for n in _LAYER_FIELDS]
+
+
+class EncWeights(C.Structure):
+    _fields_ = [("emb_depot_w", _vp), ("emb_depot_b", _vp), ("emb_w", _vp), ("emb_b", _vp),
+                ("layer", EncLayer * ENC_MAX_LAYERS),
+                ("dec_Wq_first", _vp), ("dec_Wq_last", _vp), ("dec_Wk", _vp), ("dec_Wv", _vp), ("dec_Wc", _vp),
+                ("dec_bc", _vp)]
+
+
+class EncoderArgs(C.Structure):
+    _fields_ = [("problem", C.c_int32), ("B", C.c_int32), ("N1", C.c_int32), ("n_layers", C.c_int32),
+                ("ff_hidden", C.c_int32), ("save", C.c_int32), ("eps", C.c_float), ("pad0", C.c_int32),
+                ("xy", _vp), ("demand", _vp), ("W", EncWeights),
+                ("enc", _vp), ("K", _vp), ("V", _vp), ("PK", _vp), ("pb", _vp), ("Q1", _vp), ("Q2", _vp), ("wl", _vp),
+                ("ws", _vp), ("ws_floats", C.c_int64)]
+
+
+class EncoderBwdArgs(C.Structure):
+    _fields_ = [("fwd", EncoderArgs), ("g_enc", _vp), ("gK", _vp), ("gV", _vp), ("gPK", _vp), ("gpb", _vp),
+                ("gQ1", _vp), ("gQ2", _vp), ("gwl", _vp), ("G", EncWeights), ("ws2", _vp), ("ws2_floats", C.c_int64)]
+
+
 EXPORTS = ["elg_version", "elg_last_error", "elg_aug8", "elg_dist_matrix", "elg_nbr_tables", "elg_route_length",
            "elg_rollout_fwd", "elg_rollout_bwd", "elg_glimpse_rows_bwd", "elg_glimpse_bwd_fused", "elg_gemm_f32",
            "elg_pomo_loss", "elg_rows_prep", "elg_adam_step", "elg_local_bwd_rows",
-           "elg_add_instnorm_fwd", "elg_add_instnorm_bwd", "elg_rows_segsum"]
+           "elg_add_instnorm_fwd", "elg_add_instnorm_bwd", "elg_rows_segsum",
+           "elg_encoder_ws_floats", "elg_encoder_fwd", "elg_encoder_bwd_ws_floats", "elg_encoder_bwd"]
 
 _lib = None
 
@@ -89,6 +118,14 @@ def lib() -> C.CDLL:
         L.elg_add_instnorm_bwd.argtypes = [f, f, f, f, f, f, f, i, i, i, f]
         L.elg_local_bwd_rows.argtypes = [f, f, f, f, f, i, i, i64, i, f]
         L.elg_adam_step.argtypes = [f, f, f, i, f, f, f, i64, fl, fl, fl, fl, fl, i64, fl, f]
+        L.elg_encoder_ws_floats.argtypes = [i, i, i, i, i]
+        L.elg_encoder_ws_floats.restype = i64
+        L.elg_encoder_bwd_ws_floats.argtypes = [i, i, i]
+        L.elg_encoder_bwd_ws_floats.restype = i64
+        L.elg_encoder_fwd.argtypes = [C.POINTER(EncoderArgs), f]
+        L.elg_encoder_bwd.argtypes = [C.POINTER(EncoderBwdArgs), f]
+        L.elg_encoder_fwd.restype = C.c_int
+        L.elg_encoder_bwd.restype = C.c_int
         for n in ("elg_aug8", "elg_dist_matrix", "elg_nbr_tables", "elg_route_length", "elg_rollout_fwd",
                   "elg_rollout_bwd", "elg_glimpse_rows_bwd", "elg_glimpse_bwd_fused", "elg_gemm_f32",
                   "elg_pomo_loss", "elg_rows_prep", "elg_adam_step", "elg_local_bwd_rows",

@@ -71,7 +71,7 @@ template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                        float* __restrict__ C, const float* __restrict__ bias,
                                                        int M, int N, int K, int lda, int ldb, int ldc, int relu,
-                                                       int k_per_split, float* __restrict__ a_rowsum) {
+                                                       int k_per_split, float* __restrict__ a_rowsum, float alpha) {
     __shared__ __attribute__((aligned(16))) float sA[BK * LDT];
     __shared__ __attribute__((aligned(16))) float sB[BK * LDT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     for (int reg = 0; reg < 16; ++reg) {
         const int row = m0 + wm + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
         if (row < M && col < N) {
-            float v = acc[reg] + bv;
+            float v = acc[reg] * alpha + bv;
             if (gridDim.z > 1) atomicAdd(C + (size_t)row * ldc + col, v);
             else {
                 if (relu) v = fmaxf(v, 0.f);
@@ -125,9 +125,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 
 using namespace elg;
 
-extern "C" int elg_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
-                            int lda, int ldb, int ldc, int transA, int transB, int relu, int split_k, float* a_rowsum,
-                            void* stream) {
+extern "C" int elg_gemm_f32_alpha(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                                  int lda, int ldb, int ldc, int transA, int transB, int relu, int split_k, float* a_rowsum,
+                                  float alpha, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) return fail(ELG_EINVAL, "gemm: empty problem");
     if (split_k < 1) split_k = 1;
     if (split_k > 1 && relu) return fail(ELG_EINVAL, "gemm: ReLU epilogue needs split_k == 1");
@@ -139,9 +139,15 @@ extern "C" int elg_gemm_f32(const float* A, const float* B, float* C, const floa
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, splits), block(256);
     hipStream_t s = (hipStream_t)stream;
     (void)hipGetLastError();
-    if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, relu, kps, a_rowsum);
-    else if (!transA && transB) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, relu, kps, a_rowsum);
-    else if (transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, relu, kps, a_rowsum);
-    else hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, relu, kps, a_rowsum);
+    if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, relu, kps, a_rowsum, alpha);
+    else if (!transA && transB) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, relu, kps, a_rowsum, alpha);
+    else if (transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, relu, kps, a_rowsum, alpha);
+    else hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, relu, kps, a_rowsum, alpha);
     return launch_status("gemm_f32");
+}
+
+extern "C" int elg_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                            int lda, int ldb, int ldc, int transA, int transB, int relu, int split_k, float* a_rowsum,
+                            void* stream) {
+    return elg_gemm_f32_alpha(A, B, C, bias, M, N, K, lda, ldb, ldc, transA, transB, relu, split_k, a_rowsum, 1.0f, stream);
 }

@@ -30,7 +30,6 @@ def _stream() -> C.c_void_p:
 
 
 _SIDE = {}
-_MFMA_DW = os.environ.get("ELG_MFMA_DW", "1") != "0"      # encoder weight gradients on the hand-written MFMA GEMM
 
 
 def _side_stream(dev) -> "torch.cuda.Stream":
@@ -143,83 +142,6 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, bias
     return out
 
 
-_DW_WGS = int(os.environ.get("ELG_DW_WGS", "512"))
-
-
-def _dw_split(out_f: int, in_f: int, rows: int) -> int:
-    """split-K factor of a weight-gradient GEMM: enough workgroups to fill the 256 CUs, no more -- every split adds
-    one f32 atomic per output element."""
-    tiles = ((out_f + 63) // 64) * ((in_f + 63) // 64)
-    return max(1, min(64, rows // 128, max(4, _DW_WGS // tiles)))
-
-
-class _LinearFn(torch.autograd.Function):
-    """y = x W^T (+ b) with x (rows, in), W (out, in).  Forward and dX are plain library GEMMs (hipBLASLt is
-    already at ~6 us for these shapes); the weight gradient dW = dY^T X reduces over rows = batch*nodes (6464),
-    where the library's single-pass kernel takes ~39 us: it runs on the hand-written split-K MFMA GEMM
-    (csrc/elg_gemm.hip, 16-31 us)."""
-
-    @staticmethod
-    def forward(ctx, x2, W, b):
-        ctx.save_for_backward(x2, W)
-        ctx.has_bias = b is not None
-        return torch.nn.functional.linear(x2, W, b)
-
-    @staticmethod
-    def backward(ctx, dy):
-        x2, W = ctx.saved_tensors
-        dy = dy.contiguous()
-        dx = dy @ W if ctx.needs_input_grad[0] else None
-        split = _dw_split(W.shape[0], W.shape[1], x2.shape[0])
-        # dW and (bias: its row sums, from the same staged tiles) in one zero-filled buffer and one launch
-        buf = torch.zeros(W.shape[0] * (W.shape[1] + 1), device=dy.device)
-        dW = buf[:W.numel()].view_as(W)
-        db = buf[W.numel():] if ctx.has_bias else None
-        gemm(dy, x2, trans_a=True, split_k=split, out=dW, a_rowsum=db)
-        return dx, dW, db
-
-
-class _QKVFn(torch.autograd.Function):
-    """The three bias-free projections of an attention layer (reference models.py:546-552) as one GEMM each way:
-    y = x [Wq; Wk; Wv]^T forward, dX = dY W and dW = dY^T X (split-K MFMA) backward."""
-
-    @staticmethod
-    def forward(ctx, x2, Wq, Wk, Wv):
-        W = torch.cat((Wq, Wk, Wv), dim=0)
-        ctx.save_for_backward(x2, W)
-        ctx.sizes = (Wq.shape[0], Wk.shape[0], Wv.shape[0])
-        y = x2 @ W.t()
-        return torch.split(y, ctx.sizes, dim=1)
-
-    @staticmethod
-    def backward(ctx, dq, dk, dv):
-        x2, W = ctx.saved_tensors
-        dy = torch.cat((dq, dk, dv), dim=1)
-        dx = dy @ W if ctx.needs_input_grad[0] else None
-        dW = gemm(dy, x2, trans_a=True, split_k=_dw_split(W.shape[0], W.shape[1], x2.shape[0]))
-        gq, gk, gv = torch.split(dW, ctx.sizes, dim=0)
-        return dx, gq, gk, gv
-
-
-def qkv_linear(x: torch.Tensor, Wq: torch.Tensor, Wk: torch.Tensor, Wv: torch.Tensor):
-    """(x Wq^T, x Wk^T, x Wv^T) with shared-input fusion (GPU tensors; falls back to three F.linear otherwise)."""
-    if not _MFMA_DW or not x.is_cuda or not torch.is_grad_enabled():
-        Fn = torch.nn.functional.linear
-        return Fn(x, Wq), Fn(x, Wk), Fn(x, Wv)
-    lead = x.shape[:-1]
-    q, k, v = _QKVFn.apply(x.reshape(-1, x.shape[-1]), Wq, Wk, Wv)
-    return q.reshape(*lead, -1), k.reshape(*lead, -1), v.reshape(*lead, -1)
-
-
-def linear(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """F.linear whose weight gradient runs on the split-K MFMA GEMM (GPU tensors, in/out multiples of 4)."""
-    if (not _MFMA_DW or not x.is_cuda or (x.shape[-1] % 4) or (W.shape[0] % 4) or not torch.is_grad_enabled()):
-        return torch.nn.functional.linear(x, W, b)
-    lead = x.shape[:-1]
-    y = _LinearFn.apply(x.reshape(-1, x.shape[-1]), W, b)
-    return y.view(*lead, W.shape[0])
-
-
 # ----------------------------------------------------------------------------------------------
 # weight folding (differentiable torch: autograd carries the kernel's table gradients back)
 # ----------------------------------------------------------------------------------------------
@@ -273,29 +195,6 @@ def fold_local_tables(lp: Dict[str, torch.Tensor], nfeat: int, n_slots: int) -> 
     out = torch.cat(pieces).contiguous()
     assert out.numel() == L.LOC_SIZE
     return out
-
-
-def fold_decoder_tables(dec: Dict[str, torch.Tensor], enc: torch.Tensor, problem: int) -> Dict[str, torch.Tensor]:
-    """Per-instance tables of the pointer decoder (reference models.py:300-352, TSP/models.py:231-270):
-    K = Wk enc, V = Wv enc, PK = enc Wc / sqrt(E) (pointer keys with multi_head_combine folded in),
-    pb = enc . bc / sqrt(E), Q1/Q2 = the per-node query contributions."""
-    Wc, bc = dec["multi_head_combine.weight"], dec["multi_head_combine.bias"]
-    t = {
-        "K": (enc @ dec["Wk.weight"].T).contiguous(),
-        "V": (enc @ dec["Wv.weight"].T).contiguous(),
-        "PK": ((enc @ Wc) / math.sqrt(E)).contiguous(),
-        "pb": ((enc @ bc) / math.sqrt(E)).contiguous(),
-    }
-    if problem == L.PROBLEM_CVRP:
-        Wq = dec["Wq_last.weight"]
-        t["Q1"] = (enc @ Wq[:, :E].T).contiguous()
-        t["wl"] = Wq[:, E].contiguous()
-        t["Q2"] = None
-    else:
-        t["Q1"] = (enc @ dec["Wq_last.weight"].T).contiguous()
-        t["Q2"] = (enc @ dec["Wq_first.weight"].T).contiguous()
-        t["wl"] = None
-    return t
 
 
 # ----------------------------------------------------------------------------------------------
@@ -687,7 +586,8 @@ def pomo_loss(probs: torch.Tensor, rewards: torch.Tensor, scale_norm: bool = Tru
 
 
 # ----------------------------------------------------------------------------------------------
-# residual add + instance norm (encoder, reference models.py:506-527)
+# residual add + instance norm (reference models.py:506-527) as a stand-alone op: the N1 > 128 path of elg_encoder_fwd /
+# the norm backward of elg_encoder_bwd use these two kernels; this wrapper exists for their unit test
 # ----------------------------------------------------------------------------------------------
 class _AddInstNorm(torch.autograd.Function):
     @staticmethod
@@ -721,59 +621,6 @@ def add_instance_norm(a: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, bet
 
 
 # ----------------------------------------------------------------------------------------------
-# encoder self-attention (reference models.py:455-503) with the MFMA attention backward
-# ----------------------------------------------------------------------------------------------
-_ZMASK = {}
-
-
-class _SelfAttention(torch.autograd.Function):
-    """softmax(q k^T / 4) v over the nodes of an instance, 8 heads x 16 (channel = head * 16 + d).  Forward: the
-    library SDPA kernel.  Backward: csrc/elg_bwd.hip::glimpse_bwd_mfma_kernel in its recompute mode -- the same
-    attention backward the decoder's glimpse uses (rows = the instance's own nodes, nothing masked): one launch for
-    dq, dk, dv instead of the library's 59 us kernel."""
-
-    @staticmethod
-    def forward(ctx, q, k, v):
-        B, n, _ = q.shape
-
-        def heads(t):
-            return t.view(B, n, H, DK).transpose(1, 2)
-        out = torch.nn.functional.scaled_dot_product_attention(heads(q), heads(k), heads(v))
-        out = out.transpose(1, 2).reshape(B, n, E)
-        ctx.save_for_backward(q, k, v, out)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        q, k, v, out = ctx.saved_tensors
-        B, n, _ = q.shape
-        dev = q.device
-        q, k, v, dout = q.contiguous(), k.contiguous(), v.contiguous(), dout.contiguous()
-        key = (B, n, str(dev))
-        zm = _ZMASK.get(key)
-        if zm is None:
-            zm = _ZMASK[key] = torch.zeros(B, n, 2, device=dev, dtype=torch.int64)      # every node open
-        dq = torch.empty(B, n, E, device=dev)
-        dkv = torch.empty(2, 1, B, n, E, device=dev)
-        L.check(L.lib().elg_glimpse_bwd_fused(None, _ptr(zm), _ptr(dout), _ptr(out), _ptr(q), _ptr(k), _ptr(v), _ptr(dq),
-                                              _ptr(dkv[0]), _ptr(dkv[1]), B, n, n, 0, n, n, 1, _stream()),
-                "elg_glimpse_bwd_fused(encoder)")
-        return dq, dkv[0, 0], dkv[1, 0]
-
-
-def self_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
-    """(B,n,128) x3 -> (B,n,128): multi-head self-attention of the encoder layers (4 <= n <= 128 on the MFMA path)."""
-    B, n, e = q.shape
-    if (q.is_cuda and torch.is_grad_enabled() and e == E and 4 <= n <= 128
-            and os.environ.get("ELG_MFMA_ATTN_BWD", "0") == "1"):      # measured neutral at n = 101 (7 row tiles): off
-        return _SelfAttention.apply(q, k, v)
-    def heads(t):
-        return t.view(B, n, H, -1).transpose(1, 2)
-    att = torch.nn.functional.scaled_dot_product_attention(heads(q), heads(k), heads(v))
-    return att.transpose(1, 2).reshape(B, n, -1)
-
-
-# ----------------------------------------------------------------------------------------------
 # orderly shutdown: drop the cached device / pinned buffers, events and the side stream while the HIP runtime is
 # still alive (module globals are otherwise destroyed in arbitrary order at interpreter exit)
 # ----------------------------------------------------------------------------------------------
@@ -783,7 +630,7 @@ def _teardown():
             torch.cuda.synchronize()
     except Exception:
         pass
-    for cache in (_PINNED, TrainRows._cache, _ZMASK, _SIDE):
+    for cache in (_PINNED, TrainRows._cache, _SIDE):
         cache.clear()
 
 

@@ -255,6 +255,73 @@ int elg_gemm_f32(const float* A, const float* B, float* C, const float* bias, in
                  int lda, int ldb, int ldc, int transA, int transB, int relu, int split_k, float* a_rowsum,
                  void* stream);
 
+
+/* ---- attention encoder + decoder tables (CVRPModel.pre_forward: CVRP/CVRPModel.py:21-34 -> CVRP_Encoder.forward,
+ * CVRP/models.py:211-229; EncoderLayer :249-269; multi_head_attention :455-503; AddAndInstanceNormalization :506-527;
+ * FeedForward :550-561; CVRP_Decoder.set_kv :300-308.  TSP: TSP/models.py:134-194, 231-243), forward and backward,
+ * entirely on hand-written gfx950 kernels (f32 MFMA).  Weight pointers are the reference's parameters where they lie
+ * (nn.Linear layout (out, in), row-major; state_dict names in the comments).  embedding 128, 8 heads x 16. */
+#define ELG_ENC_MAX_LAYERS 8
+typedef struct elg_enc_layer {          /* encoder.layers.{l}.                                                     */
+    const float *Wq, *Wk, *Wv;          /* Wq / Wk / Wv .weight (128,128), no bias                                 */
+    const float *Wc, *bc;               /* multi_head_combine.weight (128,128), .bias (128)                        */
+    const float *g1, *b1;               /* add_n_normalization_1.norm.weight / .bias (TSP: addAndNormalization1)   */
+    const float *W1, *bf1;              /* feed_forward.W1.weight (ff,128), .bias (ff)   (TSP: feedForward)        */
+    const float *W2, *bf2;              /* feed_forward.W2.weight (128,ff), .bias (128)                            */
+    const float *g2, *b2;               /* add_n_normalization_2.norm.weight / .bias                               */
+} elg_enc_layer;
+typedef struct elg_enc_weights {
+    const float *emb_depot_w, *emb_depot_b;   /* CVRP encoder.embedding_depot (128,2), (128); TSP: NULL            */
+    const float *emb_w, *emb_b;               /* CVRP encoder.embedding_node (128,3); TSP encoder.embedding (128,2) */
+    elg_enc_layer layer[ELG_ENC_MAX_LAYERS];
+    const float *dec_Wq_first;                /* TSP decoder.Wq_first.weight (128,128); CVRP: NULL                 */
+    const float *dec_Wq_last;                 /* decoder.Wq_last.weight: CVRP (128,129) (last column = load), TSP (128,128) */
+    const float *dec_Wk, *dec_Wv;             /* decoder.Wk / Wv .weight (128,128)                                 */
+    const float *dec_Wc, *dec_bc;             /* decoder.multi_head_combine.weight (128,128), .bias (128)          */
+} elg_enc_weights;
+
+typedef struct elg_encoder_args {
+    int32_t problem;        /* ELG_PROBLEM_*                                                                       */
+    int32_t B, N1;          /* instances, nodes per instance (CVRP: depot = node 0)                                */
+    int32_t n_layers;       /* model_params.encoder_layer_num (<= ELG_ENC_MAX_LAYERS)                              */
+    int32_t ff_hidden;      /* model_params.ff_hidden_dim (multiple of 64)                                         */
+    int32_t save;           /* 1: keep every layer's activations in `ws` for elg_encoder_bwd (training)            */
+    float eps;              /* InstanceNorm1d eps (1e-5)                                                           */
+    int32_t pad0;
+    const float* xy;        /* (B,N1,2)                                                                            */
+    const float* demand;    /* (B,N1) CVRP (depot entry unused); TSP: NULL                                         */
+    elg_enc_weights W;
+    float* enc;             /* (B,N1,128) out: encoded nodes                                                       */
+    /* decoder tables, all-or-none (K == NULL: encoder only); same meaning as in elg_rollout_args               */
+    float *K, *V, *PK;      /* (B,N1,128)                                                                          */
+    float* pb;              /* (B,N1)                                                                              */
+    float* Q1;              /* (B,N1,128)                                                                          */
+    float* Q2;              /* (B,N1,128) TSP                                                                      */
+    float* wl;              /* (128) CVRP: contiguous copy of Wq_last[:, 128]                                      */
+    float* ws;              /* workspace, elg_encoder_ws_floats() floats, 16-byte aligned; with save = 1 it must stay
+                               untouched until elg_encoder_bwd has run                                             */
+    int64_t ws_floats;
+} elg_encoder_args;
+int64_t elg_encoder_ws_floats(int B, int N1, int n_layers, int ff_hidden, int save);
+int elg_encoder_fwd(const elg_encoder_args* args, void* stream);
+
+/* Backward of elg_encoder_fwd (what autograd records for CVRPModel.pre_forward in train.py:105-125): cotangents of
+ * the outputs in, parameter gradients out.  N1 <= 128 (training sizes). */
+typedef struct elg_encoder_bwd_args {
+    elg_encoder_args fwd;   /* exactly the forward's arguments (same ws, save = 1)                                 */
+    const float* g_enc;     /* (B,N1,128) d loss / d enc, or NULL                                                  */
+    const float *gK, *gV, *gPK;   /* (B,N1,128) or NULL (= zero)                                                   */
+    const float* gpb;       /* (B,N1) or NULL (needs gPK)                                                          */
+    const float *gQ1, *gQ2; /* (B,N1,128) or NULL                                                                  */
+    const float* gwl;       /* (128) or NULL                                                                       */
+    elg_enc_weights G;      /* gradient destinations, same shapes as the weights; written through (float*), every
+                               gradient is ACCUMULATED (+=): the caller zero-fills                                 */
+    float* ws2;             /* scratch, elg_encoder_bwd_ws_floats() floats                                         */
+    int64_t ws2_floats;
+} elg_encoder_bwd_args;
+int64_t elg_encoder_bwd_ws_floats(int B, int N1, int ff_hidden);
+int elg_encoder_bwd(const elg_encoder_bwd_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,17 +26,3 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
-
-
-@pytest.fixture(autouse=True)
-def _quiesce_gpu_between_tests(request):
-    """Models captured as hipGraphs become cyclic garbage when a test returns; if Python collects them while a later
-    test replays another graph on the autograd thread, the HIP runtime can crash (seen once in ~25 suite runs, inside
-    torch/cuda/graphs.py::replay).  Collect and synchronise at the test boundary instead."""
-    yield
-    if "gpu" in request.keywords:
-        import gc
-        import torch
-        gc.collect()
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()

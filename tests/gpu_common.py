@@ -1,4 +1,6 @@
 """Helpers shared by the `-m gpu` parity tests: build engine inputs from golden weights/problems."""
+from typing import Dict
+
 import numpy as np
 import torch
 
@@ -18,10 +20,36 @@ def sub(P, prefix):
     return {k[len(prefix):]: v for k, v in P.items() if k.startswith(prefix)}
 
 
+import math  # noqa: E402
+
+
+def fold_decoder_tables(dec: Dict[str, torch.Tensor], enc: torch.Tensor, problem: int) -> Dict[str, torch.Tensor]:
+    """Per-instance tables of the pointer decoder (reference models.py:300-352, TSP/models.py:231-270):
+    K = Wk enc, V = Wv enc, PK = enc Wc / sqrt(E) (pointer keys with multi_head_combine folded in),
+    pb = enc . bc / sqrt(E), Q1/Q2 = the per-node query contributions."""
+    Wc, bc = dec["multi_head_combine.weight"], dec["multi_head_combine.bias"]
+    t = {
+        "K": (enc @ dec["Wk.weight"].T).contiguous(),
+        "V": (enc @ dec["Wv.weight"].T).contiguous(),
+        "PK": ((enc @ Wc) / math.sqrt(128)).contiguous(),
+        "pb": ((enc @ bc) / math.sqrt(128)).contiguous(),
+    }
+    if problem == L.PROBLEM_CVRP:
+        Wq = dec["Wq_last.weight"]
+        t["Q1"] = (enc @ Wq[:, :128].T).contiguous()
+        t["wl"] = Wq[:, 128].contiguous()
+        t["Q2"] = None
+    else:
+        t["Q1"] = (enc @ dec["Wq_last.weight"].T).contiguous()
+        t["Q2"] = (enc @ dec["Wq_first.weight"].T).contiguous()
+        t["wl"] = None
+    return t
+
+
 def make_policy(P, cfg, enc_gpu, kind, has_local=True):
     """Fold oracle-format weights (CPU dict) into engine tables on the GPU."""
     Pg = {k: v.to(DEV) for k, v in P.items()}
-    tables = eng.fold_decoder_tables(sub(Pg, "decoder."), enc_gpu, kind)
+    tables = fold_decoder_tables(sub(Pg, "decoder."), enc_gpu, kind)
     lp_prefix = "decoder.local_policies.0." if kind == L.PROBLEM_CVRP else "decoder.local_policy_0."
     nfeat = 3 if kind == L.PROBLEM_CVRP else 2
     nslots = cfg.local_size + (1 if kind == L.PROBLEM_CVRP else 0)

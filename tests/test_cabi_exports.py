@@ -16,7 +16,7 @@ def test_build_and_exports():
     assert os.path.exists(lib_path)
     from elg_amd import _lib
     L = _lib.lib()
-    declared = set(re.findall(r"^\s*(?:const\s+char\*|int)\s+(elg_\w+)\s*\(", open(HDR).read(), re.M))
+    declared = set(re.findall(r"^\s*(?:const\s+char\*|int|int64_t)\s+(elg_\w+)\s*\(", open(HDR).read(), re.M))
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
@@ -28,30 +28,31 @@ def test_build_and_exports():
 
 def test_struct_layout_matches_c():
     from elg_amd import _lib
-    fields = ["problem", "seed", "Kmat", "loc", "st_vis", "full_probs"]
-    bfields = ["T", "gprob", "rowA", "rowLoad", "gloc"]
+    pairs = [("elg_rollout_args", _lib.RolloutArgs, ["problem", "seed", "Kmat", "loc", "st_vis", "full_probs", "trMask"]),
+             ("elg_bwd_args", _lib.BwdArgs, ["T", "gprob", "rowA", "rowLoad", "gloc", "row_stride"]),
+             ("elg_enc_layer", _lib.EncLayer, ["Wq", "bc", "W1", "b2"]),
+             ("elg_enc_weights", _lib.EncWeights, ["emb_depot_w", "emb_w", "layer", "dec_Wq_first", "dec_bc"]),
+             ("elg_encoder_args", _lib.EncoderArgs, ["problem", "eps", "xy", "W", "enc", "Q2", "wl", "ws", "ws_floats"]),
+             ("elg_encoder_bwd_args", _lib.EncoderBwdArgs, ["fwd", "g_enc", "gpb", "gwl", "G", "ws2", "ws2_floats"])]
     src = '#include <stdio.h>\n#include <stddef.h>\n#include "elg_hip.h"\nint main(){\n'
-    src += 'printf("%zu %zu\\n", sizeof(elg_rollout_args), sizeof(elg_bwd_args));\n'
-    for f in fields:
-        src += f'printf("%zu\\n", offsetof(elg_rollout_args, {f}));\n'
-    for f in bfields:
-        src += f'printf("%zu\\n", offsetof(elg_bwd_args, {f}));\n'
+    for cname, _, fields in pairs:
+        src += f'printf("%zu\\n", sizeof({cname}));\n'
+        for f in fields:
+            src += f'printf("%zu\\n", offsetof({cname}, {f}));\n'
     src += "return 0;}\n"
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "t.c")
         open(c, "w").write(src)
         exe = os.path.join(d, "t")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
-        out = subprocess.check_output([exe], text=True).split()
-    sizes = [int(x) for x in out]
-    assert sizes[0] == C.sizeof(_lib.RolloutArgs) and sizes[1] == C.sizeof(_lib.BwdArgs)
-    i = 2
-    for f in fields:
-        assert sizes[i] == getattr(_lib.RolloutArgs, f).offset, f
+        out = [int(x) for x in subprocess.check_output([exe], text=True).split()]
+    i = 0
+    for cname, ct, fields in pairs:
+        assert out[i] == C.sizeof(ct), cname
         i += 1
-    for f in bfields:
-        assert sizes[i] == getattr(_lib.BwdArgs, f).offset, f
-        i += 1
+        for f in fields:
+            assert out[i] == getattr(ct, f).offset, (cname, f)
+            i += 1
 
 
 def test_loc_layout_constants():

@@ -1,0 +1,136 @@
+"""elg_encoder_fwd / elg_encoder_bwd (csrc/elg_enc.hip) against the oracle's encoder + set_kv (reference
+CVRP/models.py:199-269,300-308,455-561; TSP/models.py:134-194,231-243): encoded nodes and every decoder table in the
+forward, every parameter gradient in the backward (oracle = torch autograd on the CPU restatement)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+import gpu_common as gc
+from oracle import elg_oracle as orc
+from elg_amd import _lib as L
+from elg_amd import encoder as enc_host
+
+pytestmark = pytest.mark.gpu
+DEV = gc.DEV
+
+
+def _setup(problem, B, N1, seed, dtype=torch.float32):
+    mp = dict(gu.CVRP_MODEL_PARAMS if problem == "cvrp" else gu.TSP_MODEL_PARAMS)
+    cfg = orc.ModelCfg.from_model_params(mp, problem)
+    P = gc.weights(problem, seed, mp)
+    g = torch.Generator().manual_seed(seed)
+    xy = torch.rand(B, N1, 2, generator=g)
+    dem = None
+    if problem == "cvrp":
+        dem = torch.cat([torch.zeros(B, 1), torch.randint(1, 10, (B, N1 - 1), generator=g).float() / 30.0], 1)
+    kind = L.PROBLEM_CVRP if problem == "cvrp" else L.PROBLEM_TSP
+    names = enc_host.parameter_names(kind, cfg.encoder_layer_num)
+    return mp, cfg, P, xy, dem, kind, names
+
+
+def _oracle_tables(P, cfg, xy, dem, kind):
+    enc = orc.encoder_forward(P, cfg, xy, dem)
+    t = gc.fold_decoder_tables(gc.sub(P, "decoder."), enc, kind)
+    return enc, t
+
+
+@pytest.mark.parametrize("problem,B,N1", [("cvrp", 3, 21), ("cvrp", 2, 51), ("cvrp", 4, 101), ("tsp", 2, 100),
+                                          ("tsp", 3, 20), ("cvrp", 2, 128), ("cvrp", 2, 113), ("tsp", 1, 7)])
+def test_encoder_forward_matches_oracle(problem, B, N1):
+    mp, cfg, P, xy, dem, kind, names = _setup(problem, B, N1, 3)
+    enc_ref, t_ref = _oracle_tables(P, cfg, xy, dem, kind)
+    params = [P[n].to(DEV).contiguous() for n in names]
+    with torch.no_grad():
+        enc, t = enc_host.encode_and_fold(kind, xy.to(DEV), None if dem is None else dem.to(DEV), params,
+                                          cfg.encoder_layer_num, mp["ff_hidden_dim"])
+    worst = {}
+
+    def chk(name, got, ref, tol):
+        got, ref = got.cpu().numpy(), ref.numpy()
+        scale = np.abs(ref).max()
+        err = np.abs(got - ref).max() / scale
+        worst[name] = err
+        assert err < tol, (name, err)
+    chk("enc", enc, enc_ref, 2e-5)
+    for k in ("K", "V", "PK", "pb", "Q1"):
+        chk(k, t[k], t_ref[k], 3e-5)
+    if problem == "tsp":
+        chk("Q2", t["Q2"], t_ref["Q2"], 3e-5)
+    else:
+        assert torch.equal(t["wl"].cpu(), P["decoder.Wq_last.weight"][:, 128])
+    print("worst relative-to-max errors:", {k: f"{v:.2e}" for k, v in worst.items()})
+
+
+@pytest.mark.parametrize("problem,B,N1", [("cvrp", 2, 200), ("tsp", 2, 300), ("cvrp", 1, 1001)])
+def test_encoder_forward_large_instances(problem, B, N1):
+    """N1 > 128: row blocks of 128, stand-alone instance-norm kernels, attention over key chunks (online softmax)."""
+    mp, cfg, P, xy, dem, kind, names = _setup(problem, B, N1, 5)
+    enc_ref, t_ref = _oracle_tables(P, cfg, xy, dem, kind)
+    params = [P[n].to(DEV).contiguous() for n in names]
+    with torch.no_grad():
+        enc, t = enc_host.encode_and_fold(kind, xy.to(DEV), None if dem is None else dem.to(DEV), params,
+                                          cfg.encoder_layer_num, mp["ff_hidden_dim"])
+    for name, got, ref in [("enc", enc, enc_ref), ("K", t["K"], t_ref["K"]), ("PK", t["PK"], t_ref["PK"]),
+                           ("pb", t["pb"], t_ref["pb"]), ("Q1", t["Q1"], t_ref["Q1"])]:
+        err = (got.cpu() - ref).abs().max() / ref.abs().max()
+        assert err < 5e-5, (name, float(err))
+
+
+@pytest.mark.parametrize("problem,B,N1", [("cvrp", 2, 21), ("cvrp", 2, 51), ("cvrp", 3, 101), ("tsp", 2, 100),
+                                          ("tsp", 2, 128)])
+def test_encoder_backward_matches_oracle_autograd(problem, B, N1):
+    mp, cfg, P, xy, dem, kind, names = _setup(problem, B, N1, 7)
+    g = torch.Generator().manual_seed(11)
+    keys = ["enc", "K", "V", "PK", "pb", "Q1"] + (["Q2"] if problem == "tsp" else ["wl"])
+    shapes = {"enc": (B, N1, 128), "K": (B, N1, 128), "V": (B, N1, 128), "PK": (B, N1, 128), "pb": (B, N1),
+              "Q1": (B, N1, 128), "Q2": (B, N1, 128), "wl": (128,)}
+    cot = {k: torch.randn(*shapes[k], generator=g) for k in keys}
+    # oracle autograd in double precision (the reference values) and in single precision (what fp32 rounding alone
+    # costs: the yardstick for tensors whose exact gradient is ~0, e.g. the biases in front of an instance norm)
+    def oracle_grads(dt):
+        Pd = {k: v.detach().clone().to(dt).requires_grad_(True) for k, v in P.items()}
+        e, t = _oracle_tables(Pd, cfg, xy.to(dt), None if dem is None else dem.to(dt), kind)
+        t = dict(t, enc=e)
+        loss = sum((t[k] * cot[k].to(dt)).sum() for k in keys)
+        loss.backward()
+        return float(loss.detach()), {n: Pd[n].grad.double().numpy() for n in names}
+    loss64, g64 = oracle_grads(torch.float64)
+    _, g32 = oracle_grads(torch.float32)
+    params = [P[n].detach().clone().to(DEV).contiguous().requires_grad_(True) for n in names]
+    enc, t = enc_host.encode_and_fold(kind, xy.to(DEV), None if dem is None else dem.to(DEV), params,
+                                      cfg.encoder_layer_num, mp["ff_hidden_dim"])
+    t = dict(t, enc=enc)
+    loss_g = sum((t[k] * cot[k].to(DEV)).sum() for k in keys)
+    loss_g.backward()
+    assert abs(float(loss_g.detach()) - loss64) <= 1e-4 * abs(loss64) + 1e-3
+    worst = {}
+    for n, p in zip(names, params):
+        ref = g64[n]
+        got = p.grad.cpu().double().numpy()
+        scale = np.abs(ref).max()
+        err = np.abs(got - ref).max()
+        err32 = np.abs(g32[n] - ref).max()
+        worst[n] = err / max(scale, 1e-30)
+        assert err <= max(1e-4 * scale, 4.0 * err32), (n, err, err32, scale)
+    top = sorted(((k, v) for k, v in worst.items() if v < 1.0), key=lambda kv: -kv[1])[:3]
+    print("largest gradient errors (relative to the tensor's max):", [(k, f"{v:.2e}") for k, v in top])
+
+
+def test_set_kv_on_given_encodings():
+    from elg_amd.CVRP.CVRPModel import CVRPModel
+    mp = dict(gu.CVRP_MODEL_PARAMS)
+    model = CVRPModel(**mp)
+    model.decoder.add_local_policy(DEV)
+    model.to(DEV).eval()
+    enc = torch.randn(2, 33, 128, device=DEV)
+    with torch.no_grad():
+        model.decoder.set_kv(enc)
+    t = model.decoder.policy.tables
+    sd = {k: v.detach() for k, v in model.decoder.named_parameters()}
+    ref = gc.fold_decoder_tables(sd, enc, L.PROBLEM_CVRP)
+    for k in ("K", "V", "PK", "pb", "Q1"):
+        assert float((t[k] - ref[k]).abs().max() / ref[k].abs().max()) < 3e-5, k
+    assert math.isclose(float(t["wl"].sum()), float(ref["wl"].sum()), rel_tol=1e-6)

@@ -11,6 +11,7 @@ import golden_util as gu
 from oracle import elg_oracle as orc
 from elg_amd import _lib as L
 from elg_amd import engine as eng
+import gpu_common as gc
 
 
 def _weights(problem, seed, mp):
@@ -66,7 +67,7 @@ def test_fold_decoder_tables_matches_decoder_math():
     cfg = orc.ModelCfg.from_model_params(mp, "cvrp")
     torch.manual_seed(2)
     enc = torch.randn(2, 11, 128)
-    t = eng.fold_decoder_tables(_sub(P, "decoder."), enc, L.PROBLEM_CVRP)
+    t = gc.fold_decoder_tables(_sub(P, "decoder."), enc, L.PROBLEM_CVRP)
     kh, vh = orc.set_kv(P, cfg, enc)
     np.testing.assert_allclose(t["K"].view(2, 11, 8, 16).transpose(1, 2).numpy(), kh.numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(t["V"].view(2, 11, 8, 16).transpose(1, 2).numpy(), vh.numpy(), rtol=1e-5, atol=1e-6)
