@@ -124,7 +124,7 @@ def main():
     def one_step():
         batch = generate_vrp_data(LOCAL_BATCH, N_NODES, dist_cfg)
         model.train()
-        return train_step(model, env, opt, batch, cfg["params"]["scale_norm"], bucket, world, check=False)
+        return train_step(model, env, opt, batch, cfg["params"]["scale_norm"], bucket, world, check=True)
 
     for _ in range(args.warmup):
         one_step()

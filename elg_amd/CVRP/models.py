@@ -43,7 +43,7 @@ class local_policy_att(nn.Module):
 
     def folded_tables(self, n_slots: int) -> torch.Tensor:
         lp = {k: v for k, v in self.named_parameters()}
-        return eng.fold_local_tables(lp, self.init_emb.in_features, n_slots)
+        return eng.fold_local_tables(lp, self.init_emb.in_features, n_slots, bool(self.model_params.get('positional', True)))
 
 
 class AddAndInstanceNormalization(nn.Module):

@@ -28,7 +28,7 @@ def rollout(model, env, eval_type='greedy'):
     needs_grad = (eval_type != 'greedy' and torch.is_grad_enabled()
                   and any(p.requires_grad for p in model.parameters()))
     res = eng.rollout_forward(env.problem, pol, M, starts, mode, seed=seed, train=needs_grad)
-    T = int(res.tlen.max().item())                  # the one host sync of the rollout
+    T, zero_prob = eng.rollout_stats(res)           # the one host sync of the rollout
     actions = res.actions[:, :, :T].long()
     env.selected_count = T
     env.selected_node_list = actions
@@ -37,9 +37,10 @@ def rollout(model, env, eval_type='greedy'):
     if eval_type == 'greedy':
         return actions, None, reward
     probs = eng.chosen_probs(env.problem, pol, M, res, T) if needs_grad else res.probs[:, :T, :]
-    # reference CVRPModel.py:67-68: a step in which some chosen probability is exactly 0 gets +1e-6
-    zero_step = (probs.detach() == 0).flatten(2).any(dim=2).any(dim=0)
-    probs = probs + 1e-6 * zero_step[None, :, None].to(probs.dtype)
+    if zero_prob:
+        # reference CVRPModel.py:67-68: a step in which some chosen probability is exactly 0 gets +1e-6
+        zero_step = (probs.detach() == 0).flatten(2).any(dim=2).any(dim=0)
+        probs = probs + 1e-6 * zero_step[None, :, None].to(probs.dtype)
     return actions, probs, reward
 
 
@@ -49,20 +50,14 @@ def augment_xy_data_by_8_fold(problems):
 
 
 def check_feasible(pi, demand):
-    """reference utils.py:90-119: every customer exactly once, capacity never exceeded.
-    pi (1, multi, T) node ids, demand (1, problem)."""
+    """reference utils.py:90-119: every customer exactly once, capacity never exceeded (the reference's sequential
+    fp32 scan).  pi (1, multi, T) node ids, demand (1, problem).  One HIP launch (elg_check_feasible)."""
     pi = pi.squeeze(0)
-    multi, n = pi.shape[0], demand.shape[1]
-    srt = pi.sort(1)[0]
-    ok = (srt[:, -n:] == torch.arange(1, n + 1, device=pi.device)[None]).all() and (srt[:, :-n] == 0).all()
-    assert ok, "Invalid tour"
-    d = torch.cat((torch.full((1, 1), -1.0, device=demand.device), demand), 1).expand(multi, n + 1).gather(1, pi)
-    # the reference's scan `used = max(0, used + d_i)` (depot demand -1 = reset) in closed form: a running sum
-    # reflected at zero equals the running sum minus its running minimum (clamped at 0) -- three kernels instead of
-    # two per tour position (~240 launches between the rollout and its backward)
-    S = d.cumsum(dim=1)
-    used = S - torch.cummin(S, dim=1).values.clamp(max=0.0)
-    assert (used.max(dim=1).values <= 1 + 1e-4).all(), "Used more than capacity"
+    if pi.stride(1) != 1:
+        pi = pi.contiguous()
+    bad, over = eng.feasibility_flags(pi.long(), demand.reshape(-1))
+    assert not bad, "Invalid tour"
+    assert not over, "Used more than capacity"
 
 
 def seed_everything(seed=2022):

@@ -39,10 +39,12 @@ def augment_xy_data_by_8_fold(problems):
 
 
 def check_feasible(pi):
-    """reference TSP/utils.py:72-78: every node exactly once.  pi (1, multi, problem)."""
+    """reference TSP/utils.py:72-78: every node exactly once.  pi (1, multi, problem).  One HIP launch."""
     pi = pi.squeeze(0)
-    n = pi.shape[1]
-    return bool((pi.sort(1)[0] == torch.arange(n, device=pi.device)[None]).all())
+    if pi.stride(1) != 1:
+        pi = pi.contiguous()
+    bad, _ = eng.feasibility_flags(pi.long(), None)
+    return not bad
 
 
 class Logger(object):

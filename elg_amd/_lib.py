@@ -62,6 +62,10 @@ class EncWeights(C.Structure):
                 ("dec_bc", _vp)]
 
 
+class LocalWeights(C.Structure):
+    _fields_ = [(n, _vp) for n in ("init_emb_w", "init_emb_b", "cur_token_emb", "Wq", "Wk", "Wv", "combine_w", "combine_b")]
+
+
 class EncoderArgs(C.Structure):
     _fields_ = [("problem", C.c_int32), ("B", C.c_int32), ("N1", C.c_int32), ("n_layers", C.c_int32),
                 ("ff_hidden", C.c_int32), ("save", C.c_int32), ("eps", C.c_float), ("pad0", C.c_int32),
@@ -79,7 +83,8 @@ EXPORTS = ["elg_version", "elg_last_error", "elg_aug8", "elg_dist_matrix", "elg_
            "elg_rollout_fwd", "elg_rollout_bwd", "elg_glimpse_rows_bwd", "elg_glimpse_bwd_fused", "elg_gemm_f32",
            "elg_pomo_loss", "elg_rows_prep", "elg_adam_step", "elg_local_bwd_rows",
            "elg_add_instnorm_fwd", "elg_add_instnorm_bwd", "elg_rows_segsum",
-           "elg_encoder_ws_floats", "elg_encoder_fwd", "elg_encoder_bwd_ws_floats", "elg_encoder_bwd"]
+           "elg_encoder_ws_floats", "elg_encoder_fwd", "elg_encoder_bwd_ws_floats", "elg_encoder_bwd",
+           "elg_local_fold_fwd", "elg_local_fold_bwd", "elg_check_feasible", "elg_rollout_stats"]
 
 _lib = None
 
@@ -124,6 +129,14 @@ def lib() -> C.CDLL:
         L.elg_encoder_bwd_ws_floats.restype = i64
         L.elg_encoder_fwd.argtypes = [C.POINTER(EncoderArgs), f]
         L.elg_encoder_bwd.argtypes = [C.POINTER(EncoderBwdArgs), f]
+        L.elg_local_fold_fwd.argtypes = [C.POINTER(LocalWeights), i, i, i, f, f]
+        L.elg_local_fold_bwd.argtypes = [C.POINTER(LocalWeights), i, i, i, f, C.POINTER(LocalWeights), f]
+        L.elg_check_feasible.argtypes = [f, i64, f, i, i, i, f, f]
+        L.elg_rollout_stats.argtypes = [f, f, i, i, i, f, f]
+        L.elg_check_feasible.restype = C.c_int
+        L.elg_rollout_stats.restype = C.c_int
+        L.elg_local_fold_fwd.restype = C.c_int
+        L.elg_local_fold_bwd.restype = C.c_int
         L.elg_encoder_fwd.restype = C.c_int
         L.elg_encoder_bwd.restype = C.c_int
         for n in ("elg_aug8", "elg_dist_matrix", "elg_nbr_tables", "elg_route_length", "elg_rollout_fwd",

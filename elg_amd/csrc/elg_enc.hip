@@ -44,6 +44,7 @@ struct EncGemm {
     int epi; float alpha;
     const float* gamma; const float* beta; float* xhat; float* rstd; float eps;   // EPI_NORM
     const float* rv; const float* cv; float alpha2;                               // EPI_ADD: + alpha2 rv[row] cv[n]
+    int dbg;
 };
 
 // wave-uniform pick from a kernel-argument pointer table (a select chain: a dynamic index would move the whole
@@ -62,61 +63,111 @@ __device__ __forceinline__ T* pick6(T* const (&p)[6], int i) {
 // ------------------------------------------------------------------------------------------------------------------
 // C[row][n] = epilogue( alpha * sum_k A[row][k] W(n, k) )
 // grid (N / (16 NWC), row blocks), 256 threads = NWC column tiles x KS k-splits.
+// The row block's activations go through LDS in slabs of 128 k (coalesced 16-byte global loads, pitch 136 floats: the
+// fragment reads ds_read_b128 [row lo][k 4 hi ..] are bank-conflict free), shared by the workgroup's column tiles; the
+// next slab and its weight fragments are fetched while the current one is multiplied.  Feeding the MFMAs straight from
+// global memory (first version) was bound by the vector-memory path: every column tile re-read the whole row block.
+constexpr int ENC_KS = 128;         // k per slab
+constexpr int ENC_AP = 136;         // LDS pitch of a slab row (floats)
+
 template <int RT, int KS>
 __global__ __launch_bounds__(256) void enc_gemm_kernel(const EncGemm g) {
     constexpr int NWC = 4 / KS;
-    __shared__ float red[(KS > 1) ? (KS - 1) * NWC * RT * 4 * 64 : 64];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int ROWS = RT * 16;
+    constexpr int NST = ROWS * 32 / 256;          // 16-byte staging loads per thread and slab
+    constexpr int NCH = ENC_KS / 16 / KS;         // 16-k chunks of a slab per wave
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lo = lane & 15, hi = lane >> 4;
     const int wc = wave % NWC, ks = wave / NWC;
     const int n0 = (blockIdx.x * NWC + wc) * 16;
     const int row0 = blockIdx.y * g.blk_stride;
     const int nrows = min(g.blk_rows, g.rows_total - row0);
-    const int kspan = g.K / KS, kbeg = ks * kspan, kend = kbeg + kspan;
-
-    const float* ap[RT];
-#pragma unroll
-    for (int t = 0; t < RT; ++t) ap[t] = g.A + (size_t)(row0 + min(16 * t + lo, nrows - 1)) * g.lda + 4 * hi;
+    const int nslab = g.K / ENC_KS;
     const int ncol = n0 + lo;
-    const float* wp = nullptr;
     const int nwb = __builtin_amdgcn_readfirstlane(n0 / g.wblk);        // 16 | wblk: one block per wave
+    const float* wp = nullptr;
     if (g.wmode != W_KN) wp = pick6(g.W, nwb) + (size_t)(ncol - nwb * g.wblk) * g.ldw + 4 * hi;
 
+    // staging addresses: thread -> (row, 16-byte column) of the slab, rows past the block clamped (finite duplicates)
+    const float* sp[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        const int idx = tid + i * 256, row = idx >> 5, c4 = idx & 31;
+        sp[i] = g.A + (size_t)(row0 + min(row, nrows - 1)) * g.lda + 4 * c4;
+    }
+    const int sdst = (tid >> 5) * ENC_AP + 4 * (tid & 31);              // + i * 8 rows
+
+#define ENC_WLOAD(K0, WV)                                                                                         \
+    {                                                                                                             \
+        _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                                                         \
+            const int kk_ = (K0) + 16 * c;                                                                        \
+            if (g.wmode == W_NK) WV[c] = *reinterpret_cast<const float4*>(wp + kk_);                              \
+            else if (g.wmode == W_NK_SCALAR) WV[c] = make_float4(wp[kk_], wp[kk_ + 1], wp[kk_ + 2], wp[kk_ + 3]); \
+            else {                                                                                                \
+                const int kb_ = __builtin_amdgcn_readfirstlane(kk_ / g.wblk), kr_ = kk_ - kb_ * g.wblk + 4 * hi;  \
+                const float* p_ = pick6(g.W, kb_) + (size_t)kr_ * g.ldw + ncol;                                   \
+                WV[c] = make_float4(p_[0], p_[g.ldw], p_[2 * g.ldw], p_[3 * g.ldw]);                              \
+            }                                                                                                     \
+        }                                                                                                         \
+    }
     f32x4 acc[RT];
 #pragma unroll
     for (int t = 0; t < RT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    float4 a[RT], w;
-#define ENC_LOAD(KK, AV, WV)                                                                                  \
-    {                                                                                                         \
-        _Pragma("unroll") for (int t = 0; t < RT; ++t) AV[t] = *reinterpret_cast<const float4*>(ap[t] + (KK)); \
-        if (g.wmode == W_NK) WV = *reinterpret_cast<const float4*>(wp + (KK));                                \
-        else if (g.wmode == W_NK_SCALAR) WV = make_float4(wp[(KK)], wp[(KK) + 1], wp[(KK) + 2], wp[(KK) + 3]); \
-        else {                                                                                                \
-            const int kb_ = __builtin_amdgcn_readfirstlane((KK) / g.wblk), kr_ = (KK) - kb_ * g.wblk + 4 * hi; \
-            const float* p_ = pick6(g.W, kb_) + (size_t)kr_ * g.ldw + ncol;                                   \
-            WV = make_float4(p_[0], p_[g.ldw], p_[2 * g.ldw], p_[3 * g.ldw]);                                 \
-        }                                                                                                     \
+    float4 w[NCH];
+    {
+        float4 st[NST];
+#pragma unroll
+        for (int i = 0; i < NST; ++i) st[i] = (g.dbg & 4) ? make_float4(1.f, 1.f, 1.f, 1.f) : *reinterpret_cast<const float4*>(sp[i]);
+        ENC_WLOAD(ks * (ENC_KS / KS), w)
+#pragma unroll
+        for (int i = 0; i < NST; ++i) *reinterpret_cast<float4*>(lds + sdst + i * 8 * ENC_AP) = st[i];
     }
-    ENC_LOAD(kbeg, a, w)
-    for (int k = kbeg; k < kend; k += 16) {
-        float4 an[RT], wn;
-        const int kn = min(k + 16, kend - 16);
-        ENC_LOAD(kn, an, wn)
+    __syncthreads();
+    for (int sl = 0; sl < nslab; ++sl) {
+        const float* sA = lds + (sl & 1) * (ROWS * ENC_AP) + lo * ENC_AP + ks * (ENC_KS / KS) + 4 * hi;
+        const bool more = sl + 1 < nslab;               // uniform
+        // unconditional (the last iteration re-reads its own slab): a conditional prefetch lands in scratch memory
+        float4 st[NST], wn[NCH];
+        const int sn = min(sl + 1, nslab - 1);
 #pragma unroll
-        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].x, w.x, acc[t], 0, 0, 0);
+        for (int i = 0; i < NST; ++i) st[i] = *reinterpret_cast<const float4*>(sp[i] + sn * ENC_KS);
+        ENC_WLOAD(sn * ENC_KS + ks * (ENC_KS / KS), wn)
+        float4 a[RT];
 #pragma unroll
-        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].y, w.y, acc[t], 0, 0, 0);
+        for (int t = 0; t < RT; ++t) a[t] = *reinterpret_cast<const float4*>(sA + t * 16 * ENC_AP);
 #pragma unroll
-        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].z, w.z, acc[t], 0, 0, 0);
+        for (int c = 0; c < ((g.dbg & 2) ? 1 : NCH); ++c) {
+            float4 an[RT];
+            if (c + 1 < NCH) {
 #pragma unroll
-        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].w, w.w, acc[t], 0, 0, 0);
+                for (int t = 0; t < RT; ++t) an[t] = *reinterpret_cast<const float4*>(sA + t * 16 * ENC_AP + 16 * (c + 1));
+            }
 #pragma unroll
-        for (int t = 0; t < RT; ++t) a[t] = an[t];
-        w = wn;
+            for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].x, w[c].x, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].y, w[c].y, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].z, w[c].z, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].w, w[c].w, acc[t], 0, 0, 0);
+            if (c + 1 < NCH) {
+#pragma unroll
+                for (int t = 0; t < RT; ++t) a[t] = an[t];
+            }
+        }
+        if (more) {
+            float* d = lds + ((sl + 1) & 1) * (ROWS * ENC_AP) + sdst;
+#pragma unroll
+            for (int i = 0; i < NST; ++i) *reinterpret_cast<float4*>(d + i * 8 * ENC_AP) = st[i];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) w[c] = wn[c];
+        }
+        __syncthreads();
     }
-#undef ENC_LOAD
+#undef ENC_WLOAD
     if (KS > 1) {
+        float* red = lds;                                 // the slabs are dead: reuse
         if (ks > 0) {
             float* my = red + (size_t)((ks - 1) * NWC + wc) * RT * 4 * 64;
 #pragma unroll
@@ -135,6 +186,7 @@ __global__ __launch_bounds__(256) void enc_gemm_kernel(const EncGemm g) {
                 for (int i = 0; i < 4; ++i) acc[t][i] += o[(t * 4 + i) * 64 + lane];
         }
     }
+    if ((g.dbg & 1) && acc[0][0] != 12345.f) return;
     // D layout: acc[t][i] = C[row 16 t + 4 hi + i][column n0 + lo]
     const int ncb = __builtin_amdgcn_readfirstlane(n0 / g.cblk);
     float* cp = pick6(g.C, ncb) + (ncol - ncb * g.cblk);
@@ -205,32 +257,48 @@ __global__ __launch_bounds__(256) void enc_gemm_kernel(const EncGemm g) {
         }
 }
 
-static int launch_gemm(const EncGemm& g, hipStream_t s) {
+template <int RT, int KS>
+static int launch_gemm_t(const EncGemm& g, dim3 grid, hipStream_t s) {
+    const int nbuf = g.K > ENC_KS ? 2 : 1;
+    const size_t lds = (size_t)nbuf * RT * 16 * ENC_AP * sizeof(float);
+    auto kern = enc_gemm_kernel<RT, KS>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipGetLastError();
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(2 * RT * 16 * ENC_AP * sizeof(float))) != hipSuccess)
+            return fail(ELG_ELAUNCH, "encoder gemm: hipFuncSetAttribute failed");
+        attr_done = true;
+    }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, g);
+    return launch_status("enc_gemm");
+}
+
+static int launch_gemm(const EncGemm& g_in, hipStream_t s) {
+    EncGemm g = g_in;
+    { const char* e = getenv("ELG_ENC_DBG"); g.dbg = e ? atoi(e) : 0; }
     if ((g.N & 15) || g.N <= 0) return fail(ELG_EINVAL, "encoder gemm: N must be a multiple of 16");
     const int nblk = (g.rows_total + g.blk_stride - 1) / g.blk_stride;
     const int ctiles = g.N / 16;
-    if ((g.wblk % 16) || (g.cblk % 16) || (g.K % 16)) return fail(ELG_EINVAL, "encoder gemm: K and the weight / output blocks must be multiples of 16");
-    // K split over the waves of a workgroup: enough waves for the chip's 1024 SIMDs, at least 64 of K per wave
+    if ((g.wblk % 16) || (g.cblk % 16) || (g.K % ENC_KS)) return fail(ELG_EINVAL, "encoder gemm: K must be a multiple of 128, weight / output blocks of 16");
+    // K split over the waves of a workgroup: enough waves for the chip's 1024 SIMDs
     int ks = 1;
-    if (g.K >= 512 && (g.K % 64) == 0) ks = 4;
-    else if ((long)ctiles * nblk < 1024 && (g.K % 32) == 0 && g.K >= 128) ks = 2;
+    if ((long)ctiles * nblk < 1024) ks = 2;
     while (ks < 4 && (ctiles % (4 / ks))) ks *= 2;
-    if (g.K % (16 * ks)) return fail(ELG_EINVAL, "encoder gemm: unsupported N / K combination");
-    dim3 grid(ctiles / (4 / ks), nblk), block(256);
-    (void)hipGetLastError();
-#define ENC_GO(RT)                                                                              \
-    {                                                                                           \
-        if (ks == 1) hipLaunchKernelGGL((enc_gemm_kernel<RT, 1>), grid, block, 0, s, g);        \
-        else if (ks == 2) hipLaunchKernelGGL((enc_gemm_kernel<RT, 2>), grid, block, 0, s, g);   \
-        else hipLaunchKernelGGL((enc_gemm_kernel<RT, 4>), grid, block, 0, s, g);                \
+    dim3 grid(ctiles / (4 / ks), nblk);
+#define ENC_GO(RT)                                                \
+    {                                                             \
+        if (ks == 1) return launch_gemm_t<RT, 1>(g, grid, s);     \
+        if (ks == 2) return launch_gemm_t<RT, 2>(g, grid, s);     \
+        return launch_gemm_t<RT, 4>(g, grid, s);                  \
     }
     if (g.blk_rows <= 32) ENC_GO(2)
-    else if (g.blk_rows <= 64) ENC_GO(4)
-    else if (g.blk_rows <= 112) ENC_GO(7)
-    else if (g.blk_rows <= 128) ENC_GO(8)
-    else return fail(ELG_EINVAL, "encoder gemm: row block > 128");
+    if (g.blk_rows <= 64) ENC_GO(4)
+    if (g.blk_rows <= 112) ENC_GO(7)
+    if (g.blk_rows <= 128) ENC_GO(8)
 #undef ENC_GO
-    return launch_status("enc_gemm");
+    return fail(ELG_EINVAL, "encoder gemm: row block > 128");
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -540,7 +608,7 @@ static int check_enc_args(const elg_encoder_args* a) {
         if (!a->enc || !a->K) return fail(ELG_EINVAL, "encoder: n_layers = 0 needs enc (input) and the table buffers");
         return ELG_OK;
     }
-    if (a->ff_hidden <= 0 || (a->ff_hidden % 64)) return fail(ELG_EINVAL, "encoder: ff_hidden must be a multiple of 64");
+    if (a->ff_hidden <= 0 || (a->ff_hidden % 128)) return fail(ELG_EINVAL, "encoder: ff_hidden must be a multiple of 128");
     if ((long)a->B * a->N1 > 0x7fffffffL / (4 * ELG_E)) return fail(ELG_EINVAL, "encoder: batch * nodes too large");
     if (!a->xy || !a->enc || !a->ws) return fail(ELG_EINVAL, "encoder: null buffer");
     if (a->problem == ELG_PROBLEM_CVRP && (!a->demand || !a->W.emb_depot_w || !a->W.emb_depot_b))

@@ -202,9 +202,90 @@ __global__ __launch_bounds__(256) void rows_segsum_kernel(const float* __restric
         }
 }
 
+
+// utils.check_feasible (reference CVRP/utils.py:90-119, TSP/utils.py:72-78) for the M tours of one instance: one
+// workgroup per tour.  flags[0] |= 1: some customer not visited exactly once (or an entry outside 0..N);
+// flags[1] |= 1: the reference's sequential scan `used += d; used[used < 0] = 0; used <= 1 + 1e-4` failed (same fp32
+// additions in the same order; a depot visit adds -1).  demand == NULL: TSP (every node 0..N-1 exactly once, no depot).
+__global__ __launch_bounds__(256) void check_feasible_kernel(const long long* __restrict__ pi, long long m_stride,
+                                                             const float* __restrict__ demand, int T, int N, int* flags) {
+    extern __shared__ int sm[];
+    const bool tsp = demand == nullptr;
+    const int nn = tsp ? N : N + 1;                     // node ids
+    int* cnt = sm;
+    float* dseq = reinterpret_cast<float*>(sm + nn);
+    const long long* row = pi + (long long)blockIdx.x * m_stride;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nn; i += 256) cnt[i] = 0;
+    __syncthreads();
+    bool bad = false;
+    for (int t = tid; t < T; t += 256) {
+        const long long v = row[t];
+        if (v < 0 || v >= nn) { bad = true; if (!tsp) dseq[t] = 0.f; continue; }
+        atomicAdd(cnt + (int)v, 1);
+        if (!tsp) dseq[t] = v == 0 ? -1.0f : demand[v - 1];
+    }
+    __syncthreads();
+    for (int i = tid + (tsp ? 0 : 1); i < nn; i += 256) bad |= cnt[i] != 1;
+    if (bad) atomicOr(flags, 1);
+    if (!tsp && tid == 0) {
+        float used = 0.f;
+        bool over = false;
+        for (int t = 0; t < T; ++t) {
+            used = __fadd_rn(used, dseq[t]);
+            if (used < 0.f) used = 0.f;
+            over |= !(used <= 1.0001f);
+        }
+        if (over) atomicOr(flags + 1, 1);
+    }
+}
+
+// stats[0] = max tlen, stats[1] = 1 if some chosen probability of a decoded step is exactly 0 (CVRPModel.py:67-68)
+__global__ __launch_bounds__(256) void rollout_stats_kernel(const int* __restrict__ tlen, const float* __restrict__ probs,
+                                                            long long n_traj, int M, int Tcap, int* stats) {
+    __shared__ int smax[4], szero[4];
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    int tl = 0, z = 0;
+    if (i < n_traj) {
+        tl = tlen[i];
+        const long long b = i / M, m = i % M;
+        const float* p = probs + b * (long long)Tcap * M + m;
+        for (int t = 0; t < tl; ++t) z |= p[(long long)t * M] == 0.f;
+    }
+    tl = (int)wave_max((float)tl);
+    z = __any(z);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { smax[w] = tl; szero[w] = z; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMax(stats, max(max(smax[0], smax[1]), max(smax[2], smax[3])));
+        if (szero[0] | szero[1] | szero[2] | szero[3]) atomicOr(stats + 1, 1);
+    }
+}
+
 }  // namespace elg
 
 using namespace elg;
+
+extern "C" int elg_check_feasible(const int64_t* pi, int64_t m_stride, const float* demand, int M, int T, int N, int32_t* flags,
+                                  void* stream) {
+    if (!pi || !flags || M <= 0 || T <= 0 || N <= 0) return fail(ELG_EINVAL, "check_feasible: bad arguments");
+    const size_t lds = (size_t)(N + 1 + T) * 4;
+    if (lds > 64 * 1024) return fail(ELG_ENOTIMPL, "check_feasible: tour too long for the on-chip counters");
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(check_feasible_kernel, dim3(M), dim3(256), lds, (hipStream_t)stream,
+                       reinterpret_cast<const long long*>(pi), (long long)m_stride, demand, T, N, flags);
+    return launch_status("check_feasible");
+}
+
+extern "C" int elg_rollout_stats(const int32_t* tlen, const float* probs, int B, int M, int Tcap, int32_t* stats, void* stream) {
+    if (!tlen || !probs || !stats || B <= 0 || M <= 0 || Tcap <= 0) return fail(ELG_EINVAL, "rollout_stats: bad arguments");
+    const long long n = (long long)B * M;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(rollout_stats_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tlen, probs, n,
+                       M, Tcap, stats);
+    return launch_status("rollout_stats");
+}
 
 extern "C" int elg_pomo_loss(const float* probs, const float* reward, int B, int T, int M, int64_t probs_bstride,
                              int64_t probs_tstride, float* J_raw, float* J_scaled, float* adv_max, float* coef_raw,

@@ -25,8 +25,8 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def _stream() -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(dev=None) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
 _SIDE = {}
@@ -122,6 +122,22 @@ def route_length(xy: torch.Tensor, tour: torch.Tensor, rounding: bool = False) -
     return out
 
 
+def feasibility_flags(pi: torch.Tensor, demand: Optional[torch.Tensor]) -> tuple:
+    """(invalid_tour, over_capacity) of the tours `pi` (multi, T) int64 of ONE instance (elg_check_feasible: the
+    reference's utils.check_feasible as one launch; demand (problem,) of the customers, None for TSP).  One host sync."""
+    _need_cuda(pi, "pi")
+    assert pi.dim() == 2 and pi.dtype == torch.int64 and pi.stride(1) == 1
+    n = int(demand.numel()) if demand is not None else int(pi.shape[1])
+    if demand is not None:
+        demand = demand.contiguous().float()
+    flags = torch.zeros(2, dtype=torch.int32, device=pi.device)
+    with torch.cuda.device(pi.device):
+        L.check(L.lib().elg_check_feasible(_ptr(pi), pi.stride(0), _ptr(demand), pi.shape[0], pi.shape[1], n, _ptr(flags),
+                                           _stream(pi.device)), "elg_check_feasible")
+    bad, over = flags.tolist()
+    return bool(bad), bool(over)
+
+
 # ----------------------------------------------------------------------------------------------
 # fp32 MFMA GEMM (encoder layers)
 # ----------------------------------------------------------------------------------------------
@@ -145,56 +161,52 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, bias
 # ----------------------------------------------------------------------------------------------
 # weight folding (differentiable torch: autograd carries the kernel's table gradients back)
 # ----------------------------------------------------------------------------------------------
-def position_encoding(Lslots: int, emb: int, device) -> torch.Tensor:
-    """Sinusoid table of the local policy, sin block then cos block (reference models.py:28-49)."""
-    nts = emb // 2
-    inc = math.log(10000.0) / max(nts - 1, 1)
-    inv = torch.exp(torch.arange(nts, dtype=torch.float32, device=device) * -inc)
-    pos = torch.arange(Lslots, dtype=torch.float32, device=device)
-    st = pos[:, None] * inv[None, :]
-    return torch.cat([torch.sin(st), torch.cos(st)], dim=1)
+class _FoldLocal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, nfeat, n_slots, positional, We, be, c, Wq, Wk, Wv, Wc, bc):
+        params = (We, be, c, Wq, Wk, Wv, Wc, bc)
+        w = L.LocalWeights(*[C.c_void_p(p.data_ptr()) for p in params])
+        loc = torch.empty(L.LOC_SIZE, device=We.device)
+        with torch.cuda.device(We.device):
+            L.check(L.lib().elg_local_fold_fwd(C.byref(w), nfeat, n_slots, int(positional), _ptr(loc), _stream(We.device)),
+                    "elg_local_fold_fwd")
+        ctx.save_for_backward(*params)
+        ctx.meta = (nfeat, n_slots, int(positional))
+        return loc
+
+    @staticmethod
+    def backward(ctx, gloc):
+        params = ctx.saved_tensors
+        nfeat, n_slots, positional = ctx.meta
+        dev = params[0].device
+        w = L.LocalWeights(*[C.c_void_p(p.data_ptr()) for p in params])
+        sizes = [p.numel() for p in params]
+        flat = torch.empty(sum(sizes), device=dev)
+        grads, off = [], 0
+        for p, n in zip(params, sizes):
+            grads.append(flat[off:off + n].view_as(p))
+            off += n
+        g = L.LocalWeights(*[C.c_void_p(t.data_ptr()) for t in grads])
+        gloc = gloc.contiguous().float()
+        with torch.cuda.device(dev):
+            L.check(L.lib().elg_local_fold_bwd(C.byref(w), nfeat, n_slots, positional, _ptr(gloc), C.byref(g), _stream(dev)),
+                    "elg_local_fold_bwd")
+        return (None, None, None, *grads)
 
 
-def fold_local_tables(lp: Dict[str, torch.Tensor], nfeat: int, n_slots: int) -> torch.Tensor:
-    """Fold local_policy_att's projections into slot tables (layout: include/elg_hip.h ELG_LOC_*).
-
-    reference models.py:133-166:  e_j = We f_j + be + PE[j];  q = Wq c;  k_j = Wk e_j;  v_j = Wv e_j;
-    u_j = (Wc softmax(q k / sqrt 8) v + bc) . e_j / sqrt 32.  Everything that does not depend on the
-    features f_j is precomputed per slot j here."""
-    We, be = lp["init_emb.weight"], lp["init_emb.bias"]
-    dev = We.device
-    pe = position_encoding(n_slots, LE, dev)
-    base = be[None, :] + pe                                        # (L,32)  be + PE[j]
-    q = (lp["Wq.weight"] @ lp["cur_token_emb"]).view(LH, LDK)
-    WkWe = (lp["Wk.weight"] @ We).view(LH, LDK, nfeat)
-    la = torch.einsum("hd,hdf->hf", q, WkWe) / math.sqrt(LDK)      # (4,F)
-    kb = (base @ lp["Wk.weight"].T).view(n_slots, LH, LDK)
-    lt = torch.einsum("hd,jhd->jh", q, kb) / math.sqrt(LDK)        # (L,4)
-    lAv = lp["Wv.weight"] @ We                                     # (32,F)
-    lcv = base @ lp["Wv.weight"].T                                 # (L,32)
-    lWc = lp["multi_head_combine.weight"]
-    lbc = lp["multi_head_combine.bias"]
-    lWe = We / math.sqrt(LE)
-    lpe = base / math.sqrt(LE)
-
-    def pad_cols(x, cols):
-        return torch.nn.functional.pad(x, (0, cols - x.shape[1]))
-
-    def pad_rows(x, rows):
-        return torch.nn.functional.pad(x, (0, 0, 0, rows - x.shape[0]))
-    pieces = [
-        torch.nn.functional.pad(pad_cols(la, 3).reshape(-1), (0, 4)),          # LA   16
-        pad_rows(lt, L.LOC_ROWS).reshape(-1),                                   # LT   256
-        pad_cols(lAv, 3).reshape(-1),                                           # LAV  96
-        pad_rows(lcv, L.LOC_ROWS).reshape(-1),                                  # LCV  2048
-        lWc.reshape(-1),                                                        # LWC  1024
-        lbc.reshape(-1),                                                        # LBC  32
-        pad_cols(lWe, 3).reshape(-1),                                           # LWE  96
-        pad_rows(lpe, L.LOC_ROWS).reshape(-1),                                  # LPE  2048
-    ]
-    out = torch.cat(pieces).contiguous()
-    assert out.numel() == L.LOC_SIZE
-    return out
+def fold_local_tables(lp: Dict[str, torch.Tensor], nfeat: int, n_slots: int, positional: bool = True) -> torch.Tensor:
+    """Fold local_policy_att's projections into slot tables (layout: include/elg_hip.h ELG_LOC_*), one HIP launch each
+    way (csrc/elg_fold.hip).  reference models.py:133-166: e_j = We f_j + be + PE[j]; q = Wq c; k_j = Wk e_j; v_j = Wv e_j;
+    u_j = (Wc softmax(q k / sqrt 8) v + bc) . e_j / sqrt 32 -- everything that does not depend on the features f_j is
+    precomputed per slot j.  `positional` = model_params['positional'] (models.py:142-143)."""
+    names = ("init_emb.weight", "init_emb.bias", "cur_token_emb", "Wq.weight", "Wk.weight", "Wv.weight",
+             "multi_head_combine.weight", "multi_head_combine.bias")
+    params = [lp[n] for n in names]
+    _need_cuda(params[0], "local policy parameters")
+    for p in params:
+        if p.dtype != torch.float32 or not p.is_contiguous():
+            raise ValueError("local policy parameters must be contiguous fp32 tensors")
+    return _FoldLocal.apply(nfeat, n_slots, bool(positional), *params)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -307,6 +319,18 @@ class TrainRows:
 
     def prepare(self):
         self.gen += 1
+
+
+def rollout_stats(res: "RolloutResult") -> tuple:
+    """(T, zero_prob): longest trajectory and whether some chosen probability is exactly 0 -- one tiny launch and THE
+    host sync of a rollout (elg_rollout_stats)."""
+    B, M = res.tlen.shape
+    stats = torch.zeros(2, dtype=torch.int32, device=res.tlen.device)
+    with torch.cuda.device(res.tlen.device):
+        L.check(L.lib().elg_rollout_stats(_ptr(res.tlen), _ptr(res.probs), B, M, res.probs.shape[1], _ptr(stats),
+                                          _stream(res.tlen.device)), "elg_rollout_stats")
+    T, z = stats.tolist()
+    return int(T), bool(z)
 
 
 @dataclass

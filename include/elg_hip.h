@@ -322,6 +322,30 @@ typedef struct elg_encoder_bwd_args {
 int64_t elg_encoder_bwd_ws_floats(int B, int N1, int ff_hidden);
 int elg_encoder_bwd(const elg_encoder_bwd_args* args, void* stream);
 
+/* ---- local policy: parameters -> slot tables (ELG_LOC_* above).  local_policy_att's parameters (CVRP/models.py:8-36,
+ * TSP/models.py:12-33; state_dict decoder.local_policies.0.* / decoder.local_policy_0.*): init_emb (32,nfeat) + (32),
+ * cur_token_emb (32), Wq / Wk / Wv (32,32), multi_head_combine (32,32) + (32).  nfeat = 3 (CVRP) or 2 (TSP); n_slots =
+ * local_size (+1 for the CVRP depot slot); positional = model_params['positional'] (sinusoid table added to the
+ * slot embedding, models.py:142-143).  The backward WRITES the eight gradients (grads: same struct, float*). */
+typedef struct elg_local_weights {
+    const float *init_emb_w, *init_emb_b, *cur_token_emb, *Wq, *Wk, *Wv, *combine_w, *combine_b;
+} elg_local_weights;
+int elg_local_fold_fwd(const elg_local_weights* w, int nfeat, int n_slots, int positional, float* loc, void* stream);
+int elg_local_fold_bwd(const elg_local_weights* w, int nfeat, int n_slots, int positional, const float* gloc,
+                       const elg_local_weights* grads, void* stream);
+
+/* utils.check_feasible (CVRP/utils.py:90-119; TSP/utils.py:72-78) for the M tours of ONE instance: pi (M rows of T node
+ * ids, int64, row stride m_stride elements), demand (N) of the customers (NULL: TSP, nodes 0..N-1 exactly once).
+ * flags (2 x int32, caller zeroes): flags[0] = 1 "Invalid tour", flags[1] = 1 "Used more than capacity" (the
+ * reference's sequential fp32 scan, threshold 1 + 1e-4). */
+int elg_check_feasible(const int64_t* pi, int64_t m_stride, const float* demand, int M, int T, int N, int32_t* flags,
+                       void* stream);
+
+/* After elg_rollout_fwd: stats[0] = max over tlen (the T of utils.rollout's outputs), stats[1] = 1 if a chosen
+ * probability of a decoded step is exactly 0 (CVRPModel.py:67-68 then adds 1e-6 to that step).  stats: 2 x int32,
+ * caller zeroes.  tlen (B,M), probs (B,Tcap,M). */
+int elg_rollout_stats(const int32_t* tlen, const float* probs, int B, int M, int Tcap, int32_t* stats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

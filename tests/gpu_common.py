@@ -46,6 +46,58 @@ def fold_decoder_tables(dec: Dict[str, torch.Tensor], enc: torch.Tensor, problem
     return t
 
 
+def position_encoding(Lslots: int, emb: int, device) -> torch.Tensor:
+    """Sinusoid table of the local policy, sin block then cos block (reference models.py:28-49)."""
+    nts = emb // 2
+    inc = math.log(10000.0) / max(nts - 1, 1)
+    inv = torch.exp(torch.arange(nts, dtype=torch.float32, device=device) * -inc)
+    pos = torch.arange(Lslots, dtype=torch.float32, device=device)
+    st = pos[:, None] * inv[None, :]
+    return torch.cat([torch.sin(st), torch.cos(st)], dim=1)
+
+
+def fold_local_tables(lp: Dict[str, torch.Tensor], nfeat: int, n_slots: int, pe_scale: float = 1.0) -> torch.Tensor:
+    """Fold local_policy_att's projections into slot tables (layout: include/elg_hip.h ELG_LOC_*).
+
+    reference models.py:133-166:  e_j = We f_j + be + PE[j];  q = Wq c;  k_j = Wk e_j;  v_j = Wv e_j;
+    u_j = (Wc softmax(q k / sqrt 8) v + bc) . e_j / sqrt 32.  Everything that does not depend on the
+    features f_j is precomputed per slot j here."""
+    We, be = lp["init_emb.weight"], lp["init_emb.bias"]
+    dev = We.device
+    pe = position_encoding(n_slots, 32, dev).to(We.dtype) * pe_scale
+    base = be[None, :] + pe                                        # (L,32)  be + PE[j]
+    q = (lp["Wq.weight"] @ lp["cur_token_emb"]).view(4, 8)
+    WkWe = (lp["Wk.weight"] @ We).view(4, 8, nfeat)
+    la = torch.einsum("hd,hdf->hf", q, WkWe) / math.sqrt(8)      # (4,F)
+    kb = (base @ lp["Wk.weight"].T).view(n_slots, 4, 8)
+    lt = torch.einsum("hd,jhd->jh", q, kb) / math.sqrt(8)        # (L,4)
+    lAv = lp["Wv.weight"] @ We                                     # (32,F)
+    lcv = base @ lp["Wv.weight"].T                                 # (L,32)
+    lWc = lp["multi_head_combine.weight"]
+    lbc = lp["multi_head_combine.bias"]
+    lWe = We / math.sqrt(32)
+    lpe = base / math.sqrt(32)
+
+    def pad_cols(x, cols):
+        return torch.nn.functional.pad(x, (0, cols - x.shape[1]))
+
+    def pad_rows(x, rows):
+        return torch.nn.functional.pad(x, (0, 0, 0, rows - x.shape[0]))
+    pieces = [
+        torch.nn.functional.pad(pad_cols(la, 3).reshape(-1), (0, 4)),          # LA   16
+        pad_rows(lt, 64).reshape(-1),                                   # LT   256
+        pad_cols(lAv, 3).reshape(-1),                                           # LAV  96
+        pad_rows(lcv, 64).reshape(-1),                                  # LCV  2048
+        lWc.reshape(-1),                                                        # LWC  1024
+        lbc.reshape(-1),                                                        # LBC  32
+        pad_cols(lWe, 3).reshape(-1),                                           # LWE  96
+        pad_rows(lpe, 64).reshape(-1),                                  # LPE  2048
+    ]
+    out = torch.cat(pieces).contiguous()
+    assert out.numel() == 5616
+    return out
+
+
 def make_policy(P, cfg, enc_gpu, kind, has_local=True):
     """Fold oracle-format weights (CPU dict) into engine tables on the GPU."""
     Pg = {k: v.to(DEV) for k, v in P.items()}
@@ -53,7 +105,7 @@ def make_policy(P, cfg, enc_gpu, kind, has_local=True):
     lp_prefix = "decoder.local_policies.0." if kind == L.PROBLEM_CVRP else "decoder.local_policy_0."
     nfeat = 3 if kind == L.PROBLEM_CVRP else 2
     nslots = cfg.local_size + (1 if kind == L.PROBLEM_CVRP else 0)
-    loc = eng.fold_local_tables(sub(Pg, lp_prefix), nfeat, nslots) if has_local else None
+    loc = fold_local_tables(sub(Pg, lp_prefix), nfeat, nslots) if has_local else None
     return eng.Policy(tables, loc, cfg.local_size, cfg.xi, cfg.logit_clipping, 1.0 / cfg.ensemble_size,
                       has_local and cfg.ensemble, cfg.distance_penalty)
 

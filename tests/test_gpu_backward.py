@@ -73,7 +73,7 @@ def _run(problem, tag, loss_kind, geometry=None, train=False):
     Pg = {k: v.clone().to(gc.DEV).requires_grad_(k.startswith("decoder.")) for k, v in P.items()}
     enc_g = enc0.clone().to(gc.DEV).requires_grad_(True)
     tables = gc.fold_decoder_tables(gc.sub(Pg, "decoder."), enc_g, kind)
-    loc = eng.fold_local_tables(gc.sub(Pg, lp_prefix), nfeat, nslots)
+    loc = gc.fold_local_tables(gc.sub(Pg, lp_prefix), nfeat, nslots)
     pol = eng.Policy(tables, loc, cfg.local_size, cfg.xi, cfg.logit_clipping, 1.0 / cfg.ensemble_size, True, True)
     prob = gc.make_problem(xy, dem, kind)
     starts = acts[0, :, 1] if problem == "cvrp" else acts[0, :, 0]

@@ -134,3 +134,29 @@ def test_set_kv_on_given_encodings():
     for k in ("K", "V", "PK", "pb", "Q1"):
         assert float((t[k] - ref[k]).abs().max() / ref[k].abs().max()) < 3e-5, k
     assert math.isclose(float(t["wl"].sum()), float(ref["wl"].sum()), rel_tol=1e-6)
+
+
+@pytest.mark.parametrize("problem,positional", [("cvrp", True), ("tsp", True), ("cvrp", False)])
+def test_local_fold_kernels_match_torch_restatement(problem, positional):
+    """elg_local_fold_fwd / _bwd (csrc/elg_fold.hip) against the differentiable torch restatement of the fold in
+    tests/gpu_common.py (itself checked against the oracle's unfolded local policy in test_host_logic)."""
+    from elg_amd import engine as eng
+    mp = dict(gu.CVRP_MODEL_PARAMS if problem == "cvrp" else gu.TSP_MODEL_PARAMS)
+    P = gc.weights(problem, 9, mp)
+    pre = "decoder.local_policies.0." if problem == "cvrp" else "decoder.local_policy_0."
+    nfeat = 3 if problem == "cvrp" else 2
+    n_slots = mp["local_size"][0] + (1 if problem == "cvrp" else 0)
+    lp64 = {k: v.double().requires_grad_(True) for k, v in gc.sub(P, pre).items()}
+    ref = gc.fold_local_tables(lp64, nfeat, n_slots)
+    if not positional:
+        # the same fold without the sinusoid (models.py:142-143 adds it only if model_params['positional'])
+        ref = gc.fold_local_tables(lp64, nfeat, n_slots, pe_scale=0.0)
+    cot = torch.randn(ref.shape, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+    (ref * cot).sum().backward()
+    lpg = {k: v.detach().clone().to(DEV).requires_grad_(True) for k, v in gc.sub(P, pre).items()}
+    got = eng.fold_local_tables(lpg, nfeat, n_slots, positional)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-5, atol=2e-6)
+    (got * cot.float().to(DEV)).sum().backward()
+    for k in lp64:
+        r = lp64[k].grad.numpy()
+        np.testing.assert_allclose(lpg[k].grad.cpu().numpy(), r, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(r).max()), err_msg=k)

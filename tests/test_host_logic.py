@@ -49,7 +49,7 @@ def test_fold_local_tables_matches_unfolded_math():
         cfg = orc.ModelCfg.from_model_params(mp, problem)
         pre = "decoder.local_policies.0." if problem == "cvrp" else "decoder.local_policy_0."
         Ls = cfg.local_size + (1 if problem == "cvrp" else 0)
-        loc = eng.fold_local_tables(_sub(P, pre), nf, Ls)
+        loc = gc.fold_local_tables(_sub(P, pre), nf, Ls)
         assert loc.numel() == L.LOC_SIZE
         torch.manual_seed(1)
         feats = torch.rand(1, 1, Ls, nf)
