@@ -125,7 +125,7 @@ def lib() -> C.CDLL:
         L.elg_adam_step.argtypes = [f, f, f, i, f, f, f, i64, fl, fl, fl, fl, fl, i64, fl, f]
         L.elg_encoder_ws_floats.argtypes = [i, i, i, i, i]
         L.elg_encoder_ws_floats.restype = i64
-        L.elg_encoder_bwd_ws_floats.argtypes = [i, i, i]
+        L.elg_encoder_bwd_ws_floats.argtypes = [i, i, i, i]
         L.elg_encoder_bwd_ws_floats.restype = i64
         L.elg_encoder_fwd.argtypes = [C.POINTER(EncoderArgs), f]
         L.elg_encoder_bwd.argtypes = [C.POINTER(EncoderBwdArgs), f]

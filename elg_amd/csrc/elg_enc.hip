@@ -44,7 +44,6 @@ struct EncGemm {
     int epi; float alpha;
     const float* gamma; const float* beta; float* xhat; float* rstd; float eps;   // EPI_NORM
     const float* rv; const float* cv; float alpha2;                               // EPI_ADD: + alpha2 rv[row] cv[n]
-    int dbg;
 };
 
 // wave-uniform pick from a kernel-argument pointer table (a select chain: a dynamic index would move the whole
@@ -70,7 +69,7 @@ __device__ __forceinline__ T* pick6(T* const (&p)[6], int i) {
 constexpr int ENC_KS = 128;         // k per slab
 constexpr int ENC_AP = 136;         // LDS pitch of a slab row (floats)
 
-template <int RT, int KS>
+template <int RT, int KS, int WMODE>
 __global__ __launch_bounds__(256) void enc_gemm_kernel(const EncGemm g) {
     constexpr int NWC = 4 / KS;
     constexpr int ROWS = RT * 16;
@@ -87,7 +86,7 @@ __global__ __launch_bounds__(256) void enc_gemm_kernel(const EncGemm g) {
     const int ncol = n0 + lo;
     const int nwb = __builtin_amdgcn_readfirstlane(n0 / g.wblk);        // 16 | wblk: one block per wave
     const float* wp = nullptr;
-    if (g.wmode != W_KN) wp = pick6(g.W, nwb) + (size_t)(ncol - nwb * g.wblk) * g.ldw + 4 * hi;
+    if (WMODE != W_KN) wp = pick6(g.W, nwb) + (size_t)(ncol - nwb * g.wblk) * g.ldw + 4 * hi;
 
     // staging addresses: thread -> (row, 16-byte column) of the slab, rows past the block clamped (finite duplicates)
     const float* sp[NST];
@@ -102,8 +101,8 @@ __global__ __launch_bounds__(256) void enc_gemm_kernel(const EncGemm g) {
     {                                                                                                             \
         _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                                                         \
             const int kk_ = (K0) + 16 * c;                                                                        \
-            if (g.wmode == W_NK) WV[c] = *reinterpret_cast<const float4*>(wp + kk_);                              \
-            else if (g.wmode == W_NK_SCALAR) WV[c] = make_float4(wp[kk_], wp[kk_ + 1], wp[kk_ + 2], wp[kk_ + 3]); \
+            if (WMODE == W_NK) WV[c] = *reinterpret_cast<const float4*>(wp + kk_);                                \
+            else if (WMODE == W_NK_SCALAR) WV[c] = make_float4(wp[kk_], wp[kk_ + 1], wp[kk_ + 2], wp[kk_ + 3]); \
             else {                                                                                                \
                 const int kb_ = __builtin_amdgcn_readfirstlane(kk_ / g.wblk), kr_ = kk_ - kb_ * g.wblk + 4 * hi;  \
                 const float* p_ = pick6(g.W, kb_) + (size_t)kr_ * g.ldw + ncol;                                   \
@@ -118,7 +117,7 @@ __global__ __launch_bounds__(256) void enc_gemm_kernel(const EncGemm g) {
     {
         float4 st[NST];
 #pragma unroll
-        for (int i = 0; i < NST; ++i) st[i] = (g.dbg & 4) ? make_float4(1.f, 1.f, 1.f, 1.f) : *reinterpret_cast<const float4*>(sp[i]);
+        for (int i = 0; i < NST; ++i) st[i] = *reinterpret_cast<const float4*>(sp[i]);
         ENC_WLOAD(ks * (ENC_KS / KS), w)
 #pragma unroll
         for (int i = 0; i < NST; ++i) *reinterpret_cast<float4*>(lds + sdst + i * 8 * ENC_AP) = st[i];
@@ -137,7 +136,7 @@ __global__ __launch_bounds__(256) void enc_gemm_kernel(const EncGemm g) {
 #pragma unroll
         for (int t = 0; t < RT; ++t) a[t] = *reinterpret_cast<const float4*>(sA + t * 16 * ENC_AP);
 #pragma unroll
-        for (int c = 0; c < ((g.dbg & 2) ? 1 : NCH); ++c) {
+        for (int c = 0; c < NCH; ++c) {
             float4 an[RT];
             if (c + 1 < NCH) {
 #pragma unroll
@@ -166,8 +165,13 @@ __global__ __launch_bounds__(256) void enc_gemm_kernel(const EncGemm g) {
         __syncthreads();
     }
 #undef ENC_WLOAD
+    // ---- epilogue.  The D tiles (lane = one column, four rows) would be written as 64-byte row pieces (measured: 0.4 TB/s,
+    // the dominant cost of the first version); instead the workgroup's TC = 16 NWC output columns are transposed through LDS
+    // and written / combined with the residual as whole 16-byte-per-lane row segments (128 or 256 contiguous bytes per row).
+    constexpr int TC = 16 * NWC, TP = TC + 4, CG = TC / 4, RPP = 256 / CG;
+    float* red = lds;                                     // the slabs are dead: reuse
+    float* T = lds + ((KS > 1) ? (KS - 1) * NWC * RT * 4 * 64 : 0);
     if (KS > 1) {
-        float* red = lds;                                 // the slabs are dead: reuse
         if (ks > 0) {
             float* my = red + (size_t)((ks - 1) * NWC + wc) * RT * 4 * 64;
 #pragma unroll
@@ -176,92 +180,133 @@ __global__ __launch_bounds__(256) void enc_gemm_kernel(const EncGemm g) {
                 for (int i = 0; i < 4; ++i) my[(t * 4 + i) * 64 + lane] = acc[t][i];
         }
         __syncthreads();
-        if (ks > 0) return;
-#pragma unroll
-        for (int s = 0; s < KS - 1; ++s) {
-            const float* o = red + (size_t)(s * NWC + wc) * RT * 4 * 64;
-#pragma unroll
-            for (int t = 0; t < RT; ++t)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[t][i] += o[(t * 4 + i) * 64 + lane];
-        }
     }
-    if ((g.dbg & 1) && acc[0][0] != 12345.f) return;
-    // D layout: acc[t][i] = C[row 16 t + 4 hi + i][column n0 + lo]
-    const int ncb = __builtin_amdgcn_readfirstlane(n0 / g.cblk);
-    float* cp = pick6(g.C, ncb) + (ncol - ncb * g.cblk);
-    const float bv = g.bias ? g.bias[ncol] : 0.f;
+    if (ks == 0) {
+        if (KS > 1) {
+#pragma unroll
+            for (int s = 0; s < KS - 1; ++s) {
+                const float* o = red + (size_t)(s * NWC + wc) * RT * 4 * 64;
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[t][i] += o[(t * 4 + i) * 64 + lane];
+            }
+        }
+        // D layout: acc[t][i] = C[row 16 t + 4 hi + i][column n0 + lo]
+        const float bv = (g.bias && g.epi != EPI_ADD && g.epi != EPI_RELUMASK) ? g.bias[ncol] : 0.f;
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = fmaf(acc[t][i], g.alpha, bv);
+                if (g.epi == EPI_RELU) v = fmaxf(v, 0.f);
+                T[(16 * t + 4 * hi + i) * TP + 16 * wc + lo] = v;
+            }
+    }
+    __syncthreads();
+    const int cg = tid % CG, rl = tid / CG;
+    const int c0 = blockIdx.x * TC;                       // first output column of the workgroup
+    const int ncb = __builtin_amdgcn_readfirstlane(c0 / g.cblk);
+    float* cbase = pick6(g.C, ncb) + (c0 - ncb * g.cblk) + 4 * cg;
+    const int gc = c0 + 4 * cg;                           // global column of this thread's 4 values
+    constexpr int NP = (ROWS + RPP - 1) / RPP;
     if (g.epi == EPI_NORM) {
-        // s = residual + x W^T + b over the instance's rows; InstanceNorm1d statistics per channel (= per lane column)
-        float s[RT][4];
-        float sum = 0.f;
+        // s = residual + (x W^T + b); InstanceNorm1d statistics per channel over the block's rows (two passes, like the
+        // stand-alone kernel): column partials per thread, summed over the threads of a column group
+        float* stat = T + ROWS * TP;                      // [4 waves][TC]
+        auto colsum = [&](float4 v) -> float4 {
 #pragma unroll
-        for (int t = 0; t < RT; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 16 * t + 4 * hi + i;
-                const bool ok = r < nrows;
-                const float res = g.R[(size_t)(row0 + min(r, nrows - 1)) * g.ldr + ncol];
-                s[t][i] = ok ? (acc[t][i] + bv) + res : 0.f;
-                sum += s[t][i];
+            for (int m = CG; m < 64; m <<= 1) {
+                v.x += shfl_xor(v.x, m); v.y += shfl_xor(v.y, m); v.z += shfl_xor(v.z, m); v.w += shfl_xor(v.w, m);
             }
-        sum += shfl_xor(sum, 16);
-        sum += shfl_xor(sum, 32);
-        const float mean = sum / (float)nrows;
-        float sq = 0.f;
+            if (lane < CG) *reinterpret_cast<float4*>(stat + wave * TC + 4 * lane) = v;
+            __syncthreads();
+            float4 r = *reinterpret_cast<const float4*>(stat + 4 * cg);
 #pragma unroll
-        for (int t = 0; t < RT; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 16 * t + 4 * hi + i;
-                const float d = (r < nrows) ? s[t][i] - mean : 0.f;
-                s[t][i] = d;
-                sq = fmaf(d, d, sq);
+            for (int w2 = 1; w2 < 4; ++w2) {
+                const float4 o = *reinterpret_cast<const float4*>(stat + w2 * TC + 4 * cg);
+                r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
             }
-        sq += shfl_xor(sq, 16);
-        sq += shfl_xor(sq, 32);
-        const float rs = 1.0f / sqrtf(sq / (float)nrows + g.eps);
-        const float ga = g.gamma[ncol], be = g.beta[ncol];
+            __syncthreads();
+            return r;
+        };
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int t = 0; t < RT; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 16 * t + 4 * hi + i;
-                if (r < nrows) {
-                    const float xh = s[t][i] * rs;
-                    cp[(size_t)(row0 + r) * g.ldc] = fmaf(xh, ga, be);
-                    if (g.xhat) g.xhat[(size_t)(row0 + r) * g.N + ncol] = xh;
-                }
+        for (int p = 0; p < NP; ++p) {
+            const int r = rl + p * RPP;
+            if (r < nrows) {
+                float4 v = *reinterpret_cast<const float4*>(T + r * TP + 4 * cg);
+                const float4 res = *reinterpret_cast<const float4*>(g.R + (size_t)(row0 + r) * g.ldr + gc);
+                v.x += res.x; v.y += res.y; v.z += res.z; v.w += res.w;
+                *reinterpret_cast<float4*>(T + r * TP + 4 * cg) = v;
+                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
             }
-        if (hi == 0 && g.rstd) g.rstd[(size_t)blockIdx.y * g.N + ncol] = rs;
+        }
+        sum = colsum(sum);
+        const float inv_n = 1.0f / (float)nrows;
+        const float4 mean = make_float4(sum.x * inv_n, sum.y * inv_n, sum.z * inv_n, sum.w * inv_n);
+        float4 sq = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int r = rl + p * RPP;
+            if (r < nrows) {
+                const float4 v = *reinterpret_cast<const float4*>(T + r * TP + 4 * cg);
+                const float dx = v.x - mean.x, dy = v.y - mean.y, dz = v.z - mean.z, dw = v.w - mean.w;
+                sq.x = fmaf(dx, dx, sq.x); sq.y = fmaf(dy, dy, sq.y); sq.z = fmaf(dz, dz, sq.z); sq.w = fmaf(dw, dw, sq.w);
+            }
+        }
+        sq = colsum(sq);
+        const float4 rs = make_float4(1.0f / sqrtf(sq.x * inv_n + g.eps), 1.0f / sqrtf(sq.y * inv_n + g.eps),
+                                      1.0f / sqrtf(sq.z * inv_n + g.eps), 1.0f / sqrtf(sq.w * inv_n + g.eps));
+        const float4 ga = *reinterpret_cast<const float4*>(g.gamma + gc);
+        const float4 be = *reinterpret_cast<const float4*>(g.beta + gc);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int r = rl + p * RPP;
+            if (r < nrows) {
+                const float4 v = *reinterpret_cast<const float4*>(T + r * TP + 4 * cg);
+                const float4 xh = make_float4((v.x - mean.x) * rs.x, (v.y - mean.y) * rs.y, (v.z - mean.z) * rs.z, (v.w - mean.w) * rs.w);
+                *reinterpret_cast<float4*>(cbase + (size_t)(row0 + r) * g.ldc) =
+                    make_float4(fmaf(xh.x, ga.x, be.x), fmaf(xh.y, ga.y, be.y), fmaf(xh.z, ga.z, be.z), fmaf(xh.w, ga.w, be.w));
+                if (g.xhat) *reinterpret_cast<float4*>(g.xhat + (size_t)(row0 + r) * g.N + gc) = xh;
+            }
+        }
+        if (rl == 0 && g.rstd) *reinterpret_cast<float4*>(g.rstd + (size_t)blockIdx.y * g.N + gc) = rs;
         return;
     }
-    const float cvv = (g.epi == EPI_ADD && g.cv) ? g.cv[ncol] * g.alpha2 : 0.f;
+    float4 cv4 = make_float4(0.f, 0.f, 0.f, 0.f), bias4 = cv4;
+    if (g.epi == EPI_ADD && g.cv) {
+        cv4 = *reinterpret_cast<const float4*>(g.cv + gc);
+        cv4.x *= g.alpha2; cv4.y *= g.alpha2; cv4.z *= g.alpha2; cv4.w *= g.alpha2;
+    }
+    (void)bias4;
 #pragma unroll
-    for (int t = 0; t < RT; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 16 * t + 4 * hi + i;
-            if (r < nrows) {
-                const size_t grow = (size_t)(row0 + r);
-                float v = acc[t][i] * g.alpha;
-                if (g.epi == EPI_STORE) v += bv;
-                else if (g.epi == EPI_RELU) v = fmaxf(v + bv, 0.f);
-                else if (g.epi == EPI_ADD) {
-                    v += g.R[grow * g.ldr + ncol];
-                    if (g.cv) v = fmaf(g.rv[grow], cvv, v);
-                } else if (g.epi == EPI_RELUMASK) v = (g.R[grow * g.ldr + ncol] > 0.f) ? v : 0.f;
-                else if (g.epi == EPI_ADDBIAS) v = (v + bv) + g.R[grow * g.ldr + ncol];
-                cp[grow * g.ldc] = v;
+    for (int p = 0; p < NP; ++p) {
+        const int r = rl + p * RPP;
+        if (r < nrows) {
+            const size_t grow = (size_t)(row0 + r);
+            float4 v = *reinterpret_cast<const float4*>(T + r * TP + 4 * cg);
+            if (g.epi == EPI_ADD || g.epi == EPI_ADDBIAS) {
+                const float4 res = *reinterpret_cast<const float4*>(g.R + grow * g.ldr + gc);
+                v.x += res.x; v.y += res.y; v.z += res.z; v.w += res.w;
+                if (g.epi == EPI_ADD && g.cv) {
+                    const float rvv = g.rv[grow];
+                    v.x = fmaf(rvv, cv4.x, v.x); v.y = fmaf(rvv, cv4.y, v.y); v.z = fmaf(rvv, cv4.z, v.z); v.w = fmaf(rvv, cv4.w, v.w);
+                }
+            } else if (g.epi == EPI_RELUMASK) {
+                const float4 m = *reinterpret_cast<const float4*>(g.R + grow * g.ldr + gc);
+                v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
             }
+            *reinterpret_cast<float4*>(cbase + grow * g.ldc) = v;
         }
+    }
 }
 
-template <int RT, int KS>
+template <int RT, int KS, int WMODE>
 static int launch_gemm_t(const EncGemm& g, dim3 grid, hipStream_t s) {
     const int nbuf = g.K > ENC_KS ? 2 : 1;
     const size_t lds = (size_t)nbuf * RT * 16 * ENC_AP * sizeof(float);
-    auto kern = enc_gemm_kernel<RT, KS>;
+    auto kern = enc_gemm_kernel<RT, KS, WMODE>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipGetLastError();
@@ -275,29 +320,33 @@ static int launch_gemm_t(const EncGemm& g, dim3 grid, hipStream_t s) {
     return launch_status("enc_gemm");
 }
 
-static int launch_gemm(const EncGemm& g_in, hipStream_t s) {
-    EncGemm g = g_in;
-    { const char* e = getenv("ELG_ENC_DBG"); g.dbg = e ? atoi(e) : 0; }
+static int launch_gemm(const EncGemm& g, hipStream_t s) {
     if ((g.N & 15) || g.N <= 0) return fail(ELG_EINVAL, "encoder gemm: N must be a multiple of 16");
     const int nblk = (g.rows_total + g.blk_stride - 1) / g.blk_stride;
     const int ctiles = g.N / 16;
     if ((g.wblk % 16) || (g.cblk % 16) || (g.K % ENC_KS)) return fail(ELG_EINVAL, "encoder gemm: K must be a multiple of 128, weight / output blocks of 16");
     // K split over the waves of a workgroup: enough waves for the chip's 1024 SIMDs
+    if (g.N & 31) return fail(ELG_EINVAL, "encoder gemm: N must be a multiple of 32");
     int ks = 1;
-    if ((long)ctiles * nblk < 1024) ks = 2;
-    while (ks < 4 && (ctiles % (4 / ks))) ks *= 2;
+    if (((long)ctiles * nblk < 1024) || (ctiles & 3)) ks = 2;
     dim3 grid(ctiles / (4 / ks), nblk);
-#define ENC_GO(RT)                                                \
-    {                                                             \
-        if (ks == 1) return launch_gemm_t<RT, 1>(g, grid, s);     \
-        if (ks == 2) return launch_gemm_t<RT, 2>(g, grid, s);     \
-        return launch_gemm_t<RT, 4>(g, grid, s);                  \
+#define ENC_GO2(RT, KSV)                                                                  \
+    {                                                                                     \
+        if (g.wmode == W_NK) return launch_gemm_t<RT, KSV, W_NK>(g, grid, s);             \
+        if (g.wmode == W_KN) return launch_gemm_t<RT, KSV, W_KN>(g, grid, s);             \
+        return launch_gemm_t<RT, KSV, W_NK_SCALAR>(g, grid, s);                           \
+    }
+#define ENC_GO(RT)                  \
+    {                               \
+        if (ks == 1) ENC_GO2(RT, 1) \
+        ENC_GO2(RT, 2)              \
     }
     if (g.blk_rows <= 32) ENC_GO(2)
     if (g.blk_rows <= 64) ENC_GO(4)
     if (g.blk_rows <= 112) ENC_GO(7)
     if (g.blk_rows <= 128) ENC_GO(8)
 #undef ENC_GO
+#undef ENC_GO2
     return fail(ELG_EINVAL, "encoder gemm: row block > 128");
 }
 
@@ -543,6 +592,134 @@ __global__ __launch_bounds__(256) void enc_attn_bwd_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// All weight gradients of the encoder in ONE launch: dW_j[M,N] += alpha_j dY_j^T X_j over the batch*nodes rows, for every
+// nn.Linear of every layer (and the decoder tables' projections), bias gradients = column sums of dY_j.
+// Both operands are row-major with the contraction index (the row) outermost, which is exactly the operand order of
+// v_mfma_f32_32x32x2_f32: lane (i = lane & 31, q = lane >> 5) feeds A[i][k = q] = dY[row + q][m] and B[k = q][j = i] =
+// X[row + q][n] -- coalesced global loads, no LDS.  A lane loads two neighbouring m (and n) per row, so a wave owns a
+// 64 x 64 block of dW as 2 x 2 MFMA tiles (rows / columns interleaved by two), a workgroup 128 x 128, and the row range is
+// split over gridDim.y workgroups that accumulate with f32 atomics (the per-layer split-K GEMMs this replaces issued ~4x
+// more atomics and ran 40 launches of ~22 us).
+struct DwJob {
+    const float* dY; const float* X; float* dW; float* db;
+    int ldy, ldx, ldw, M, N, tile0; float alpha;
+};
+constexpr int DW_MAX_JOBS = 48;
+struct DwBatch {
+    DwJob job[DW_MAX_JOBS];
+    int njobs, ntiles, rows, rows_per_split;
+};
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+__global__ __launch_bounds__(256) void enc_dw_kernel(const DwBatch bt) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 31, kq = lane >> 5;
+    int j = 0;
+    for (int t = 1; t < bt.njobs; ++t) j = (int)blockIdx.x >= bt.job[t].tile0 ? t : j;
+    // copy the job out of the (SGPR-resident) argument array with a uniform select chain
+    const float* dY = nullptr; const float* X = nullptr; float* dW = nullptr; float* db = nullptr;
+    int ldy = 0, ldx = 0, ldw = 0, N = 0, tile0 = 0; float alpha = 1.f;
+#pragma unroll
+    for (int t = 0; t < DW_MAX_JOBS; ++t)
+        if (t == j) {
+            dY = bt.job[t].dY; X = bt.job[t].X; dW = bt.job[t].dW; db = bt.job[t].db; ldy = bt.job[t].ldy; ldx = bt.job[t].ldx;
+            ldw = bt.job[t].ldw; N = bt.job[t].N; tile0 = bt.job[t].tile0; alpha = bt.job[t].alpha;
+        }
+    const int tile = blockIdx.x - tile0, ntn = N >> 7;
+    const int mt = tile / ntn, nt = tile - mt * ntn;
+    const int m0 = mt * 128 + (wave >> 1) * 64, n0 = nt * 128 + (wave & 1) * 64;
+    const int kbeg = blockIdx.y * bt.rows_per_split, kend = min(bt.rows, kbeg + bt.rows_per_split);
+    if (kbeg >= kend) return;
+    const float* ap = dY + m0 + 2 * li;
+    const float* bp = X + n0 + 2 * li;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum0 = 0.f, bsum1 = 0.f;
+    constexpr int U = 8;                               // MFMA k-steps (2 rows each) per batch of loads
+    float2 av[U], bv[U];
+#define DW_LOAD(K0, AV, BV)                                                                            \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                    \
+        const int r_ = (K0) + 2 * u + kq;                                                              \
+        const int rc_ = min(r_, kend - 1);                                                             \
+        const float mk_ = r_ < kend ? 1.f : 0.f;                                                       \
+        float2 a_ = *reinterpret_cast<const float2*>(ap + (size_t)rc_ * ldy);                          \
+        a_.x *= mk_; a_.y *= mk_;                                                                      \
+        AV[u] = a_;                                                                                    \
+        BV[u] = *reinterpret_cast<const float2*>(bp + (size_t)rc_ * ldx);                              \
+    }
+    DW_LOAD(kbeg, av, bv)
+    for (int k = kbeg; k < kend; k += 2 * U) {
+        float2 an[U], bn[U];
+        const int kn = min(k + 2 * U, kend - 1);       // the last prefetch re-reads in-range rows, unused
+        DW_LOAD(kn, an, bn)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u].x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u].y, acc[1][1], 0, 0, 0);
+            bsum0 += av[u].x; bsum1 += av[u].y;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { av[u] = an[u]; bv[u] = bn[u]; }
+    }
+#undef DW_LOAD
+    // C/D layout of 32x32: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); tile (a, b) holds
+    // dW[m0 + 2 row + a][n0 + 2 col + b]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * kq;
+                atomicAdd(dW + (size_t)(m0 + 2 * row + a) * ldw + n0 + 2 * li + b, acc[a][b][r] * alpha);
+            }
+    if (db && nt == 0 && (wave & 1) == 0) {
+        bsum0 += shfl_xor(bsum0, 32);
+        bsum1 += shfl_xor(bsum1, 32);
+        if (kq == 0) { atomicAdd(db + m0 + 2 * li, bsum0); atomicAdd(db + m0 + 2 * li + 1, bsum1); }
+    }
+}
+
+struct DwList {
+    DwBatch bt;
+    long rows;
+    hipStream_t s;
+    DwList(long rows_, hipStream_t s_) : rows(rows_), s(s_) { bt.njobs = 0; bt.ntiles = 0; }
+    int add(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, int M, int N, float* db, float alpha) {
+        if (bt.njobs >= DW_MAX_JOBS) {
+            const int rc = launch();
+            if (rc != ELG_OK) return rc;
+        }
+        if ((M & 127) || (N & 127) || (ldy & 1) || (ldx & 1)) return fail(ELG_EINVAL, "encoder bwd: dW shapes must be multiples of 128");
+        DwJob& j = bt.job[bt.njobs++];
+        j.dY = dY; j.X = X; j.dW = dW; j.db = db; j.ldy = ldy; j.ldx = ldx; j.ldw = ldw; j.M = M; j.N = N; j.alpha = alpha;
+        j.tile0 = bt.ntiles;
+        bt.ntiles += (M >> 7) * (N >> 7);
+        return ELG_OK;
+    }
+    int launch() {
+        if (bt.njobs == 0) return ELG_OK;
+        // row split: ~8 workgroups per CU in flight overall, at least 128 rows each
+        int splits = (int)max(1L, min(rows / 128, (long)((2048 + bt.ntiles - 1) / bt.ntiles)));
+        int rps = (int)((rows + splits - 1) / splits);
+        rps = (rps + 15) / 16 * 16;
+        splits = (int)((rows + rps - 1) / rps);
+        bt.rows = (int)rows; bt.rows_per_split = rps;
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(enc_dw_kernel, dim3(bt.ntiles, splits), dim3(256), 0, s, bt);
+        bt.njobs = 0; bt.ntiles = 0;
+        return launch_status("enc_dw");
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------------
 // workspace layout (floats)
 struct EncWs {
     long R, X0, tmp, layer0, layer_stride;
@@ -595,9 +772,10 @@ extern "C" int64_t elg_encoder_ws_floats(int B, int N1, int n_layers, int ff_hid
     return enc_ws(B, N1, n_layers, ff_hidden, save).total;
 }
 
-extern "C" int64_t elg_encoder_bwd_ws_floats(int B, int N1, int ff_hidden) {
-    if (B <= 0 || N1 <= 0 || ff_hidden <= 0) return 0;
-    return (int64_t)B * N1 * (4 * ELG_E + ff_hidden + 3 * ELG_E);
+extern "C" int64_t elg_encoder_bwd_ws_floats(int B, int N1, int n_layers, int ff_hidden) {
+    if (B <= 0 || N1 <= 0 || n_layers <= 0 || ff_hidden <= 0) return 0;
+    // d x / d att / d x1 (shared) + per layer: dS2, dH, dS1, dQKV (kept until the grouped weight-gradient launch)
+    return (int64_t)B * N1 * (3 * ELG_E + (int64_t)n_layers * (5 * ELG_E + ff_hidden));
 }
 
 static int check_enc_args(const elg_encoder_args* a) {
@@ -722,14 +900,6 @@ extern "C" int elg_encoder_fwd(const elg_encoder_args* a, void* stream) {
     return launch_status("enc_pb_wl");
 }
 
-static int dw_gemm(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, int M, int N, long rows, float* dbias,
-                   float alpha, void* stream) {
-    // dW[M,N] += alpha dY^T X over `rows` rows, bias gradient = column sums of dY (split-K MFMA GEMM, csrc/elg_gemm.hip)
-    const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
-    int split = (int)max(1L, min(64L, min(rows / 128, (long)max(4, 512 / tiles))));
-    return elg_gemm_f32_alpha(dY, X, dW, nullptr, M, N, (int)rows, ldy, ldx, ldw, 1, 0, 0, split, dbias, alpha, stream);
-}
-
 extern "C" int elg_encoder_bwd(const elg_encoder_bwd_args* ba, void* stream) {
     if (!ba) return fail(ELG_EINVAL, "encoder bwd: null args");
     const elg_encoder_args* a = &ba->fwd;
@@ -741,15 +911,15 @@ extern "C" int elg_encoder_bwd(const elg_encoder_bwd_args* ba, void* stream) {
     const bool tsp = a->problem == ELG_PROBLEM_TSP;
     const EncWs w = enc_ws(B, N1, a->n_layers, FF, 1);
     const long R = w.R;
-    if (!ba->ws2 || ba->ws2_floats < elg_encoder_bwd_ws_floats(B, N1, FF)) return fail(ELG_EINVAL, "encoder bwd: scratch too small");
+    if (!ba->ws2 || ba->ws2_floats < elg_encoder_bwd_ws_floats(B, N1, a->n_layers, FF)) return fail(ELG_EINVAL, "encoder bwd: scratch too small");
     const elg_enc_weights& G = ba->G;
     float* gX = ba->ws2;
-    float* gS = gX + R * ELG_E;
-    float* gY = gS + R * ELG_E;
-    float* gO = gY + R * ELG_E;
-    float* gH = gO + R * ELG_E;
-    float* dQKV = gH + R * FF;
+    float* gO = gX + R * ELG_E;
+    float* gT = gO + R * ELG_E;
+    float* lay2 = gT + R * ELG_E;
+    const long lay2_stride = R * (5 * ELG_E + FF);
     float* ws = a->ws;
+    DwList dw(R, s);
     const float inv_sqrt_e = 0.08838834764831845f;
     const bool aligned = true;
     // ---- d enc from the decoder tables (autograd of set_kv / fold_decoder_tables)
@@ -773,23 +943,23 @@ extern "C" int elg_encoder_bwd(const elg_encoder_bwd_args* ba, void* stream) {
     if (ba->gK) {
         ENC_TRY(need(G.dec_Wk, "d Wk"))
         ENC_TRY(acc_into_gX(ba->gK, a->W.dec_Wk, ELG_E, W_KN, 1.f))
-        ENC_TRY(dw_gemm(ba->gK, ELG_E, a->enc, ELG_E, (float*)G.dec_Wk, ELG_E, ELG_E, ELG_E, R, nullptr, 1.f, stream))
+        ENC_TRY(dw.add(ba->gK, ELG_E, a->enc, ELG_E, (float*)G.dec_Wk, ELG_E, ELG_E, ELG_E, nullptr, 1.f))
     }
     if (ba->gV) {
         ENC_TRY(need(G.dec_Wv, "d Wv"))
         ENC_TRY(acc_into_gX(ba->gV, a->W.dec_Wv, ELG_E, W_KN, 1.f))
-        ENC_TRY(dw_gemm(ba->gV, ELG_E, a->enc, ELG_E, (float*)G.dec_Wv, ELG_E, ELG_E, ELG_E, R, nullptr, 1.f, stream))
+        ENC_TRY(dw.add(ba->gV, ELG_E, a->enc, ELG_E, (float*)G.dec_Wv, ELG_E, ELG_E, ELG_E, nullptr, 1.f))
     }
     if (ba->gQ1) {
         ENC_TRY(need(G.dec_Wq_last, "d Wq_last"))
         const int ldq = tsp ? ELG_E : ELG_E + 1;
         ENC_TRY(acc_into_gX(ba->gQ1, a->W.dec_Wq_last, ldq, W_KN, 1.f))
-        ENC_TRY(dw_gemm(ba->gQ1, ELG_E, a->enc, ELG_E, (float*)G.dec_Wq_last, ldq, ELG_E, ELG_E, R, nullptr, 1.f, stream))
+        ENC_TRY(dw.add(ba->gQ1, ELG_E, a->enc, ELG_E, (float*)G.dec_Wq_last, ldq, ELG_E, ELG_E, nullptr, 1.f))
     }
     if (tsp && ba->gQ2) {
         ENC_TRY(need(G.dec_Wq_first, "d Wq_first"))
         ENC_TRY(acc_into_gX(ba->gQ2, a->W.dec_Wq_first, ELG_E, W_KN, 1.f))
-        ENC_TRY(dw_gemm(ba->gQ2, ELG_E, a->enc, ELG_E, (float*)G.dec_Wq_first, ELG_E, ELG_E, ELG_E, R, nullptr, 1.f, stream))
+        ENC_TRY(dw.add(ba->gQ2, ELG_E, a->enc, ELG_E, (float*)G.dec_Wq_first, ELG_E, ELG_E, ELG_E, nullptr, 1.f))
     }
     if (ba->gPK) {
         ENC_TRY(need(G.dec_Wc, "d Wc"))
@@ -803,7 +973,7 @@ extern "C" int elg_encoder_bwd(const elg_encoder_bwd_args* ba, void* stream) {
         g.alpha = inv_sqrt_e;
         if (ba->gpb) { g.rv = ba->gpb; g.cv = a->W.dec_bc; g.alpha2 = inv_sqrt_e; }
         ENC_TRY(launch_gemm(g, s))
-        ENC_TRY(dw_gemm(a->enc, ELG_E, ba->gPK, ELG_E, (float*)G.dec_Wc, ELG_E, ELG_E, ELG_E, R, nullptr, inv_sqrt_e, stream))
+        ENC_TRY(dw.add(a->enc, ELG_E, ba->gPK, ELG_E, (float*)G.dec_Wc, ELG_E, ELG_E, ELG_E, nullptr, inv_sqrt_e))
     } else if (ba->gpb) return fail(ELG_EINVAL, "encoder bwd: gpb without gPK");
     if (ba->gpb || (ba->gwl && !tsp)) {
         if (ba->gpb) ENC_TRY(need(G.dec_bc, "d bc"))
@@ -818,27 +988,31 @@ extern "C" int elg_encoder_bwd(const elg_encoder_bwd_args* ba, void* stream) {
     for (int l = a->n_layers - 1; l >= 0; --l) {
         const elg_enc_layer& L = a->W.layer[l];
         const elg_enc_layer& GL = G.layer[l];
+        float* gS = lay2 + lay2_stride * l;
+        float* gH = gS + R * ELG_E;
+        float* gY = gH + R * FF;
+        float* dQKV = gY + R * ELG_E;
         float* lb = ws + w.layer0 + w.layer_stride * l;
         const float *QKV = lb + w.oQKV, *O = lb + w.oO, *LSE = lb + w.oLSE, *XH1 = lb + w.oXH1, *RS1 = lb + w.oRS1;
         const float *X1 = lb + w.oX1, *H = lb + w.oH, *XH2 = lb + w.oXH2, *RS2 = lb + w.oRS2;
         const float* Xin = (l == 0) ? ws + w.X0 : ws + w.layer0 + w.layer_stride * (l - 1) + w.oXout;
         // second add & norm
         ENC_TRY(elg_add_instnorm_bwd(gX, XH2, RS2, L.g2, gS, (float*)GL.g2, (float*)GL.b2, B, N1, ELG_E, stream))
-        ENC_TRY(dw_gemm(gS, ELG_E, H, FF, (float*)GL.W2, FF, ELG_E, FF, R, (float*)GL.bf2, 1.f, stream))
+        ENC_TRY(dw.add(gS, ELG_E, H, FF, (float*)GL.W2, FF, ELG_E, FF, (float*)GL.bf2, 1.f))
         {   // dH = (dS2 W2) * [h > 0]
             EncGemm g = gemm_base(gS, ELG_E, FF, ELG_E, R, N1, aligned);
             g.W[0] = L.W2; g.ldw = FF; g.wmode = W_KN; g.wblk = ELG_E; g.C[0] = gH; g.ldc = FF; g.epi = EPI_RELUMASK; g.R = H; g.ldr = FF;
             ENC_TRY(launch_gemm(g, s))
         }
-        ENC_TRY(dw_gemm(gH, FF, X1, ELG_E, (float*)GL.W1, ELG_E, FF, ELG_E, R, (float*)GL.bf1, 1.f, stream))
+        ENC_TRY(dw.add(gH, FF, X1, ELG_E, (float*)GL.W1, ELG_E, FF, ELG_E, (float*)GL.bf1, 1.f))
         {   // d x1 = dS2 + dH W1
             EncGemm g = gemm_base(gH, FF, ELG_E, FF, R, N1, aligned);
-            g.W[0] = L.W1; g.ldw = ELG_E; g.wmode = W_KN; g.wblk = FF; g.C[0] = gS; g.ldc = ELG_E; g.epi = EPI_ADD; g.R = gS; g.ldr = ELG_E;
+            g.W[0] = L.W1; g.ldw = ELG_E; g.wmode = W_KN; g.wblk = FF; g.C[0] = gT; g.ldc = ELG_E; g.epi = EPI_ADD; g.R = gS; g.ldr = ELG_E;
             ENC_TRY(launch_gemm(g, s))
         }
         // first add & norm
-        ENC_TRY(elg_add_instnorm_bwd(gS, XH1, RS1, L.g1, gY, (float*)GL.g1, (float*)GL.b1, B, N1, ELG_E, stream))
-        ENC_TRY(dw_gemm(gY, ELG_E, O, ELG_E, (float*)GL.Wc, ELG_E, ELG_E, ELG_E, R, (float*)GL.bc, 1.f, stream))
+        ENC_TRY(elg_add_instnorm_bwd(gT, XH1, RS1, L.g1, gY, (float*)GL.g1, (float*)GL.b1, B, N1, ELG_E, stream))
+        ENC_TRY(dw.add(gY, ELG_E, O, ELG_E, (float*)GL.Wc, ELG_E, ELG_E, ELG_E, (float*)GL.bc, 1.f))
         {   // d att = dY Wc
             EncGemm g = gemm_base(gY, ELG_E, ELG_E, ELG_E, R, N1, aligned);
             g.W[0] = L.Wc; g.ldw = ELG_E; g.wmode = W_KN; g.wblk = ELG_E; g.C[0] = gO; g.ldc = ELG_E;
@@ -853,9 +1027,9 @@ extern "C" int elg_encoder_bwd(const elg_encoder_bwd_args* ba, void* stream) {
             else hipLaunchKernelGGL((enc_attn_bwd_kernel<8>), dim3(B * 8), dim3(256), 0, s, QKV, gO, O, LSE, dQKV, N1);
         }
         ENC_TRY(launch_status("enc_attn_bwd"))
-        ENC_TRY(dw_gemm(dQKV, 3 * ELG_E, Xin, ELG_E, (float*)GL.Wq, ELG_E, ELG_E, ELG_E, R, nullptr, 1.f, stream))
-        ENC_TRY(dw_gemm(dQKV + ELG_E, 3 * ELG_E, Xin, ELG_E, (float*)GL.Wk, ELG_E, ELG_E, ELG_E, R, nullptr, 1.f, stream))
-        ENC_TRY(dw_gemm(dQKV + 2 * ELG_E, 3 * ELG_E, Xin, ELG_E, (float*)GL.Wv, ELG_E, ELG_E, ELG_E, R, nullptr, 1.f, stream))
+        ENC_TRY(dw.add(dQKV, 3 * ELG_E, Xin, ELG_E, (float*)GL.Wq, ELG_E, ELG_E, ELG_E, nullptr, 1.f))
+        ENC_TRY(dw.add(dQKV + ELG_E, 3 * ELG_E, Xin, ELG_E, (float*)GL.Wk, ELG_E, ELG_E, ELG_E, nullptr, 1.f))
+        ENC_TRY(dw.add(dQKV + 2 * ELG_E, 3 * ELG_E, Xin, ELG_E, (float*)GL.Wv, ELG_E, ELG_E, ELG_E, nullptr, 1.f))
         {   // d x = dY + dQ Wq + dK Wk + dV Wv
             EncGemm g = gemm_base(dQKV, 3 * ELG_E, ELG_E, 3 * ELG_E, R, N1, aligned);
             g.W[0] = L.Wq; g.W[1] = L.Wk; g.W[2] = L.Wv; g.ldw = ELG_E; g.wmode = W_KN; g.wblk = ELG_E; g.C[0] = gX; g.ldc = ELG_E;
@@ -872,5 +1046,5 @@ extern "C" int elg_encoder_bwd(const elg_encoder_bwd_args* ba, void* stream) {
                            (float*)G.emb_w, (float*)G.emb_b, N1, R, rpb);
         ENC_TRY(launch_status("enc_embed_bwd"))
     }
-    return ELG_OK;
+    return dw.launch();          // every weight gradient of the call in one grouped launch
 }

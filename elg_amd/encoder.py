@@ -132,8 +132,8 @@ class _EncodeFold(torch.autograd.Function):
             ptrs.append(g.data_ptr())
             off += n
         _fill_weights(ba.G, a.problem, a.n_layers, ptrs)
-        n2 = int(lib.elg_encoder_bwd_ws_floats(a.B, a.N1, a.ff_hidden))
-        ws2 = _Workspace.get(("bwd", a.B, a.N1, a.ff_hidden, str(dev)), n2, dev)
+        n2 = int(lib.elg_encoder_bwd_ws_floats(a.B, a.N1, a.n_layers, a.ff_hidden))
+        ws2 = _Workspace.get(("bwd", a.B, a.N1, a.n_layers, a.ff_hidden, str(dev)), n2, dev)
         ba.ws2, ba.ws2_floats = _ptr(ws2.buf), ws2.buf.numel()
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)

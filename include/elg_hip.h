@@ -319,7 +319,7 @@ typedef struct elg_encoder_bwd_args {
     float* ws2;             /* scratch, elg_encoder_bwd_ws_floats() floats                                         */
     int64_t ws2_floats;
 } elg_encoder_bwd_args;
-int64_t elg_encoder_bwd_ws_floats(int B, int N1, int ff_hidden);
+int64_t elg_encoder_bwd_ws_floats(int B, int N1, int n_layers, int ff_hidden);
 int elg_encoder_bwd(const elg_encoder_bwd_args* args, void* stream);
 
 /* ---- local policy: parameters -> slot tables (ELG_LOC_* above).  local_policy_att's parameters (CVRP/models.py:8-36,
