@@ -62,6 +62,15 @@ class EncWeights(C.Structure):
                 ("dec_bc", _vp)]
 
 
+class DecoderBwdArgs(C.Structure):
+    _fields_ = [("problem", C.c_int32), ("B", C.c_int32), ("M", C.c_int32), ("N1", C.c_int32), ("T", C.c_int32),
+                ("Tcap_actions", C.c_int32), ("first_decode_step", C.c_int32), ("inv_ens", C.c_float), ("Rcap", C.c_int64),
+                ("gprob", _vp), ("pval", _vp), ("tlen", _vp), ("actions", _vp), ("trPC", _vp), ("trCsel", _vp), ("trQ", _vp),
+                ("trO", _vp), ("trLoad", _vp), ("trSlot", _vp), ("trA", _vp), ("trMask", _vp), ("Kmat", _vp), ("Vmat", _vp),
+                ("PK", _vp), ("dK", _vp), ("dV", _vp), ("dPK", _vp), ("dpb", _vp), ("dQ1", _vp), ("dQ2", _vp), ("dwl", _vp),
+                ("rowDU", _vp), ("dO", _vp), ("idx_prev", _vp), ("idx_first", _vp), ("rowW", _vp)]
+
+
 class LocalWeights(C.Structure):
     _fields_ = [(n, _vp) for n in ("init_emb_w", "init_emb_b", "cur_token_emb", "Wq", "Wk", "Wv", "combine_w", "combine_b")]
 
@@ -84,7 +93,7 @@ EXPORTS = ["elg_version", "elg_last_error", "elg_aug8", "elg_dist_matrix", "elg_
            "elg_pomo_loss", "elg_rows_prep", "elg_adam_step", "elg_local_bwd_rows",
            "elg_add_instnorm_fwd", "elg_add_instnorm_bwd", "elg_rows_segsum",
            "elg_encoder_ws_floats", "elg_encoder_fwd", "elg_encoder_bwd_ws_floats", "elg_encoder_bwd",
-           "elg_local_fold_fwd", "elg_local_fold_bwd", "elg_check_feasible", "elg_rollout_stats"]
+           "elg_local_fold_fwd", "elg_local_fold_bwd", "elg_check_feasible", "elg_rollout_stats", "elg_decoder_bwd"]
 
 _lib = None
 
@@ -133,6 +142,8 @@ def lib() -> C.CDLL:
         L.elg_local_fold_bwd.argtypes = [C.POINTER(LocalWeights), i, i, i, f, C.POINTER(LocalWeights), f]
         L.elg_check_feasible.argtypes = [f, i64, f, i, i, i, f, f]
         L.elg_rollout_stats.argtypes = [f, f, i, i, i, f, f]
+        L.elg_decoder_bwd.argtypes = [C.POINTER(DecoderBwdArgs), f]
+        L.elg_decoder_bwd.restype = C.c_int
         L.elg_check_feasible.restype = C.c_int
         L.elg_rollout_stats.restype = C.c_int
         L.elg_local_fold_fwd.restype = C.c_int

@@ -8,6 +8,7 @@
 //   local_bwd_kernel   : k-NN + local-policy replay, gradient of the folded local tables reduced
 //                        in LDS accumulators, one flush per workgroup
 #include "elg_rollout.h"
+#include "elg_bwd_internal.h"
 #include <string>
 
 namespace elg {
@@ -595,13 +596,13 @@ __device__ __forceinline__ int grp_start(int nt, int q, int N1) { return min(16 
 // RECOMP: the weights a are not read (3.3 GB at the bench shape, written by the forward and read here) but recomputed
 // per tile from the saved query rows and the rows' feasibility mask words: S = q_h K_h^T / 4 (28 more MFMAs per tile),
 // masked softmax over the row's nodes (16-lane DPP reductions).
-template <int NT, bool RECOMP>
+template <int NT, bool RECOMP, bool SEG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void glimpse_bwd_mfma_kernel(
     const float* __restrict__ rowA, const unsigned long long* __restrict__ rowMask, const float* __restrict__ dO,
     const float* __restrict__ rowO,
     const float* __restrict__ rowQ, const float* __restrict__ Kmat, const float* __restrict__ Vmat,
     float* __restrict__ dQ, float* __restrict__ dKp, float* __restrict__ dVp, int B, int R, int N1,
-    size_t rowA_rows, size_t rowO_rows, size_t rowQ_rows, int splits) {
+    size_t rowA_rows, size_t rowO_rows, size_t rowQ_rows, int splits, const GlimpseSeg seg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // LDS: [K operand image: NT*4 x 64] then the 4 x 2 x NT*256 reduction buffer
     float* sK = lds;
@@ -610,6 +611,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int lo = lane & 15, hi = lane >> 4;
     float* sTr = lds + NT * 256 + 4 * 2 * NT * 256 + wave * (2 * 320);    // two 16 x 16 transpose tiles (pitch 20)
     float* sK2 = lds + NT * 256 + 4 * 2 * NT * 256 + 4 * 2 * 320;          // RECOMP: K as the B operand of q K^T
+    float* sSeg1 = sRed;       // [(16 NT + 1)][16] d Q1 (+ the load row): aliases the reduction buffer, which is only
+                               // used after the row loop (more LDS would halve the workgroups per CU)
+    // channel-major [16][SNP] with an odd pitch: the 64 lanes of one atomic (fixed i: channels 4 hi + i, nodes of 16 rows)
+    // spread over the banks (node-major [node][16] put them on 8 banks)
+    constexpr int SNP = 16 * NT + 9;
+    float* sSeg2 = sSeg1 + 16 * SNP;                                       // d Q2
+    if (SEG)
+        for (int i = threadIdx.x; i < 2 * 16 * SNP; i += 256) sSeg1[i] = 0.f;
+    // SEG: the gather indices / load of the tile's rows are fetched with the tile (a load issued after dq is known would
+    // expose a full memory latency per tile)
+    const int* seg_first = (SEG && seg.idx_first) ? seg.idx_first : seg.idx_prev;
+    const float* seg_load = (SEG && seg.load) ? seg.load : reinterpret_cast<const float*>(seg.idx_prev);
+    const size_t seg_lrows = (SEG && seg.load) ? (size_t)seg.load_rows : (size_t)R;
     const int bh = blockIdx.y, b = bh >> 3, h = bh & 7;
     const int split = blockIdx.x;
 
@@ -654,10 +668,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // memory latency).  Rows past R are clamped to the last valid row (finite duplicates): they meet zeroed Q / dO
     // operands in dK / dV and an unstored dQ column.  Q / dO rows past R must be exact zeros: 0/1 mask multiply.
     // The loads of tile i + 1 are issued before tile i is consumed (software prefetch, 44 registers).
-#define ELG_GB_LOAD(TILE, A1, DOA, OA, DOB, QB, QA, MW)                                                           \
+#define ELG_GB_LOAD(TILE, A1, DOA, OA, DOB, QB, QA, MW, SP, SF, SL)                                               \
     {                                                                                                             \
         const int r0_ = (TILE) << 4;                                                                              \
         const int rleft_ = R - 1 - r0_;                                                                           \
+        if (SEG) {                                                                                                \
+            const size_t rr_ = (size_t)(r0_ + min(lo, rleft_));                                                   \
+            SP = seg.idx_prev[(size_t)b * R + rr_];                                                               \
+            SF = seg_first[(size_t)b * R + rr_];                                                                  \
+            SL = seg_load[(size_t)b * seg_lrows + rr_];                                                           \
+        }                                                                                                         \
         if (!RECOMP) {                                                                                            \
             const float* __restrict__ At = Abh + (size_t)r0_ * N1;                                                \
             _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                                       \
@@ -690,15 +710,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float a1[NT][4], doA[4], oA[4], doB[4], qB[4], qA[4];
     unsigned long long mw[4][2];
     const int tile0 = t_lo + wave_u;
-    if (tile0 < t_hi) ELG_GB_LOAD(tile0, a1, doA, oA, doB, qB, qA, mw)
+    int sgp = 0, sgf = 0;
+    float sgl = 0.f;
+    if (tile0 < t_hi) ELG_GB_LOAD(tile0, a1, doA, oA, doB, qB, qA, mw, sgp, sgf, sgl)
     for (int tile = tile0; tile < t_hi; tile += 4) {
         const int r0 = tile << 4;                                  // wave-uniform
         const int rT = r0 + lo;                                    // row of this lane in the row-on-lane layout
         float a1n[NT][4], doAn[4], oAn[4], doBn[4], qBn[4], qAn[4];
         unsigned long long mwn[4][2];
+        int sgpn = 0, sgfn = 0;
+        float sgln = 0.f;
         {
             const int tn = min(tile + 4, t_hi - 1);                // the last prefetch re-reads a valid tile, unused
-            ELG_GB_LOAD(tn, a1n, doAn, oAn, doBn, qBn, qAn, mwn)
+            ELG_GB_LOAD(tn, a1n, doAn, oAn, doBn, qBn, qAn, mwn, sgpn, sgfn, sgln)
         }
         if (RECOMP) {
             // a_h[row 4 hi + v][position lo] = softmax over the row's open nodes of q_h . K_h[node] / 4
@@ -780,8 +804,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 dq = __builtin_amdgcn_mfma_f32_16x16x4f32(sK[((NT - 1) * 4 + v) * 64 + lane], pb[(4 * hi + v) * 20 + lo], dq, 0, 0, 0);
         }
         wave_lds_fence();
-        if (rT < R) *reinterpret_cast<float4*>(dQ + ((size_t)b * R + rT) * ELG_E + h * 16 + 4 * hi) =
+        if (rT < R) {
+            if (dQ) *reinterpret_cast<float4*>(dQ + ((size_t)b * R + rT) * ELG_E + h * 16 + 4 * hi) =
                         make_float4(dq[0], dq[1], dq[2], dq[3]);
+            if (SEG) {
+                float* p1 = sSeg1 + 4 * hi * SNP + sgp;
+                atomicAdd(p1, dq[0]); atomicAdd(p1 + SNP, dq[1]); atomicAdd(p1 + 2 * SNP, dq[2]); atomicAdd(p1 + 3 * SNP, dq[3]);
+                if (seg.load) {
+                    // d wl: every row adds to the same 16 cells -- reduce over the tile's rows first (DPP row sums)
+                    const float l0 = row16_sum(sgl * dq[0]), l1 = row16_sum(sgl * dq[1]);
+                    const float l2 = row16_sum(sgl * dq[2]), l3 = row16_sum(sgl * dq[3]);
+                    if (lo == 0) {
+                        float* pl = sSeg1 + 4 * hi * SNP + 16 * NT;
+                        atomicAdd(pl, l0); atomicAdd(pl + SNP, l1); atomicAdd(pl + 2 * SNP, l2); atomicAdd(pl + 3 * SNP, l3);
+                    }
+                }
+                if (seg.idx_first) {
+                    float* p2 = sSeg2 + 4 * hi * SNP + sgf;
+                    atomicAdd(p2, dq[0]); atomicAdd(p2 + SNP, dq[1]); atomicAdd(p2 + 2 * SNP, dq[2]); atomicAdd(p2 + 3 * SNP, dq[3]);
+                }
+            }
+        }
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
 #pragma unroll
@@ -789,8 +832,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             doA[v] = doAn[v]; oA[v] = oAn[v]; doB[v] = doBn[v]; qB[v] = qBn[v];
             qA[v] = qAn[v]; mw[v][0] = mwn[v][0]; mw[v][1] = mwn[v][1];
         }
+        sgp = sgpn; sgf = sgfn; sgl = sgln;
     }
 #undef ELG_GB_LOAD
+    if (SEG) {
+        __syncthreads();                                            // every wave's LDS atomics are done
+        for (int i = threadIdx.x; i < N1 * 16; i += 256) {
+            const int n = i >> 4, d = i & 15;
+            const float v1 = sSeg1[d * SNP + n];
+            if (v1 != 0.f) atomicAdd(seg.dQ1 + ((size_t)b * N1 + n) * ELG_E + h * 16 + d, v1);
+            if (seg.dQ2) {
+                const float v2 = sSeg2[d * SNP + n];
+                if (v2 != 0.f) atomicAdd(seg.dQ2 + ((size_t)b * N1 + n) * ELG_E + h * 16 + d, v2);
+            }
+        }
+        if (seg.dwl && threadIdx.x < 16) atomicAdd(seg.dwl + h * 16 + threadIdx.x, sSeg1[threadIdx.x * SNP + 16 * NT]);
+        __syncthreads();                                            // the accumulators are dead: the buffer is reused below
+    }
     // ---- sum the four waves' dK_h / dV_h and write this split's partial (B,N1,128) image.
     // D rows are positions 4 hi + v of chunk nt; position -> node, owners only.
     float* my = sRed + (size_t)wave * (2 * NT * 256);
@@ -811,29 +869,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int g = grp_start(nt, q, N1) + (pos & 3);
         if (g >= 16 * nt + 4 * q) {                                 // owner (implies g < N1)
             float* out = which ? dVp : dKp;
-            out[(((size_t)split * B + b) * N1 + g) * ELG_E + h * 16 + d] = sum;
+            if (seg.accumulate) atomicAdd(out + ((size_t)b * N1 + g) * ELG_E + h * 16 + d, sum);
+            else out[(((size_t)split * B + b) * N1 + g) * ELG_E + h * 16 + d] = sum;
         }
     }
 }
 
-template <int NT, bool RECOMP>
-static int launch_glimpse_bwd_mfma(const float* rowA, const unsigned long long* rowMask, const float* dO, const float* rowO,
+template <int NT, bool RECOMP, bool SEG>
+static int launch_glimpse_bwd_mfma_t(const float* rowA, const unsigned long long* rowMask, const float* dO, const float* rowO,
                                    const float* rowQ, const float* Kmat, const float* Vmat, float* dQ, float* dKp,
                                    float* dVp, int B, int R, int N1, size_t ra, size_t ro, size_t rq, int splits,
-                                   hipStream_t stream) {
-    const size_t lds = (size_t)(NT * 256 + 4 * 2 * NT * 256 + 4 * 2 * 320 + (RECOMP ? NT * 256 : 0)) * sizeof(float);
-    auto kern = glimpse_bwd_mfma_kernel<NT, RECOMP>;
+                                   const GlimpseSeg& seg, hipStream_t stream) {
+    const size_t lds = (size_t)(NT * 256 + 4 * 2 * NT * 256 + 4 * 2 * 320 + (RECOMP ? NT * 256 : 0) +
+                                0) * sizeof(float);
+    auto kern = glimpse_bwd_mfma_kernel<NT, RECOMP, SEG>;
     static bool attr_done = false;
-    if (!attr_done && lds > 65536) {
+    if (!attr_done) {
         (void)hipGetLastError();
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
+                                (int)((NT * 256 * 10 + 4 * 2 * 320 + (32 * NT + 1) * 16) * sizeof(float))) != hipSuccess)
             return fail(ELG_ELAUNCH, "glimpse_bwd_fused: hipFuncSetAttribute failed");
         attr_done = true;
     }
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3(splits, B * 8), dim3(256), lds, stream, rowA, rowMask, dO, rowO, rowQ, Kmat, Vmat, dQ,
-                       dKp, dVp, B, R, N1, ra, ro, rq, splits);
+                       dKp, dVp, B, R, N1, ra, ro, rq, splits, seg);
     return launch_status("glimpse_bwd_fused");
 }
 
@@ -841,31 +901,53 @@ static int launch_glimpse_bwd_mfma(const float* rowA, const unsigned long long* 
 
 using namespace elg;
 
-extern "C" int elg_glimpse_bwd_fused(const float* rowA, const uint64_t* rowMask, const float* dO, const float* rowO,
-                                     const float* rowQ, const float* Kmat, const float* Vmat, float* dQ, float* dK_part,
-                                     float* dV_part, int B, int R, int N1, int64_t rowA_rows, int64_t rowO_rows,
-                                     int64_t rowQ_rows, int splits, void* stream) {
-    if ((!rowMask && rowA_rows < R) || rowO_rows < R || rowQ_rows < R)
+namespace elg {
+template <int NT, bool RECOMP>
+static int launch_glimpse_bwd_mfma(const float* rowA, const unsigned long long* rowMask, const float* dO, const float* rowO,
+                                   const float* rowQ, const float* Kmat, const float* Vmat, float* dQ, float* dKp,
+                                   float* dVp, int B, int R, int N1, size_t ra, size_t ro, size_t rq, int splits,
+                                   const GlimpseSeg& seg, hipStream_t stream) {
+    if (seg.idx_prev)
+        return launch_glimpse_bwd_mfma_t<NT, RECOMP, true>(rowA, rowMask, dO, rowO, rowQ, Kmat, Vmat, dQ, dKp, dVp, B, R, N1, ra,
+                                                           ro, rq, splits, seg, stream);
+    return launch_glimpse_bwd_mfma_t<NT, RECOMP, false>(rowA, rowMask, dO, rowO, rowQ, Kmat, Vmat, dQ, dKp, dVp, B, R, N1, ra, ro,
+                                                        rq, splits, seg, stream);
+}
+
+int glimpse_bwd_launch(const float* rowA, const unsigned long long* mk, const float* dO, const float* rowO, const float* rowQ,
+                       const float* Kmat, const float* Vmat, float* dQ, float* dK_part, float* dV_part, int B, int R, int N1,
+                       long long rowA_rows, long long rowO_rows, long long rowQ_rows, int splits, const GlimpseSeg& seg,
+                       hipStream_t s) {
+    if ((!mk && rowA_rows < R) || rowO_rows < R || rowQ_rows < R)
         return fail(ELG_EINVAL, "glimpse_bwd_fused: row strides smaller than R");
-    if (!rowA && !rowMask) return fail(ELG_EINVAL, "glimpse_bwd_fused: neither weights nor mask rows given");
+    if (!rowA && !mk) return fail(ELG_EINVAL, "glimpse_bwd_fused: neither weights nor mask rows given");
     if (B <= 0 || R <= 0 || N1 < 4 || splits <= 0) return fail(ELG_EINVAL, "glimpse_bwd_fused: bad sizes");
     if (N1 > 128) return fail(ELG_ENOTIMPL, "glimpse_bwd_fused: N1 > 128 not built (use elg_glimpse_rows_bwd)");
-    hipStream_t s = (hipStream_t)stream;
+    if (!dQ && !seg.idx_prev) return fail(ELG_EINVAL, "glimpse_bwd_fused: neither dQ nor the gather epilogue requested");
     const int nt = (N1 + 15) / 16;
-    const unsigned long long* mk = reinterpret_cast<const unsigned long long*>(rowMask);
 #define ELG_GB(NT)                                                                                                       \
     {                                                                                                                    \
         if (mk) return launch_glimpse_bwd_mfma<NT, true>(rowA, mk, dO, rowO, rowQ, Kmat, Vmat, dQ, dK_part, dV_part, B,  \
                                                          R, N1, (size_t)rowA_rows, (size_t)rowO_rows, (size_t)rowQ_rows, \
-                                                         splits, s);                                                     \
+                                                         splits, seg, s);                                                \
         return launch_glimpse_bwd_mfma<NT, false>(rowA, mk, dO, rowO, rowQ, Kmat, Vmat, dQ, dK_part, dV_part, B, R, N1,  \
-                                                  (size_t)rowA_rows, (size_t)rowO_rows, (size_t)rowQ_rows, splits, s);   \
+                                                  (size_t)rowA_rows, (size_t)rowO_rows, (size_t)rowQ_rows, splits, seg, s); \
     }
     if (nt <= 2) ELG_GB(2)
     if (nt <= 4) ELG_GB(4)
     if (nt <= 7) ELG_GB(7)
     ELG_GB(8)
 #undef ELG_GB
+}
+}  // namespace elg
+
+extern "C" int elg_glimpse_bwd_fused(const float* rowA, const uint64_t* rowMask, const float* dO, const float* rowO,
+                                     const float* rowQ, const float* Kmat, const float* Vmat, float* dQ, float* dK_part,
+                                     float* dV_part, int B, int R, int N1, int64_t rowA_rows, int64_t rowO_rows,
+                                     int64_t rowQ_rows, int splits, void* stream) {
+    GlimpseSeg seg{};
+    return glimpse_bwd_launch(rowA, reinterpret_cast<const unsigned long long*>(rowMask), dO, rowO, rowQ, Kmat, Vmat, dQ,
+                              dK_part, dV_part, B, R, N1, rowA_rows, rowO_rows, rowQ_rows, splits, seg, (hipStream_t)stream);
 }
 
 extern "C" int elg_glimpse_rows_bwd(const float* rowA, const float* dO, const float* rowO, const float* Kmat,

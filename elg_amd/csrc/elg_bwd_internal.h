@@ -1,0 +1,28 @@
+// Internal (not part of the C ABI): pieces of the decoder backward shared between csrc/elg_bwd.hip and csrc/elg_dbwd.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace elg {
+
+// Optional epilogue: the query-gather backward (d Q1[node] = sum of dQ over the rows whose query was gathered at that node,
+// d Q2 likewise for the tour's first node, d wl = sum_r load_r dQ_r) taken from the dQ tile while it is still in
+// registers: LDS float atomics into a (N1 + 1) x 16 accumulator per (instance, head), flushed once per workgroup with
+// global atomics.  dQ then never reaches memory (it was 0.4 GB written + a one-hot GEMM over (B,R,N1+1) to read it back).
+struct GlimpseSeg {
+    const int* idx_prev;    // (B,R) node the row's query was gathered at, or NULL: no epilogue
+    const int* idx_first;   // (B,R) TSP: first node of the tour, or NULL
+    const float* load;      // (B,load_rows) CVRP: vehicle load of the row, or NULL
+    float* dQ1;             // (B,N1,128) accumulated (caller zeroes)
+    float* dQ2;             // (B,N1,128) or NULL
+    float* dwl;             // (128) or NULL
+    long long load_rows;
+    int accumulate;         // 1: dK / dV are added to dKp / dVp (B,N1,128, caller zeroes) instead of written per split
+};
+
+
+int glimpse_bwd_launch(const float* rowA, const unsigned long long* mk, const float* dO, const float* rowO, const float* rowQ,
+                       const float* Kmat, const float* Vmat, float* dQ, float* dK_part, float* dV_part, int B, int R, int N1,
+                       long long rowA_rows, long long rowO_rows, long long rowQ_rows, int splits, const GlimpseSeg& seg,
+                       hipStream_t s);
+
+}  // namespace elg

@@ -421,15 +421,18 @@ class _ChosenProbs(torch.autograd.Function):
         dev = Kt.device
         B, N1 = prob.B, prob.N1
         R = M * T
+        g = gprob[:, :T, :].contiguous().float()
+        rows = ctx.rows
+        use_saved = rows is not None and rows.gen == ctx.rows_gen and T <= rows.Tcap
+        if use_saved:
+            return _ChosenProbs._backward_saved_rows(ctx, g, rows)
         tables = dict(K=Kt, V=Vt, PK=PKt, pb=pbt, Q1=Q1t, Q2=Q2t if hasQ2 else None, wl=wlt if haswl else None)
         pol = Policy(tables, loct if hasloc else None, meta.K, meta.xi, meta.clip, meta.inv_ens, meta.has_local,
                      meta.has_penalty)
         forced = actions[:, :, :T].contiguous()
         fl = forced.long()
-        g = gprob[:, :T, :].contiguous().float()
-        rows = ctx.rows
-        use_saved = rows is not None and rows.gen == ctx.rows_gen and T <= rows.Tcap
-        join_side = None
+        # ---- replay path (rollouts that were not run as a training forward, N1 > 128): the recorded actions are replayed
+        # inside rollout_bwd_kernel (rows r = m*T + t), dense contractions on the rows it emits
         ba = L.BwdArgs()
         _fill_common(ba.fwd, prob, pol, M, ctx.geometry)
         ba.fwd.Tmax, ba.fwd.mode, ba.fwd.max_steps, ba.fwd.do_decode, ba.fwd.do_update = T, L.MODE_FORCED, 0, 1, 1
@@ -437,126 +440,118 @@ class _ChosenProbs(torch.autograd.Function):
         ba.T = T
         gloc = torch.zeros(L.LOC_SIZE, device=dev)
         ba.gloc = _ptr(gloc)
-        if use_saved:
-            # rows saved by the training forward (time-major r = t*M + m): no glimpse replay needed
-            rowA, rowO_rows = (None if rows.use_mask else rows.A), rows.Rcap
-            rowMask = rows.Mask if rows.use_mask else None
-            rowO, rowQ = rows.O, rows.Q[:, :R]
-            t0 = 1 if prob.kind == L.PROBLEM_TSP else 2
-            # one launch: row weights (decoded steps only), d loss / d score rows, local-policy cotangents and
-            # the query-gather scatter matrices
-            rowDL = torch.empty(B, R, N1, device=dev)
-            rowDU = torch.empty(B, R, 48, device=dev) if meta.has_local else None
-            # node the query of the row was gathered at (and the tour's first node for TSP): plain indices, the
-            # one-hot operand of the gather backward is built in registers (elg_rows_segsum)
-            # ELG_SEGSUM=1: d Q1 through elg_rows_segsum (one-hot operand built in registers, no (B,R,N1) matrix);
-            # measured 0.25-0.55 ms against 0.21 ms for the library GEMM + 0.1 ms for writing the matrix: off
-            seg = os.environ.get("ELG_SEGSUM", "0") == "1"
-            idxP = torch.empty(B, R, device=dev, dtype=torch.int32) if seg else None
-            idxF = torch.empty(B, R, device=dev, dtype=torch.int32) if (hasQ2 and seg) else None
-            onehotP = None if seg else torch.empty(B, R, N1 + (1 if haswl else 0), device=dev)
-            onehotF = None if (seg or not hasQ2) else torch.empty(B, R, N1, device=dev)
-            L.check(L.lib().elg_rows_prep(_ptr(g), _ptr(ctx.probs_out), _ptr(ctx.tlen), _ptr(actions), _ptr(rows.PC),
-                                          _ptr(rows.Csel), _ptr(rows.Slot), None if seg or not haswl else _ptr(rows.Load),
-                                          _ptr(rowDL), _ptr(rowDU), _ptr(onehotP), _ptr(onehotF),
-                                          _ptr(idxP), _ptr(idxF), B, T, M, N1, actions.shape[2], rows.Rcap, t0,
-                                          float(meta.inv_ens), _stream()), "elg_rows_prep")
-            rowLoad = rows.Load[:, :R] if haswl else None
-            if meta.has_local and os.environ.get("ELG_LOCAL_BWD_MFMA", "1") != "0":
-                # rows are independent given the saved slot features: 16 rows per wavefront on the matrix cores
-                n_slots = meta.K + (0 if prob.kind == L.PROBLEM_TSP else 1)
-                L.check(L.lib().elg_local_bwd_rows(_ptr(loct), _ptr(rows.F), _ptr(rows.Slot), _ptr(rowDU), _ptr(gloc),
-                                                   B, R, rows.Rcap, n_slots, _stream()), "elg_local_bwd_rows")
-            elif meta.has_local:
-                ba.rowDU, ba.time_major, ba.local_only, ba.row_stride = _ptr(rowDU), 1, 1, R
-                # per-trajectory replay of the environment + local policy (register accumulators), side stream
-                side = _side_stream(dev)
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    L.check(L.lib().elg_rollout_bwd(C.byref(ba), _stream()), "elg_rollout_bwd(local)")
-                join_side = side
-            rowA_rows = rows.Rcap
-            rowA_v = None if rows.use_mask else rows.A[:, :, :R]
-            rowO_v = rows.O[:, :R]
-        else:
-            rowA = torch.empty(B, H, R, N1, device=dev)
-            rowDL = torch.empty(B, R, N1, device=dev)
-            rowQ = torch.empty(B, R, E, device=dev)
-            rowO = torch.empty(B, R, E, device=dev)
-            rowLoad = torch.empty(B, R, device=dev) if haswl else None
-            rowDU = torch.empty(B, R, 48, device=dev) if meta.has_local else None
-            ba.gprob = _ptr(g)
-            ba.rowA, ba.rowDL, ba.rowQ, ba.rowO = _ptr(rowA), _ptr(rowDL), _ptr(rowQ), _ptr(rowO)
-            ba.rowLoad, ba.rowDU = _ptr(rowLoad), _ptr(rowDU)
-            L.check(L.lib().elg_rollout_bwd(C.byref(ba), _stream()), "elg_rollout_bwd")
-            rowA_rows = rowO_rows = R
-            rowA_v, rowO_v = rowA, rowO
-            rowMask = None
-            # the query of decode step t was gathered at cur = action[t-1] (and first = action[0] for TSP)
-            prev = torch.cat([torch.zeros(B, M, 1, dtype=torch.long, device=dev), fl[:, :, :-1]], dim=2).reshape(B, R)
-            first = fl[:, :, :1].expand(B, M, T).reshape(B, R) if hasQ2 else None
-        # ---- dense part: glimpse / pointer backward over the R decode rows of every instance
-        # (batched GEMMs on the matrix cores + one fused row kernel; formulas in include/elg_hip.h)
+        rowA = torch.empty(B, H, R, N1, device=dev)
+        rowDL = torch.empty(B, R, N1, device=dev)
+        rowQ = torch.empty(B, R, E, device=dev)
+        rowO = torch.empty(B, R, E, device=dev)
+        rowLoad = torch.empty(B, R, device=dev) if haswl else None
+        rowDU = torch.empty(B, R, 48, device=dev) if meta.has_local else None
+        ba.gprob = _ptr(g)
+        ba.rowA, ba.rowDL, ba.rowQ, ba.rowO = _ptr(rowA), _ptr(rowDL), _ptr(rowQ), _ptr(rowO)
+        ba.rowLoad, ba.rowDU = _ptr(rowLoad), _ptr(rowDU)
+        L.check(L.lib().elg_rollout_bwd(C.byref(ba), _stream()), "elg_rollout_bwd")
+        # the query of decode step t was gathered at cur = action[t-1] (and first = action[0] for TSP)
+        prev = torch.cat([torch.zeros(B, M, 1, dtype=torch.long, device=dev), fl[:, :, :-1]], dim=2).reshape(B, R)
+        first = fl[:, :, :1].expand(B, M, T).reshape(B, R) if hasQ2 else None
+
         def heads(x):                                               # (B,X,128) -> (B,H,X,16)
             return x.view(B, x.shape[1], H, DK).permute(0, 2, 1, 3)
         dO = torch.bmm(rowDL, PKt)                                  # (B,R,128)   d o = d s . PK
         dQ = torch.empty(B, R, E, device=dev)
-        if N1 <= 128 and (rowMask is not None or os.environ.get("ELG_FUSED_GLIMPSE_BWD", "1") != "0"):
-            # one MFMA launch: dS stays in registers, dQ / dK / dV come out directly
+        if N1 <= 128:
             splits = max(1, min(8, 1024 // (B * H)))
             dKp = torch.empty(splits, B, N1, E, device=dev)
             dVp = torch.empty(splits, B, N1, E, device=dev)
-            L.check(L.lib().elg_glimpse_bwd_fused(_ptr(rowA), _ptr(rowMask), _ptr(dO), _ptr(rowO), _ptr(rowQ), _ptr(Kt), _ptr(Vt),
-                                                  _ptr(dQ), _ptr(dKp), _ptr(dVp), B, R, N1, rowA_rows, rowO_rows,
-                                                  rowQ.stride(0) // E, splits, _stream()), "elg_glimpse_bwd_fused")
+            L.check(L.lib().elg_glimpse_bwd_fused(_ptr(rowA), None, _ptr(dO), _ptr(rowO), _ptr(rowQ), _ptr(Kt), _ptr(Vt),
+                                                  _ptr(dQ), _ptr(dKp), _ptr(dVp), B, R, N1, R, R, R, splits, _stream()),
+                    "elg_glimpse_bwd_fused")
             dK = dKp[0] if splits == 1 else dKp.sum(0)
             dV = dVp[0] if splits == 1 else dVp.sum(0)
         else:
             dS = torch.empty(B, H, R, N1, device=dev)               # d(q.K)
             L.check(L.lib().elg_glimpse_rows_bwd(_ptr(rowA), _ptr(dO), _ptr(rowO), _ptr(Kt), _ptr(Vt), _ptr(dS),
-                                                 _ptr(dQ), B, R, N1, rowA_rows, rowO_rows, _stream()),
-                    "elg_glimpse_rows_bwd")
+                                                 _ptr(dQ), B, R, N1, R, R, _stream()), "elg_glimpse_rows_bwd")
             dK = torch.matmul(dS.transpose(2, 3), heads(rowQ)).permute(0, 2, 1, 3).reshape(B, N1, E)
-            dV = torch.matmul(rowA_v.transpose(2, 3), heads(dO)).permute(0, 2, 1, 3).reshape(B, N1, E)
-        dPK = torch.bmm(rowDL.transpose(1, 2), rowO_v)
+            dV = torch.matmul(rowA.transpose(2, 3), heads(dO)).permute(0, 2, 1, 3).reshape(B, N1, E)
+        dPK = torch.bmm(rowDL.transpose(1, 2), rowO)
         dpb = rowDL.sum(dim=1)
-        # dQ1[n] = sum of dQ over the rows whose query was gathered at node n: a one-hot GEMM (deterministic,
-        # and ~4x faster than 1.6 M float atomics into 100 rows)
         dQ2 = dwl = None
-        if use_saved and not seg:
-            dQ1 = torch.bmm(onehotP.transpose(1, 2), dQ)
-            if hasQ2:
-                dQ2 = torch.bmm(onehotF.transpose(1, 2), dQ)
-            if haswl:
-                dwl = dQ1[:, N1].sum(dim=0)
-                dQ1 = dQ1[:, :N1]
-        elif use_saved:
-            def segsum(idx, with_load):
-                no = N1 + (1 if with_load else 0)
-                sp = max(1, min(8, 256 // B))
-                part = torch.empty(sp, B, no, E, device=dev)
-                L.check(L.lib().elg_rows_segsum(_ptr(dQ), _ptr(idx), _ptr(rows.Load) if with_load else None, _ptr(part),
-                                                B, R, no, N1 if with_load else -1, rows.Rcap, sp, _stream()),
-                        "elg_rows_segsum")
-                return part[0] if sp == 1 else part.sum(0)
-            dQ1 = segsum(idxP, haswl)
-            if haswl:
-                dwl = dQ1[:, N1].sum(dim=0)                          # the load row
-                dQ1 = dQ1[:, :N1]
-            if hasQ2:
-                dQ2 = segsum(idxF, False)
-        else:
-            onehotP = torch.zeros(B, R, N1, device=dev).scatter_(2, prev[:, :, None], 1.0)
-            dQ1 = torch.bmm(onehotP.transpose(1, 2), dQ)
-            if hasQ2:
-                onehotF = torch.zeros(B, R, N1, device=dev).scatter_(2, first[:, :, None], 1.0)
-                dQ2 = torch.bmm(onehotF.transpose(1, 2), dQ)
-            if haswl:
-                dwl = torch.einsum("br,bre->e", rowLoad, dQ)
-        if join_side is not None:
-            torch.cuda.current_stream().wait_stream(join_side)
+        onehotP = torch.zeros(B, R, N1, device=dev).scatter_(2, prev[:, :, None], 1.0)
+        dQ1 = torch.bmm(onehotP.transpose(1, 2), dQ)
+        if hasQ2:
+            onehotF = torch.zeros(B, R, N1, device=dev).scatter_(2, first[:, :, None], 1.0)
+            dQ2 = torch.bmm(onehotF.transpose(1, 2), dQ)
+        if haswl:
+            dwl = torch.einsum("br,bre->e", rowLoad, dQ)
         return (None, None, None, None, None, None, None,
                 dK, dV, dPK, dpb, dQ1, dQ2, dwl, gloc if hasloc else None, None, None, None)
+
+    @staticmethod
+    def _backward_saved_rows(ctx, g, rows):
+        """Training path: elg_decoder_bwd over the rows the forward saved (+ elg_local_bwd_rows) -- two calls into
+        libelg_hip.so, no framework kernels besides the zero fill of the gradient buffer."""
+        actions, Kt, Vt, PKt, pbt, Q1t, Q2t, wlt, loct = ctx.saved_tensors
+        hasQ2, haswl, hasloc = ctx.has
+        prob, meta, M, T = ctx.prob, ctx.pol_meta, ctx.M, ctx.T
+        dev = Kt.device
+        B, N1 = prob.B, prob.N1
+        R = M * T
+        tsp = prob.kind == L.PROBLEM_TSP
+        # one zero-filled buffer for every accumulated output: dK dV dPK dQ1 [dQ2] | dpb | dwl | gloc
+        nt = 5 if hasQ2 else 4
+        flat = torch.zeros(nt * B * N1 * E + B * N1 + E + L.LOC_SIZE, device=dev)
+        blk = B * N1 * E
+        dK, dV, dPK, dQ1 = (flat[i * blk:(i + 1) * blk].view(B, N1, E) for i in range(4))
+        dQ2 = flat[4 * blk:5 * blk].view(B, N1, E) if hasQ2 else None
+        o = nt * blk
+        dpb = flat[o:o + B * N1].view(B, N1)
+        dwl = flat[o + B * N1:o + B * N1 + E]
+        gloc = flat[o + B * N1 + E:]
+        ws = _BwdScratch.get(B, rows.Rcap, dev, meta.has_local, hasQ2)        # sized for Rcap, used densely over R rows
+        a = L.DecoderBwdArgs()
+        a.problem, a.B, a.M, a.N1, a.T, a.Tcap_actions = prob.kind, B, M, N1, T, actions.shape[2]
+        a.first_decode_step, a.inv_ens, a.Rcap = (1 if tsp else 2), float(meta.inv_ens), rows.Rcap
+        a.gprob, a.pval, a.tlen, a.actions = _ptr(g), _ptr(ctx.probs_out), _ptr(ctx.tlen), _ptr(actions)
+        a.trPC, a.trCsel, a.trQ, a.trO = _ptr(rows.PC), _ptr(rows.Csel), _ptr(rows.Q), _ptr(rows.O)
+        a.trLoad = _ptr(rows.Load) if haswl else None
+        a.trSlot = _ptr(rows.Slot) if meta.has_local else None
+        a.trA = None if rows.use_mask else _ptr(rows.A)
+        a.trMask = _ptr(rows.Mask) if rows.use_mask else None
+        a.Kmat, a.Vmat, a.PK = _ptr(Kt), _ptr(Vt), _ptr(PKt)
+        a.dK, a.dV, a.dPK, a.dpb, a.dQ1, a.dQ2 = _ptr(dK), _ptr(dV), _ptr(dPK), _ptr(dpb), _ptr(dQ1), _ptr(dQ2)
+        a.dwl = _ptr(dwl) if haswl else None
+        a.rowDU = _ptr(ws.rowDU) if meta.has_local else None
+        a.dO, a.idx_prev, a.idx_first, a.rowW = _ptr(ws.dO), _ptr(ws.idx_prev), _ptr(ws.idx_first), _ptr(ws.rowW)
+        L.check(L.lib().elg_decoder_bwd(C.byref(a), _stream()), "elg_decoder_bwd")
+        if meta.has_local:
+            # rows are independent given the saved slot features: 16 rows per wavefront on the matrix cores
+            n_slots = meta.K + (0 if tsp else 1)
+            L.check(L.lib().elg_local_bwd_rows(_ptr(loct), _ptr(rows.F), _ptr(rows.Slot), _ptr(ws.rowDU), _ptr(gloc),
+                                               B, R, rows.Rcap, n_slots, _stream()), "elg_local_bwd_rows")
+        return (None, None, None, None, None, None, None,
+                dK, dV, dPK, dpb, dQ1, dQ2, dwl if haswl else None, gloc if hasloc else None, None, None, None)
+
+
+class _BwdScratch:
+    """Scratch of the saved-rows backward, cached per shape (dO, the gather indices, the local-policy cotangents)."""
+    _cache: Dict[tuple, "_BwdScratch"] = {}
+
+    def __init__(self, B, R, dev, local, first):
+        self.dO = torch.empty(B, R, E, device=dev)
+        self.idx_prev = torch.empty(B, R, device=dev, dtype=torch.int32)
+        self.rowW = torch.empty(B, R, 4, device=dev)
+        self.idx_first = torch.empty(B, R, device=dev, dtype=torch.int32) if first else None
+        self.rowDU = torch.empty(B, R, 48, device=dev) if local else None
+
+    @classmethod
+    def get(cls, B, R, dev, local, first):
+        key = (B, R, str(dev), bool(local), bool(first))
+        ws = cls._cache.get(key)
+        if ws is None:
+            if len(cls._cache) > 8:
+                cls._cache.clear()
+            ws = cls._cache[key] = _BwdScratch(B, R, dev, local, first)
+        return ws
 
 
 def chosen_probs(prob: Problem, pol: Policy, M: int, res: RolloutResult, T: int, geometry=None) -> torch.Tensor:
@@ -654,7 +649,7 @@ def _teardown():
             torch.cuda.synchronize()
     except Exception:
         pass
-    for cache in (_PINNED, TrainRows._cache, _SIDE):
+    for cache in (_PINNED, TrainRows._cache, _BwdScratch._cache, _SIDE):
         cache.clear()
 
 

@@ -346,6 +346,47 @@ int elg_check_feasible(const int64_t* pi, int64_t m_stride, const float* demand,
  * caller zeroes.  tlen (B,M), probs (B,Tcap,M). */
 int elg_rollout_stats(const int32_t* tlen, const float* probs, int B, int M, int Tcap, int32_t* stats, void* stream);
 
+/* ---- decoder backward over the rows saved by a training forward (elg_rollout_args.tr*, time-major r = t*M + m) ----
+ * Autograd of the chosen-node probabilities (CVRP/models.py:322-423 under train.py:112-125) w.r.t. the decoder tables:
+ *   w_r = gprob * pval * [first_decode_step <= t < tlen[b,m]]
+ *   dl[r,n] = w_r (Csel_r [n == action_r] - PC[r,n])          d loss / d (pre-clip score), kept on chip
+ *   dO = dl PK,  dPK += dl^T O,  dpb += sum_r dl,  rowDU[r,j] = dl[r, Slot[r,j]] * inv_ens
+ *   glimpse attention backward (dK, dV) from dO, and the query-gather backward
+ *   dQ1[n] += sum_{r: prev node = n} dQ_r,  dQ2[n] += sum_{r: first node = n} dQ_r (TSP),  dwl += sum_r load_r dQ_r (CVRP)
+ * Every d* output is ACCUMULATED with atomics: the caller zero-fills.  N1 <= 128. */
+typedef struct elg_decoder_bwd_args {
+    int32_t problem, B, M, N1;
+    int32_t T;                  /* decode steps covered (R = T*M rows per instance)                               */
+    int32_t Tcap_actions;       /* time extent of `actions`                                                       */
+    int32_t first_decode_step;  /* 2 (CVRP: depot, POMO start) or 1 (TSP)                                         */
+    float inv_ens;              /* 1 / ensemble_size                                                              */
+    int64_t Rcap;               /* rows per instance in the tr* buffers (>= R)                                    */
+    const float* gprob;         /* (B,T,M) d loss / d prob                                                        */
+    const float* pval;          /* (B,T,M) the chosen probabilities                                               */
+    const int32_t* tlen;        /* (B,M)                                                                          */
+    const int32_t* actions;     /* (B,M,Tcap_actions)                                                             */
+    const float* trPC;          /* (B,Rcap,N1)   as saved by elg_rollout_fwd                                      */
+    const float* trCsel;        /* (B,Rcap)                                                                       */
+    const float* trQ;           /* (B,Rcap,128)                                                                   */
+    const float* trO;           /* (B,Rcap,128)                                                                   */
+    const float* trLoad;        /* (B,Rcap) CVRP                                                                  */
+    const int32_t* trSlot;      /* (B,Rcap,48) or NULL (no local policy)                                          */
+    const float* trA;           /* (B,8,Rcap,N1) glimpse weights, or NULL if trMask is given                      */
+    const uint64_t* trMask;     /* (B,Rcap,2) mask words: the weights are recomputed from trQ, Kmat               */
+    const float *Kmat, *Vmat, *PK;          /* (B,N1,128) decoder tables                                          */
+    float *dK, *dV, *dPK;       /* (B,N1,128) out (+=)                                                            */
+    float* dpb;                 /* (B,N1) out (+=)                                                                */
+    float* dQ1;                 /* (B,N1,128) out (+=)                                                            */
+    float* dQ2;                 /* (B,N1,128) out (+=), TSP                                                       */
+    float* dwl;                 /* (128) out (+=), CVRP                                                           */
+    float* rowDU;               /* (B,R,48) out (written) for elg_local_bwd_rows, or NULL                         */
+    float* dO;                  /* (B,R,128) scratch                                                              */
+    int32_t* idx_prev;          /* (B,R) scratch                                                                  */
+    int32_t* idx_first;         /* (B,R) scratch, TSP                                                             */
+    float* rowW;                /* (B,R,4) scratch, 16-byte aligned                                               */
+} elg_decoder_bwd_args;
+int elg_decoder_bwd(const elg_decoder_bwd_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,6 +107,7 @@ def test_encoder_backward_matches_oracle_autograd(problem, B, N1):
     loss_g.backward()
     assert abs(float(loss_g.detach()) - loss64) <= 1e-4 * abs(loss64) + 1e-3
     worst = {}
+    gmax = max(np.abs(v).max() for v in g64.values())
     for n, p in zip(names, params):
         ref = g64[n]
         got = p.grad.cpu().double().numpy()
@@ -114,7 +115,8 @@ def test_encoder_backward_matches_oracle_autograd(problem, B, N1):
         err = np.abs(got - ref).max()
         err32 = np.abs(g32[n] - ref).max()
         worst[n] = err / max(scale, 1e-30)
-        assert err <= max(1e-4 * scale, 4.0 * err32), (n, err, err32, scale)
+        # (1e-6 of the model's largest gradient entry: the rounding floor of sums whose exact value is ~0)
+        assert err <= max(1e-4 * scale, 4.0 * err32, 1e-6 * gmax), (n, err, err32, scale, gmax)
     top = sorted(((k, v) for k, v in worst.items() if v < 1.0), key=lambda kv: -kv[1])[:3]
     print("largest gradient errors (relative to the tensor's max):", [(k, f"{v:.2e}") for k, v in top])
 
