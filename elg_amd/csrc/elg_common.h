@@ -32,6 +32,30 @@ __device__ __forceinline__ float quad_bcast(float v) { return dpp<J * 0x55>(v); 
 __device__ __forceinline__ float shfl_xor(float v, int m) { return __shfl_xor(v, m, ELG_WAVE); }
 __device__ __forceinline__ int shfl_xor(int v, int m) { return __shfl_xor(v, m, ELG_WAVE); }
 
+// lane i <-> lane i ^ 16 / i ^ 32 all-reduce steps on the VALU (gfx950 v_permlane16_swap / v_permlane32_swap: with both
+// operands = v, the pair returned holds {rows 0,0,2,2 | rows 1,1,3,3} resp. {lower half twice | upper half twice}); the
+// ds_bpermute route of __shfl_xor costs an LDS round trip per step
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float x16_sum(float v) {
+    const u32x2_t r = __builtin_amdgcn_permlane16_swap((unsigned)f2i(v), (unsigned)f2i(v), false, false);
+    return i2f((int)r[0]) + i2f((int)r[1]);
+}
+__device__ __forceinline__ float x32_sum(float v) {
+    const u32x2_t r = __builtin_amdgcn_permlane32_swap((unsigned)f2i(v), (unsigned)f2i(v), false, false);
+    return i2f((int)r[0]) + i2f((int)r[1]);
+}
+__device__ __forceinline__ float x16_max(float v) {
+    const u32x2_t r = __builtin_amdgcn_permlane16_swap((unsigned)f2i(v), (unsigned)f2i(v), false, false);
+    return fmaxf(i2f((int)r[0]), i2f((int)r[1]));
+}
+__device__ __forceinline__ float x32_max(float v) {
+    const u32x2_t r = __builtin_amdgcn_permlane32_swap((unsigned)f2i(v), (unsigned)f2i(v), false, false);
+    return fmaxf(i2f((int)r[0]), i2f((int)r[1]));
+}
+// sum / max over the four lanes {i, i ^ 16, i ^ 32, i ^ 48} (the four "quarters" holding one MFMA column)
+__device__ __forceinline__ float quarters_sum(float v) { return x32_sum(x16_sum(v)); }
+__device__ __forceinline__ float quarters_max(float v) { return x32_max(x16_max(v)); }
+
 // row (16-lane) all-reduce with DPP only: quad butterflies, then row_half_mirror / row_mirror
 __device__ __forceinline__ float row16_sum(float v) {
     v += quad_xor1(v);

@@ -1055,7 +1055,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
     I.loc = A.loc;
 
     // ---- step-invariant MFMA operands in registers
-    // glimpse: wave = head h.  kop[nt][kk] = K[n = 16 nt + lo][16 h + 4 kk + hi]   (A operand of S^T = K Q^T)
+    // glimpse: wave = head h.  kop[nt][kk] = K[n = 16 nt + lo][16 h + 4 hi + kk]   (A operand of S^T = K Q^T)
     //                         vop[nt][v]  = V[n = 16 nt + 4 hi + v][16 h + lo]     (A operand of O^T = V^T P^T)
     // pointer: wave = node tile w (w < 7).  pop[s] = PK[n = 16 w + lo][4 s + hi]   (A operand of s^T = PK o^T)
     const float* gK = A.Kmat + b * NE + wave * 16;
@@ -1063,8 +1063,11 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
 #define ELG_CO_LOAD_KV()                                                                                   \
     _Pragma("unroll") for (int nt = 0; nt < CO_NT; ++nt) {                                                  \
         const int n = 16 * nt + lo_t;                                                                       \
-        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                    \
-            kop[nt][kk] = gK[(unsigned)(min(n, N1 - 1) * ELG_E + 4 * kk + hi_t)] * ((n < N1) ? 1.f : 0.f); \
+        {   /* one 16-byte load: channels 4 hi .. 4 hi + 3 (the MFMA visits the 16 channels in the order 4 hi + kk) */ \
+            const float4 k4_ = *reinterpret_cast<const float4*>(gK + (unsigned)(min(n, N1 - 1) * ELG_E + 4 * hi_t));   \
+            const float mk_ = (n < N1) ? 1.f : 0.f;                                                         \
+            kop[nt][0] = k4_.x * mk_; kop[nt][1] = k4_.y * mk_; kop[nt][2] = k4_.z * mk_; kop[nt][3] = k4_.w * mk_; \
+        }                                                                                                   \
         _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                                     \
             const int n2 = 16 * nt + 4 * hi_t + v;                                                          \
             vop[nt][v] = gV[(unsigned)(min(n2, N1 - 1) * ELG_E + lo_t)] * ((n2 < N1) ? 1.f : 0.f);         \
@@ -1108,7 +1111,11 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
         for (int nt = 0; nt < CO_NT; ++nt)
 #pragma unroll
             for (int v = 0; v < 4; ++v) { kop[nt][v] = 0.f; vop[nt][v] = 0.f; }
+        long long pc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const bool prof_ = A.dump_T == -7;
         for (int t = 0; t < step_cap && t < A.Tmax; ++t) {
+            long long c0_ = prof_ ? clock64() : 0;
+#define PCLK(i) if (prof_) { const long long c_ = clock64(); pc_[i] += c_ - c0_; c0_ = c_; }
             // Opaque per-iteration copy of the lane id: every address below is a function of it, so the compiler cannot
             // hoist the (loop-invariant) address arithmetic of ~300 loads out of the step loop -- it did, and then
             // spilled ~250 VGPRs of precomputed 64-bit addresses; recomputing them costs a few hundred VALU ops a step.
@@ -1127,50 +1134,54 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                     const int traj = 16 * rt + lo_t;
                     const float* qrow = sQ + traj * CO_QP + 16 * wave;
                     float qb[4];
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) qb[kk] = qrow[4 * kk + hi_t];
-                    const unsigned long long w0 = sMask[2 * traj], w1 = sMask[2 * traj + 1];
+                    {
+                        const float4 q4 = *reinterpret_cast<const float4*>(qrow + 4 * hi_t);     // channels 4 hi + kk, as kop
+                        qb[0] = q4.x; qb[1] = q4.y; qb[2] = q4.z; qb[3] = q4.w;
+                    }
+                    // the trajectory's mask as four dwords; this lane's nodes of chunk nt are bits 4 hi .. 4 hi + 3 of the
+                    // chunk's 16-bit slice (nodes past N1 are closed in the mask words themselves)
+                    const uint4 mwords = *reinterpret_cast<const uint4*>(sMask + 2 * traj);
                     f32x4c sc[CO_NT];
-                    float mx = ELG_NEG_INF;
+                    float mx = -1e30f;                                  // finite floor: a fully closed row gives exp2(-inf) = 0
 #pragma unroll
                     for (int nt = 0; nt < CO_NT; ++nt) {
                         f32x4c acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kop[nt][kk], qb[kk], acc, 0, 0, 0);
+                        const unsigned dw = (nt >> 1) == 0 ? mwords.x : (nt >> 1) == 1 ? mwords.y : (nt >> 1) == 2 ? mwords.z : mwords.w;
+                        const unsigned nib = (dw >> (16 * (nt & 1) + 4 * hi_t)) & 0xFu;
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
-                            const int n = 16 * nt + 4 * hi_t + v;
-                            const unsigned long long w = (nt < 4) ? w0 : w1;
-                            const bool masked = (n >= N1) || ((w >> (n & 63)) & 1ull);
-                            const float x = masked ? ELG_NEG_INF : acc[v] * 0.25f;
+                            const float x = (nib & (1u << v)) ? ELG_NEG_INF : acc[v];
                             acc[v] = x;
                             mx = fmaxf(mx, x);
                         }
                         sc[nt] = acc;
                     }
-                    mx = fmaxf(mx, shfl_xor(mx, 16));
-                    mx = fmaxf(mx, shfl_xor(mx, 32));
+                    mx = quarters_max(mx);
+                    // softmax of q.k / 4: exp2((s - max) * log2(e) / 4) as one fma + v_exp
+                    const float cs = 0.25f * 1.4426950408889634f, cm = -mx * cs;
                     float den = 0.f;
 #pragma unroll
                     for (int nt = 0; nt < CO_NT; ++nt)
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
-                            const float e = (sc[nt][v] > ELG_NEG_INF) ? __expf(sc[nt][v] - mx) : 0.f;
+                            const float e = __builtin_amdgcn_exp2f(fmaf(sc[nt][v], cs, cm));
                             sc[nt][v] = e;
                             den += e;
                         }
-                    den += shfl_xor(den, 16);
-                    den += shfl_xor(den, 32);
+                    den = quarters_sum(den);
                     const bool live = den > 0.f;                    // a decoding trajectory has an open node
                     const float inv = live ? 1.0f / den : 0.f;
-                    f32x4c o = {0.f, 0.f, 0.f, 0.f};
+                    f32x4c o = {0.f, 0.f, 0.f, 0.f}, o2 = {0.f, 0.f, 0.f, 0.f};      // two chains: dependent MFMAs stall
                     const size_t r = (size_t)t * A.M + g_lo + traj;
 #pragma unroll
                     for (int nt = 0; nt < CO_NT; ++nt) {
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
                             sc[nt][v] *= inv;
-                            o = __builtin_amdgcn_mfma_f32_16x16x4f32(vop[nt][v], sc[nt][v], o, 0, 0, 0);
+                            if (v & 1) o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vop[nt][v], sc[nt][v], o2, 0, 0, 0);
+                            else o = __builtin_amdgcn_mfma_f32_16x16x4f32(vop[nt][v], sc[nt][v], o, 0, 0, 0);
                         }
                         if (TRAIN && live && A.trA) {
                             float* rA = A.trA + (((size_t)b * ELG_H + wave) * Rcap + r) * N1 + 16 * nt + 4 * hi_t;
@@ -1181,13 +1192,16 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                                 if (16 * nt + 4 * hi_t + v < N1) rA[v] = sc[nt][v];
                         }
                     }
+                    o[0] += o2[0]; o[1] += o2[1]; o[2] += o2[2]; o[3] += o2[3];
                     // O^T[d = 4 hi_t + v][traj = lo_t] -> this head's 16 channels of the trajectory's exchange row
                     *reinterpret_cast<float4*>(sQ + traj * CO_QP + 16 * wave + 4 * hi_t) = make_float4(o[0], o[1], o[2], o[3]);
                     if (TRAIN && live)
                         *reinterpret_cast<float4*>(A.trO + ((size_t)b * Rcap + r) * ELG_E + 16 * wave + 4 * hi_t) =
                             make_float4(o[0], o[1], o[2], o[3]);
                 }
+                PCLK(0)
                 __syncthreads();
+                PCLK(1)
                 // =============== pointer (waves 0-5: 7 node tiles x 2 trajectory tiles) || local policy (waves 6, 7) ====
                 if (wave < 6) {
 #pragma unroll 1
@@ -1210,7 +1224,9 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                     // wave 6: trajectories 0-15, wave 7: trajectories 16-31
                     co_local16(sT, la, sX + (wave - 6) * 16 * CO_XP, lo_t, hi_t);
                 }
+                PCLK(2)
                 __syncthreads();
+                PCLK(3)
             }
             // =============== owners: finish this step, advance, prepare the next ===============
             int any_left = 0;
@@ -1232,11 +1248,13 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                 } else {
                     sel = (!TSP && t == 0) ? 0 : A.starts[m4];
                 }
+                PCLK(4)
                 if (active && (lane_t & 15) == 0) {
                     if (A.actions) A.actions[bm4 * A.Tmax + t] = sel;
                     if (A.probs) A.probs[((size_t)b * A.Tmax + t) * A.M + m4] = pr;
                 }
                 co_advance4<TSP, TRAIN>(A, I, N1, lane_t, wave, ntraj, t, g_lo, (size_t)b, Rcap, row, sel, active, sMask, sQ, sX);
+                PCLK(5)
                 any_left = (q4 < ntraj && !row.fin) ? 1 : 0;
             } else {
             int dsel = 0;
@@ -1307,8 +1325,16 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
             }
             }
             ELG_CO_LOAD_KV()                                         // next step's glimpse operands, in flight over the barrier
-            if (!__syncthreads_or(any_left)) break;                  // also orders the exchange rows for the next step
+            PCLK(6)
+            const int more_ = __syncthreads_or(any_left);
+            PCLK(7)
+            if (!more_) break;                                       // also orders the exchange rows for the next step
         }
+        if (prof_ && lane == 0 && A.full_probs) {
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(A.full_probs) + wave * 8;
+            for (int i = 0; i < 8; ++i) atomicAdd(dst + i, (unsigned long long)pc_[i]);
+        }
+#undef PCLK
         // ---- results of the group
         if (!(A.debug_skip & 96)) {
             const int q4 = 4 * wave + (lane >> 4);
