@@ -34,7 +34,7 @@ class RolloutArgs(C.Structure):
         ("st_cur", _vp), ("st_cnt", _vp), ("st_fin", _vp), ("st_first", _vp), ("st_load", _vp), ("st_len", _vp),
         ("st_vis", _vp),
         ("actions", _vp), ("probs", _vp), ("reward", _vp), ("tlen", _vp), ("full_probs", _vp),
-        ("trA", _vp), ("trPC", _vp), ("trCsel", _vp), ("trQ", _vp), ("trO", _vp), ("trLoad", _vp), ("trSlot", _vp), ("trF", _vp), ("trMask", _vp),
+        ("trA", _vp), ("trPC", _vp), ("trCsel", _vp), ("trQ", _vp), ("trO", _vp), ("trLoad", _vp), ("trSlot", _vp), ("trF", _vp), ("trMask", _vp), ("trLse", _vp),
     ]
 
 
@@ -66,7 +66,7 @@ class DecoderBwdArgs(C.Structure):
     _fields_ = [("problem", C.c_int32), ("B", C.c_int32), ("M", C.c_int32), ("N1", C.c_int32), ("T", C.c_int32),
                 ("Tcap_actions", C.c_int32), ("first_decode_step", C.c_int32), ("inv_ens", C.c_float), ("Rcap", C.c_int64),
                 ("gprob", _vp), ("pval", _vp), ("tlen", _vp), ("actions", _vp), ("trPC", _vp), ("trCsel", _vp), ("trQ", _vp),
-                ("trO", _vp), ("trLoad", _vp), ("trSlot", _vp), ("trA", _vp), ("trMask", _vp), ("Kmat", _vp), ("Vmat", _vp),
+                ("trO", _vp), ("trLoad", _vp), ("trSlot", _vp), ("trA", _vp), ("trMask", _vp), ("trLse", _vp), ("Kmat", _vp), ("Vmat", _vp),
                 ("PK", _vp), ("dK", _vp), ("dV", _vp), ("dPK", _vp), ("dpb", _vp), ("dQ1", _vp), ("dQ2", _vp), ("dwl", _vp),
                 ("rowDU", _vp), ("dO", _vp), ("idx_prev", _vp), ("idx_first", _vp), ("rowW", _vp)]
 

@@ -606,11 +606,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // LDS: [K operand image: NT*4 x 64] then the 4 x 2 x NT*256 reduction buffer
     float* sK = lds;
-    float* sRed = lds + NT * 256;
+    float* sRed = lds + NT * 256;                                          // [2][2 NT 256] reduction buffer
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lo = lane & 15, hi = lane >> 4;
-    float* sTr = lds + NT * 256 + 4 * 2 * NT * 256 + wave * (2 * 320);    // two 16 x 16 transpose tiles (pitch 20)
-    float* sK2 = lds + NT * 256 + 4 * 2 * NT * 256 + 4 * 2 * 320;          // RECOMP: K as the B operand of q K^T
+    float* sTr = lds + NT * 256 + 2 * 2 * NT * 256 + wave * (2 * 320);    // two 16 x 16 transpose tiles (pitch 20)
+    float* sK2 = lds + NT * 256 + 2 * 2 * NT * 256 + 4 * 2 * 320;          // RECOMP: K as the B operand of q K^T
     float* sSeg1 = sRed;       // [(16 NT + 1)][16] d Q1 (+ the load row): aliases the reduction buffer, which is only
                                // used after the row loop (more LDS would halve the workgroups per CU)
     // channel-major [16][SNP] with an odd pitch: the 64 lanes of one atomic (fixed i: channels 4 hi + i, nodes of 16 rows)
@@ -621,6 +621,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int i = threadIdx.x; i < 2 * 16 * SNP; i += 256) sSeg1[i] = 0.f;
     // SEG: the gather indices / load of the tile's rows are fetched with the tile (a load issued after dq is known would
     // expose a full memory latency per tile)
+    // RECOMP with the forward's per-(row, head) log2-sum-exp: a = exp2(s log2(e) / 4 - lse), no max / sum passes
+    const bool has_lse = RECOMP && seg.lse != nullptr;
+    const float* lsep = has_lse ? seg.lse : rowQ;                          // (always a readable address: loads are unguarded)
+    const size_t lse_pitch = has_lse ? 8 : 1;
     const int* seg_first = (SEG && seg.idx_first) ? seg.idx_first : seg.idx_prev;
     const float* seg_load = (SEG && seg.load) ? seg.load : reinterpret_cast<const float*>(seg.idx_prev);
     const size_t seg_lrows = (SEG && seg.load) ? (size_t)seg.load_rows : (size_t)R;
@@ -668,7 +672,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // memory latency).  Rows past R are clamped to the last valid row (finite duplicates): they meet zeroed Q / dO
     // operands in dK / dV and an unstored dQ column.  Q / dO rows past R must be exact zeros: 0/1 mask multiply.
     // The loads of tile i + 1 are issued before tile i is consumed (software prefetch, 44 registers).
-#define ELG_GB_LOAD(TILE, A1, DOA, OA, DOB, QB, QA, MW, SP, SF, SL)                                               \
+#define ELG_GB_LOAD(TILE, A1, DOA, OA, DOB, QB, QA, MW, SP, SF, SL, LS)                                           \
     {                                                                                                             \
         const int r0_ = (TILE) << 4;                                                                              \
         const int rleft_ = R - 1 - r0_;                                                                           \
@@ -689,6 +693,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                                       \
                 const unsigned offm = (unsigned)(min(4 * hi + v, rleft_) * 2);                                    \
                 MW[v][0] = Mt[offm]; MW[v][1] = Mt[offm + 1];                                                     \
+                LS[v] = lsep[((size_t)b * rowQ_rows + r0_ + min(4 * hi + v, rleft_)) * lse_pitch + (has_lse ? h : 0)]; \
             }                                                                                                     \
             const float* __restrict__ Qa = rowQ + ((size_t)b * rowQ_rows + r0_) * ELG_E + h * 16;                 \
             const unsigned offq = (unsigned)(min(lo, rleft_) * ELG_E + hi);                                       \
@@ -712,19 +717,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tile0 = t_lo + wave_u;
     int sgp = 0, sgf = 0;
     float sgl = 0.f;
-    if (tile0 < t_hi) ELG_GB_LOAD(tile0, a1, doA, oA, doB, qB, qA, mw, sgp, sgf, sgl)
+    float lsv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (tile0 < t_hi) ELG_GB_LOAD(tile0, a1, doA, oA, doB, qB, qA, mw, sgp, sgf, sgl, lsv)
     for (int tile = tile0; tile < t_hi; tile += 4) {
         const int r0 = tile << 4;                                  // wave-uniform
         const int rT = r0 + lo;                                    // row of this lane in the row-on-lane layout
         float a1n[NT][4], doAn[4], oAn[4], doBn[4], qBn[4], qAn[4];
         unsigned long long mwn[4][2];
         int sgpn = 0, sgfn = 0;
-        float sgln = 0.f;
+        float sgln = 0.f, lsvn[4] = {0.f, 0.f, 0.f, 0.f};
         {
             const int tn = min(tile + 4, t_hi - 1);                // the last prefetch re-reads a valid tile, unused
-            ELG_GB_LOAD(tn, a1n, doAn, oAn, doBn, qBn, qAn, mwn, sgpn, sgfn, sgln)
+            ELG_GB_LOAD(tn, a1n, doAn, oAn, doBn, qBn, qAn, mwn, sgpn, sgfn, sgln, lsvn)
         }
-        if (RECOMP) {
+        if (RECOMP && has_lse) {
+            const float cs = 0.25f * 1.4426950408889634f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 S = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    S = __builtin_amdgcn_mfma_f32_16x16x4f32(qA[kk], sK2[(nt * 4 + kk) * 64 + lane], S, 0, 0, 0);
+                const unsigned node = gl[nt];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const unsigned long long w = (node < 64u) ? mw[v][0] : mw[v][1];
+                    const bool closed = !own_lo[nt] || ((w >> (node & 63u)) & 1ull);
+                    a1[nt][v] = closed ? 0.f : __builtin_amdgcn_exp2f(fmaf(S[v], cs, -lsv[v]));
+                }
+            }
+        } else if (RECOMP) {
             // a_h[row 4 hi + v][position lo] = softmax over the row's open nodes of q_h . K_h[node] / 4
             float mx[4] = {ELG_NEG_INF, ELG_NEG_INF, ELG_NEG_INF, ELG_NEG_INF};
 #pragma unroll
@@ -833,6 +855,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             qA[v] = qAn[v]; mw[v][0] = mwn[v][0]; mw[v][1] = mwn[v][1];
         }
         sgp = sgpn; sgf = sgfn; sgl = sgln;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) lsv[v] = lsvn[v];
     }
 #undef ELG_GB_LOAD
     if (SEG) {
@@ -849,20 +873,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (seg.dwl && threadIdx.x < 16) atomicAdd(seg.dwl + h * 16 + threadIdx.x, sSeg1[threadIdx.x * SNP + 16 * NT]);
         __syncthreads();                                            // the accumulators are dead: the buffer is reused below
     }
-    // ---- sum the four waves' dK_h / dV_h and write this split's partial (B,N1,128) image.
-    // D rows are positions 4 hi + v of chunk nt; position -> node, owners only.
-    float* my = sRed + (size_t)wave * (2 * NT * 256);
+    // ---- sum the four waves' dK_h / dV_h (pairwise through LDS: a buffer for all four at once cost a workgroup per CU) and
+    // write this split's partial (B,N1,128) image.  D rows are positions 4 hi + v of chunk nt; position -> node, owners only.
+    auto dump = [&](float* dst) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int idx = (16 * nt + 4 * hi + v) * 16 + lo;
-            my[idx] = dKacc[nt][v];
-            my[NT * 256 + idx] = dVacc[nt][v];
-        }
+            for (int v = 0; v < 4; ++v) {
+                const int idx = (16 * nt + 4 * hi + v) * 16 + lo;
+                dst[idx] = dKacc[nt][v];
+                dst[NT * 256 + idx] = dVacc[nt][v];
+            }
+    };
+    auto addin = [&](const float* src) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int idx = (16 * nt + 4 * hi + v) * 16 + lo;
+                dKacc[nt][v] += src[idx];
+                dVacc[nt][v] += src[NT * 256 + idx];
+            }
+    };
+    if (wave >= 2) dump(sRed + (size_t)(wave - 2) * (2 * NT * 256));
+    __syncthreads();
+    if (wave < 2) addin(sRed + (size_t)wave * (2 * NT * 256));
+    __syncthreads();
+    if (wave == 1) dump(sRed);
+    __syncthreads();
+    if (wave == 0) addin(sRed);
+    __syncthreads();
+    if (wave == 0) dump(sRed);
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * NT * 256; i += 256) {
-        const float sum = (sRed[i] + sRed[2 * NT * 256 + i]) + (sRed[4 * NT * 256 + i] + sRed[6 * NT * 256 + i]);
+        const float sum = sRed[i];
         const int which = i / (NT * 256), idx = i % (NT * 256);
         const int pos = idx >> 4, d = idx & 15;
         const int nt = pos >> 4, q = (pos >> 2) & 3;
@@ -880,8 +924,7 @@ static int launch_glimpse_bwd_mfma_t(const float* rowA, const unsigned long long
                                    const float* rowQ, const float* Kmat, const float* Vmat, float* dQ, float* dKp,
                                    float* dVp, int B, int R, int N1, size_t ra, size_t ro, size_t rq, int splits,
                                    const GlimpseSeg& seg, hipStream_t stream) {
-    const size_t lds = (size_t)(NT * 256 + 4 * 2 * NT * 256 + 4 * 2 * 320 + (RECOMP ? NT * 256 : 0) +
-                                0) * sizeof(float);
+    const size_t lds = (size_t)(NT * 256 + 2 * 2 * NT * 256 + 4 * 2 * 320 + (RECOMP ? NT * 256 : 0)) * sizeof(float);
     auto kern = glimpse_bwd_mfma_kernel<NT, RECOMP, SEG>;
     static bool attr_done = false;
     if (!attr_done) {

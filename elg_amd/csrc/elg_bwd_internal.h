@@ -16,6 +16,7 @@ struct GlimpseSeg {
     float* dQ2;             // (B,N1,128) or NULL
     float* dwl;             // (128) or NULL
     long long load_rows;
+    const float* lse;       // (B,rowQ_rows,8) log2-sum-exp of the glimpse scores per (row, head) (mask-row mode), or NULL
     int accumulate;         // 1: dK / dV are added to dKp / dVp (B,N1,128, caller zeroes) instead of written per split
 };
 

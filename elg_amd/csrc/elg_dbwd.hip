@@ -201,6 +201,7 @@ extern "C" int elg_decoder_bwd(const elg_decoder_bwd_args* p, void* stream) {
     seg.idx_prev = p->idx_prev; seg.idx_first = tsp ? p->idx_first : nullptr; seg.load = tsp ? nullptr : p->trLoad;
     seg.dQ1 = p->dQ1; seg.dQ2 = tsp ? p->dQ2 : nullptr; seg.dwl = tsp ? nullptr : p->dwl; seg.load_rows = p->Rcap;
     seg.accumulate = 1;
+    seg.lse = p->trMask ? p->trLse : nullptr;
     const int splits = max(1, min(8, 1024 / (B * 8)));
     return glimpse_bwd_launch(p->trMask ? nullptr : p->trA, reinterpret_cast<const unsigned long long*>(p->trMask), p->dO, p->trO,
                               p->trQ, p->Kmat, p->Vmat, nullptr, p->dK, p->dV, B, (int)R, N1, p->Rcap, p->Rcap, p->Rcap, splits, seg, s);

@@ -1172,6 +1172,8 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                         }
                     den = quarters_sum(den);
                     const bool live = den > 0.f;                    // a decoding trajectory has an open node
+                    if (TRAIN && A.trLse && hi_t == 0 && live)
+                        A.trLse[((size_t)b * Rcap + (size_t)t * A.M + g_lo + traj) * ELG_H + wave] = __log2f(den) - cm;
                     const float inv = live ? 1.0f / den : 0.f;
                     f32x4c o = {0.f, 0.f, 0.f, 0.f}, o2 = {0.f, 0.f, 0.f, 0.f};      // two chains: dependent MFMAs stall
                     const size_t r = (size_t)t * A.M + g_lo + traj;

@@ -288,6 +288,7 @@ class TrainRows:
         self.B, self.M, self.N1, self.Tcap, self.Rcap = B, M, N1, Tcap, Rcap
         self._A = None                          # glimpse weights: only for forwards that cannot save mask rows
         self.Mask = torch.zeros(B, Rcap, 2, device=dev, dtype=torch.int64)    # feasibility mask words per row
+        self.Lse = torch.zeros(B, Rcap, H, device=dev)                        # glimpse log2-sum-exp per (row, head)
         self.use_mask = False                   # set by the forward that filled the rows
         self.PC = torch.empty(B, Rcap, N1, device=dev)
         self.Csel = torch.empty(B, Rcap, device=dev)
@@ -375,14 +376,14 @@ def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mo
     if train and N1 <= 128:
         rows = TrainRows.get(B, M, N1, Tcap, dev)
         rows.prepare()
-        # ELG_SAVE_GLIMPSE=0: the cooperative kernel (what dispatch_fwd picks for this launch shape) saves only the rows'
-        # 128-bit mask words and the backward recomputes the glimpse weights from q, K and the mask -- 4.2 GB less
-        # workspace and 3.3 GB less written + read per step, but measured 5 % slower end to end at the bench shape (the
-        # forward's stores are asynchronous, the backward kernel is MFMA/VALU bound: +28 MFMAs and a softmax per tile)
-        rows.use_mask = bool(a.lds_stage and a.waves == 8 and 4 <= N1 <= 112 and not (debug & 0xB)
-                             and os.environ.get("ELG_SAVE_GLIMPSE", "1") == "0")
+        # the cooperative kernel (what dispatch_fwd picks for this launch shape) saves the rows' 128-bit mask words and the
+        # glimpse log2-sum-exp per head instead of the glimpse weights: the backward recomputes the weights from q, K, the
+        # mask and the saved normaliser (28 MFMAs + one exp2 per weight).  4.2 GB less workspace and 6.6 GB less HBM traffic
+        # per step at the bench shape, and no slower (the forward's 3.3 GB of scattered stores cost what the recompute does)
+        rows.use_mask = bool(a.lds_stage and a.waves == 8 and 4 <= N1 <= 112 and not (debug & 0xB))
         a.trA = None if rows.use_mask else _ptr(rows.A)
         a.trMask = _ptr(rows.Mask) if rows.use_mask else None
+        a.trLse = _ptr(rows.Lse) if rows.use_mask else None
         a.trPC, a.trCsel, a.trQ, a.trO = _ptr(rows.PC), _ptr(rows.Csel), _ptr(rows.Q), _ptr(rows.O)
         a.trLoad, a.trSlot, a.trF = _ptr(rows.Load), _ptr(rows.Slot), _ptr(rows.F)
     L.check(L.lib().elg_rollout_fwd(C.byref(a), _stream()), "elg_rollout_fwd")
@@ -517,6 +518,7 @@ class _ChosenProbs(torch.autograd.Function):
         a.trSlot = _ptr(rows.Slot) if meta.has_local else None
         a.trA = None if rows.use_mask else _ptr(rows.A)
         a.trMask = _ptr(rows.Mask) if rows.use_mask else None
+        a.trLse = _ptr(rows.Lse) if rows.use_mask else None
         a.Kmat, a.Vmat, a.PK = _ptr(Kt), _ptr(Vt), _ptr(PKt)
         a.dK, a.dV, a.dPK, a.dpb, a.dQ1, a.dQ2 = _ptr(dK), _ptr(dV), _ptr(dPK), _ptr(dpb), _ptr(dQ1), _ptr(dQ2)
         a.dwl = _ptr(dwl) if haswl else None

@@ -130,6 +130,8 @@ typedef struct elg_rollout_args {
     float* trF;             /* (B,Rcap,3,48)  local-policy features of every slot (NULL: not saved)   */
     uint64_t* trMask;       /* (B,Rcap,2)     feasibility mask words of the row (bit n = node n closed); with it the
                                cooperative kernel (N1 <= 112) may skip trA: the backward recomputes a_h from q, K   */
+    float* trLse;           /* (B,Rcap,8)     with trMask: log2 of the glimpse softmax denominator per head, in the units of
+                               s log2(e) / 4, so that a_h[n] = exp2(q_h.K_h[n] log2(e) / 4 - trLse) (NULL: not saved) */
 } elg_rollout_args;
 
 /* POMO construction: CVRPEnv.reset/step + CVRPModel.one_step_rollout + utils.rollout fused into one
@@ -373,6 +375,7 @@ typedef struct elg_decoder_bwd_args {
     const int32_t* trSlot;      /* (B,Rcap,48) or NULL (no local policy)                                          */
     const float* trA;           /* (B,8,Rcap,N1) glimpse weights, or NULL if trMask is given                      */
     const uint64_t* trMask;     /* (B,Rcap,2) mask words: the weights are recomputed from trQ, Kmat               */
+    const float* trLse;         /* (B,Rcap,8) with trMask: the forward's log2-sum-exp per head (NULL: recompute)  */
     const float *Kmat, *Vmat, *PK;          /* (B,N1,128) decoder tables                                          */
     float *dK, *dV, *dPK;       /* (B,N1,128) out (+=)                                                            */
     float* dpb;                 /* (B,N1) out (+=)                                                                */

@@ -116,7 +116,9 @@ def test_saved_rows_backward_equals_replay_backward(kind, N, recompute, monkeypa
     local-policy backward kernels) = gradients through the replay kernels, also for 104 < N1 <= 112 where the
     per-wavefront kernels read their tables from L2."""
     from elg_amd import _lib as L, engine as eng
-    monkeypatch.setenv("ELG_SAVE_GLIMPSE", "0" if recompute else "1")
+    # stored weights: the per-wavefront forward (debug bit 3; what 112 < N1 <= 128 uses) saves the glimpse weights; the
+    # cooperative forward saves mask rows + normalisers and the backward recomputes the weights
+    dbg = 0 if recompute else 8
     B, M = 2, 23
     P, cfg, xy, dem, enc, prob, pol = _setup(kind, N, B, 5)
     off = 1 if kind == "cvrp" else 0
@@ -131,7 +133,7 @@ def test_saved_rows_backward_equals_replay_backward(kind, N, recompute, monkeypa
         tabs = {k: (v.detach().clone().requires_grad_(True) if v is not None else None) for k, v in pol.tables.items()}
         loc = pol.loc.detach().clone().requires_grad_(True)
         p2 = eng.Policy(tabs, loc, pol.K, pol.xi, pol.clip, pol.inv_ens, pol.has_local, pol.has_penalty)
-        res = eng.rollout_forward(prob, p2, M, starts, L.MODE_FORCED, forced=acts, train=train)
+        res = eng.rollout_forward(prob, p2, M, starts, L.MODE_FORCED, forced=acts, train=train, debug=dbg if train else 0)
         if train:
             assert res.rows.use_mask == recompute
         probs = eng.chosen_probs(prob, p2, M, res, T)

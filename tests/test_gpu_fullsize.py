@@ -65,12 +65,20 @@ def test_cvrp100_bench_shape_properties():
     # saved training rows: finite everywhere, softmax Jacobian rows sum to ~0 weight outside the open nodes
     rows = res.rows
     R = T * M
-    for name in ("A", "PC", "Csel", "Q", "O", "Load", "F"):
+    names = ("PC", "Csel", "Q", "O", "Load", "F") + (("Lse",) if rows.use_mask else ("A",))
+    for name in names:
         assert torch.isfinite(getattr(rows, name)[:, ..., :R, :] if name == "A" else getattr(rows, name)[:, :R]).all(), name
     valid = ((torch.arange(T, device=DEV)[None, :, None] >= 2) & (torch.arange(T, device=DEV)[None, :, None] < res.tlen[:, None, :])).reshape(B, R)
-    A = rows.A[:, :, :R]                                                # glimpse weights: rows of decoded steps sum to 1 per head
-    s = A.sum(-1)[valid[:, None, :].expand(B, 8, R)]
-    assert torch.allclose(s, torch.ones_like(s), atol=1e-5)
+    if rows.use_mask:
+        # mask rows: the node chosen at a decoded step was open in the row's mask words
+        act = res.actions[:, :, :T].permute(0, 2, 1).reshape(B, R).long()           # time-major rows
+        w = torch.where(act < 64, rows.Mask[:, :R, 0], rows.Mask[:, :R, 1])
+        bit = (w >> (act & 63)) & 1
+        assert int(bit[valid].sum()) == 0
+    else:
+        A = rows.A[:, :, :R]                                            # glimpse weights: rows of decoded steps sum to 1 per head
+        s = A.sum(-1)[valid[:, None, :].expand(B, 8, R)]
+        assert torch.allclose(s, torch.ones_like(s), atol=1e-5)
 
 
 def test_tsp500_properties():
