@@ -43,6 +43,7 @@ class CVRPEnv:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("elg_amd.CVRPEnv runs on the GPU only (no CPU fallback)")
+        torch.cuda.set_device(self.device)       # kernels launch on the current device / its current stream
         self.vrplib = False
         self.problem_size = None
         self.multi_width = multi_width

@@ -12,12 +12,12 @@ import sys
 import numpy as np
 import torch
 import yaml
-from elg_amd.optim import Adam as Optimizer      # one-launch Adam, torch.optim.Adam-compatible checkpoints
 from torch.utils.data import DataLoader
 
 if __package__ in (None, ""):                      # `cd elg_amd/CVRP && python train.py`, as the reference is run
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
+from elg_amd.optim import Adam as Optimizer      # one-launch Adam, torch.optim.Adam-compatible checkpoints
 from elg_amd import engine as eng
 from elg_amd import parallel
 from elg_amd.CVRP.CVRPEnv import CVRPEnv
@@ -69,20 +69,23 @@ def test_rollout(loader, env, model):
     return total / max(batches, 1)
 
 
-def validate(model, multiple_width, device, mixed=True):
-    """reference train.py:42-80 (needs the data/*.pkl validation sets next to this file)."""
+def validate(model, multiple_width, device, mixed=True, data_dir='data'):
+    """reference train.py:42-80 (the data/*.pkl validation sets next to this file)."""
     env = CVRPEnv(multi_width=multiple_width, device=device)
     if mixed:
-        sets = [('data/vrp_uniform100_1000_seed1234.pkl', 1000, 1000), ('data/vrp_cluster100_1000_seed1234.pkl', 1000, 1000),
-                ('data/vrp_mixed100_1000_seed1234.pkl', 1000, 1000)]
+        sets = [('vrp_uniform100_1000_seed1234.pkl', 1000, 1000), ('vrp_cluster100_1000_seed1234.pkl', 1000, 1000),
+                ('vrp_mixed100_1000_seed1234.pkl', 1000, 1000)]
     else:
-        sets = [('data/vrp100_val.pkl', 1000, 1000), ('data/vrp200_val.pkl', 1000, 1000), ('data/vrp500_val.pkl', 100, 10)]
-    return [test_rollout(DataLoader(VRPDataset(f, num_samples=n), batch_size=bs), env, model) for f, n, bs in sets]
+        sets = [('vrp100_val.pkl', 1000, 1000), ('vrp200_val.pkl', 1000, 1000), ('vrp500_val.pkl', 100, 10)]
+    return [test_rollout(DataLoader(VRPDataset(os.path.join(data_dir, f), num_samples=n), batch_size=bs), env, model)
+            for f, n, bs in sets]
 
 
 def train(model, training, T, start_steps, train_steps, mixed, train_batch_size, problem_size, distribution,
           multiple_width, lr, device, logger, scale_norm, fileLogger, dir_path, log_step):
     rank, world, _ = parallel.world_info()
+    if train_batch_size % world:
+        raise ValueError(f"train_batch_size {train_batch_size} is not divisible by the {world} data-parallel ranks")
     env = CVRPEnv(multi_width=multiple_width, device=device)
     distribution_ = dict(distribution)
     gaps = np.array([1, 1, 1])
@@ -98,24 +101,23 @@ def train(model, training, T, start_steps, train_steps, mixed, train_batch_size,
             optimizer = Optimizer(model.parameters(), lr=lr, weight_decay=1e-6)
             bucket = parallel.GradBucket(model.parameters(), optimizer) if world > 1 else None
         if mixed:
-            kind = np.random.choice(['uniform', 'cluster', 'mixed'], size=1, p=softmax(gaps))[0]
-            if world > 1:                                           # every rank must draw the same family
-                obj = [kind]
-                torch.distributed.broadcast_object_list(obj, src=0)
-                kind = obj[0]
-            distribution_['data_type'] = kind
+            kind = str(np.random.choice(['uniform', 'cluster', 'mixed'], size=1, p=softmax(gaps))[0])
+            distribution_['data_type'] = parallel.broadcast_object(kind)     # every rank must draw the same family
         else:
             distribution_['data_type'] = 'uniform'
         batch = generate_vrp_data(batch_size=local_batch, problem_size=problem_size, distribution=distribution_)
         train_step(model, env, optimizer, batch, scale_norm, bucket, world)
-        if (i + 1) % log_step == 0 and rank == 0:
-            val_info = validate(model, multiple_width, device, mixed)
-            fileLogger.log(val_info)
-            if logger is not None:
-                logger.log({'val_100_cost': val_info[0], 'val_300_cost': val_info[1], 'val_500_cost': val_info[2]}, step=i)
-            torch.save({'step': i, 'model_state_dict': model.state_dict(), 'optimizer_state_dict': optimizer.state_dict()},
-                       dir_path + '/model_epoch_{}.pt'.format(int((i + 1) / log_step)))
+        if (i + 1) % log_step == 0:
+            val_info = None
+            if rank == 0:
+                val_info = validate(model, multiple_width, device, mixed)
+                fileLogger.log(val_info)
+                if logger is not None:
+                    logger.log({'val_100_cost': val_info[0], 'val_300_cost': val_info[1], 'val_500_cost': val_info[2]}, step=i)
+                torch.save({'step': i, 'model_state_dict': model.state_dict(), 'optimizer_state_dict': optimizer.state_dict()},
+                           dir_path + '/model_epoch_{}.pt'.format(int((i + 1) / log_step)))
             if mixed:
+                val_info = parallel.broadcast_object(val_info)      # the gaps drive every rank's next draws
                 opts = np.array([15.740834, 7.909336, 14.294179])  # reference solver means (train.py:146)
                 gaps = (np.array(val_info) - opts) / opts
 

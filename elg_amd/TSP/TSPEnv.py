@@ -31,6 +31,7 @@ class TSPEnv:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("elg_amd.TSPEnv runs on the GPU only (no CPU fallback)")
+        torch.cuda.set_device(self.device)       # kernels launch on the current device / its current stream
         self.problem_size = None
         self.pomo_size = multi_width
         self.tsplib = False

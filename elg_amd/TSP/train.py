@@ -9,16 +9,17 @@ import sys
 import numpy as np
 import torch
 import yaml
-from elg_amd.optim import Adam as Optimizer      # one-launch Adam, torch.optim.Adam-compatible checkpoints
+from torch.utils.data import DataLoader
 
-if __package__ in (None, ""):
+if __package__ in (None, ""):                      # `cd elg_amd/TSP && python train.py`, as the reference is run
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
+from elg_amd.optim import Adam as Optimizer      # one-launch Adam, torch.optim.Adam-compatible checkpoints
 from elg_amd import engine as eng
 from elg_amd import parallel
 from elg_amd.TSP.TSPEnv import TSPEnv
 from elg_amd.TSP.TSPModel import TSPModel
-from elg_amd.TSP.generate_data import generate_tsp_data
+from elg_amd.TSP.generate_data import TSPDataset, generate_tsp_data
 from elg_amd.TSP.utils import Logger, check_feasible, rollout, seed_everything
 
 
@@ -42,11 +43,47 @@ def train_step(model, env, optimizer, batch, scale_norm=True, bucket=None, world
     return J.detach(), rewards
 
 
+def softmax(x):
+    e = np.exp(x)
+    return e / e.sum(axis=0)
+
+
+def test_rollout(loader, env, model):
+    """reference TSP/train.py:20-38: mean over batches of the best-of-POMO greedy tour length."""
+    total, batches = 0.0, 0
+    for batch in loader:
+        env.load_random_problems(batch)
+        reset_state, _, _ = env.reset()
+        model.eval()
+        with torch.no_grad():
+            model.pre_forward(reset_state)
+            solutions, _, rewards = rollout(model=model, env=env, eval_type='greedy')
+        check_feasible(solutions[0:1])
+        total += float(-rewards.max(1)[0].mean())
+        batches += 1
+    return total / max(batches, 1)
+
+
+def validate(model, multiple_width, device, mixed=True, data_dir='data'):
+    """reference TSP/train.py:40-78 (the data/*.pkl validation sets next to this file)."""
+    env = TSPEnv(multi_width=multiple_width, device=device)
+    if mixed:
+        sets = [('tsp_uniform100_1000_seed1234.pkl', 1000, 1000), ('tsp_cluster100_1000_seed1234.pkl', 1000, 1000),
+                ('tsp_mixed100_1000_seed1234.pkl', 1000, 1000)]
+    else:
+        sets = [('tsp_100_val.pkl', 1000, 500), ('tsp_200_val.pkl', 1000, 500), ('tsp_500_val.pkl', 100, 10)]
+    return [test_rollout(DataLoader(TSPDataset(os.path.join(data_dir, f), num_samples=n), batch_size=bs), env, model)
+            for f, n, bs in sets]
+
+
 def train(model, training, T, start_steps, train_steps, mixed, train_batch_size, problem_size, distribution,
           multiple_width, lr, device, logger, scale_norm, fileLogger, dir_path, log_step):
     rank, world, _ = parallel.world_info()
+    if train_batch_size % world:
+        raise ValueError(f"train_batch_size {train_batch_size} is not divisible by the {world} data-parallel ranks")
     env = TSPEnv(multi_width=multiple_width, device=device)
     distribution_ = dict(distribution)
+    gaps = np.array([1, 1, 1])
     optimizer = Optimizer(model.parameters(), lr=lr, weight_decay=1e-6)
     bucket = parallel.GradBucket(model.parameters(), optimizer) if world > 1 else None
     for i in range(train_steps - start_steps + 1):
@@ -57,12 +94,27 @@ def train(model, training, T, start_steps, train_steps, mixed, train_batch_size,
             parallel.broadcast_parameters(model)
             optimizer = Optimizer(model.parameters(), lr=lr, weight_decay=1e-6)
             bucket = parallel.GradBucket(model.parameters(), optimizer) if world > 1 else None
-        distribution_['data_type'] = 'uniform' if not mixed else str(np.random.choice(['uniform', 'cluster', 'mixed']))
+        if mixed:                                                   # curriculum: families weighted by their validation gaps
+            kind = str(np.random.choice(['uniform', 'cluster', 'mixed'], size=1, p=softmax(gaps))[0])
+            kind = parallel.broadcast_object(kind)                   # every rank must draw the same family
+            distribution_['data_type'] = kind
+        else:
+            distribution_['data_type'] = 'uniform'
         batch = generate_tsp_data(batch_size=train_batch_size // world, problem_size=problem_size, distribution=distribution_)
         train_step(model, env, optimizer, batch, scale_norm, bucket, world)
-        if (i + 1) % log_step == 0 and rank == 0:
-            torch.save({'step': i, 'model_state_dict': model.state_dict(), 'optimizer_state_dict': optimizer.state_dict()},
-                       dir_path + '/model_epoch_{}.pt'.format(int((i + 1) / log_step)))
+        if (i + 1) % log_step == 0:
+            val_info = None
+            if rank == 0:
+                val_info = validate(model, multiple_width, device, mixed)
+                fileLogger.log(val_info)
+                if logger is not None:
+                    logger.log({'val_100_cost': val_info[0], 'val_200_cost': val_info[1], 'val_500_cost': val_info[2]}, step=i)
+                torch.save({'step': i, 'model_state_dict': model.state_dict(), 'optimizer_state_dict': optimizer.state_dict()},
+                           dir_path + '/model_epoch_{}.pt'.format(int((i + 1) / log_step)))
+            if mixed:
+                val_info = parallel.broadcast_object(val_info)       # the gaps drive every rank's next draws
+                opts = np.array([7.753418, 3.667576, 6.729566])      # reference solver means (TSP/train.py:148)
+                gaps = (np.array(val_info) - opts) / opts
 
 
 if __name__ == "__main__":

@@ -67,6 +67,10 @@ def h2d(t: torch.Tensor, dev) -> torch.Tensor:
 def _need_cuda(t: torch.Tensor, what: str):
     if not t.is_cuda:
         raise RuntimeError(f"elg_amd: {what} must live on the GPU -- the HIP path has no CPU fallback")
+    # the C ABI launches on the calling thread's current HIP device and on the stream passed in: both must be the tensor's
+    if t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"elg_amd: {what} lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                           "call torch.cuda.set_device() first (CVRPEnv / TSPEnv / elg_amd.optim.Adam do it for their device)")
 
 
 # ----------------------------------------------------------------------------------------------
@@ -349,6 +353,7 @@ def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mo
                     train: bool = False, debug: int = 0) -> RolloutResult:
     """Run every trajectory to completion in one persistent launch (reference CVRP/utils.py:7-29)."""
     dev = prob.xy.device
+    _need_cuda(prob.xy, "the problem")
     B, N1 = prob.B, prob.N1
     Tcap = Tcap or max_steps(prob.kind, N1)
     actions = torch.zeros(B, M, Tcap, device=dev, dtype=torch.int32)       # finished -> depot (0)

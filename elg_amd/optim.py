@@ -25,6 +25,7 @@ class Adam:
         dev = self.params[0].device
         if dev.type != "cuda":
             raise RuntimeError("elg_amd.optim.Adam runs on the GPU only (no CPU fallback)")
+        torch.cuda.set_device(dev)                # the update kernel launches on the current device / its current stream
         for p in self.params:
             if p.dtype != torch.float32 or not p.is_contiguous() or p.device != dev:
                 raise ValueError("parameters must be contiguous fp32 tensors on one device")
@@ -80,7 +81,10 @@ class Adam:
         g = self.param_groups[0]
         self.step_count += 1
         b1, b2 = g["betas"]
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        dev = self.grad_flat.device
+        if dev.index != torch.cuda.current_device():
+            raise RuntimeError(f"elg_amd.optim.Adam: parameters on {dev}, current device cuda:{torch.cuda.current_device()}")
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         L.check(L.lib().elg_adam_step(None, C.c_void_p(self._table.data_ptr()), C.c_void_p(self._off_dev.data_ptr()),
                                       len(self.params), C.c_void_p(self.grad_flat.data_ptr()),
                                       C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()),

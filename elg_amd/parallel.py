@@ -80,6 +80,15 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0):
             dist.broadcast(t.data, src=src)
 
 
+def broadcast_object(obj, src: int = 0):
+    """The same Python object on every rank (curriculum choice, validation costs); identity without a process group."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        box = [obj]
+        dist.broadcast_object_list(box, src=src)
+        return box[0]
+    return obj
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

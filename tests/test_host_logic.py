@@ -137,3 +137,32 @@ def test_best_costs_of_the_test_entry_points():
     per_aug = rewards.reshape(8, 5, 7).max(dim=2)[0]
     assert torch.equal(plain, -per_aug[0]) and torch.equal(aug, -per_aug.max(dim=0)[0])
     assert (aug <= plain).all()
+
+
+def test_entry_points_import_from_their_own_directory():
+    """`cd elg_amd/CVRP && python train.py` is how the reference is run: the scripts must find the package themselves."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for sub, mods in (("CVRP", ("train", "test", "test_vrplib")), ("TSP", ("train", "test", "test_tsplib"))):
+        for m in mods:
+            env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+            r = subprocess.run([sys.executable, "-c", f"import {m}"], cwd=os.path.join(root, "elg_amd", sub), env=env,
+                               capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, (sub, m, r.stderr[-1500:])
+
+
+def test_train_batch_must_divide_over_the_ranks(monkeypatch):
+    from elg_amd import parallel
+    from elg_amd.CVRP import train as ctrain
+    monkeypatch.setattr(parallel, "world_info", lambda: (0, 3, 0))
+
+    class _Env:
+        def __init__(self, **kw):
+            pass
+    monkeypatch.setattr(ctrain, "CVRPEnv", _Env)
+    import pytest
+    with pytest.raises(ValueError, match="not divisible"):
+        ctrain.train(model=None, training="only_global", T=10, start_steps=0, train_steps=1, mixed=False, train_batch_size=64,
+                     problem_size=20, distribution={}, multiple_width=20, lr=1e-4, device="cuda:0", logger=None, scale_norm=True,
+                     fileLogger=None, dir_path=".", log_step=10)
