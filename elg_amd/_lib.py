@@ -26,7 +26,8 @@ class RolloutArgs(C.Structure):
         ("has_penalty", C.c_int32), ("max_steps", C.c_int32), ("do_decode", C.c_int32), ("do_update", C.c_int32),
         ("use_state", C.c_int32), ("waves", C.c_int32), ("tiles", C.c_int32), ("lds_stage", C.c_int32),
         ("dump_T", C.c_int32),
-        ("xi", C.c_float), ("clip", C.c_float), ("inv_ens", C.c_float), ("debug_skip", C.c_int32),
+        ("xi", C.c_float), ("clip", C.c_float), ("inv_ens", C.c_float), ("variant", C.c_int32),
+        ("dump_logits", C.c_int32), ("pad0", C.c_int32),
         ("seed", C.c_uint64),
         ("Kmat", _vp), ("Vmat", _vp), ("PK", _vp), ("pb", _vp), ("Q1", _vp), ("Q2", _vp), ("wl", _vp),
         ("xy", _vp), ("demand", _vp), ("nbr_idx", _vp), ("nbr_dist", _vp), ("nbr_theta", _vp), ("loc", _vp),
@@ -90,8 +91,8 @@ class EncoderBwdArgs(C.Structure):
 
 EXPORTS = ["elg_version", "elg_last_error", "elg_aug8", "elg_dist_matrix", "elg_nbr_tables", "elg_route_length",
            "elg_rollout_fwd", "elg_rollout_bwd", "elg_glimpse_rows_bwd", "elg_glimpse_bwd_fused", "elg_gemm_f32",
-           "elg_pomo_loss", "elg_rows_prep", "elg_adam_step", "elg_local_bwd_rows",
-           "elg_add_instnorm_fwd", "elg_add_instnorm_bwd", "elg_rows_segsum",
+           "elg_pomo_loss", "elg_adam_step", "elg_local_bwd_rows",
+           "elg_add_instnorm_fwd", "elg_add_instnorm_bwd",
            "elg_encoder_ws_floats", "elg_encoder_fwd", "elg_encoder_bwd_ws_floats", "elg_encoder_bwd",
            "elg_local_fold_fwd", "elg_local_fold_bwd", "elg_check_feasible", "elg_rollout_stats", "elg_decoder_bwd"]
 
@@ -126,8 +127,6 @@ def lib() -> C.CDLL:
         L.elg_gemm_f32.argtypes = [f, f, f, f, i, i, i, i, i, i, i, i, i, i, f, f]
         i64, fl = C.c_int64, C.c_float
         L.elg_pomo_loss.argtypes = [f, f, i, i, i, i64, i64, f, f, f, f, f, f]
-        L.elg_rows_prep.argtypes = [f, f, f, f, f, f, f, f, f, f, f, f, f, f, i, i, i, i, i, i64, i, fl, f]
-        L.elg_rows_segsum.argtypes = [f, f, f, f, i, i, i, i, i64, i, f]
         L.elg_add_instnorm_fwd.argtypes = [f, f, f, f, f, f, f, i, i, i, fl, f]
         L.elg_add_instnorm_bwd.argtypes = [f, f, f, f, f, f, f, i, i, i, f]
         L.elg_local_bwd_rows.argtypes = [f, f, f, f, f, i, i, i64, i, f]
@@ -152,8 +151,8 @@ def lib() -> C.CDLL:
         L.elg_encoder_bwd.restype = C.c_int
         for n in ("elg_aug8", "elg_dist_matrix", "elg_nbr_tables", "elg_route_length", "elg_rollout_fwd",
                   "elg_rollout_bwd", "elg_glimpse_rows_bwd", "elg_glimpse_bwd_fused", "elg_gemm_f32",
-                  "elg_pomo_loss", "elg_rows_prep", "elg_adam_step", "elg_local_bwd_rows",
-                  "elg_add_instnorm_fwd", "elg_add_instnorm_bwd", "elg_rows_segsum"):
+                  "elg_pomo_loss", "elg_adam_step", "elg_local_bwd_rows",
+                  "elg_add_instnorm_fwd", "elg_add_instnorm_bwd"):
             getattr(L, n).restype = C.c_int
         _lib = L
     return _lib

@@ -826,21 +826,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 dq = __builtin_amdgcn_mfma_f32_16x16x4f32(sK[((NT - 1) * 4 + v) * 64 + lane], pb[(4 * hi + v) * 20 + lo], dq, 0, 0, 0);
         }
         wave_lds_fence();
+        if (SEG && seg.load) {
+            // d wl: every row adds to the same 16 cells -- reduce over the tile's rows first.  The DPP row sums need all
+            // lanes active (a disabled lane's register is read as is): rows past R enter with weight 0, outside the branch
+            const float lw = rT < R ? sgl : 0.f;
+            const float l0 = row16_sum(lw * dq[0]), l1 = row16_sum(lw * dq[1]);
+            const float l2 = row16_sum(lw * dq[2]), l3 = row16_sum(lw * dq[3]);
+            if (lo == 0) {
+                float* pl = sSeg1 + 4 * hi * SNP + 16 * NT;
+                atomicAdd(pl, l0); atomicAdd(pl + SNP, l1); atomicAdd(pl + 2 * SNP, l2); atomicAdd(pl + 3 * SNP, l3);
+            }
+        }
         if (rT < R) {
             if (dQ) *reinterpret_cast<float4*>(dQ + ((size_t)b * R + rT) * ELG_E + h * 16 + 4 * hi) =
                         make_float4(dq[0], dq[1], dq[2], dq[3]);
             if (SEG) {
                 float* p1 = sSeg1 + 4 * hi * SNP + sgp;
                 atomicAdd(p1, dq[0]); atomicAdd(p1 + SNP, dq[1]); atomicAdd(p1 + 2 * SNP, dq[2]); atomicAdd(p1 + 3 * SNP, dq[3]);
-                if (seg.load) {
-                    // d wl: every row adds to the same 16 cells -- reduce over the tile's rows first (DPP row sums)
-                    const float l0 = row16_sum(sgl * dq[0]), l1 = row16_sum(sgl * dq[1]);
-                    const float l2 = row16_sum(sgl * dq[2]), l3 = row16_sum(sgl * dq[3]);
-                    if (lo == 0) {
-                        float* pl = sSeg1 + 4 * hi * SNP + 16 * NT;
-                        atomicAdd(pl, l0); atomicAdd(pl + SNP, l1); atomicAdd(pl + 2 * SNP, l2); atomicAdd(pl + 3 * SNP, l3);
-                    }
-                }
                 if (seg.idx_first) {
                     float* p2 = sSeg2 + 4 * hi * SNP + sgf;
                     atomicAdd(p2, dq[0]); atomicAdd(p2 + SNP, dq[1]); atomicAdd(p2 + 2 * SNP, dq[2]); atomicAdd(p2 + 3 * SNP, dq[3]);

@@ -166,7 +166,14 @@ __device__ __forceinline__ FwdOut finish_step(const elg_rollout_args& A, int N1,
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             const int n = lane + 64 * ch;
-            if (n < N1) full_row[n] = e[ch] * inv;
+            if (n < N1) {
+                float v = e[ch] * inv;                                   // probabilities
+                if (A.dump_logits) {                                     // 1: clipped logits, 2: the score before the clip
+                    const bool open = lg[ch] > ELG_NEG_INF;
+                    v = !open ? ELG_NEG_INF : (A.dump_logits == 2 ? s[ch] + sb[n] : lg[ch]);
+                }
+                full_row[n] = v;
+            }
         }
     }
 
@@ -281,7 +288,7 @@ __device__ __forceinline__ FwdOut decode_step(const elg_rollout_args& A, const I
     constexpr int NG = GlimpseGroups<NCH, SMALL>::value;
     GlimpseSave<NG> gs;
     float4 o4 = q4;
-    if (!(A.debug_skip & 1)) o4 = glimpse<NCH, LDSK, NG>(I, N1, lane, q4, mk, TRAIN ? &gs : nullptr);
+    o4 = glimpse<NCH, LDSK, NG>(I, N1, lane, q4, mk, TRAIN ? &gs : nullptr);
     if (TRAIN) {
         const int half = lane >> 5, hq = lane & 31, rr = 2 * (lane & 3) + half;
         float* rA = A.trA + ((b * ELG_H + (hq >> 2)) * Rcap + r) * N1;
@@ -298,11 +305,7 @@ __device__ __forceinline__ FwdOut decode_step(const elg_rollout_args& A, const I
         if (lane == 0 && A.trLoad) A.trLoad[b * Rcap + r] = st.load;
     }
     float s[NCH];
-    if (!(A.debug_skip & 2)) pointer_scores<NCH, LDSK>(I, N1, lane, o4, sb, s);
-    else {
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) s[ch] = o4.x * (lane + ch);
-    }
+    pointer_scores<NCH, LDSK>(I, N1, lane, o4, sb, s);
 
     return finish_step<NCH, TSP, TRAIN>(A, N1, lane, sb, mk, s, snid, addval, forced_sel, uni, full_row, b, r, Rcap);
 }
@@ -777,7 +780,17 @@ __device__ __forceinline__ void co_finish4(const elg_rollout_args& A, int N1, in
     if (A.full_probs && t < A.dump_T && act) {
         float* frow = A.full_probs + (bm * A.dump_T + t) * N1;
 #pragma unroll
-        for (int k = 0; k < NK; ++k) if (lo + 16 * k < N1) frow[lo + 16 * k] = e[k] * inv;
+        for (int k = 0; k < NK; ++k) {
+            const int n = lo + 16 * k;
+            if (n < N1) {
+                float v = e[k] * inv;                                   // probabilities
+                if (A.dump_logits) {                                    // 1: clipped logits, 2: the score before the clip
+                    const bool masked = (((k < 4) ? w0 : w1) >> (n & 63)) & 1ull;
+                    v = masked ? ELG_NEG_INF : (A.dump_logits == 2 ? sSc[q * CO_SP + n] + dflt : A.clip * th[k]);
+                }
+                frow[n] = v;
+            }
+        }
     }
     // ---- choose
     int sel = 0;
@@ -1111,11 +1124,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
         for (int nt = 0; nt < CO_NT; ++nt)
 #pragma unroll
             for (int v = 0; v < 4; ++v) { kop[nt][v] = 0.f; vop[nt][v] = 0.f; }
-        long long pc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const bool prof_ = A.dump_T == -7;
         for (int t = 0; t < step_cap && t < A.Tmax; ++t) {
-            long long c0_ = prof_ ? clock64() : 0;
-#define PCLK(i) if (prof_) { const long long c_ = clock64(); pc_[i] += c_ - c0_; c0_ = c_; }
             // Opaque per-iteration copy of the lane id: every address below is a function of it, so the compiler cannot
             // hoist the (loop-invariant) address arithmetic of ~300 loads out of the step loop -- it did, and then
             // spilled ~250 VGPRs of precomputed 64-bit addresses; recomputing them costs a few hundred VALU ops a step.
@@ -1123,7 +1132,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
             asm volatile("" : "+v"(lane_t));
             const int lo_t = lane_t & 15, hi_t = lane_t >> 4;
             const bool decode_step = TSP ? (t >= 1) : (t >= 2);     // uniform over the workgroup: lockstep
-            if (decode_step && !(A.debug_skip & 16)) {
+            if (decode_step) {
                 // =============== glimpse: wave = head ===============
                 // (kop / vop: this head's K_h / V_h operand images, 56 registers, re-read from L2 for every step right
                 // after the owners' phase so the latency hides behind the barrier.  The instance's 103 KB of K / V stay
@@ -1201,9 +1210,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                         *reinterpret_cast<float4*>(A.trO + ((size_t)b * Rcap + r) * ELG_E + 16 * wave + 4 * hi_t) =
                             make_float4(o[0], o[1], o[2], o[3]);
                 }
-                PCLK(0)
                 __syncthreads();
-                PCLK(1)
                 // =============== pointer (waves 0-5: 7 node tiles x 2 trajectory tiles) || local policy (waves 6, 7) ====
                 if (wave < 6) {
 #pragma unroll 1
@@ -1226,133 +1233,41 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                     // wave 6: trajectories 0-15, wave 7: trajectories 16-31
                     co_local16(sT, la, sX + (wave - 6) * 16 * CO_XP, lo_t, hi_t);
                 }
-                PCLK(2)
                 __syncthreads();
-                PCLK(3)
             }
             // =============== owners: finish this step, advance, prepare the next ===============
             int any_left = 0;
-            const bool batched = !(A.debug_skip & 32);                  // bit 5: per-trajectory finish_step (A/B)
-            const bool all4 = !(A.debug_skip & 96);                     // bit 6: batched choice, per-trajectory advance (A/B)
-            if (all4) {
-                // the wave's four trajectories side by side, 16 lanes each: choice, transition, next step's inputs
-                const int q4 = 4 * wave + (lane_t >> 4);
-                const int m4 = g_lo + min(q4, ntraj - 1);
-                const size_t bm4 = (size_t)b * A.M + m4;
-                const bool active = q4 < ntraj && !row.fin;
-                int sel = 0;
-                float pr = 1.0f;
-                if (decode_step) {
-                    co_finish4<TSP, TRAIN>(A, N1, lane_t, wave, ntraj, t, g_lo, (size_t)b, Rcap, sSc, sMask, sX, sState,
-                                           q4 < ntraj ? row.fin : 1, sel, pr);
-                } else if (A.mode == ELG_MODE_FORCED) {
-                    sel = (A.forced && t < A.Tforced) ? A.forced[bm4 * A.Tforced + t] : 0;
-                } else {
-                    sel = (!TSP && t == 0) ? 0 : A.starts[m4];
-                }
-                PCLK(4)
-                if (active && (lane_t & 15) == 0) {
-                    if (A.actions) A.actions[bm4 * A.Tmax + t] = sel;
-                    if (A.probs) A.probs[((size_t)b * A.Tmax + t) * A.M + m4] = pr;
-                }
-                co_advance4<TSP, TRAIN>(A, I, N1, lane_t, wave, ntraj, t, g_lo, (size_t)b, Rcap, row, sel, active, sMask, sQ, sX);
-                PCLK(5)
-                any_left = (q4 < ntraj && !row.fin) ? 1 : 0;
+            // the wave's four trajectories side by side, 16 lanes each: choice, transition, next step's inputs
+            const int q4 = 4 * wave + (lane_t >> 4);
+            const int m4 = g_lo + min(q4, ntraj - 1);
+            const size_t bm4 = (size_t)b * A.M + m4;
+            const bool active = q4 < ntraj && !row.fin;
+            int sel = 0;
+            float pr = 1.0f;
+            if (decode_step) {
+                co_finish4<TSP, TRAIN>(A, N1, lane_t, wave, ntraj, t, g_lo, (size_t)b, Rcap, sSc, sMask, sX, sState,
+                                       q4 < ntraj ? row.fin : 1, sel, pr);
+            } else if (A.mode == ELG_MODE_FORCED) {
+                sel = (A.forced && t < A.Tforced) ? A.forced[bm4 * A.Tforced + t] : 0;
             } else {
-            int dsel = 0;
-            float dpr = 1.0f;
-            if (decode_step && batched)
-                co_finish4<TSP, TRAIN>(A, N1, lane_t, wave, ntraj, t, g_lo, (size_t)b, Rcap, sSc, sMask, sX, sState, -1, dsel, dpr);
-#pragma unroll 1
-            for (int qi = 0; qi < 4; ++qi) {
-                const int q = 4 * wave + qi;                            // wave w owns trajectories 4 w .. 4 w + 3
-                if (q >= ntraj) break;
-                Traj<2> st;
-                co_load_state(sState + 16 * q, st, lane_t);
-                const int m = g_lo + q;
-                const size_t bm = (size_t)b * A.M + m;
-                const size_t r = (size_t)t * A.M + m;
-                if (!st.fin) {
-                    int fsel = 0;
-                    if (A.forced && t < A.Tforced) fsel = __builtin_amdgcn_readfirstlane(A.forced[bm * A.Tforced + t]);
-                    int sel;
-                    float pr = 1.0f;
-                    if (!decode_step) {
-                        if (A.mode == ELG_MODE_FORCED) sel = fsel;
-                        else sel = (!TSP && t == 0) ? 0 : __builtin_amdgcn_readfirstlane(A.starts[m]);
-                    } else if (batched) {
-                        sel = __builtin_amdgcn_readfirstlane(sState[16 * q + 12]);
-                        pr = i2f(__builtin_amdgcn_readfirstlane(sState[16 * q + 13]));
-                    } else {
-                        unsigned long long mk[2];
-                        {
-                            const unsigned long long x0 = sMask[2 * q], x1 = sMask[2 * q + 1];
-                            mk[0] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(x0 >> 32)) << 32) |
-                                    (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)x0);
-                            mk[1] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(x1 >> 32)) << 32) |
-                                    (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)x1);
-                        }
-                        float addval = 0.f;
-                        int snid = -1;
-                        if (lane_t < ELG_SLOT_STRIDE) {
-                            const float* X = sX + q * CO_XP;
-                            const int code = reinterpret_cast<const int*>(X)[CO_XS + lane_t];
-                            snid = (code == -2) ? 0 : code;
-                            addval = X[CO_XPEN + lane_t] + X[CO_XU + lane_t] * A.inv_ens;
-                        }
-                        float s[2];
-                        s[0] = (lane_t < N1) ? sSc[q * CO_SP + lane_t] : 0.f;
-                        s[1] = (lane_t + 64 < N1) ? sSc[q * CO_SP + 64 + lane_t] : 0.f;
-                        float uni = 0.f;
-                        if (A.mode == ELG_MODE_SAMPLE)
-                            uni = A.uniforms ? A.uniforms[bm * A.Tmax + t] : philox_uniform(A.seed, (unsigned)bm, (unsigned)t);
-                        float* frow = (A.full_probs && t < A.dump_T) ? A.full_probs + (bm * A.dump_T + t) * N1 : nullptr;
-                        const FwdOut o = finish_step<2, TSP, TRAIN>(A, N1, lane_t, sb, mk, s, snid, addval, fsel, uni, frow,
-                                                                    (size_t)b, r, Rcap);
-                        sel = __builtin_amdgcn_readfirstlane(o.sel);
-                        pr = i2f(__builtin_amdgcn_readfirstlane(f2i(o.p)));
-                    }
-                    if (lane_t == 0) {
-                        if (A.actions) A.actions[bm * A.Tmax + t] = sel;
-                        if (A.probs) A.probs[((size_t)b * A.Tmax + t) * A.M + m] = pr;
-                    }
-                    env_update<2, TSP>(st, I, N1, sel);
-                }
-                // the step this trajectory decodes next (t + 1): its mask and query, or an inert row
-                const bool next_decodes = !st.fin && (t + 1 < A.Tmax) && (TSP ? (t + 1 >= 1) : (t + 1 >= 2));
-                co_prepare<TSP, TRAIN>(A, I, st, N1, lane_t, next_decodes, sMask + 2 * q, sQ + q * CO_QP, sX + q * CO_XP, sb,
-                                       (size_t)b, (size_t)(t + 1) * A.M + m, Rcap);
-                co_store_state<TSP>(sState + 16 * q, st, lane_t);
-                any_left |= st.fin ? 0 : 1;
+                sel = (!TSP && t == 0) ? 0 : A.starts[m4];
             }
+            if (active && (lane_t & 15) == 0) {
+                if (A.actions) A.actions[bm4 * A.Tmax + t] = sel;
+                if (A.probs) A.probs[((size_t)b * A.Tmax + t) * A.M + m4] = pr;
             }
+            co_advance4<TSP, TRAIN>(A, I, N1, lane_t, wave, ntraj, t, g_lo, (size_t)b, Rcap, row, sel, active, sMask, sQ, sX);
+            any_left = (q4 < ntraj && !row.fin) ? 1 : 0;
             ELG_CO_LOAD_KV()                                         // next step's glimpse operands, in flight over the barrier
-            PCLK(6)
-            const int more_ = __syncthreads_or(any_left);
-            PCLK(7)
-            if (!more_) break;                                       // also orders the exchange rows for the next step
+            if (!__syncthreads_or(any_left)) break;                  // also orders the exchange rows for the next step
         }
-        if (prof_ && lane == 0 && A.full_probs) {
-            unsigned long long* dst = reinterpret_cast<unsigned long long*>(A.full_probs) + wave * 8;
-            for (int i = 0; i < 8; ++i) atomicAdd(dst + i, (unsigned long long)pc_[i]);
-        }
-#undef PCLK
         // ---- results of the group
-        if (!(A.debug_skip & 96)) {
+        {
             const int q4 = 4 * wave + (lane >> 4);
             if (q4 < ntraj && (lane & 15) == 0) {
                 const size_t bm = (size_t)b * A.M + g_lo + q4;
                 if (A.reward) A.reward[bm] = -row.len;
                 if (A.tlen) A.tlen[bm] = row.cnt;
-            }
-        } else
-        for (int q = 4 * wave; q < min(ntraj, 4 * wave + 4); ++q) {
-            Traj<2> st;
-            co_load_state(sState + 16 * q, st, lane);
-            const size_t bm = (size_t)b * A.M + g_lo + q;
-            if (lane == 0) {
-                if (A.reward) A.reward[bm] = -st.len;
-                if (A.tlen) A.tlen[bm] = st.cnt;
             }
         }
         __syncthreads();
@@ -1682,13 +1597,13 @@ template <bool TSP>
 static int dispatch_fwd(const elg_rollout_args& A, hipStream_t stream) {
     const int nch = (A.N1 + 63) / 64;
     if (A.lds_stage && A.N1 > 16 * CO_NT) return fail(ELG_EINVAL, "lds_stage needs N1 <= 112");
-    if (A.waves != 8 && A.waves != 9 && A.waves != 13) return fail(ELG_EINVAL, "waves must be 8, 9 or 13");
+    if (A.waves != 8) return fail(ELG_EINVAL, "waves must be 8");
     // lds_stage = "keep the instance's tables on chip": MFMA operand images (cooperative kernel, N1 <= 112) or the
     // LDS copies of the one-wavefront-per-trajectory kernel (N1 <= 104; 105..112 fall back to its L2 variant)
     const bool lds = A.lds_stage != 0 && A.N1 <= 104;
 #define ELG_GO(NCHV, L, W) return launch_fwd<NCHV, TSP, L, W>(A, stream)
     if (A.lds_stage && A.waves == 8 && A.N1 >= 4 && A.N1 <= 16 * CO_NT && !A.use_state && A.do_decode && A.do_update &&
-        A.max_steps <= 0 && !(A.debug_skip & 0xB)) {   // bits 4, 5: coop-kernel ablations / variants
+        A.max_steps <= 0 && A.variant == 0) {
         // fused rollout at the training scale: lockstep trajectories, tables as MFMA operands in registers
         if (A.trA || A.trMask) {        // training forward (glimpse weights saved, or recomputed from the mask rows)
             if (!A.trPC || !A.trCsel || !A.trQ || !A.trO) return fail(ELG_EINVAL, "rollout: incomplete training rows");
@@ -1702,7 +1617,6 @@ static int dispatch_fwd(const elg_rollout_args& A, hipStream_t stream) {
         if (A.use_state) return fail(ELG_EINVAL, "rollout: training rows need the fused rollout");
         if (nch == 1) { if (lds) return launch_fwd<1, TSP, true, 8, true>(A, stream); return launch_fwd<1, TSP, false, 8, true>(A, stream); }
         if (nch == 2) {
-            if (lds && A.waves == 9) return launch_fwd<2, TSP, true, 9, true>(A, stream);
             if (lds) return launch_fwd<2, TSP, true, 8, true>(A, stream);
             return launch_fwd<2, TSP, false, 8, true>(A, stream);
         }
@@ -1710,11 +1624,11 @@ static int dispatch_fwd(const elg_rollout_args& A, hipStream_t stream) {
     }
     if (nch == 1) { if (lds) ELG_GO(1, true, 8); else ELG_GO(1, false, 8); }
     if (nch == 2) {
-        if (lds) { if (A.waves == 9) ELG_GO(2, true, 9); if (A.waves == 13) ELG_GO(2, true, 13); ELG_GO(2, true, 8); }
+        if (lds) ELG_GO(2, true, 8);
         else ELG_GO(2, false, 8);
     }
     if (lds) return fail(ELG_EINVAL, "lds_stage needs N1 <= 104");
-    if (!A.use_state && A.do_decode && A.do_update && A.max_steps <= 0 && !(A.debug_skip & 4)) {
+    if (!A.use_state && A.do_decode && A.do_update && A.max_steps <= 0 && A.variant == 0) {
         // fused rollout of a large instance: node-tiled kernel (tables shared through LDS tiles)
         if (nch <= 4) return launch_fwd_tiled<4, TSP, 8, 128>(A, stream);
         if (nch <= 8) return launch_fwd_tiled<8, TSP, 8, 128>(A, stream);

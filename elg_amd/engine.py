@@ -350,7 +350,7 @@ class RolloutResult:
 
 def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mode: int, *, forced=None, seed: int = 0,
                     uniforms=None, dump_T: int = 0, geometry=None, Tcap: Optional[int] = None,
-                    train: bool = False, debug: int = 0) -> RolloutResult:
+                    train: bool = False, variant: int = 0, dump: str = "probs") -> RolloutResult:
     """Run every trajectory to completion in one persistent launch (reference CVRP/utils.py:7-29)."""
     dev = prob.xy.device
     _need_cuda(prob.xy, "the problem")
@@ -365,7 +365,8 @@ def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mo
     _fill_common(a, prob, pol, M, geometry)
     a.Tmax, a.mode, a.max_steps, a.do_decode, a.do_update, a.use_state = Tcap, mode, 0, 1, 1, 0
     a.seed = seed & 0xFFFFFFFFFFFFFFFF
-    a.debug_skip = debug
+    a.variant = variant
+    a.dump_logits = {"probs": 0, "logits": 1, "scores": 2}[dump]
     starts = starts.to(device=dev, dtype=torch.int32).contiguous()
     a.starts = _ptr(starts)
     if forced is not None:
@@ -385,7 +386,7 @@ def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mo
         # glimpse log2-sum-exp per head instead of the glimpse weights: the backward recomputes the weights from q, K, the
         # mask and the saved normaliser (28 MFMAs + one exp2 per weight).  4.2 GB less workspace and 6.6 GB less HBM traffic
         # per step at the bench shape, and no slower (the forward's 3.3 GB of scattered stores cost what the recompute does)
-        rows.use_mask = bool(a.lds_stage and a.waves == 8 and 4 <= N1 <= 112 and not (debug & 0xB))
+        rows.use_mask = bool(a.lds_stage and a.waves == 8 and 4 <= N1 <= 112 and variant == 0)
         a.trA = None if rows.use_mask else _ptr(rows.A)
         a.trMask = _ptr(rows.Mask) if rows.use_mask else None
         a.trLse = _ptr(rows.Lse) if rows.use_mask else None

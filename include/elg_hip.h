@@ -63,7 +63,7 @@ int elg_nbr_tables(const float* xy, int32_t* nbr_idx, float* nbr_dist, float* nb
 int elg_route_length(const float* xy, const int64_t* tour, float* out, int B, int M, int T, int N,
                      int rounding, void* stream);
 
-/* Arguments of the construction kernels.  One trajectory = one wavefront. */
+/* Arguments of the construction kernels (three kernels behind one entry point: `variant`, `lds_stage`). */
 typedef struct elg_rollout_args {
     int32_t problem;        /* ELG_PROBLEM_*                                                    */
     int32_t B, M, N1;       /* instances, POMO trajectories per instance, nodes (CVRP: + depot) */
@@ -77,7 +77,7 @@ typedef struct elg_rollout_args {
     int32_t do_decode;      /* 0: env update only with forced actions (CVRPEnv.step)            */
     int32_t do_update;      /* 0: decode only (CVRPModel.one_step_rollout)                      */
     int32_t use_state;      /* 1: load/store the st_* arrays (step-wise protocol)               */
-    int32_t waves;          /* wavefronts per workgroup: 8 (9 / 13: per-wavefront kernel experiments) */
+    int32_t waves;          /* wavefronts per workgroup: 8                                      */
     int32_t tiles;          /* workgroups per instance                                          */
     int32_t lds_stage;      /* 1: keep the instance's tables on chip (N1 <= 112): fused rollouts run the
                                cooperative lockstep MFMA kernel, step-wise calls the LDS-staged kernel   */
@@ -85,9 +85,12 @@ typedef struct elg_rollout_args {
     float xi;               /* model_params.xi                                                  */
     float clip;             /* model_params.logit_clipping                                      */
     float inv_ens;          /* 1 / ensemble_size                                                */
-    int32_t debug_skip;     /* diagnostics only (0 in production): bit0 skip glimpse, bit1 skip pointer,
-                               bit2 run N1 > 128 through the untiled kernel,
-                               bit3 run N1 <= 112 through the one-wavefront-per-trajectory kernel */
+    int32_t variant;        /* 0: pick the kernel by shape (cooperative MFMA kernel for N1 <= 112, node-tiled kernel for
+                               N1 > 128); 1: the one-wavefront-per-trajectory kernel for any N1 (what the step-wise
+                               protocol and 112 < N1 <= 128 always use; the A/B reference of the parity tests)      */
+    int32_t dump_logits;    /* what full_probs receives: 0 probabilities, 1 the clipped + masked logits
+                               clip * tanh(s) (-inf at closed nodes), 2 the scores s before the clip            */
+    int32_t pad0;
     uint64_t seed;          /* sampling seed (Philox key)                                       */
     const float* Kmat;      /* (B,N1,128) decoder.Wk enc                                        */
     const float* Vmat;      /* (B,N1,128) decoder.Wv enc                                        */
@@ -207,28 +210,6 @@ int elg_glimpse_bwd_fused(const float* rowA, const uint64_t* rowMask, const floa
 int elg_pomo_loss(const float* probs, const float* reward, int B, int T, int M, int64_t probs_bstride,
                   int64_t probs_tstride, float* J_raw, float* J_scaled, float* adv_max, float* coef_raw,
                   float* coef_scaled, void* stream);
-
-/* Cotangent rows of the decoder backward from the rows saved by a training forward (time-major r = t*M + m):
- *   w = gprob * pval * [first_decode_step <= t < tlen[b,m]]
- *   rowDL[b,r,n] = w (Csel [n == action] - PC[n]);  rowDU[b,r,j] = rowDL[b,r,Slot[j]] * inv_ens (0 for empty slots)
- *   onehot_prev[b,r,n] = [n == action at t-1 (0 at t = 0)],  onehot_first[b,r,n] = [n == action at t = 0]
- * gprob, pval (B,T,M) dense; tlen (B,M); actions (B,M,Tcap_actions); PC (B,Rcap,N1); Csel (B,Rcap); Slot (B,Rcap,48);
- * outputs dense over R = T*M rows.  rowDU / onehot_* may be NULL.  If `load` (B,Rcap: vehicle load of the row, CVRP)
- * is given, onehot_prev is (B,R,N1+1) and its last column holds the load, so that onehot_prev^T dQ also produces
- * d wl (the load column of Wq_last) in row N1.  idx_prev / idx_first (B,R) int32, may be NULL: the same node indices
- * as plain integers, for elg_rows_segsum (which needs no one-hot matrix). */
-int elg_rows_prep(const float* gprob, const float* pval, const int32_t* tlen, const int32_t* actions,
-                  const float* PC, const float* Csel, const int32_t* Slot, const float* load, float* rowDL,
-                  float* rowDU, float* onehot_prev, float* onehot_first, int32_t* idx_prev, int32_t* idx_first,
-                  int B, int T, int M, int N1, int Tcap_actions,
-                  int64_t Rcap, int first_decode_step, float inv_ens, void* stream);
-
-/* out_part[s, b, n, :] = sum over the rows r (in row split s) of instance b with idx[b, r] == n of X[b, r, :]; if
- * wrow >= 0, row wrow instead holds sum_r w[b, r] X[b, r, :].  X (B,R,128), idx (B,R), w (B,w_stride), out_part
- * (splits,B,NO,128), NO <= 128.  This is onehot^T X (the query-gather backward, models.py:330-333 / the load column
- * of Wq_last) with the one-hot operand built in registers. */
-int elg_rows_segsum(const float* X, const int32_t* idx, const float* w, float* out_part, int B, int R, int NO, int wrow,
-                    int64_t w_stride, int splits, void* stream);
 
 /* torch.optim.Adam update (L2 weight decay added to the gradient, bias correction; reference train.py:101) over n
  * floats in one launch.  grad / exp_avg / exp_avg_sq are flat.  Parameters: either flat (`param`), or left in place

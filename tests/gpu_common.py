@@ -152,3 +152,32 @@ def assert_same_mask(got, ref, what=""):
     assert not (got[ref == 0] != 0).any(), f"{what}: masked node received probability"
     dead = (got == 0) & (ref > 1e-35)
     assert not dead.any(), f"{what}: unmasked node lost its probability ({ref[dead][:5]})"
+
+
+def record_parity(name: str, value: float):
+    """Keep the worst observed error of a parity test: merged into gpurun_out/parity_r02.json (copied to profiles/)."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r02.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        cur = json.load(open(path)) if os.path.exists(path) else {}
+        cur[name] = max(float(value), float(cur.get(name, 0.0)))
+        with open(path, "w") as f:
+            json.dump(cur, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def load_model(problem, wseed, mp, gain=1.0, local=True):
+    """elg_amd model on the GPU carrying the golden weights (the state_dict names are the reference's)."""
+    if problem == "cvrp":
+        from elg_amd.CVRP.CVRPModel import CVRPModel as Model
+    else:
+        from elg_amd.TSP.TSPModel import TSPModel as Model
+    model = Model(**mp)
+    if local:
+        model.decoder.add_local_policy(DEV)
+    w = gu.golden_weights(problem, wseed, mp, local, gain)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
+    return model.to(DEV).eval()

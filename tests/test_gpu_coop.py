@@ -52,7 +52,7 @@ def test_coop_matches_per_wave_kernel(kind, N, B, M, tiles):
     acts = a.actions[:, :, :T].contiguous()
     # same sampled tours teacher-forced through both kernels: probabilities, rewards, step counts
     c = eng.rollout_forward(prob, pol, M, starts, L.MODE_FORCED, forced=acts, geometry=geom, dump_T=min(T, 12))
-    w = eng.rollout_forward(prob, pol, M, starts, L.MODE_FORCED, forced=acts, geometry=geom, dump_T=min(T, 12), debug=8)
+    w = eng.rollout_forward(prob, pol, M, starts, L.MODE_FORCED, forced=acts, geometry=geom, dump_T=min(T, 12), variant=1)
     assert torch.equal(c.actions, w.actions) and torch.equal(c.tlen, w.tlen) and torch.equal(a.tlen, c.tlen)
     np.testing.assert_allclose(c.probs.cpu().numpy(), w.probs.cpu().numpy(), rtol=2e-4, atol=1e-9)
     np.testing.assert_allclose(a.probs.cpu().numpy(), c.probs.cpu().numpy(), rtol=1e-6, atol=0)     # sampled = forced replay
@@ -69,7 +69,7 @@ def test_coop_matches_per_wave_kernel(kind, N, B, M, tiles):
     np.testing.assert_allclose(c.reward.cpu().numpy(), out["reward"].numpy(), rtol=1e-5)
     # greedy: identical tours except where a rounding tie flips a choice
     g1 = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, geometry=geom)
-    g2 = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, geometry=geom, debug=8)
+    g2 = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, geometry=geom, variant=1)
     same = (g1.actions == g2.actions).all(-1).float().mean().item()
     assert same >= 0.9, same
 
@@ -89,8 +89,8 @@ def test_coop_training_rows_match_per_wave_kernel(kind):
     acts = a.actions[:, :, :T].contiguous()
     R = T * M
     keep = {}
-    for tag, dbg in (("coop", 0), ("wave", 8)):
-        r = eng.rollout_forward(prob, pol, M, starts, L.MODE_FORCED, forced=acts, train=True, debug=dbg)
+    for tag, dbg in (("coop", 0), ("wave", 1)):
+        r = eng.rollout_forward(prob, pol, M, starts, L.MODE_FORCED, forced=acts, train=True, variant=dbg)
         rows = r.rows
         keep[tag] = dict(PC=rows.PC[:, :R].clone(), Csel=rows.Csel[:, :R].clone(),
                          Q=rows.Q[:, :R].clone(), O=rows.O[:, :R].clone(), Load=rows.Load[:, :R].clone(),
@@ -116,9 +116,9 @@ def test_saved_rows_backward_equals_replay_backward(kind, N, recompute, monkeypa
     local-policy backward kernels) = gradients through the replay kernels, also for 104 < N1 <= 112 where the
     per-wavefront kernels read their tables from L2."""
     from elg_amd import _lib as L, engine as eng
-    # stored weights: the per-wavefront forward (debug bit 3; what 112 < N1 <= 128 uses) saves the glimpse weights; the
+    # stored weights: the per-wavefront forward (variant 1; what 112 < N1 <= 128 uses) saves the glimpse weights; the
     # cooperative forward saves mask rows + normalisers and the backward recomputes the weights
-    dbg = 0 if recompute else 8
+    dbg = 0 if recompute else 1
     B, M = 2, 23
     P, cfg, xy, dem, enc, prob, pol = _setup(kind, N, B, 5)
     off = 1 if kind == "cvrp" else 0
@@ -133,7 +133,7 @@ def test_saved_rows_backward_equals_replay_backward(kind, N, recompute, monkeypa
         tabs = {k: (v.detach().clone().requires_grad_(True) if v is not None else None) for k, v in pol.tables.items()}
         loc = pol.loc.detach().clone().requires_grad_(True)
         p2 = eng.Policy(tabs, loc, pol.K, pol.xi, pol.clip, pol.inv_ens, pol.has_local, pol.has_penalty)
-        res = eng.rollout_forward(prob, p2, M, starts, L.MODE_FORCED, forced=acts, train=train, debug=dbg if train else 0)
+        res = eng.rollout_forward(prob, p2, M, starts, L.MODE_FORCED, forced=acts, train=train, variant=dbg if train else 0)
         if train:
             assert res.rows.use_mask == recompute
         probs = eng.chosen_probs(prob, p2, M, res, T)

@@ -51,7 +51,7 @@ def test_cvrp_large_sampled_replay(N, B, M):
     np.testing.assert_allclose(got, out["probs"].numpy(), rtol=PROB_RTOL, atol=1e-9)
     np.testing.assert_allclose(res.reward.cpu().numpy(), out["reward"].numpy(), rtol=1e-5)
     # the untiled kernel (every trajectory streams the tables itself) takes the same decisions
-    ref = eng.rollout_forward(prob, pol, M, starts, L.MODE_FORCED, forced=acts, debug=4)
+    ref = eng.rollout_forward(prob, pol, M, starts, L.MODE_FORCED, forced=acts, variant=1)
     np.testing.assert_allclose(ref.probs[:, :T].cpu().numpy(), got, rtol=2e-4, atol=1e-9)
     np.testing.assert_allclose(ref.reward.cpu().numpy(), res.reward.cpu().numpy(), rtol=1e-6)
 
@@ -111,7 +111,7 @@ def test_tsp_large_sampled_replay(N, B, M):
         ref = out["full_probs"][t - 1].numpy()
         gc.assert_same_mask(full[:, :, t, :], ref, f"t={t}")
         assert gc.rel_err_probs(full[:, :, t, :], ref) < PROB_RTOL
-    ref = eng.rollout_forward(prob, pol, M, starts, L.MODE_FORCED, forced=acts, debug=4)
+    ref = eng.rollout_forward(prob, pol, M, starts, L.MODE_FORCED, forced=acts, variant=1)
     np.testing.assert_allclose(ref.probs.cpu().numpy(), got, rtol=2e-4, atol=1e-9)
 
 
@@ -130,6 +130,6 @@ def test_tiled_uneven_rounds_and_tiles():
         b = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, geometry=(8, tiles, 0))
         assert torch.equal(a.actions, b.actions) and torch.equal(a.tlen, b.tlen)
         assert torch.equal(a.reward, b.reward)
-    c = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, debug=4)
+    c = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, variant=1)
     agree = (a.actions == c.actions).all(-1).float().mean().item()
     assert agree > 0.8, agree            # greedy ties can flip a tour; most are identical

@@ -1,0 +1,124 @@
+"""north_star's tolerance tested where it is stated: on the logits.  The reference's decoder internals at teacher-forced
+steps (tests/golden/r02_*_logits_*.npz, tools/make_golden_r02.py) against what the HIP kernels compute from the same
+weights THROUGH THE WHOLE PRODUCT PATH -- native encoder + set_kv (elg_encoder_fwd), then the cooperative kernel, the
+one-wavefront-per-trajectory kernel and (N1 > 128) the node-tiled kernel:
+    scores before the clip:   |got - ref| <= 1e-4 max(|ref|, 1)      on every open node
+    clipped logits:           |got - ref| <= 1e-4 * logit_clipping   on every open node, closed nodes -inf in both"""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+import gpu_common as gc
+from elg_amd import _lib as L
+from elg_amd import engine as eng
+
+pytestmark = pytest.mark.gpu
+DEV = gc.DEV
+TOL = 1e-4
+
+
+def _check(tag, kernel, lg, scores, logits, clip, steps, t_index, tlen):
+    """Trajectories that are already finished at step t (the reference keeps decoding them, depot only) are not decoded
+    by the engine: compared are the rows of the trajectories still under construction."""
+    worst_s = worst_l = 0.0
+    tl = tlen.cpu().numpy()
+    for i, t in enumerate(steps):
+        live = (int(t) < tl)[:, :, None]
+        ref_l = lg["logits"][i]
+        open_ = np.isfinite(ref_l) & live
+        got_l = logits[:, :, t_index(t)].cpu().numpy()
+        got_s = scores[:, :, t_index(t)].cpu().numpy()
+        assert np.array_equal(np.isfinite(got_l) & live, open_), (tag, kernel, int(t), "mask pattern")
+        assert open_.any()
+        ref_s = lg["pre_clip"][i]
+        es = float((np.abs(got_s[open_] - ref_s[open_]) / np.maximum(np.abs(ref_s[open_]), 1.0)).max())
+        el = float((np.abs(got_l[open_] - ref_l[open_]) / clip).max())
+        worst_s, worst_l = max(worst_s, es), max(worst_l, el)
+        assert es <= TOL, (tag, kernel, int(t), "score", es)
+        assert el <= TOL, (tag, kernel, int(t), "logit", el)
+    gc.record_parity(f"logits/{tag}/{kernel}/score_rel", worst_s)
+    gc.record_parity(f"logits/{tag}/{kernel}/logit_over_clip", worst_l)
+    print(tag, kernel, f"scores {worst_s:.2e}  logits/clip {worst_l:.2e}")
+
+
+@pytest.mark.parametrize("variant", [0, 1], ids=["cooperative", "wave_per_trajectory"])
+@pytest.mark.parametrize("tag", ["n50", "n20k8", "n100"])
+def test_cvrp_logits_through_the_product_path(tag, variant):
+    from elg_amd.CVRP.CVRPEnv import CVRPEnv
+    lg = gu.load_golden(f"r02_cvrp_logits_{tag}.npz")
+    fx = gu.load_golden(f"cvrp_rollout_{str(lg['src'])}.npz")
+    B, N, M, wseed, pseed, local_size, rseed = [int(x) for x in fx["meta"]]
+    mp = dict(gu.CVRP_MODEL_PARAMS)
+    mp["local_size"] = [local_size]
+    model = gc.load_model("cvrp", wseed, mp, float(fx["gain"]))
+    depot, loc, demand = gu.golden_cvrp_problem(pseed, B, N, float(fx["capacity"]))
+    env = CVRPEnv(multi_width=M, device=DEV)
+    env.load_random_problems(dict(loc=torch.from_numpy(loc), demand=torch.from_numpy(demand), depot=torch.from_numpy(depot)))
+    rs, _, _ = env.reset()
+    with torch.no_grad():
+        model.pre_forward(rs)
+    acts = torch.from_numpy(fx["actions"].astype(np.int32))
+    T = acts.shape[2]
+    pol = model.decoder.policy
+    dumps = {}
+    for what in ("scores", "logits"):
+        r = eng.rollout_forward(env.problem, pol, M, acts[0, :, 1], L.MODE_FORCED, forced=acts, dump_T=T, variant=variant, dump=what)
+        dumps[what] = r.full_probs
+    _check(f"cvrp_{tag}", "coop" if variant == 0 else "wave", lg, dumps["scores"], dumps["logits"], mp["logit_clipping"],
+           lg["steps"], lambda t: int(t), r.tlen)
+
+
+@pytest.mark.parametrize("variant", [0, 1], ids=["cooperative", "wave_per_trajectory"])
+@pytest.mark.parametrize("tag", ["n50", "n20"])
+def test_tsp_logits_through_the_product_path(tag, variant):
+    from elg_amd.TSP.TSPEnv import TSPEnv
+    lg = gu.load_golden(f"r02_tsp_logits_{tag}.npz")
+    fx = gu.load_golden(f"tsp_rollout_{str(lg['src'])}.npz")
+    B, N, M, wseed, pseed, local_size, rseed = [int(x) for x in fx["meta"]]
+    mp = dict(gu.TSP_MODEL_PARAMS)
+    mp["local_size"] = [local_size]
+    model = gc.load_model("tsp", wseed, mp, float(fx["gain"]))
+    env = TSPEnv(multi_width=M, device=DEV)
+    env.load_random_problems(torch.from_numpy(gu.golden_tsp_problem(pseed, B, N)))
+    rs, _, _ = env.reset()
+    with torch.no_grad():
+        model.pre_forward(rs)
+    acts = torch.from_numpy(fx["actions"].astype(np.int32))
+    pol = model.decoder.policy
+    dumps = {}
+    for what in ("scores", "logits"):
+        r = eng.rollout_forward(env.problem, pol, M, acts[0, :, 0], L.MODE_FORCED, forced=acts, dump_T=N, variant=variant, dump=what)
+        dumps[what] = r.full_probs
+    _check(f"tsp_{tag}", "coop" if variant == 0 else "wave", lg, dumps["scores"], dumps["logits"], mp["logit_clipping"],
+           lg["steps"], lambda t: int(t), r.tlen)
+
+
+@pytest.mark.parametrize("variant", [0, 1], ids=["node_tiled", "wave_per_trajectory"])
+def test_large_instance_logits(variant):
+    """N1 = 151: the node-tiled kernel (and the untiled one) against the reference's own greedy construction."""
+    from elg_amd.CVRP.CVRPEnv import CVRPEnv
+    lg = gu.load_golden("r02_cvrp_logits_n150.npz")
+    B, N, M, wseed, pseed = [int(x) for x in lg["meta"]]
+    mp = dict(gu.CVRP_MODEL_PARAMS)
+    model = gc.load_model("cvrp", wseed, mp, 1.0)
+    depot, loc, demand = gu.golden_cvrp_problem(pseed, B, N, float(lg["capacity"]))
+    env = CVRPEnv(multi_width=M, device=DEV)
+    env.load_random_problems(dict(loc=torch.from_numpy(loc), demand=torch.from_numpy(demand), depot=torch.from_numpy(depot)))
+    rs, _, _ = env.reset()
+    with torch.no_grad():
+        model.pre_forward(rs)
+    acts = torch.from_numpy(lg["actions"].astype(np.int32))
+    T = acts.shape[2]
+    pol = model.decoder.policy
+    dumps = {}
+    for what in ("scores", "logits"):
+        r = eng.rollout_forward(env.problem, pol, M, acts[0, :, 1], L.MODE_FORCED, forced=acts, dump_T=T, variant=variant, dump=what)
+        dumps[what] = r.full_probs
+    np.testing.assert_allclose(r.reward.cpu().numpy(), lg["reward"], rtol=2e-6)
+    _check("cvrp_n150", "tiled" if variant == 0 else "wave", lg, dumps["scores"], dumps["logits"], mp["logit_clipping"],
+           lg["steps"], lambda t: int(t), r.tlen)
+    # and free-running greedy reproduces the reference's tours
+    g = eng.rollout_forward(env.problem, pol, M, acts[0, :, 1], L.MODE_GREEDY, variant=variant)
+    Tg = int(g.tlen.max())
+    assert Tg == T and torch.equal(g.actions[:, :, :T].cpu(), acts)

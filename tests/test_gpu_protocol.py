@@ -8,6 +8,7 @@ import pytest
 import torch
 
 import golden_util as gu
+import gpu_common as gc
 from oracle import elg_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -143,8 +144,17 @@ def test_train_step_against_reference_train():
         g = named[name].numpy().astype(np.float64)
         g = g if kind == "full" else g.reshape(-1)[::stride]
         ref = fx[key]
-        bad = np.abs(g - ref) > 3e-3 * np.abs(ref).max() + atol       # see the ReLU note in test_gpu_tsp_protocol.py
-        assert bad.mean() < 0.01 and np.abs(g - ref).max() <= 0.1 * np.abs(ref).max() + atol, name
+        err = np.abs(g - ref)
+        if name.startswith("decoder."):
+            # exact arithmetic from the recorded actions to these gradients (no ReLU in between): every entry within
+            # 1e-3 of the tensor's largest entry, no outliers
+            assert err.max() <= 1e-3 * np.abs(ref).max() + atol, (name, err.max(), np.abs(ref).max())
+            gc.record_parity("train_step_grad/" + name, float(err.max() / (np.abs(ref).max() + atol)))
+        else:
+            # encoder: an activation within rounding distance of 0 may take the other ReLU branch than in the reference's
+            # fp32 evaluation, which moves every gradient upstream of it: allow 1 % of entries beyond the tight bound
+            bad = err > 3e-3 * np.abs(ref).max() + atol
+            assert bad.mean() < 0.01 and err.max() <= 0.1 * np.abs(ref).max() + atol, name
         n += 1
     assert n == len(named)
     opt.step()

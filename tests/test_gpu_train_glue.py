@@ -51,53 +51,97 @@ def test_pomo_loss_tsp_zero_normaliser_guard():
     assert torch.isfinite(J) and abs(J.item() - ref.item()) <= 1e-5 * mag
 
 
-@pytest.mark.parametrize("tsp", [False, True])
-def test_rows_prep_matches_torch(tsp):
+@pytest.mark.parametrize("tsp,recompute", [(False, False), (True, False), (False, True)])
+def test_decoder_bwd_matches_torch(tsp, recompute):
+    """elg_decoder_bwd on synthetic saved rows against the dense torch algebra it stands for (include/elg_hip.h):
+    dl = w (Csel [n == a] - PC), dO = dl PK, dPK = dl^T O, dpb = sum dl, dU = dl[slot] / ens, glimpse backward
+    (dK, dV, dQ) from dO, and dQ1 / dQ2 / dwl = the query-gather backward of dQ."""
+    import ctypes as C
     from elg_amd import _lib as L, engine as eng
-    B, T, M, N1, Tcap = 2, 9, 5, 23, 12
+    B, T, M, N1, Tcap, H = 2, 9, 5, 23, 12, 8
     R, Rcap = T * M, Tcap * M
     g = torch.Generator().manual_seed(3)
-    gp = torch.randn(B, T, M, generator=g).to(DEV)
-    pv = torch.rand(B, T, M, generator=g).to(DEV)
+
+    def rnd(*shape):
+        return torch.randn(*shape, generator=g).to(DEV)
+    gp, pv = rnd(B, T, M), torch.rand(B, T, M, generator=g).to(DEV)
     tlen = torch.randint(4, T + 1, (B, M), generator=g, dtype=torch.int32).to(DEV)
     acts = torch.randint(0, N1, (B, M, Tcap), generator=g, dtype=torch.int32).to(DEV)
-    PC = torch.randn(B, Rcap, N1, generator=g).to(DEV)
-    Csel = torch.randn(B, Rcap, generator=g).to(DEV)
-    Slot = torch.randint(-1, N1, (B, Rcap, 48), generator=g, dtype=torch.int32).to(DEV)
-    t0 = 1 if tsp else 2
-    inv = 0.5
-    rowDL = torch.full((B, R, N1), float("nan"), device=DEV)
-    rowDU = torch.full((B, R, 48), float("nan"), device=DEV)
+    PC, Csel, Q, O = rnd(B, Rcap, N1), rnd(B, Rcap), rnd(B, Rcap, 128), rnd(B, Rcap, 128)
     Load = torch.rand(B, Rcap, generator=g).to(DEV)
-    ohP = torch.full((B, R, N1 + (0 if tsp else 1)), float("nan"), device=DEV)
-    ohF = torch.full((B, R, N1), float("nan"), device=DEV) if tsp else None
-    ixP = torch.full((B, R), -7, device=DEV, dtype=torch.int32)
-    ixF = torch.full((B, R), -7, device=DEV, dtype=torch.int32) if tsp else None
-    L.check(L.lib().elg_rows_prep(eng._ptr(gp), eng._ptr(pv), eng._ptr(tlen), eng._ptr(acts), eng._ptr(PC), eng._ptr(Csel),
-                                  eng._ptr(Slot), eng._ptr(Load) if not tsp else None, eng._ptr(rowDL), eng._ptr(rowDU), eng._ptr(ohP), eng._ptr(ohF), eng._ptr(ixP), eng._ptr(ixF),
-                                  B, T, M, N1, Tcap, Rcap, t0, inv, eng._stream()), "rows_prep")
-    # the torch chain this kernel replaces (engine._ChosenProbs.backward before the fusion)
+    Slot = torch.randint(-1, N1, (B, Rcap, 48), generator=g, dtype=torch.int32).to(DEV)
+    K, V, PK = rnd(B, N1, 128), rnd(B, N1, 128), rnd(B, N1, 128)
+    closed = (torch.rand(B, Rcap, N1, generator=g) < 0.3).to(DEV)
+    closed[:, :, 1] = False
+    # glimpse weights of the rows: softmax over the open nodes of q.K / 4 per head
+    S = torch.einsum("brhd,bnhd->bhrn", Q.view(B, Rcap, H, 16), K.view(B, N1, H, 16)) / 4
+    S = S.masked_fill(closed[:, None], float("-inf"))
+    A = torch.softmax(S, dim=-1).contiguous()
+    bits = torch.zeros(B, Rcap, 2, dtype=torch.int64, device=DEV)
+    for n in range(N1):
+        bits[:, :, n // 64] |= closed[:, :, n].long() << (n % 64)
+    bits[:, :, 0] |= (-1 << N1)                         # nodes past N1 closed
+    bits[:, :, 1] = -1
+    lse = (torch.logsumexp(S, dim=-1) * 1.4426950408889634).permute(0, 2, 1).contiguous()        # (B,Rcap,8), log2 units
+    t0, inv = (1 if tsp else 2), 0.5
+    nt = 5 if tsp else 4
+    flat = torch.zeros(nt * B * N1 * 128 + B * N1 + 128, device=DEV)
+    blk = B * N1 * 128
+    dK, dV, dPK, dQ1 = (flat[i * blk:(i + 1) * blk].view(B, N1, 128) for i in range(4))
+    dQ2 = flat[4 * blk:5 * blk].view(B, N1, 128) if tsp else None
+    dpb = flat[nt * blk:nt * blk + B * N1].view(B, N1)
+    dwl = flat[nt * blk + B * N1:]
+    rowDU = torch.full((B, R, 48), float("nan"), device=DEV)
+    dO = torch.empty(B, R, 128, device=DEV)
+    ixP = torch.empty(B, R, dtype=torch.int32, device=DEV)
+    ixF = torch.empty(B, R, dtype=torch.int32, device=DEV)
+    rowW = torch.empty(B, R, 4, device=DEV)
+    a = L.DecoderBwdArgs()
+    a.problem, a.B, a.M, a.N1, a.T, a.Tcap_actions = (L.PROBLEM_TSP if tsp else L.PROBLEM_CVRP), B, M, N1, T, Tcap
+    a.first_decode_step, a.inv_ens, a.Rcap = t0, inv, Rcap
+    p = eng._ptr
+    a.gprob, a.pval, a.tlen, a.actions = p(gp), p(pv), p(tlen), p(acts)
+    a.trPC, a.trCsel, a.trQ, a.trO, a.trLoad, a.trSlot = p(PC), p(Csel), p(Q), p(O), (None if tsp else p(Load)), p(Slot)
+    a.trA, a.trMask, a.trLse = (None, p(bits), p(lse)) if recompute else (p(A), None, None)
+    a.Kmat, a.Vmat, a.PK = p(K), p(V), p(PK)
+    a.dK, a.dV, a.dPK, a.dpb, a.dQ1, a.dQ2, a.dwl = p(dK), p(dV), p(dPK), p(dpb), p(dQ1), p(dQ2), (None if tsp else p(dwl))
+    a.rowDU, a.dO, a.idx_prev, a.idx_first, a.rowW = p(rowDU), p(dO), p(ixP), p(ixF), p(rowW)
+    L.check(L.lib().elg_decoder_bwd(C.byref(a), eng._stream()), "elg_decoder_bwd")
+    # ---- the dense algebra in torch (double precision)
     fl = acts[:, :, :T].long()
     tt = torch.arange(T, device=DEV)[None, :, None]
     valid = (tt >= t0) & (tt < tlen[:, None, :])
-    W = (gp * pv * valid).reshape(B, R)
+    W = (gp * pv * valid).reshape(B, R).double()
     sel = fl.permute(0, 2, 1).reshape(B, R)
-    ref = PC[:, :R] * (-W)[:, :, None]
-    ref.scatter_add_(2, sel[:, :, None], (W * Csel[:, :R])[:, :, None])
+    dl = PC[:, :R].double() * (-W)[:, :, None]
+    dl.scatter_add_(2, sel[:, :, None], (W * Csel[:, :R].double())[:, :, None])
     slot = Slot[:, :R].long()
-    refU = torch.gather(ref, 2, slot.clamp(min=0)) * (slot >= 0) * inv
+    refU = torch.gather(dl, 2, slot.clamp(min=0)) * (slot >= 0) * inv
+    Kd, Vd, PKd, Qd, Od, Ad = K.double(), V.double(), PK.double(), Q[:, :R].double(), O[:, :R].double(), A[:, :, :R].double()
+    dOr = dl @ PKd                                                       # (B,R,128)
+    dPKr = dl.transpose(1, 2) @ Od
+    dOh = dOr.view(B, R, H, 16).permute(0, 2, 1, 3)
+    dA = dOh @ Vd.view(B, N1, H, 16).permute(0, 2, 3, 1)                 # (B,H,R,N1)
+    dotO = (dOh * Od.view(B, R, H, 16).permute(0, 2, 1, 3)).sum(-1, keepdim=True)
+    dS = Ad * (dA - dotO) / 4
+    dQr = (dS @ Kd.view(B, N1, H, 16).permute(0, 2, 1, 3)).permute(0, 2, 1, 3).reshape(B, R, 128)
+    dKr = (dS.transpose(2, 3) @ Qd.view(B, R, H, 16).permute(0, 2, 1, 3)).permute(0, 2, 1, 3).reshape(B, N1, 128)
+    dVr = (Ad.transpose(2, 3) @ dOh).permute(0, 2, 1, 3).reshape(B, N1, 128)
     prev = torch.cat([torch.zeros(B, 1, M, dtype=torch.long, device=DEV), fl.permute(0, 2, 1)[:, :-1]], dim=1).reshape(B, R)
-    refP = torch.zeros(B, R, N1, device=DEV).scatter_(2, prev[:, :, None], 1.0)
-    np.testing.assert_allclose(rowDL.cpu().numpy(), ref.cpu().numpy(), rtol=1e-6, atol=1e-7)
-    np.testing.assert_allclose(rowDU.cpu().numpy(), refU.cpu().numpy(), rtol=1e-6, atol=1e-7)
-    assert torch.equal(ohP[:, :, :N1], refP)
+    dQ1r = torch.zeros(B, N1, 128, dtype=torch.float64, device=DEV).scatter_add_(1, prev[:, :, None].expand(B, R, 128), dQr)
+
+    def close(got, ref, what):
+        err = float((got.double() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-5, (what, err)
+    close(dO, dOr, "dO"); close(dPK, dPKr, "dPK"); close(dpb, dl.sum(1), "dpb"); close(rowDU, refU, "dU")
+    close(dK, dKr, "dK"); close(dV, dVr, "dV"); close(dQ1, dQ1r, "dQ1")
     assert torch.equal(ixP.long(), prev)
-    if not tsp:
-        assert torch.equal(ohP[:, :, N1], Load[:, :R])
     if tsp:
         first = fl[:, :, 0][:, None, :].expand(B, T, M).reshape(B, R)
-        assert torch.equal(ohF, torch.zeros(B, R, N1, device=DEV).scatter_(2, first[:, :, None], 1.0))
-        assert torch.equal(ixF.long(), first)
+        dQ2r = torch.zeros(B, N1, 128, dtype=torch.float64, device=DEV).scatter_add_(1, first[:, :, None].expand(B, R, 128), dQr)
+        close(dQ2, dQ2r, "dQ2")
+    else:
+        close(dwl, torch.einsum("br,bre->e", Load[:, :R].double(), dQr), "dwl")
 
 
 def test_adam_matches_torch_and_checkpoints():
@@ -195,27 +239,3 @@ def test_add_instance_norm_matches_torch(B, N, C):
     gg = torch.autograd.grad((got * w).sum(), [a, b, norm.weight, norm.bias])
     for x, y in zip(gg, gr):
         np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=0, atol=1e-5 * max(1.0, y.abs().max().item()))
-
-
-@pytest.mark.parametrize("B,R,NO,wrow,splits", [(3, 203, 102, 101, 2), (2, 37, 21, -1, 1), (1, 1000, 128, -1, 4), (2, 64, 52, 51, 3)])
-def test_rows_segsum_is_onehot_transpose_times_x(B, R, NO, wrow, splits):
-    """elg_rows_segsum = the one-hot GEMM of the query-gather backward (fp64 reference; exact zeros for untouched nodes)."""
-    from elg_amd import _lib as L, engine as eng
-    g = torch.Generator().manual_seed(R)
-    X = torch.randn(B, R, 128, generator=g).to(DEV)
-    nn = NO - (1 if wrow >= 0 else 0)
-    idx = torch.randint(0, max(1, nn - 3), (B, R), generator=g, dtype=torch.int32).to(DEV)      # last nodes never hit
-    Rcap = R + 5
-    w = torch.randn(B, Rcap, generator=g).to(DEV)
-    part = torch.full((splits, B, NO, 128), float("nan"), device=DEV)
-    L.check(L.lib().elg_rows_segsum(eng._ptr(X), eng._ptr(idx), eng._ptr(w) if wrow >= 0 else None, eng._ptr(part), B, R, NO,
-                                    wrow, Rcap, splits, eng._stream()), "segsum")
-    got = part.sum(0).cpu().double()
-    oh = torch.zeros(B, R, NO, dtype=torch.float64, device=DEV).scatter_(2, idx.long()[:, :, None], 1.0)
-    if wrow >= 0:
-        oh[:, :, wrow] = w[:, :R].double()
-    ref = torch.bmm(oh.transpose(1, 2), X.double()).cpu()
-    assert torch.isfinite(got).all()
-    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=2e-5 * ref.abs().max().item())
-    if nn >= 4:
-        assert (got[:, nn - 2] == 0).all()

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 import golden_util as gu
+import gpu_common as gc
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -81,10 +82,18 @@ def test_tsp_train_step_against_reference_train():
         kind, name = key[5:].split("/", 1)
         g = named[name].numpy().astype(np.float64)
         g = g if kind == "full" else g.reshape(-1)[::stride]
-        # a ReLU pre-activation that sits at ~0 may switch side between CPU and GPU arithmetic, which moves one
-        # row of the feed-forward gradients discretely: bound the outliers, require the bulk to agree
-        bad = np.abs(g - fx[key]) > 3e-3 * np.abs(fx[key]).max() + 1e-3 * rms
-        assert bad.mean() < 0.01 and np.abs(g - fx[key]).max() <= 0.1 * np.abs(fx[key]).max() + 1e-3 * rms, name
+        ref, atol = fx[key], 1e-3 * rms
+        err = np.abs(g - ref)
+        if name.startswith("decoder."):
+            # exact arithmetic from the recorded actions to these gradients (no ReLU in between): every entry within
+            # 1e-3 of the tensor's largest entry, no outliers
+            assert err.max() <= 1e-3 * np.abs(ref).max() + atol, (name, err.max(), np.abs(ref).max())
+            gc.record_parity("tsp_train_step_grad/" + name, float(err.max() / (np.abs(ref).max() + atol)))
+        else:
+            # encoder: a ReLU pre-activation that sits at ~0 may switch side between CPU and GPU arithmetic, which moves every
+            # gradient upstream of it discretely: bound the outliers, require the bulk to agree
+            bad = err > 3e-3 * np.abs(ref).max() + atol
+            assert bad.mean() < 0.01 and err.max() <= 0.1 * np.abs(ref).max() + atol, name
 
 
 def test_tsplib_instances_run():

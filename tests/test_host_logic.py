@@ -166,3 +166,40 @@ def test_train_batch_must_divide_over_the_ranks(monkeypatch):
         ctrain.train(model=None, training="only_global", T=10, start_steps=0, train_steps=1, mixed=False, train_batch_size=64,
                      problem_size=20, distribution={}, multiple_width=20, lr=1e-4, device="cuda:0", logger=None, scale_norm=True,
                      fileLogger=None, dir_path=".", log_step=10)
+
+
+def _stats_of(xy):
+    xy = np.asarray(xy, dtype=np.float64)
+    c = xy.mean(1, keepdims=True)
+    d = np.sqrt(((xy[:, :, None, :] - xy[:, None, :, :]) ** 2).sum(-1))
+    d2 = d + np.eye(xy.shape[1])[None] * 1e9
+    return dict(mean_x=xy[:, :, 0].mean(1), mean_y=xy[:, :, 1].mean(1), std_x=xy[:, :, 0].std(1), std_y=xy[:, :, 1].std(1),
+                spread=np.sqrt(((xy - c) ** 2).sum(-1)).mean(1), nn=d2.min(-1).mean(1), lo=xy.min((1, 2)), hi=xy.max((1, 2)))
+
+
+def test_cluster_and_mixed_generators_follow_the_reference_distributions():
+    """The vectorised `cluster` / `mixed` generators against per-instance statistics of the reference's loops
+    (generate_data.py:16-72, 2000 instances, tools/make_golden_r02.py): two-sample Kolmogorov-Smirnov on every statistic
+    (centroid, per-axis spread, mean distance to the centroid, mean nearest-neighbour distance, extremes, demand)."""
+    from scipy.stats import ks_2samp
+    from elg_amd.CVRP.generate_data import generate_vrp_data
+    from elg_amd.TSP.generate_data import generate_tsp_data
+    dist_cfg = dict(n_cluster=3, n_cluster_mix=1, lower=0.2, upper=0.8, std=0.07)
+    fx = gu.load_golden("r02_generators_cvrp.npz")
+    torch.manual_seed(99)
+    worst = 1.0
+    for kind in ("cluster", "mixed"):
+        d = generate_vrp_data(2000, 100, dict(dist_cfg, data_type=kind))
+        st = _stats_of(d["loc"].numpy())
+        st["demand_mean"] = d["demand"].numpy().mean(1)
+        for k, v in st.items():
+            p = ks_2samp(v, fx[f"cvrp_{kind}/{k}"]).pvalue
+            worst = min(worst, p)
+            assert p > 1e-3, (kind, k, p)
+        assert d["depot"].shape == (2000, 1, 2) and float(d["depot"].min()) >= 0 and float(d["depot"].max()) <= 1
+    fx = gu.load_golden("r02_generators_tsp.npz")
+    d = generate_tsp_data(2000, 100, dict(dist_cfg, data_type="cluster"))
+    for k, v in _stats_of(d.numpy()).items():
+        p = ks_2samp(v, fx[f"tsp_cluster/{k}"]).pvalue
+        assert p > 1e-3, ("tsp", k, p)
+    print("smallest KS p-value", worst)

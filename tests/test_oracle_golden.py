@@ -253,3 +253,51 @@ def test_vrplib_instance_end_to_end():
     for i, p in enumerate(out["full_probs"]):
         agree.append((p.argmax(-1) == acts[:2, :, i + 2]).float().mean().item())
     assert min(agree) > 0.98, agree
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# round 2: decoder internals -- the tolerance north_star states, on the logits themselves
+# ------------------------------------------------------------------------------------------------------------------
+# north_star: "within 1e-4 rel on logits".  Scores (before the clip, O(1)): |got - ref| <= 1e-4 max(|ref|, 1) on every open
+# node.  Clipped logits clip * tanh(s), range +-clip: |got - ref| <= 1e-4 * clip (a bound relative to |logit| itself is
+# void where the logit crosses 0 -- two fp32 evaluations of the reference differ by more than that there).
+LOGIT_RTOL = 1e-4
+
+
+def logit_errors(got, ref, open_, scale=None):
+    """Worst error of `got` against `ref` over the open nodes, in units of max(|ref|, 1), or of `scale` if given."""
+    den = np.maximum(np.abs(ref[open_]), 1.0) if scale is None else scale
+    d = np.abs(got[open_] - ref[open_]) / den
+    return float(d.max()) if d.size else 0.0
+
+
+@pytest.mark.parametrize("problem,tag", [("cvrp", "n50"), ("cvrp", "n20k8"), ("cvrp", "n100"), ("tsp", "n50"), ("tsp", "n20")])
+def test_oracle_decoder_internals(problem, tag):
+    """Pointer score before the penalty, local-policy output, score before the clip and the clipped logits of the
+    reference's decoder (tools/make_golden_r02.py hooks), teacher-forced, against the oracle: 1e-4 on open nodes."""
+    lg = gu.load_golden(f"r02_{problem}_logits_{tag}.npz")
+    fx = gu.load_golden(f"{problem}_rollout_{str(lg['src'])}.npz")
+    acts = torch.from_numpy(fx["actions"].astype(np.int64))
+    if problem == "cvrp":
+        cfg, P, xy, dem, B, N, M = _cvrp_setup(fx, torch.float32)
+        out = orc.rollout_cvrp(P, cfg, xy, dem, M, starts=acts[0, :, 1], forced=acts, keep_parts=True)
+        t0 = 2
+    else:
+        cfg, P, xy, B, N, M = _tsp_setup(fx, torch.float32)
+        out = orc.rollout_tsp(P, cfg, xy, M, starts=acts[0, :, 0], forced=acts, keep_parts=True)
+        t0 = 1
+    worst = {}
+    for i, t in enumerate(lg["steps"]):
+        parts = out["parts"][int(t) - t0]
+        ref_logits = lg["logits"][i]
+        open_ = np.isfinite(ref_logits)
+        s = parts["s"].numpy()
+        u = parts["u"].numpy() if "u" in parts else np.zeros_like(s)
+        pen = parts["pen"].numpy() if "pen" in parts else np.zeros_like(s)
+        got = {"pre_clip": s, "local": u, "score_scaled": s - pen - u / cfg.ensemble_size,
+               "logits": cfg.logit_clipping * np.tanh(s)}
+        for k, g in got.items():
+            e = logit_errors(g, lg[k][i], open_, cfg.logit_clipping if k == "logits" else None)
+            worst[k] = max(worst.get(k, 0.0), e)
+            assert e <= LOGIT_RTOL, (k, int(t), e)
+    print(problem, tag, {k: f"{v:.2e}" for k, v in worst.items()})

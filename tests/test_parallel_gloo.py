@@ -63,3 +63,38 @@ def test_gradient_allreduce_world2():
     for p, g in zip(model.parameters(), a["grads"]):
         assert torch.allclose(p.grad, g, rtol=1e-5, atol=1e-7)
     assert a["numel"] == sum(p.numel() for p in model.parameters())
+
+
+def _curriculum_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import numpy as np
+    from elg_amd import parallel
+    from elg_amd.CVRP.train import softmax
+    parallel.init_distributed("gloo")
+    np.random.seed(1000 + rank)                    # every rank has its own generator state (seed + rank in train.py) ...
+    gaps = np.array([0.3, 0.1, 0.2])
+    draws = []
+    for _ in range(20):                            # ... yet must train on the same family (reference train.py:98-100)
+        kind = str(np.random.choice(['uniform', 'cluster', 'mixed'], size=1, p=softmax(gaps))[0])
+        draws.append(parallel.broadcast_object(kind))
+    val = parallel.broadcast_object([15.9, 8.1, 14.5] if rank == 0 else None)      # rank 0 validates, all update the gaps
+    out[rank] = dict(draws=draws, val=val)
+    torch.distributed.destroy_process_group()
+
+
+def test_curriculum_choice_is_rank0s_on_every_rank():
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_curriculum_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert out[0]["draws"] == out[1]["draws"] and len(set(out[0]["draws"])) > 1
+    assert out[0]["val"] == out[1]["val"] == [15.9, 8.1, 14.5]
+    # without a process group the helper is the identity
+    from elg_amd import parallel
+    assert parallel.broadcast_object("x") == "x"
