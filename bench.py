@@ -42,33 +42,156 @@ def algorithmic_bytes_per_decode_step(B, M, N1, d=128, s=4):
     return B * (3 * N1 * d * s + 12 * N1) + B * M * (r + w)
 
 
-def cpu_baseline(cfg, seconds_hint=20.0):
-    """The oracle (CPU restatement of the reference, torch eager, autograd tape) timed on a bounded sample of the
-    same workload: one full training step (encoder, sampled rollout, loss, backward, Adam) at CVRP-100, pomo 100,
-    batch 8.  Test infrastructure used as the reported baseline only -- never on the product path."""
+FLOPS_PER_TRAJ_STEP_SURVEY = 0.335e6     # q 33.0 K + 3 x 25.9 K + combine 32.8 K + local policy 186 K (unfolded)
+FLOPS_PER_TRAJ_STEP_FOLDED = 0.087e6     # as executed: glimpse QK^T, AV, pointer (3 x 25.9 K) + folded local policy (~9 K)
+FP32_PEAK_TFLOPS = 157.3                 # MI355X fp32 vector = f32 MFMA peak (guides/MI355X_MICROARCH.md)
+
+
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, mean_T, budget_s=45.0):
+    """The oracle (CPU restatement of the reference: torch eager, autograd tape -- test infrastructure, used here only as the
+    reported baseline) on this box's host cores.  A whole CVRP-100 training step costs ~30 s of CPU at batch 16, so the
+    sample is bounded: at batch 16, pomo 100 it times (a) encoder + set_kv forward and backward and (b) teacher-forced
+    decode steps 2 .. 2 + S of the sampled rollout, forward and backward through the tape, after one untimed warm-up, for
+    torch thread counts {1, 8, 16, 32 (, all if <= 64)}; a step of the metric is then  t_enc + mean_T * t_decode_step  (mean_T = the
+    decode steps per trajectory the GPU run measured).  Reported: the best thread count and the 1-thread figure."""
     from oracle import elg_oracle as orc
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import golden_util as gu
-    Bc = 8
+    Bc, S = 16, 8
     torch.manual_seed(0)
     mp = cfg["model_params"]
     ocfg = orc.ModelCfg.from_model_params(mp, "cvrp")
     P = {k: torch.from_numpy(v).requires_grad_(True) for k, v in gu.golden_weights("cvrp", 1, mp, True).items()}
     xy = torch.rand(Bc, N_NODES + 1, 2)
     dem = torch.cat([torch.zeros(Bc, 1), torch.randint(1, 10, (Bc, N_NODES)).float() / 50.0], 1)
-    opt = torch.optim.Adam(list(P.values()), lr=1e-4, weight_decay=1e-6)
-    threads = torch.get_num_threads()
-    t0 = time.time()
-    uni = torch.rand(Bc, POMO, 2 * (N_NODES + 1))
-    out = orc.rollout_cvrp(P, ocfg, xy, dem, POMO, starts=torch.randperm(N_NODES)[:POMO], mode="sample", uniforms=uni)
-    J = orc.pomo_loss(out["probs"], out["reward"])
-    opt.zero_grad()
-    J.backward()
-    opt.step()
-    dt = time.time() - t0
-    return {"value": round(Bc / dt, 4), "unit": "instances/s", "cores": threads, "kind": "port",
-            "sample": f"1 full training step, CVRP-100 batch={Bc} pomo={POMO} fp32, oracle/elg_oracle.py on "
-                      f"{threads} torch threads ({dt:.1f} s, T={out['actions'].shape[2]})"}
+    starts = torch.randperm(N_NODES)[:POMO]
+    # a fixed prefix of sampled actions to teacher-force (drawn once, untimed)
+    with torch.no_grad():
+        uni = torch.rand(Bc, POMO, 2 + S + 1)
+        pre = orc.rollout_cvrp({k: v.detach() for k, v in P.items()}, ocfg, xy, dem, POMO, starts=starts, mode="sample",
+                               uniforms=uni, max_steps=2 + S)
+    forced = pre["actions"]
+
+    def sample(threads):
+        torch.set_num_threads(threads)
+        t0 = time.perf_counter()
+        enc = orc.encoder_forward(P, ocfg, xy, dem)
+        kh, vh = orc.set_kv(P, ocfg, enc)
+        (enc.sum() + kh.sum() + vh.sum()).backward()
+        t_enc = time.perf_counter() - t0
+        for p in P.values():
+            p.grad = None
+        t0 = time.perf_counter()
+        out = orc.rollout_cvrp(P, ocfg, xy, dem, POMO, starts=starts, forced=forced, enc=enc.detach(), max_steps=2 + S)
+        out["probs"][:, 2:].log().sum().backward()
+        t_dec = (time.perf_counter() - t0) / S
+        for p in P.values():
+            p.grad = None
+        return t_enc, t_dec
+    ncpu = os.cpu_count() or 1
+    sweep, t_start = {}, time.perf_counter()
+    sample(min(8, ncpu))                                               # warm-up (allocator, thread pools)
+    # (all host threads only on hosts with <= 64 of them: torch's intra-op pool at 256 threads took 98 s for ONE encoder
+    # pass on the GPU box -- oversubscription, not a baseline)
+    for th in sorted({1, 8, 16, 32} | ({ncpu} if ncpu <= 64 else set())):
+        if th > ncpu or time.perf_counter() - t_start > budget_s:
+            continue
+        t_enc, t_dec = sample(th)
+        step = t_enc + mean_T * t_dec
+        sweep[th] = {"inst_per_s": round(Bc / step, 4), "encoder_s": round(t_enc, 3), "decode_step_s": round(t_dec, 4)}
+    best = max(sweep, key=lambda k: sweep[k]["inst_per_s"])
+    # one whole training step (encoder, free-running sampled rollout, loss, backward, Adam) at the best thread count, if the
+    # sampled estimate says it fits the budget: the figure that is directly the metric
+    full = None
+    predicted = Bc / sweep[best]["inst_per_s"]
+    if 3.0 * predicted < budget_s - (time.perf_counter() - t_start) + 30.0:
+        torch.set_num_threads(best)
+        opt = torch.optim.Adam(list(P.values()), lr=1e-4, weight_decay=1e-6)
+        t0 = time.perf_counter()
+        uni = torch.rand(Bc, POMO, 2 * (N_NODES + 1))
+        out = orc.rollout_cvrp(P, ocfg, xy, dem, POMO, starts=starts, mode="sample", uniforms=uni)
+        J = orc.pomo_loss(out["probs"], out["reward"])
+        opt.zero_grad()
+        J.backward()
+        opt.step()
+        dt = time.perf_counter() - t0
+        full = {"inst_per_s": round(Bc / dt, 4), "seconds": round(dt, 2), "decode_steps": int(out["actions"].shape[2]), "threads": best}
+    value = full["inst_per_s"] if full else sweep[best]["inst_per_s"]
+    return {"value": value, "unit": "instances/s", "cores": best, "kind": "port", "full_step": full,
+            "sampled_estimate": sweep[best]["inst_per_s"],
+            "value_1thread": sweep.get(1, {}).get("inst_per_s"), "cpu_model": _cpu_model(), "host_cpus": ncpu,
+            "thread_sweep": sweep,
+            "sample": f"oracle/elg_oracle.py, CVRP-100 batch={Bc} pomo={POMO} fp32: encoder+set_kv fwd+bwd and {S} teacher-forced decode "
+                      f"steps fwd+bwd per thread count (1 warm-up), estimate = {Bc} / (t_encoder + {mean_T:.1f} * t_decode_step); "
+                      f"value = one whole training step at the best thread count when the estimate fits the time budget, else the "
+                      f"estimate; the reference's own full step measured 0.57 inst/s on 8 cores of the build container (BASELINE.md)"}
+
+
+def secondary_workloads(dev):
+    """BASELINE.json configs[3] and [4] as secondary entries: one greedy rollout each after a warm-up, random-init weights
+    (TSP-500 batch 16 pomo 500; VRPLIB X-n1001-k43, x8 augmentation, pomo 1000), HIP events around the launch."""
+    import yaml
+    from elg_amd.TSP.TSPEnv import TSPEnv
+    from elg_amd.TSP.TSPModel import TSPModel
+    from elg_amd.TSP.utils import rollout as tsp_rollout
+    from elg_amd.CVRP.CVRPEnv import CVRPEnv
+    from elg_amd.CVRP.CVRPModel import CVRPModel
+    from elg_amd.CVRP.utils import rollout as cvrp_rollout
+    from elg_amd import vrplib_io
+    out = {}
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    with open(os.path.join(ROOT, "elg_amd", "TSP", "config.yml")) as f:
+        tcfg = yaml.load(f.read(), Loader=yaml.FullLoader)
+    tm = TSPModel(**tcfg["model_params"])
+    tm.decoder.add_local_policy(dev)
+    tm.to(dev).eval()
+    tenv = TSPEnv(multi_width=500, device=dev)
+    tenv.load_random_problems(torch.rand(16, 500, 2))
+    rs, _, _ = tenv.reset()
+    with torch.no_grad():
+        tm.pre_forward(rs)
+        ms = timed(lambda: tsp_rollout(tm, tenv, "greedy"))
+    out["tsp500_b16_pomo500_greedy_rollout_ms"] = round(ms, 2)
+    out["tsp500_trajectory_steps_per_s"] = round(16 * 500 * 499 / (ms * 1e-3), 0)
+    inst_path = os.path.join(ROOT, "tests", "golden", "vrplib", "X", "X-n1001-k43.vrp")
+    if os.path.exists(inst_path):
+        with open(os.path.join(ROOT, "elg_amd", "CVRP", "config.yml")) as f:
+            ccfg = yaml.load(f.read(), Loader=yaml.FullLoader)
+        cm = CVRPModel(**ccfg["model_params"])
+        cm.decoder.add_local_policy(dev)
+        cm.to(dev).eval()
+        inst = vrplib_io.read_instance(inst_path)
+        cenv = CVRPEnv(1000, dev)
+
+        def one():
+            cenv.load_vrplib_problem(inst, aug_factor=8)
+            r, _, _ = cenv.reset()
+            cm.pre_forward(r)
+            return cvrp_rollout(cm, cenv, "greedy")
+        with torch.no_grad():
+            ms = timed(one, reps=2)
+        out["vrplib_X-n1001-k43_aug8_pomo1000_greedy_instance_ms"] = round(ms, 1)
+    return out
 
 
 def main():
@@ -77,6 +200,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the TSP-500 / VRPLIB X-n1001 secondary timings")
     args = ap.parse_args()
 
     from elg_amd import parallel
@@ -154,6 +278,9 @@ def main():
             with open(tpath) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
         achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
+        traj_steps = LOCAL_BATCH * POMO * mean_T                # decode steps of one launch (per rank)
+        tf_survey = FLOPS_PER_TRAJ_STEP_SURVEY * traj_steps / (kern_ms * 1e-3) / 1e12
+        tf_folded = FLOPS_PER_TRAJ_STEP_FOLDED * traj_steps / (kern_ms * 1e-3) / 1e12
         out = {
             "metric": "CVRP-100 train instances/sec", "value": round(LOCAL_BATCH * world * args.steps / dt, 2),
             "unit": "instances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -169,10 +296,18 @@ def main():
                          "launch_ms": round(kern_ms, 4), "decode_steps_mean": round(mean_T, 2),
                          "decode_steps_max": round(max_T, 2),
                          "algorithmic_MB_per_decode_step": round(algorithmic_bytes_per_decode_step(
-                             LOCAL_BATCH, POMO, N_NODES + 1) / 1e6, 3)},
+                             LOCAL_BATCH, POMO, N_NODES + 1) / 1e6, 3),
+                         # the decode step is ALU / latency bound, not HBM bound -- both ceilings are reported
+                         "fp32": {"bound": "fp32", "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "flops_per_launch_survey": int(FLOPS_PER_TRAJ_STEP_SURVEY * traj_steps),
+                                  "achieved_survey_count": round(tf_survey, 2), "frac_survey_count": round(tf_survey / FP32_PEAK_TFLOPS, 4),
+                                  "flops_per_launch_folded": int(FLOPS_PER_TRAJ_STEP_FOLDED * traj_steps),
+                                  "achieved_folded_count": round(tf_folded, 2), "frac_folded_count": round(tf_folded / FP32_PEAK_TFLOPS, 4)}},
         }
+        if not args.no_secondary and world == 1:
+            out["secondary"] = secondary_workloads(dev)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg)
+            out["cpu_baseline"] = cpu_baseline(cfg, mean_T)
         print(json.dumps(out), flush=True)
     parallel.barrier()
 

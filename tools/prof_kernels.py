@@ -17,7 +17,8 @@ seed_everything(924)
 dev = "cuda:0"
 model = CVRPModel(**cfg["model_params"]); model.decoder.add_local_policy(dev); model.to(dev)
 env = CVRPEnv(100, dev)
-opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-6)
+from elg_amd.optim import Adam
+opt = Adam(model.parameters(), lr=1e-4, weight_decay=1e-6)
 for i in range(reps):
     batch = generate_vrp_data(B, 100, dict(cfg["distribution"], data_type="uniform"))
     if what == "train":
