@@ -35,7 +35,7 @@ class RolloutArgs(C.Structure):
         ("st_cur", _vp), ("st_cnt", _vp), ("st_fin", _vp), ("st_first", _vp), ("st_load", _vp), ("st_len", _vp),
         ("st_vis", _vp),
         ("actions", _vp), ("probs", _vp), ("reward", _vp), ("tlen", _vp), ("full_probs", _vp),
-        ("trA", _vp), ("trPC", _vp), ("trCsel", _vp), ("trQ", _vp), ("trO", _vp), ("trLoad", _vp), ("trSlot", _vp), ("trF", _vp), ("trMask", _vp), ("trLse", _vp),
+        ("trA", _vp), ("trPC", _vp), ("trCsel", _vp), ("trQ", _vp), ("trO", _vp), ("trLoad", _vp), ("trSlot", _vp), ("trF", _vp), ("trMask", _vp), ("scratch", _vp), ("trLse", _vp),
     ]
 
 

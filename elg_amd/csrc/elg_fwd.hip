@@ -1586,6 +1586,341 @@ static int launch_fwd_tiled(const elg_rollout_args& A, hipStream_t stream) {
     return launch_status("rollout_fwd_tiled");
 }
 
+
+// =============================================================================================
+// rollout_fwd_xl_kernel: instances beyond the register-resident node layouts (N1 > 1024: Vrp-Set-XXL, N1 up to 7001).
+// Same structure as the node-tiled kernel -- 8 lockstep trajectories per workgroup share the K / V / PK tiles staged in
+// LDS -- but everything that is an NCH-sized register array there is a runtime loop here: the visited set and the mask
+// words live in per-wave LDS, the pointer scores of a trajectory in a global scratch row (N1 floats, L2-resident; read
+// back with device-scope loads), clip / softmax / choice stream over that row.  Inference only (greedy, sample, forced).
+// =============================================================================================
+__device__ __forceinline__ float ld_dev(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_dev(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <bool TSP>
+__global__ __launch_bounds__(512) void rollout_fwd_xl_kernel(const elg_rollout_args A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int WAVES = 8, NT = WAVES * 64, TR = 64, NGT = TR / 8;
+    constexpr int S0 = TSP ? 0 : 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N1 = A.N1, NW = (N1 + 63) >> 6;
+    const int G = gridDim.x;
+    int u = blockIdx.x;
+    if ((G & 7) == 0) u = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int b = u / A.tiles, tile = u % A.tiles;
+    const int tile_m = (A.M + A.tiles - 1) / A.tiles;
+    const int m_lo = tile * tile_m, m_hi = min(A.M, m_lo + tile_m);
+    const int ntiles = (N1 + TR - 1) / TR;
+    // LDS: tile A | tile B | demand | per wave { visited words | mask words | slot scratch (144) | o row (128) }
+    float* sTA = lds;
+    float* sTB = lds + TR * ELG_E;
+    float* p = lds + 2 * TR * ELG_E;
+    float* sdem = p; p += (N1 + 3) & ~3;
+    unsigned long long* svis = reinterpret_cast<unsigned long long*>(p) + (size_t)wave * 2 * NW;
+    unsigned long long* smk = svis + NW;
+    p += (size_t)WAVES * 4 * NW;
+    float* sb = p + wave * (ELG_SB_MIN + ELG_E);
+    float* so = sb + ELG_SB_MIN;
+    if (!TSP)
+        for (int i = tid; i < N1; i += NT) sdem[i] = A.demand[(size_t)b * N1 + i];
+    __syncthreads();
+    const size_t NE = (size_t)N1 * ELG_E;
+    const float4* gK = reinterpret_cast<const float4*>(A.Kmat + b * NE);
+    const float4* gV = reinterpret_cast<const float4*>(A.Vmat + b * NE);
+    const float4* gPK = reinterpret_cast<const float4*>(A.PK + b * NE);
+    const float* pbv = A.pb + (size_t)b * N1;
+    const float* Q1 = A.Q1 + b * NE;
+    const float* Q2 = TSP ? A.Q2 + b * NE : nullptr;
+    const float* xy = A.xy + (size_t)b * N1 * 2;
+    const int* nidx = A.nbr_idx + (size_t)b * N1 * N1;
+    const float* ndist = A.nbr_dist + (size_t)b * N1 * N1;
+    const float* ntheta = A.nbr_theta + (size_t)b * N1 * N1;
+    const int step_cap = TSP ? N1 : 2 * N1 + 2;
+    const float dflt = A.has_penalty ? A.xi : 0.f;
+
+    for (int m_base = m_lo; m_base < m_hi; m_base += WAVES) {
+        const int m = m_base + wave;
+        const bool has = m < m_hi;
+        const size_t bm = (size_t)b * A.M + (has ? m : m_lo);
+        float* scr = A.scratch + bm * (size_t)N1;
+        int cur = 0, first = 0, cnt = 0, fin = has ? 0 : 1, nvis = 0;     // nvis: set bits of the visited set
+        float load = 1.0f, len = 0.f, cx = 0.f, cy = 0.f;
+        for (int i = lane; i < NW; i += 64) svis[i] = 0ull;
+        wave_lds_fence();
+        for (int step = 0; step < step_cap; ++step) {
+            const bool active = has && !fin && cnt < A.Tmax;
+            if (!__syncthreads_or(active ? 1 : 0)) break;
+            const int t = cnt;
+            const bool first_move = (!TSP && t <= 1) || (TSP && t == 0);
+            const bool dec = active && !first_move;
+            int fsel = 0;
+            if (active && A.forced && t < A.Tforced) fsel = __builtin_amdgcn_readfirstlane(A.forced[bm * A.Tforced + t]);
+            int sel = 0;
+            float pr = 1.0f;
+            if (__syncthreads_or(dec ? 1 : 0)) {
+                float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                float addval = 0.f;
+                int snid = -1;
+                if (dec) {
+                    // ---- feasibility mask words (CVRPEnv.py:214-232 / TSPEnv.py:120)
+                    const float lim = __fadd_rn(load, 1e-6f);
+                    for (int ch = 0; ch < NW; ++ch) {
+                        const int n = lane + 64 * ch;
+                        bool mm = true;
+                        if (n < N1) {
+                            mm = (svis[ch] >> lane) & 1ull;
+                            if (!TSP) {
+                                mm = mm || (lim < sdem[n]);
+                                if (n == 0 && fin) mm = false;
+                            }
+                        }
+                        const unsigned long long bal = __ballot(mm);
+                        if (lane == 0) smk[ch] = bal;
+                    }
+                    wave_lds_fence();
+                    // ---- query row
+                    const int cb = (lane & 31) * 4;
+                    q4 = *reinterpret_cast<const float4*>(Q1 + (size_t)cur * ELG_E + cb);
+                    if (TSP) {
+                        const float4 qf = *reinterpret_cast<const float4*>(Q2 + (size_t)first * ELG_E + cb);
+                        q4.x += qf.x; q4.y += qf.y; q4.z += qf.z; q4.w += qf.w;
+                    } else {
+                        const float4 w = *reinterpret_cast<const float4*>(A.wl + cb);
+                        q4.x = fmaf(load, w.x, q4.x); q4.y = fmaf(load, w.y, q4.y);
+                        q4.z = fmaf(load, w.z, q4.z); q4.w = fmaf(load, w.w, q4.w);
+                    }
+                    // ---- k-NN slots: the first K open customers of cur's sorted neighbour list (knn_slots / slot_setup)
+                    if (A.has_penalty || A.has_local) {
+                        int found = 0;
+                        const size_t row = (size_t)cur * N1;
+                        for (int ch = 0; ch < NW && found < A.K; ++ch) {
+                            const int i = lane + 64 * ch;
+                            const bool valid = i < N1;
+                            const int nid = valid ? nidx[row + i] : 0;
+                            const float nd = valid ? ndist[row + i] : 0.f;
+                            const float nth = valid ? ntheta[row + i] : 0.f;
+                            bool cand = valid && !((smk[nid >> 6] >> (nid & 63)) & 1ull);
+                            if (!TSP) cand = cand && (nid != 0);
+                            const unsigned long long bal = __ballot(cand);
+                            const int rank = found + lanes_below(bal);
+                            if (cand && rank < A.K) {
+                                sb[S0 + rank] = nd;
+                                sb[ELG_SLOT_STRIDE + S0 + rank] = nth;
+                                sb[2 * ELG_SLOT_STRIDE + S0 + rank] = i2f(nid);
+                            }
+                            found += __popcll(bal);
+                        }
+                        const int k = found < A.K ? found : A.K;
+                        wave_lds_fence();
+                        const int j = lane;
+                        const bool cust = (j >= S0) && (j < S0 + k);
+                        float sd = 0.f, sth = 0.f;
+                        if (cust) { sd = sb[j]; sth = sb[ELG_SLOT_STRIDE + j]; snid = f2i(sb[2 * ELG_SLOT_STRIDE + j]); }
+                        const float dmax = (k > 0) ? sb[S0 + k - 1] : 0.f;
+                        wave_lds_fence();
+                        if (!TSP && j == 0) snid = 0;
+                        float pen = 0.f;
+                        if (A.has_penalty && cust) {
+                            if (TSP) pen = -(sd / (dmax + 1e-6f));
+                            else pen = (dmax != 0.f) ? -(sd / dmax) : -sd;
+                        }
+                        const float nf = dmax + 1e-6f;
+                        float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+                        if (cust) { f0 = sd / nf; f1 = sth; if (!TSP) f2 = sdem[snid] / load; }
+                        bool smask = !cust;
+                        if (!TSP && j == 0) smask = smk[0] & 1ull;
+                        float uu = 0.f;
+                        if (A.has_local) uu = local_policy<TSP>(A.loc, lane, f0, f1, f2, smask, nullptr);
+                        addval = pen + uu * A.inv_ens;
+                    }
+                }
+                // ---- glimpse: online softmax over the K / V tiles
+                float m_run = ELG_NEG_INF, l_run = 0.f;
+                f32x2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+                for (int tt = 0; tt < ntiles; ++tt) {
+                    __syncthreads();
+                    const int row0 = tt * TR;
+                    for (int i = tid; i < TR * 32; i += NT) {
+                        const int grow = row0 + (i >> 5);
+                        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+                        if (grow < N1) { kv = gK[(size_t)grow * 32 + (i & 31)]; vv = gV[(size_t)grow * 32 + (i & 31)]; }
+                        reinterpret_cast<float4*>(sTA)[i] = kv;
+                        reinterpret_cast<float4*>(sTB)[i] = vv;
+                    }
+                    __syncthreads();
+                    if (dec) glimpse_tile<NGT>(sTA, sTB, row0, N1, lane, q4, smk[tt], 0ull, m_run, l_run, acc01, acc23);
+                }
+                if (dec) {
+                    float l = l_run;
+                    l += quad_xor1(l); l += quad_xor2(l); l += shfl_xor(l, 32);
+                    const float inv = 1.0f / l;
+                    float4 o4 = make_float4(acc01.x, acc01.y, acc23.x, acc23.y);
+                    o4.x += shfl_xor(o4.x, 32); o4.y += shfl_xor(o4.y, 32);
+                    o4.z += shfl_xor(o4.z, 32); o4.w += shfl_xor(o4.w, 32);
+                    o4.x *= inv; o4.y *= inv; o4.z *= inv; o4.w *= inv;
+                    if (lane < 32) *reinterpret_cast<float4*>(so + 4 * lane) = o4;
+                }
+                // ---- pointer scores, PK tile by tile, into the trajectory's scratch row
+                for (int tt = 0; tt < ntiles; ++tt) {
+                    __syncthreads();
+                    const int row0 = tt * TR;
+                    for (int i = tid; i < TR * 32; i += NT) {
+                        const int lrow = i >> 5, c4 = i & 31, grow = row0 + lrow;
+                        float4 pk = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (grow < N1) pk = gPK[(size_t)grow * 32 + c4];
+                        reinterpret_cast<float4*>(sTA)[lrow * 32 + (c4 ^ (lrow & 31))] = pk;
+                    }
+                    __syncthreads();
+                    if (dec) {
+                        f32x2 acc = {0.f, 0.f};
+#pragma unroll 8
+                        for (int c4 = 0; c4 < 32; ++c4) {
+                            const float4 o = *reinterpret_cast<const float4*>(so + 4 * c4);
+                            const float4 pk = *reinterpret_cast<const float4*>(sTA + (size_t)lane * ELG_E + 4 * (c4 ^ (lane & 31)));
+                            acc = __builtin_elementwise_fma(lo2(o), lo2(pk), acc);
+                            acc = __builtin_elementwise_fma(hi2(o), hi2(pk), acc);
+                        }
+                        const int n = row0 + lane;
+                        if (n < N1) st_dev(scr + n, (acc.x + acc.y) + pbv[n]);
+                    }
+                }
+                // ---- clip, mask, softmax, choice: streaming over the scratch row   (models.py:405-420)
+                if (dec) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    if (snid >= 0) st_dev(scr + snid, ld_dev(scr + snid) + (addval - dflt));     // penalty + local terms, slot nodes
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+                    float* frow = (A.full_probs && t < A.dump_T) ? A.full_probs + (bm * A.dump_T + t) * N1 : nullptr;
+                    // pass 1: clipped logits back into the row, their maximum and (greedy) the first arg max
+                    float mx = ELG_NEG_INF;
+                    int bn = 0x7fffffff;
+                    for (int ch = 0; ch < NW; ++ch) {
+                        const int n = lane + 64 * ch;
+                        float x = ELG_NEG_INF;
+                        if (n < N1) {
+                            const bool masked = (smk[ch] >> lane) & 1ull;
+                            const float sv = ld_dev(scr + n) + dflt;
+                            if (!masked) x = A.clip * fast_tanh(sv);
+                            if (frow && A.dump_logits == 2) frow[n] = masked ? ELG_NEG_INF : sv;
+                            st_dev(scr + n, x);
+                        }
+                        if (x > mx) { mx = x; bn = n; }
+                    }
+#pragma unroll
+                    for (int mk2 = 1; mk2 < 64; mk2 <<= 1) {
+                        const float ov = shfl_xor(mx, mk2);
+                        const int on = shfl_xor(bn, mk2);
+                        if (ov > mx || (ov == mx && on < bn)) { mx = ov; bn = on; }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+                    // pass 2: normaliser
+                    float part = 0.f;
+                    for (int ch = 0; ch < NW; ++ch) {
+                        const int n = lane + 64 * ch;
+                        if (n < N1) {
+                            const float x = ld_dev(scr + n);
+                            part += (x > ELG_NEG_INF) ? __expf(x - mx) : 0.f;
+                        }
+                    }
+                    const float tot = wave_sum(part);
+                    const float inv = 1.0f / tot;
+                    if (frow && A.dump_logits != 2)
+                        for (int n = lane; n < N1; n += 64) {
+                            const float x = ld_dev(scr + n);
+                            frow[n] = A.dump_logits == 1 ? x : ((x > ELG_NEG_INF) ? __expf(x - mx) * inv : 0.f);
+                        }
+                    if (A.mode == ELG_MODE_FORCED) sel = fsel;
+                    else if (A.mode == ELG_MODE_GREEDY) sel = bn;
+                    else {
+                        // inverse CDF in node order
+                        const float uni = A.uniforms ? A.uniforms[bm * A.Tmax + t] : philox_uniform(A.seed, (unsigned)bm, (unsigned)t);
+                        const float target = uni * tot;
+                        float run = 0.f;
+                        int found = -1, lastpos = 0;
+                        for (int ch = 0; ch < NW && found < 0; ++ch) {
+                            const int n = lane + 64 * ch;
+                            float e = 0.f;
+                            if (n < N1) { const float x = ld_dev(scr + n); e = (x > ELG_NEG_INF) ? __expf(x - mx) : 0.f; }
+                            const float cs = wave_scan_incl(e, lane) + run;
+                            run = readlane(cs, 63);
+                            const unsigned long long pos = __ballot(e > 0.f);
+                            const unsigned long long hit = __ballot(e > 0.f && cs > target);
+                            if (hit) found = 64 * ch + (int)__builtin_ctzll(hit);
+                            if (pos) lastpos = 64 * ch + 63 - (int)__builtin_clzll(pos);
+                        }
+                        sel = found >= 0 ? found : lastpos;
+                    }
+                    sel = __builtin_amdgcn_readfirstlane(sel);
+                    const float xs = ld_dev(scr + sel);
+                    pr = (xs > ELG_NEG_INF) ? __expf(xs - mx) * inv : 0.f;
+                    pr = i2f(__builtin_amdgcn_readfirstlane(f2i(pr)));
+                }
+            }
+            if (active) {
+                if (first_move) {
+                    if (A.mode == ELG_MODE_FORCED) sel = fsel;
+                    else sel = (!TSP && t == 0) ? 0 : __builtin_amdgcn_readfirstlane(A.starts[m]);
+                }
+                if (lane == 0) {
+                    if (A.actions) A.actions[bm * A.Tmax + t] = sel;
+                    if (A.probs) A.probs[((size_t)b * A.Tmax + t) * A.M + m] = pr;
+                }
+                // ---- environment transition (env_update with the visited set in LDS)
+                const float sx = xy[2 * sel], sy = xy[2 * sel + 1];
+                if (cnt > 0) len += dist2d(cx, cy, sx, sy);
+                cx = sx; cy = sy;
+                if (TSP) { if (cnt == 0) first = sel; }
+                else load = (sel == 0) ? 1.0f : __fsub_rn(load, sdem[sel]);
+                if (lane == 0) {
+                    unsigned long long w = svis[sel >> 6];
+                    const unsigned long long bit = 1ull << (sel & 63);
+                    int d = (w & bit) ? 0 : 1;
+                    w |= bit;
+                    svis[sel >> 6] = w;
+                    if (!TSP) {
+                        // depot counts as visited exactly while the trajectory stands on it (CVRPEnv.py:214-216)
+                        unsigned long long w0 = svis[0];
+                        if (sel != 0 && (w0 & 1ull)) { w0 &= ~1ull; d -= 1; svis[0] = w0; }
+                    }
+                    sb[0] = i2f(d);
+                }
+                wave_lds_fence();
+                nvis += f2i(sb[0]);
+                wave_lds_fence();
+                cur = sel;
+                cnt += 1;
+                if (TSP) {
+                    if (cnt == N1) { len += dist2d(sx, sy, xy[2 * first], xy[2 * first + 1]); fin = 1; }
+                } else if (nvis == N1) fin = 1;
+            }
+        }
+        if (has && lane == 0) {
+            if (A.reward) A.reward[bm] = -len;
+            if (A.tlen) A.tlen[bm] = cnt;
+        }
+        __syncthreads();
+    }
+}
+
+template <bool TSP>
+static int launch_fwd_xl(const elg_rollout_args& A, hipStream_t stream) {
+    if (!A.scratch) return fail(ELG_EINVAL, "rollout: N1 > 1024 needs the (B,M,N1) scratch rows");
+    if (A.N1 > 8192) return fail(ELG_ENOTIMPL, "rollout: N1 > 8192 not built");
+    const int NW = (A.N1 + 63) / 64;
+    const size_t lds = ((size_t)2 * 64 * ELG_E + ((A.N1 + 3) & ~3) + (size_t)8 * 4 * NW + (size_t)8 * (ELG_SB_MIN + ELG_E)) * 4;
+    if (lds > 163840 - 256) return fail(ELG_EINVAL, "xl rollout: LDS budget exceeded");
+    auto kern = rollout_fwd_xl_kernel<TSP>;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        (void)hipGetLastError();
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(ELG_ELAUNCH, std::string("xl rollout: hipFuncSetAttribute: ") + hipGetErrorString(e));
+        attr_lds = lds;
+    }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3(A.B * A.tiles), dim3(512), lds, stream, A);
+    return launch_status("rollout_fwd_xl");
+}
+
 // SMALL: N1 <= 104 in the two-chunk build (13 row groups instead of 16)
 template <int NCH, bool TSP, bool LDSK, int WAVES, bool TRAIN = false>
 static int launch_fwd(const elg_rollout_args& A, hipStream_t stream) {
@@ -1634,11 +1969,16 @@ static int dispatch_fwd(const elg_rollout_args& A, hipStream_t stream) {
         if (nch <= 8) return launch_fwd_tiled<8, TSP, 8, 128>(A, stream);
         if (nch <= 16) return launch_fwd_tiled<16, TSP, 8, 64>(A, stream);
     }
+    const bool fused = !A.use_state && A.do_decode && A.do_update && A.max_steps <= 0;
+    if (fused && (A.variant == 2 || nch > 16)) {
+        if (A.trA || A.trMask) return fail(ELG_ENOTIMPL, "rollout: training rows for N1 > 1024 not built");
+        return launch_fwd_xl<TSP>(A, stream);                 // Vrp-Set-XXL scale: runtime node loops, scratch rows
+    }
     if (nch <= 4) { ELG_GO(4, false, 8); }
     if (nch <= 8) { ELG_GO(8, false, 8); }
     if (nch <= 16) { ELG_GO(16, false, 8); }
 #undef ELG_GO
-    return fail(ELG_ENOTIMPL, "N1 > 1024 not built");
+    return fail(ELG_ENOTIMPL, "N1 > 1024: only the fused rollout is built (step-wise protocol up to 1024 nodes)");
 }
 
 }  // namespace elg

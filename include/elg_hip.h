@@ -87,7 +87,8 @@ typedef struct elg_rollout_args {
     float inv_ens;          /* 1 / ensemble_size                                                */
     int32_t variant;        /* 0: pick the kernel by shape (cooperative MFMA kernel for N1 <= 112, node-tiled kernel for
                                N1 > 128); 1: the one-wavefront-per-trajectory kernel for any N1 (what the step-wise
-                               protocol and 112 < N1 <= 128 always use; the A/B reference of the parity tests)      */
+                               protocol and 112 < N1 <= 128 always use; the A/B reference of the parity tests);
+                               2: the N1 > 1024 kernel (Vrp-Set-XXL; runtime node loops, needs `scratch`) for any N1 */
     int32_t dump_logits;    /* what full_probs receives: 0 probabilities, 1 the clipped + masked logits
                                clip * tanh(s) (-inf at closed nodes), 2 the scores s before the clip            */
     int32_t pad0;
@@ -133,6 +134,7 @@ typedef struct elg_rollout_args {
     float* trF;             /* (B,Rcap,3,48)  local-policy features of every slot (NULL: not saved)   */
     uint64_t* trMask;       /* (B,Rcap,2)     feasibility mask words of the row (bit n = node n closed); with it the
                                cooperative kernel (N1 <= 112) may skip trA: the backward recomputes a_h from q, K   */
+    float* scratch;         /* (B,M,N1)       score rows of the N1 > 1024 kernel (variant 2), else NULL               */
     float* trLse;           /* (B,Rcap,8)     with trMask: log2 of the glimpse softmax denominator per head, in the units of
                                s log2(e) / 4, so that a_h[n] = exp2(q_h.K_h[n] log2(e) / 4 - trLse) (NULL: not saved) */
 } elg_rollout_args;

@@ -28,12 +28,14 @@ def test_build_and_exports():
 
 def test_struct_layout_matches_c():
     from elg_amd import _lib
-    pairs = [("elg_rollout_args", _lib.RolloutArgs, ["problem", "seed", "Kmat", "loc", "st_vis", "full_probs", "trMask"]),
+    pairs = [("elg_rollout_args", _lib.RolloutArgs, ["problem", "variant", "dump_logits", "seed", "Kmat", "loc", "st_vis", "full_probs", "trMask", "scratch", "trLse"]),
              ("elg_bwd_args", _lib.BwdArgs, ["T", "gprob", "rowA", "rowLoad", "gloc", "row_stride"]),
              ("elg_enc_layer", _lib.EncLayer, ["Wq", "bc", "W1", "b2"]),
              ("elg_enc_weights", _lib.EncWeights, ["emb_depot_w", "emb_w", "layer", "dec_Wq_first", "dec_bc"]),
              ("elg_encoder_args", _lib.EncoderArgs, ["problem", "eps", "xy", "W", "enc", "Q2", "wl", "ws", "ws_floats"]),
-             ("elg_encoder_bwd_args", _lib.EncoderBwdArgs, ["fwd", "g_enc", "gpb", "gwl", "G", "ws2", "ws2_floats"])]
+             ("elg_encoder_bwd_args", _lib.EncoderBwdArgs, ["fwd", "g_enc", "gpb", "gwl", "G", "ws2", "ws2_floats"]),
+             ("elg_decoder_bwd_args", _lib.DecoderBwdArgs, ["problem", "inv_ens", "Rcap", "gprob", "trLse", "Kmat", "dwl", "rowDU", "rowW"]),
+             ("elg_local_weights", _lib.LocalWeights, ["init_emb_w", "cur_token_emb", "combine_b"])]
     src = '#include <stdio.h>\n#include <stddef.h>\n#include "elg_hip.h"\nint main(){\n'
     for cname, _, fields in pairs:
         src += f'printf("%zu\\n", sizeof({cname}));\n'

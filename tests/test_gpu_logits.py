@@ -42,7 +42,7 @@ def _check(tag, kernel, lg, scores, logits, clip, steps, t_index, tlen):
     print(tag, kernel, f"scores {worst_s:.2e}  logits/clip {worst_l:.2e}")
 
 
-@pytest.mark.parametrize("variant", [0, 1], ids=["cooperative", "wave_per_trajectory"])
+@pytest.mark.parametrize("variant", [0, 1, 2], ids=["cooperative", "wave_per_trajectory", "xl"])
 @pytest.mark.parametrize("tag", ["n50", "n20k8", "n100"])
 def test_cvrp_logits_through_the_product_path(tag, variant):
     from elg_amd.CVRP.CVRPEnv import CVRPEnv
@@ -65,11 +65,11 @@ def test_cvrp_logits_through_the_product_path(tag, variant):
     for what in ("scores", "logits"):
         r = eng.rollout_forward(env.problem, pol, M, acts[0, :, 1], L.MODE_FORCED, forced=acts, dump_T=T, variant=variant, dump=what)
         dumps[what] = r.full_probs
-    _check(f"cvrp_{tag}", "coop" if variant == 0 else "wave", lg, dumps["scores"], dumps["logits"], mp["logit_clipping"],
+    _check(f"cvrp_{tag}", ("coop", "wave", "xl")[variant], lg, dumps["scores"], dumps["logits"], mp["logit_clipping"],
            lg["steps"], lambda t: int(t), r.tlen)
 
 
-@pytest.mark.parametrize("variant", [0, 1], ids=["cooperative", "wave_per_trajectory"])
+@pytest.mark.parametrize("variant", [0, 1, 2], ids=["cooperative", "wave_per_trajectory", "xl"])
 @pytest.mark.parametrize("tag", ["n50", "n20"])
 def test_tsp_logits_through_the_product_path(tag, variant):
     from elg_amd.TSP.TSPEnv import TSPEnv
@@ -90,11 +90,11 @@ def test_tsp_logits_through_the_product_path(tag, variant):
     for what in ("scores", "logits"):
         r = eng.rollout_forward(env.problem, pol, M, acts[0, :, 0], L.MODE_FORCED, forced=acts, dump_T=N, variant=variant, dump=what)
         dumps[what] = r.full_probs
-    _check(f"tsp_{tag}", "coop" if variant == 0 else "wave", lg, dumps["scores"], dumps["logits"], mp["logit_clipping"],
+    _check(f"tsp_{tag}", ("coop", "wave", "xl")[variant], lg, dumps["scores"], dumps["logits"], mp["logit_clipping"],
            lg["steps"], lambda t: int(t), r.tlen)
 
 
-@pytest.mark.parametrize("variant", [0, 1], ids=["node_tiled", "wave_per_trajectory"])
+@pytest.mark.parametrize("variant", [0, 1, 2], ids=["node_tiled", "wave_per_trajectory", "xl"])
 def test_large_instance_logits(variant):
     """N1 = 151: the node-tiled kernel (and the untiled one) against the reference's own greedy construction."""
     from elg_amd.CVRP.CVRPEnv import CVRPEnv
@@ -116,7 +116,7 @@ def test_large_instance_logits(variant):
         r = eng.rollout_forward(env.problem, pol, M, acts[0, :, 1], L.MODE_FORCED, forced=acts, dump_T=T, variant=variant, dump=what)
         dumps[what] = r.full_probs
     np.testing.assert_allclose(r.reward.cpu().numpy(), lg["reward"], rtol=2e-6)
-    _check("cvrp_n150", "tiled" if variant == 0 else "wave", lg, dumps["scores"], dumps["logits"], mp["logit_clipping"],
+    _check("cvrp_n150", ("tiled", "wave", "xl")[variant], lg, dumps["scores"], dumps["logits"], mp["logit_clipping"],
            lg["steps"], lambda t: int(t), r.tlen)
     # and free-running greedy reproduces the reference's tours
     g = eng.rollout_forward(env.problem, pol, M, acts[0, :, 1], L.MODE_GREEDY, variant=variant)
