@@ -1588,6 +1588,286 @@ static int launch_fwd_tiled(const elg_rollout_args& A, hipStream_t stream) {
 
 
 // =============================================================================================
+// rollout_fwd_mt_kernel: 128 < N1 <= 1024 (TSP-200/500, VRPLIB X).  16 lockstep trajectories per workgroup.
+//   owners   (wave w owns trajectories w and w + 8; one wavefront per trajectory, the code of rollout_fwd_kernel):
+//            feasibility mask, query row, k-NN slots, local policy  ->  exchange rows in LDS
+//   glimpse  (wave h = head h, v_mfma_f32_16x16x4_f32): S^T = K_h q^T tile by tile over the nodes with the K / V operand
+//            fragments read straight from L2 (16-byte K loads, no LDS staging, no barrier per tile), online softmax in the
+//            exp2 domain over pairs of node tiles, O^T += V_h^T P^T -- the D tile of the first product is the B operand of
+//            the second
+//   pointer  (wave w: node tiles w, w + 8, ...): s^T = PK o^T, 32 MFMAs per node tile, scores to an LDS row per trajectory
+//   owners   clip, mask, softmax, choice, environment transition
+// The node-tiled kernel this replaces shared LDS-staged K / V / PK tiles between 8 one-wavefront trajectories and did the
+// glimpse and pointer products on the VALU: two barriers + a global->LDS round trip per tile, 65 us per step of 8.
+// =============================================================================================
+template <int NCH, bool TSP>
+__global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_args A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NTR = 16, QP = 132, SP = 64 * NCH + 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lo = lane & 15, hi = lane >> 4;
+    const int N1 = A.N1;
+    const int NTn = (N1 + 15) >> 4;
+    const int G = gridDim.x;
+    int u = blockIdx.x;
+    if ((G & 7) == 0) u = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int b = u / A.tiles, tile = u % A.tiles;
+    const int m_base = tile * NTR;
+    // LDS: query / glimpse-output rows | score rows | mask words | demand | per-wave slot scratch
+    float* sQ = lds;
+    float* sSc = sQ + NTR * QP;
+    unsigned long long* sMaskW = reinterpret_cast<unsigned long long*>(sSc + NTR * SP);
+    float* sdem = reinterpret_cast<float*>(sMaskW + NTR * NCH);
+    float* sb = sdem + ((N1 + 3) & ~3) + wave * ELG_SB_MIN;
+    if (!TSP)
+        for (int i = tid; i < N1; i += 512) sdem[i] = A.demand[(size_t)b * N1 + i];
+    __syncthreads();
+    const size_t NE = (size_t)N1 * ELG_E;
+    Inst I;
+    I.K = nullptr; I.V = nullptr; I.PK = nullptr;
+    I.pb = A.pb + (size_t)b * N1;
+    I.Q1 = A.Q1 + b * NE;
+    I.Q2 = TSP ? A.Q2 + b * NE : nullptr;
+    I.wl = A.wl;
+    I.xy = A.xy + (size_t)b * N1 * 2;
+    I.dem = sdem;
+    I.nidx = A.nbr_idx + (size_t)b * N1 * N1;
+    I.ndist = A.nbr_dist + (size_t)b * N1 * N1;
+    I.ntheta = A.nbr_theta + (size_t)b * N1 * N1;
+    I.loc = A.loc;
+    const float* gK = A.Kmat + b * NE + wave * 16;
+    const float* gV = A.Vmat + b * NE + wave * 16;
+    const float* gPK = A.PK + b * NE;
+    const int step_cap = TSP ? N1 : 2 * N1 + 2;
+
+    // the wave's two trajectories as separate objects (an array of Traj lands in scratch memory)
+    Traj<NCH> st0, st1;
+    const bool has0 = m_base + wave < A.M, has1 = m_base + wave + 8 < A.M;
+    const size_t bm0 = (size_t)b * A.M + (has0 ? m_base + wave : 0), bm1 = (size_t)b * A.M + (has1 ? m_base + wave + 8 : 0);
+    auto reset = [&](Traj<NCH>& st, bool has) {
+        st.cur = 0; st.first = 0; st.cnt = 0; st.fin = has ? 0 : 1; st.load = 1.0f; st.len = 0.f; st.cx = 0.f; st.cy = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) st.vis[c] = 0ull;
+    };
+    reset(st0, has0);
+    reset(st1, has1);
+    for (int t = 0; t < step_cap && t < A.Tmax; ++t) {
+        const bool first_move = (!TSP && t <= 1) || (TSP && t == 0);
+        const bool act0 = has0 && !st0.fin, act1 = has1 && !st1.fin;
+        const bool dec0 = act0 && !first_move, dec1 = act1 && !first_move;
+        if (!__syncthreads_or((act0 || act1) ? 1 : 0)) break;
+        int sel0 = 0, sel1 = 0, snid0 = -1, snid1 = -1;
+        float pr0 = 1.0f, pr1 = 1.0f, add0 = 0.f, add1 = 0.f;
+        if (!first_move) {
+            // ================= owners: masks, query rows, k-NN slots, local policy =================
+            auto prepare = [&](const Traj<NCH>& st, bool dec, int q, float& addval, int& snid) {
+                unsigned long long mk[NCH];
+                float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (dec) {
+                    build_mask<NCH, TSP>(st, I, N1, lane, mk);
+                    const int cb = (lane & 31) * 4;
+                    q4 = *reinterpret_cast<const float4*>(I.Q1 + (size_t)st.cur * ELG_E + cb);
+                    if (TSP) {
+                        const float4 qf = *reinterpret_cast<const float4*>(I.Q2 + (size_t)st.first * ELG_E + cb);
+                        q4.x += qf.x; q4.y += qf.y; q4.z += qf.z; q4.w += qf.w;
+                    } else {
+                        const float4 w = *reinterpret_cast<const float4*>(I.wl + cb);
+                        q4.x = fmaf(st.load, w.x, q4.x); q4.y = fmaf(st.load, w.y, q4.y);
+                        q4.z = fmaf(st.load, w.z, q4.z); q4.w = fmaf(st.load, w.w, q4.w);
+                    }
+                    if (A.has_penalty || A.has_local) {
+                        const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb);
+                        snid = S.snid;
+                        float uu = 0.f;
+                        if (A.has_local) uu = local_policy<TSP>(I.loc, lane, S.f0, S.f1, S.f2, S.smask, nullptr);
+                        addval = S.pen + uu * A.inv_ens;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) mk[c] = ~0ull;
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) sMaskW[q * NCH + c] = mk[c];
+                }
+                if (lane < 32) *reinterpret_cast<float4*>(sQ + q * QP + 4 * lane) = q4;
+            };
+            prepare(st0, dec0, wave, add0, snid0);
+            prepare(st1, dec1, wave + 8, add1, snid1);
+            __syncthreads();
+            // ================= glimpse: wave = head =================
+            {
+                const float4 q4 = *reinterpret_cast<const float4*>(sQ + lo * QP + 16 * wave + 4 * hi);    // trajectory lo
+                const unsigned* mw = reinterpret_cast<const unsigned*>(sMaskW + lo * NCH);
+                const float cs = 0.25f * 1.4426950408889634f;
+                float mrun = -1e30f, lrun = 0.f;
+                f32x4c o = {0.f, 0.f, 0.f, 0.f}, o2 = {0.f, 0.f, 0.f, 0.f};
+                float4 kfa, kfb;
+                float va0, va1, va2, va3, vb0, vb1, vb2, vb3;
+#define MT_LOAD(NT0, KA, KB, A0, A1, A2, A3, B0, B1, B2, B3)                                                         \
+    {                                                                                                                \
+        const int na_ = 16 * (NT0), nb_ = na_ + 16;                                                                  \
+        KA = *reinterpret_cast<const float4*>(gK + (size_t)min(na_ + lo, N1 - 1) * ELG_E + 4 * hi);                 \
+        KB = *reinterpret_cast<const float4*>(gK + (size_t)min(nb_ + lo, N1 - 1) * ELG_E + 4 * hi);                 \
+        A0 = gV[(size_t)min(na_ + 4 * hi, N1 - 1) * ELG_E + lo]; A1 = gV[(size_t)min(na_ + 4 * hi + 1, N1 - 1) * ELG_E + lo]; \
+        A2 = gV[(size_t)min(na_ + 4 * hi + 2, N1 - 1) * ELG_E + lo]; A3 = gV[(size_t)min(na_ + 4 * hi + 3, N1 - 1) * ELG_E + lo]; \
+        B0 = gV[(size_t)min(nb_ + 4 * hi, N1 - 1) * ELG_E + lo]; B1 = gV[(size_t)min(nb_ + 4 * hi + 1, N1 - 1) * ELG_E + lo]; \
+        B2 = gV[(size_t)min(nb_ + 4 * hi + 2, N1 - 1) * ELG_E + lo]; B3 = gV[(size_t)min(nb_ + 4 * hi + 3, N1 - 1) * ELG_E + lo]; \
+    }
+                MT_LOAD(0, kfa, kfb, va0, va1, va2, va3, vb0, vb1, vb2, vb3)
+                for (int nt = 0; nt < NTn; nt += 2) {
+                    float4 kna, knb;
+                    float na0, na1, na2, na3, nb0, nb1, nb2, nb3;
+                    MT_LOAD(min(nt + 2, NTn - 1), kna, knb, na0, na1, na2, na3, nb0, nb1, nb2, nb3)   // next pair in flight
+                    const unsigned dw = mw[nt >> 1];                        // mask bits of nodes 16 nt .. 16 nt + 31
+                    f32x4c Sa = {0.f, 0.f, 0.f, 0.f}, Sb = {0.f, 0.f, 0.f, 0.f};
+                    Sa = __builtin_amdgcn_mfma_f32_16x16x4f32(kfa.x, q4.x, Sa, 0, 0, 0);
+                    Sb = __builtin_amdgcn_mfma_f32_16x16x4f32(kfb.x, q4.x, Sb, 0, 0, 0);
+                    Sa = __builtin_amdgcn_mfma_f32_16x16x4f32(kfa.y, q4.y, Sa, 0, 0, 0);
+                    Sb = __builtin_amdgcn_mfma_f32_16x16x4f32(kfb.y, q4.y, Sb, 0, 0, 0);
+                    Sa = __builtin_amdgcn_mfma_f32_16x16x4f32(kfa.z, q4.z, Sa, 0, 0, 0);
+                    Sb = __builtin_amdgcn_mfma_f32_16x16x4f32(kfb.z, q4.z, Sb, 0, 0, 0);
+                    Sa = __builtin_amdgcn_mfma_f32_16x16x4f32(kfa.w, q4.w, Sa, 0, 0, 0);
+                    Sb = __builtin_amdgcn_mfma_f32_16x16x4f32(kfb.w, q4.w, Sb, 0, 0, 0);
+                    const unsigned niba = (dw >> (4 * hi)) & 0xFu, nibb = (dw >> (16 + 4 * hi)) & 0xFu;
+                    float tm = ELG_NEG_INF;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        Sa[i] = ((niba >> i) & 1u) ? ELG_NEG_INF : Sa[i];
+                        Sb[i] = ((nibb >> i) & 1u) ? ELG_NEG_INF : Sb[i];
+                        tm = fmaxf(tm, fmaxf(Sa[i], Sb[i]));
+                    }
+                    tm = quarters_max(tm);
+                    const float mnew = fmaxf(mrun, tm);
+                    const float sc = __builtin_amdgcn_exp2f((mrun - mnew) * cs);
+                    mrun = mnew;
+                    lrun *= sc;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { o[i] *= sc; o2[i] *= sc; }
+                    const float cm = -mnew * cs;
+                    float ea[4], eb[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        ea[i] = __builtin_amdgcn_exp2f(fmaf(Sa[i], cs, cm));
+                        eb[i] = __builtin_amdgcn_exp2f(fmaf(Sb[i], cs, cm));
+                        lrun += ea[i] + eb[i];
+                    }
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(va0, ea[0], o, 0, 0, 0);
+                    o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vb0, eb[0], o2, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(va1, ea[1], o, 0, 0, 0);
+                    o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vb1, eb[1], o2, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(va2, ea[2], o, 0, 0, 0);
+                    o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vb2, eb[2], o2, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(va3, ea[3], o, 0, 0, 0);
+                    o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vb3, eb[3], o2, 0, 0, 0);
+                    kfa = kna; kfb = knb;
+                    va0 = na0; va1 = na1; va2 = na2; va3 = na3; vb0 = nb0; vb1 = nb1; vb2 = nb2; vb3 = nb3;
+                }
+#undef MT_LOAD
+                lrun = quarters_sum(lrun);
+                const float inv = lrun > 0.f ? 1.0f / lrun : 0.f;
+                *reinterpret_cast<float4*>(sQ + lo * QP + 16 * wave + 4 * hi) =
+                    make_float4((o[0] + o2[0]) * inv, (o[1] + o2[1]) * inv, (o[2] + o2[2]) * inv, (o[3] + o2[3]) * inv);
+            }
+            __syncthreads();
+            // ================= pointer: node tiles over the waves =================
+            for (int nt = wave; nt < NTn; nt += 8) {
+                const float* prow = gPK + (size_t)min(16 * nt + lo, N1 - 1) * ELG_E + 4 * hi;
+                float4 pk0 = *reinterpret_cast<const float4*>(prow), pk1 = *reinterpret_cast<const float4*>(prow + 16);
+                float4 pk2 = *reinterpret_cast<const float4*>(prow + 32), pk3 = *reinterpret_cast<const float4*>(prow + 48);
+                float4 pk4 = *reinterpret_cast<const float4*>(prow + 64), pk5 = *reinterpret_cast<const float4*>(prow + 80);
+                float4 pk6 = *reinterpret_cast<const float4*>(prow + 96), pk7 = *reinterpret_cast<const float4*>(prow + 112);
+                f32x4c a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+                const float* orow = sQ + lo * QP + 4 * hi;
+#define MT_PK(PKV, S4)                                                                         \
+    {                                                                                          \
+        const float4 ov = *reinterpret_cast<const float4*>(orow + 16 * (S4));                  \
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(PKV.x, ov.x, a0, 0, 0, 0);                   \
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(PKV.y, ov.y, a1, 0, 0, 0);                   \
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(PKV.z, ov.z, a0, 0, 0, 0);                   \
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(PKV.w, ov.w, a1, 0, 0, 0);                   \
+    }
+                MT_PK(pk0, 0) MT_PK(pk1, 1) MT_PK(pk2, 2) MT_PK(pk3, 3) MT_PK(pk4, 4) MT_PK(pk5, 5) MT_PK(pk6, 6) MT_PK(pk7, 7)
+#undef MT_PK
+                const int nb = 16 * nt + 4 * hi;
+                const float p0 = I.pb[min(nb, N1 - 1)], p1 = I.pb[min(nb + 1, N1 - 1)], p2 = I.pb[min(nb + 2, N1 - 1)], p3 = I.pb[min(nb + 3, N1 - 1)];
+                *reinterpret_cast<float4*>(sSc + lo * SP + nb) =
+                    make_float4(a0[0] + a1[0] + p0, a0[1] + a1[1] + p1, a0[2] + a1[2] + p2, a0[3] + a1[3] + p3);
+            }
+            __syncthreads();
+            // ================= owners: clip, mask, softmax, choice =================
+            auto choose = [&](bool dec, int q, size_t bm, int snid, float addval, int& sel, float& pr) {
+                if (!dec) return;
+                unsigned long long mk[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const unsigned long long x = sMaskW[q * NCH + c];
+                    mk[c] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(x >> 32)) << 32) |
+                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)x);
+                }
+                float* srow = sSc + q * SP;
+                float s[NCH];
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    const int n = lane + 64 * ch;
+                    s[ch] = (n < N1) ? srow[n] : 0.f;
+                }
+                wave_lds_fence();
+                int fsel = 0;
+                if (A.forced && t < A.Tforced) fsel = __builtin_amdgcn_readfirstlane(A.forced[bm * A.Tforced + t]);
+                float uni = 0.f;
+                if (A.mode == ELG_MODE_SAMPLE)
+                    uni = A.uniforms ? A.uniforms[bm * A.Tmax + t] : philox_uniform(A.seed, (unsigned)bm, (unsigned)t);
+                float* frow = (A.full_probs && t < A.dump_T) ? A.full_probs + (bm * A.dump_T + t) * N1 : nullptr;
+                // finish_step scatters through a node-indexed scratch row: the score row itself (the scores are in registers now)
+                const FwdOut fo = finish_step<NCH, TSP, false>(A, N1, lane, srow, mk, s, snid, addval, fsel, uni, frow, (size_t)b, 0, 0);
+                sel = __builtin_amdgcn_readfirstlane(fo.sel);
+                pr = i2f(__builtin_amdgcn_readfirstlane(f2i(fo.p)));
+            };
+            choose(dec0, wave, bm0, snid0, add0, sel0, pr0);
+            choose(dec1, wave + 8, bm1, snid1, add1, sel1, pr1);
+        }
+        auto advance = [&](Traj<NCH>& st, bool act, size_t bm, int m, int sel, float pr) {
+            if (!act) return;
+            if (first_move) {
+                if (A.mode == ELG_MODE_FORCED) sel = (A.forced && t < A.Tforced) ? __builtin_amdgcn_readfirstlane(A.forced[bm * A.Tforced + t]) : 0;
+                else sel = (!TSP && t == 0) ? 0 : __builtin_amdgcn_readfirstlane(A.starts[m]);
+            }
+            if (lane == 0) {
+                if (A.actions) A.actions[bm * A.Tmax + t] = sel;
+                if (A.probs) A.probs[((size_t)b * A.Tmax + t) * A.M + m] = pr;
+            }
+            env_update<NCH, TSP>(st, I, N1, sel);
+        };
+        advance(st0, act0, bm0, m_base + wave, sel0, pr0);
+        advance(st1, act1, bm1, m_base + wave + 8, sel1, pr1);
+    }
+    if (lane == 0) {
+        if (has0) { if (A.reward) A.reward[bm0] = -st0.len; if (A.tlen) A.tlen[bm0] = st0.cnt; }
+        if (has1) { if (A.reward) A.reward[bm1] = -st1.len; if (A.tlen) A.tlen[bm1] = st1.cnt; }
+    }
+}
+
+template <int NCH, bool TSP>
+static int launch_fwd_mt(const elg_rollout_args& A, hipStream_t stream) {
+    const size_t lds = ((size_t)16 * 132 + (size_t)16 * (64 * NCH + 4) + (size_t)16 * NCH * 2 + ((A.N1 + 3) & ~3) + (size_t)8 * ELG_SB_MIN) * 4;
+    auto kern = rollout_fwd_mt_kernel<NCH, TSP>;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        (void)hipGetLastError();
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(ELG_ELAUNCH, std::string("mt rollout: hipFuncSetAttribute: ") + hipGetErrorString(e));
+        attr_lds = lds;
+    }
+    elg_rollout_args B2 = A;
+    B2.tiles = (A.M + 15) / 16;                            // this kernel's geometry: 16 trajectories per workgroup
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3(B2.B * B2.tiles), dim3(512), lds, stream, B2);
+    return launch_status("rollout_fwd_mt");
+}
+
+// =============================================================================================
 // rollout_fwd_xl_kernel: instances beyond the register-resident node layouts (N1 > 1024: Vrp-Set-XXL, N1 up to 7001).
 // Same structure as the node-tiled kernel -- 8 lockstep trajectories per workgroup share the K / V / PK tiles staged in
 // LDS -- but everything that is an NCH-sized register array there is a runtime loop here: the visited set and the mask
@@ -1965,9 +2245,9 @@ static int dispatch_fwd(const elg_rollout_args& A, hipStream_t stream) {
     if (lds) return fail(ELG_EINVAL, "lds_stage needs N1 <= 104");
     if (!A.use_state && A.do_decode && A.do_update && A.max_steps <= 0 && A.variant == 0) {
         // fused rollout of a large instance: node-tiled kernel (tables shared through LDS tiles)
-        if (nch <= 4) return launch_fwd_tiled<4, TSP, 8, 128>(A, stream);
-        if (nch <= 8) return launch_fwd_tiled<8, TSP, 8, 128>(A, stream);
-        if (nch <= 16) return launch_fwd_tiled<16, TSP, 8, 64>(A, stream);
+        if (nch <= 4) return launch_fwd_mt<4, TSP>(A, stream);
+        if (nch <= 8) return launch_fwd_mt<8, TSP>(A, stream);
+        if (nch <= 16) return launch_fwd_mt<16, TSP>(A, stream);
     }
     const bool fused = !A.use_state && A.do_decode && A.do_update && A.max_steps <= 0;
     if (fused && (A.variant == 2 || nch > 16)) {

@@ -135,7 +135,8 @@ __device__ __forceinline__ void env_update(Traj<NCH>& st, const Inst& I, int N1,
 // ---------------------------------------------------------------------------------------------
 template <int NCH, bool TSP>
 __device__ __forceinline__ int knn_slots(const Inst& I, int N1, int K, int cur, int lane,
-                                         const unsigned long long (&mk)[NCH], float* sb) {
+                                         const unsigned long long (&mk)[NCH], float* sb,
+                                         const unsigned long long* lds_mk = nullptr) {
     constexpr int S0 = TSP ? 0 : 1;
     int found = 0;
     const size_t row = (size_t)cur * N1;
@@ -147,7 +148,8 @@ __device__ __forceinline__ int knn_slots(const Inst& I, int N1, int K, int cur, 
             const int nid = valid ? I.nidx[row + i] : 0;
             const float nd = valid ? I.ndist[row + i] : 0.f;        // issued together with the index load
             const float nth = valid ? I.ntheta[row + i] : 0.f;
-            bool cand = valid && !test_bit<NCH>(mk, nid);
+            // (many mask words: a per-lane select chain would put mk[] in scratch memory; the caller keeps a copy in LDS)
+            bool cand = valid && !(lds_mk ? (bool)((lds_mk[nid >> 6] >> (nid & 63)) & 1ull) : test_bit<NCH>(mk, nid));
             if (!TSP) cand = cand && (nid != 0);
             const unsigned long long bal = __ballot(cand);
             const int rank = found + lanes_below(bal);
@@ -175,10 +177,11 @@ struct Slots {
 
 template <int NCH, bool TSP>
 __device__ __forceinline__ Slots slot_setup(const Inst& I, int N1, int K, bool has_penalty, const Traj<NCH>& st,
-                                            int lane, const unsigned long long (&mk)[NCH], float* sb) {
+                                            int lane, const unsigned long long (&mk)[NCH], float* sb,
+                                            const unsigned long long* lds_mk = nullptr) {
     constexpr int S0 = TSP ? 0 : 1;
     Slots S;
-    S.k = knn_slots<NCH, TSP>(I, N1, K, st.cur, lane, mk, sb);
+    S.k = knn_slots<NCH, TSP>(I, N1, K, st.cur, lane, mk, sb, lds_mk);
     wave_lds_fence();
     const int j = lane;
     S.cust = (j >= S0) && (j < S0 + S.k);
