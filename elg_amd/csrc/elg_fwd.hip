@@ -2,7 +2,9 @@
 // + the small per-batch kernels (neighbour tables, distance matrix, aug8, route length).
 //   rollout_fwd_coop_kernel   N1 <= 112: lockstep trajectories, glimpse / pointer / local policy on fp32 MFMA,
 //                             clip / softmax / choice / transition / k-NN for four trajectories per wave
-//   rollout_fwd_tiled_kernel  N1 > 128: K / V / PK walked in LDS tiles shared by 8 lockstep trajectories
+//   rollout_fwd_mt_kernel     128 < N1 <= 1024: 16 lockstep trajectories per workgroup, glimpse / pointer on fp32 MFMA with
+//                             the K / V / PK fragments streamed from L2
+//   rollout_fwd_xl_kernel     N1 > 1024 (up to 8192): node-indexed state in LDS words + global scratch rows
 //   rollout_fwd_kernel        one wavefront per trajectory: the step-wise protocol (CVRPEnv.step, one_step_rollout),
 //                             explicit geometries, A/B reference
 //
@@ -656,62 +658,6 @@ __device__ __forceinline__ void co_store_state(int* sS, const Traj<2>& st, int l
         sS[10] = (int)(unsigned)st.vis[1]; sS[11] = (int)(unsigned)(st.vis[1] >> 32);
     }
 }
-__device__ __forceinline__ void co_load_state(const int* sS, Traj<2>& st, int lane) {
-    const int x = sS[lane & 15];
-    st.cur = readlane(x, 0); st.first = readlane(x, 1); st.cnt = readlane(x, 2); st.fin = readlane(x, 3);
-    st.load = i2f(readlane(x, 4)); st.len = i2f(readlane(x, 5)); st.cx = i2f(readlane(x, 6)); st.cy = i2f(readlane(x, 7));
-    st.vis[0] = ((unsigned long long)(unsigned)readlane(x, 9) << 32) | (unsigned)readlane(x, 8);
-    st.vis[1] = ((unsigned long long)(unsigned)readlane(x, 11) << 32) | (unsigned)readlane(x, 10);
-}
-
-// mask, query and k-NN slots of the step a trajectory is about to decode -> exchange buffers
-// (TRAIN: also the q / load / slot rows of that step)
-template <bool TSP, bool TRAIN>
-__device__ __forceinline__ void co_prepare(const elg_rollout_args& A, const Inst& I, const Traj<2>& st, int N1, int lane,
-                                           bool decode, unsigned long long* sMaskQ, float* sQrow, float* sXrow, float* sb,
-                                           size_t b, size_t r, size_t Rcap) {
-    unsigned long long mk[2] = {~0ull, ~0ull};
-    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    int ssave = -1;
-    float sf0 = 0.f, sf1 = 0.f, sf2 = 0.f, pen = 0.f;
-    if (decode) {
-        build_mask<2, TSP>(st, I, N1, lane, mk);
-        const int cb = (lane & 31) * 4;
-        q4 = *reinterpret_cast<const float4*>(I.Q1 + (size_t)st.cur * ELG_E + cb);
-        if (TSP) {
-            const float4 qf = *reinterpret_cast<const float4*>(I.Q2 + (size_t)st.first * ELG_E + cb);
-            q4.x += qf.x; q4.y += qf.y; q4.z += qf.z; q4.w += qf.w;
-        } else {
-            const float4 w = *reinterpret_cast<const float4*>(I.wl + cb);
-            q4.x = fmaf(st.load, w.x, q4.x); q4.y = fmaf(st.load, w.y, q4.y);
-            q4.z = fmaf(st.load, w.z, q4.z); q4.w = fmaf(st.load, w.w, q4.w);
-        }
-        if (TRAIN && lane < 32) *reinterpret_cast<float4*>(A.trQ + (b * Rcap + r) * ELG_E + cb) = q4;
-        if (TRAIN && lane == 0 && A.trLoad) A.trLoad[b * Rcap + r] = st.load;
-        if (TRAIN && lane == 0 && A.trMask) { A.trMask[(b * Rcap + r) * 2] = mk[0]; A.trMask[(b * Rcap + r) * 2 + 1] = mk[1]; }
-        if (A.has_penalty || A.has_local) {
-            const Slots S = slot_setup<2, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb);
-            ssave = (S.smask && S.snid >= 0) ? -2 : S.snid;           // -2: present but masked (CVRP depot slot)
-            sf0 = S.f0; sf1 = S.f1; sf2 = S.f2; pen = S.pen;
-        }
-        if (TRAIN && A.trSlot && lane < ELG_SLOT_STRIDE) {
-            A.trSlot[(b * Rcap + r) * ELG_SLOT_STRIDE + lane] = ssave;
-            if (A.trF) {
-                float* fr = A.trF + (b * Rcap + r) * (3 * ELG_SLOT_STRIDE) + lane;
-                fr[0] = sf0; fr[ELG_SLOT_STRIDE] = sf1; fr[2 * ELG_SLOT_STRIDE] = sf2;
-            }
-        }
-    }
-    if (lane == 0) { sMaskQ[0] = mk[0]; sMaskQ[1] = mk[1]; }
-    if (lane < 32) *reinterpret_cast<float4*>(sQrow + 4 * lane) = q4;
-    if (lane < ELG_SLOT_STRIDE) {
-        sXrow[CO_XF + lane] = sf0; sXrow[CO_XF + ELG_SLOT_STRIDE + lane] = sf1; sXrow[CO_XF + 2 * ELG_SLOT_STRIDE + lane] = sf2;
-        reinterpret_cast<int*>(sXrow)[CO_XS + lane] = ssave;
-        sXrow[CO_XPEN + lane] = pen;
-        sXrow[CO_XU + lane] = 0.f;
-    }
-}
-
 // 16-lane (DPP row) integer min / max all-reduce
 __device__ __forceinline__ int row16_min_i(int v) {
     v = min(v, f2i(quad_xor1(i2f(v)))); v = min(v, f2i(quad_xor2(i2f(v))));
@@ -1294,13 +1240,9 @@ static int launch_fwd_coop(const elg_rollout_args& A, hipStream_t stream) {
 }
 
 // =============================================================================================
-// Node-tiled rollout kernel for large instances (N1 > 128: TSP-500, VRPLIB up to 1000 nodes).
-// K / V / PK do not fit LDS, so the workgroup walks them in tiles of TR rows: a tile is staged ONCE per
-// step and consumed by all WAVES trajectories of the workgroup (they advance in lockstep), instead of every
-// trajectory streaming the whole tables from L2 on its own.  Glimpse = online softmax over the tiles
-// (flash-attention style, same quad layout as the resident kernel); pointer scores tile by tile into a
-// per-wave LDS row; everything per-trajectory (masks, k-NN, local policy, softmax, choice, env) is the
-// same code as in rollout_fwd_kernel.
+// One LDS-staged tile of the glimpse for a one-wavefront trajectory (online softmax over node tiles, flash-attention
+// style, same quad layout as the resident kernel): used by rollout_fwd_xl_kernel, whose instances are too large
+// for anything node-indexed to live in registers.
 // =============================================================================================
 template <int NGT>
 __device__ __forceinline__ void glimpse_tile(const float* __restrict__ sK, const float* __restrict__ sV, int row0, int N1,
@@ -1364,226 +1306,6 @@ __device__ __forceinline__ void glimpse_tile(const float* __restrict__ sK, const
         ELG_VT(0) ELG_VT(1) ELG_VT(2) ELG_VT(3)
 #undef ELG_VT
     }
-}
-
-template <int NCH, bool TSP, int WAVES, int TR>
-__global__ __launch_bounds__(WAVES * 64) void rollout_fwd_tiled_kernel(const elg_rollout_args A) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NT = WAVES * 64, NGT = TR / 8, CPT = TR / 64;      // threads, row groups / node chunks per tile
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int N1 = A.N1;
-    const int G = gridDim.x;
-    int u = blockIdx.x;
-    if ((G & 7) == 0) u = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-    const int b = u / A.tiles, tile = u % A.tiles;
-    const int tile_m = (A.M + A.tiles - 1) / A.tiles;
-    const int m_lo = tile * tile_m, m_hi = min(A.M, m_lo + tile_m);
-    const int ntiles = (N1 + TR - 1) / TR;
-
-    // LDS: [tile A: TR x 128 | tile B: TR x 128] | dem | per-wave { sb (slot / o scratch) | sn (node row) | smk (mask words) }
-    float* sTA = lds;
-    float* sTB = lds + TR * ELG_E;
-    float* p = lds + 2 * TR * ELG_E;
-    float* sdem = p; p += (N1 + 3) & ~3;
-    constexpr int PW = ELG_SB_MIN + 64 * NCH + 2 * NCH + 2;
-    float* sb = p + wave * PW;
-    float* sn = sb + ELG_SB_MIN;
-    unsigned long long* smk = reinterpret_cast<unsigned long long*>(sn + 64 * NCH);
-    if (!TSP)
-        for (int i = tid; i < N1; i += NT) sdem[i] = A.demand[(size_t)b * N1 + i];
-    __syncthreads();
-
-    const size_t NE = (size_t)N1 * ELG_E;
-    const float4* gK = reinterpret_cast<const float4*>(A.Kmat + b * NE);
-    const float4* gV = reinterpret_cast<const float4*>(A.Vmat + b * NE);
-    const float4* gPK = reinterpret_cast<const float4*>(A.PK + b * NE);
-    Inst I;
-    I.K = nullptr; I.V = nullptr; I.PK = nullptr;
-    I.pb = A.pb + (size_t)b * N1;
-    I.Q1 = A.Q1 + b * NE;
-    I.Q2 = TSP ? A.Q2 + b * NE : nullptr;
-    I.wl = A.wl;
-    I.xy = A.xy + (size_t)b * N1 * 2;
-    I.dem = sdem;
-    I.nidx = A.nbr_idx + (size_t)b * N1 * N1;
-    I.ndist = A.nbr_dist + (size_t)b * N1 * N1;
-    I.ntheta = A.nbr_theta + (size_t)b * N1 * N1;
-    I.loc = A.loc;
-    const int step_cap = TSP ? N1 : 2 * N1 + 2;
-
-    for (int m_base = m_lo; m_base < m_hi; m_base += WAVES) {          // rounds: WAVES trajectories in lockstep
-        const int m = m_base + wave;
-        const bool has = m < m_hi;
-        const size_t bm = (size_t)b * A.M + (has ? m : m_lo);
-        Traj<NCH> st;
-        st.cur = 0; st.first = 0; st.cnt = 0; st.fin = has ? 0 : 1; st.load = 1.0f; st.len = 0.f; st.cx = 0.f; st.cy = 0.f;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) st.vis[c] = 0ull;
-
-        for (int step = 0; step < step_cap; ++step) {
-            const bool active = has && !st.fin && st.cnt < A.Tmax;
-            if (!__syncthreads_or(active ? 1 : 0)) break;               // every trajectory of the round is done
-            const int t = st.cnt;
-            const bool first_move = (!TSP && t <= 1) || (TSP && t == 0);
-            const bool dec = active && !first_move;                      // this wave decodes in this step
-            int fsel = 0;
-            if (active && A.forced && t < A.Tforced) fsel = __builtin_amdgcn_readfirstlane(A.forced[bm * A.Tforced + t]);
-            int sel = 0;
-            float pr = 1.0f;
-            if (__syncthreads_or(dec ? 1 : 0)) {
-                // ---------------- per-trajectory part 1: masks, query, k-NN slots, local policy
-                unsigned long long mk[NCH];
-                float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                float addval = 0.f;
-                int snid = -1;
-                if (dec) {
-                    build_mask<NCH, TSP>(st, I, N1, lane, mk);
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) if (lane == 0) smk[c] = mk[c];
-                    const int cb = (lane & 31) * 4;
-                    q4 = *reinterpret_cast<const float4*>(I.Q1 + (size_t)st.cur * ELG_E + cb);
-                    if (TSP) {
-                        const float4 qf = *reinterpret_cast<const float4*>(I.Q2 + (size_t)st.first * ELG_E + cb);
-                        q4.x += qf.x; q4.y += qf.y; q4.z += qf.z; q4.w += qf.w;
-                    } else {
-                        const float4 w = *reinterpret_cast<const float4*>(I.wl + cb);
-                        q4.x = fmaf(st.load, w.x, q4.x); q4.y = fmaf(st.load, w.y, q4.y);
-                        q4.z = fmaf(st.load, w.z, q4.z); q4.w = fmaf(st.load, w.w, q4.w);
-                    }
-                    if (A.has_penalty || A.has_local) {
-                        const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb);
-                        snid = S.snid;
-                        float uu = 0.f;
-                        if (A.has_local) uu = local_policy<TSP>(I.loc, lane, S.f0, S.f1, S.f2, S.smask, nullptr);
-                        addval = S.pen + uu * A.inv_ens;
-                    }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) mk[c] = ~0ull;
-                }
-                // ---------------- glimpse: online softmax over the K / V tiles (cooperative staging)
-                float m_run = ELG_NEG_INF, l_run = 0.f;
-                f32x2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
-                for (int tt = 0; tt < ntiles; ++tt) {
-                    __syncthreads();                                     // previous tile fully consumed
-                    const int row0 = tt * TR;
-                    for (int i = tid; i < TR * 32; i += NT) {
-                        const int grow = row0 + (i >> 5);
-                        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-                        if (grow < N1) { kv = gK[(size_t)grow * 32 + (i & 31)]; vv = gV[(size_t)grow * 32 + (i & 31)]; }
-                        reinterpret_cast<float4*>(sTA)[i] = kv;
-                        reinterpret_cast<float4*>(sTB)[i] = vv;
-                    }
-                    __syncthreads();
-                    if (dec) {
-                        const unsigned long long w0 = smk[tt * CPT];
-                        const unsigned long long w1 = (CPT > 1) ? smk[tt * CPT + (CPT > 1 ? 1 : 0)] : 0ull;
-                        glimpse_tile<NGT>(sTA, sTB, row0, N1, lane, q4, w0, w1, m_run, l_run, acc01, acc23);
-                    }
-                }
-                float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (dec) {
-                    float l = l_run;
-                    l += quad_xor1(l); l += quad_xor2(l); l += shfl_xor(l, 32);
-                    const float inv = 1.0f / l;
-                    o4 = make_float4(acc01.x, acc01.y, acc23.x, acc23.y);
-                    o4.x += shfl_xor(o4.x, 32); o4.y += shfl_xor(o4.y, 32);
-                    o4.z += shfl_xor(o4.z, 32); o4.w += shfl_xor(o4.w, 32);
-                    o4.x *= inv; o4.y *= inv; o4.z *= inv; o4.w *= inv;
-                    if (lane < 32) *reinterpret_cast<float4*>(sb + 4 * lane) = o4;   // o broadcast row
-                }
-                // ---------------- pointer scores, PK tile by tile (tile A, XOR-swizzled chunks)
-                for (int tt = 0; tt < ntiles; ++tt) {
-                    __syncthreads();
-                    const int row0 = tt * TR;
-                    for (int i = tid; i < TR * 32; i += NT) {
-                        const int lrow = i >> 5, c4 = i & 31, grow = row0 + lrow;
-                        float4 pk = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (grow < N1) pk = gPK[(size_t)grow * 32 + c4];
-                        reinterpret_cast<float4*>(sTA)[lrow * 32 + (c4 ^ (lrow & 31))] = pk;
-                    }
-                    __syncthreads();
-                    if (dec) {
-                        f32x2 acc[CPT];
-#pragma unroll
-                        for (int cc = 0; cc < CPT; ++cc) acc[cc] = f32x2{0.f, 0.f};
-#pragma unroll 8
-                        for (int c4 = 0; c4 < 32; ++c4) {
-                            const float4 o = *reinterpret_cast<const float4*>(sb + 4 * c4);
-#pragma unroll
-                            for (int cc = 0; cc < CPT; ++cc) {
-                                const int lrow = lane + 64 * cc;
-                                const float4 pk = *reinterpret_cast<const float4*>(sTA + (size_t)lrow * ELG_E + 4 * (c4 ^ (lrow & 31)));
-                                acc[cc] = __builtin_elementwise_fma(lo2(o), lo2(pk), acc[cc]);
-                                acc[cc] = __builtin_elementwise_fma(hi2(o), hi2(pk), acc[cc]);
-                            }
-                        }
-#pragma unroll
-                        for (int cc = 0; cc < CPT; ++cc) {
-                            const int n = row0 + lane + 64 * cc;
-                            if (n < N1) sn[n] = (acc[cc].x + acc[cc].y) + I.pb[n];
-                        }
-                    }
-                }
-                // ---------------- per-trajectory part 2: softmax, choice
-                if (dec) {
-                    wave_lds_fence();
-                    float s[NCH];
-#pragma unroll
-                    for (int ch = 0; ch < NCH; ++ch) {
-                        const int n = lane + 64 * ch;
-                        s[ch] = (n < N1) ? sn[n] : 0.f;
-                    }
-                    wave_lds_fence();
-                    float uni = 0.f;
-                    if (A.mode == ELG_MODE_SAMPLE)
-                        uni = A.uniforms ? A.uniforms[bm * A.Tmax + t] : philox_uniform(A.seed, (unsigned)bm, (unsigned)t);
-                    float* frow = (A.full_probs && t < A.dump_T) ? A.full_probs + (bm * A.dump_T + t) * N1 : nullptr;
-                    // finish_step scatters through a node-indexed scratch row: use sn (the scores are in registers now)
-                    const FwdOut o = finish_step<NCH, TSP, false>(A, N1, lane, sn, mk, s, snid, addval, fsel, uni, frow,
-                                                                  (size_t)b, 0, 0);
-                    sel = __builtin_amdgcn_readfirstlane(o.sel);
-                    pr = i2f(__builtin_amdgcn_readfirstlane(f2i(o.p)));
-                }
-            }
-            if (active) {
-                if (first_move) {
-                    if (A.mode == ELG_MODE_FORCED) sel = fsel;
-                    else sel = (!TSP && t == 0) ? 0 : __builtin_amdgcn_readfirstlane(A.starts[m]);
-                }
-                if (lane == 0) {
-                    if (A.actions) A.actions[bm * A.Tmax + t] = sel;
-                    if (A.probs) A.probs[((size_t)b * A.Tmax + t) * A.M + m] = pr;
-                }
-                env_update<NCH, TSP>(st, I, N1, sel);
-            }
-        }
-        if (has && lane == 0) {
-            if (A.reward) A.reward[bm] = -st.len;
-            if (A.tlen) A.tlen[bm] = st.cnt;
-        }
-        __syncthreads();
-    }
-}
-
-template <int NCH, bool TSP, int WAVES, int TR>
-static int launch_fwd_tiled(const elg_rollout_args& A, hipStream_t stream) {
-    constexpr int PW = ELG_SB_MIN + 64 * NCH + 2 * NCH + 2;
-    const size_t lds = ((size_t)2 * TR * ELG_E + ((A.N1 + 3) & ~3) + (size_t)WAVES * PW) * 4;
-    // __syncthreads_or keeps a few bytes of static LDS of its own: stay clear of the 160 KiB limit
-    if (lds > 163840 - 256) return fail(ELG_EINVAL, "tiled rollout: LDS budget exceeded");
-    auto kern = rollout_fwd_tiled_kernel<NCH, TSP, WAVES, TR>;
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        (void)hipGetLastError();
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(ELG_ELAUNCH, std::string("tiled rollout: hipFuncSetAttribute: ") + hipGetErrorString(e));
-        attr_lds = lds;
-    }
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(kern, dim3(A.B * A.tiles), dim3(WAVES * 64), lds, stream, A);
-    return launch_status("rollout_fwd_tiled");
 }
 
 
@@ -1662,9 +1384,9 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
         if (!first_move) {
             // ================= owners: masks, query rows, k-NN slots, local policy =================
             auto prepare = [&](const Traj<NCH>& st, bool dec, int q, float& addval, int& snid) {
-                unsigned long long mk[NCH];
                 float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (dec) {
+                    unsigned long long mk[NCH];
                     build_mask<NCH, TSP>(st, I, N1, lane, mk);
                     const int cb = (lane & 31) * 4;
                     q4 = *reinterpret_cast<const float4*>(I.Q1 + (size_t)st.cur * ELG_E + cb);
@@ -1676,20 +1398,21 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                         q4.x = fmaf(st.load, w.x, q4.x); q4.y = fmaf(st.load, w.y, q4.y);
                         q4.z = fmaf(st.load, w.z, q4.z); q4.w = fmaf(st.load, w.w, q4.w);
                     }
+                    if (lane == 0) {
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) sMaskW[q * NCH + c] = mk[c];
+                    }
                     if (A.has_penalty || A.has_local) {
-                        const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb);
+                        wave_lds_fence();
+                        const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb, sMaskW + q * NCH);
                         snid = S.snid;
                         float uu = 0.f;
                         if (A.has_local) uu = local_policy<TSP>(I.loc, lane, S.f0, S.f1, S.f2, S.smask, nullptr);
                         addval = S.pen + uu * A.inv_ens;
                     }
-                } else {
+                } else if (lane == 0) {
 #pragma unroll
-                    for (int c = 0; c < NCH; ++c) mk[c] = ~0ull;
-                }
-                if (lane == 0) {
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) sMaskW[q * NCH + c] = mk[c];
+                    for (int c = 0; c < NCH; ++c) sMaskW[q * NCH + c] = ~0ull;
                 }
                 if (lane < 32) *reinterpret_cast<float4*>(sQ + q * QP + 4 * lane) = q4;
             };
