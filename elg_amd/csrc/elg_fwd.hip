@@ -521,10 +521,10 @@ __device__ __forceinline__ void co_stage_local(const float* __restrict__ loc, fl
 // Local policy of 16 lockstep trajectories at once (models.py:133-166, folded as in elg_rollout.h::local_policy):
 // feature-major tiles X[slot 16 jt + 4 hi + v][trajectory lo]; the three table contractions (alpha -> o', o' -> g',
 // g' -> u) are MFMAs whose D tiles are the next B operands.  Reads the trajectories' slot blocks, writes u_j.
-__device__ __forceinline__ void co_local16(const float* __restrict__ sT, const float (&la)[ELG_LH][3], float* sXrows,
-                                           int lo, int hi) {
+__device__ __forceinline__ void co_local16(const float* __restrict__ sT, const float (&la)[ELG_LH][3], const float* sXrows,
+                                           float* sUrows, int upitch, int lo, int hi) {
     constexpr int JT = 3;
-    float* X = sXrows + lo * CO_XP;                                 // this lane's trajectory
+    const float* X = sXrows + lo * CO_XP;                           // this lane's trajectory
     const bool up = hi >= 2;
     const f32x4c z4 = {0.f, 0.f, 0.f, 0.f};
     f32x4c o1[2], g1[2];
@@ -645,8 +645,19 @@ __device__ __forceinline__ void co_local16(const float* __restrict__ sT, const f
             acc[0] = fmaf(w[k], t.x, acc[0]); acc[1] = fmaf(w[k], t.y, acc[1]);
             acc[2] = fmaf(w[k], t.z, acc[2]); acc[3] = fmaf(w[k], t.w, acc[3]);
         }
-        *reinterpret_cast<float4*>(X + CO_XU + 16 * jt + 4 * hi) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(sUrows + lo * upitch + 16 * jt + 4 * hi) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
+}
+
+// out-of-line instance for rollout_fwd_mt_kernel: one wave calls it between phases, and its ~250 live registers must not
+// shape the register allocation of that kernel's streaming loops
+__device__ __attribute__((noinline)) void co_local16_call(const float* sT, const float* __restrict__ loc, float* sXrows, int lo, int hi) {
+    float la[ELG_LH][3];
+#pragma unroll
+    for (int h = 0; h < ELG_LH; ++h)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) la[h][k] = loc[ELG_LOC_LA + 3 * h + k];
+    co_local16(sT, la, sXrows, sXrows + CO_XU, CO_XP, lo, hi);
 }
 
 template <bool TSP>
@@ -1177,7 +1188,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                     }
                 } else if (A.has_local && (wave == 6 || two_rt)) {
                     // wave 6: trajectories 0-15, wave 7: trajectories 16-31
-                    co_local16(sT, la, sX + (wave - 6) * 16 * CO_XP, lo_t, hi_t);
+                    co_local16(sT, la, sX + (wave - 6) * 16 * CO_XP, sX + (wave - 6) * 16 * CO_XP + CO_XU, CO_XP, lo_t, hi_t);
                 }
                 __syncthreads();
             }
@@ -1338,12 +1349,15 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
     const int m_base = tile * NTR;
     // LDS: query / glimpse-output rows | score rows | mask words | demand | per-wave slot scratch
     float* sQ = lds;
-    float* sSc = sQ + NTR * QP;
+    float* sSc = sQ + NTR * QP;                            // score rows (pointer -> choice)
     unsigned long long* sMaskW = reinterpret_cast<unsigned long long*>(sSc + NTR * SP);
-    float* sdem = reinterpret_cast<float*>(sMaskW + NTR * NCH);
+    float* sX = reinterpret_cast<float*>(sMaskW + NTR * NCH);           // slot blocks (owners -> local policy -> owners)
+    float* sT = sX + (A.has_local ? NTR * CO_XP : 0);                   // folded local-policy tables
+    float* sdem = sT + (A.has_local ? CL_SIZE : 0);
     float* sb = sdem + ((N1 + 3) & ~3) + wave * ELG_SB_MIN;
     if (!TSP)
         for (int i = tid; i < N1; i += 512) sdem[i] = A.demand[(size_t)b * N1 + i];
+    if (A.has_local) co_stage_local(A.loc, sT, tid, 512);
     __syncthreads();
     const size_t NE = (size_t)N1 * ELG_E;
     Inst I;
@@ -1406,13 +1420,23 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                         wave_lds_fence();
                         const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb, sMaskW + q * NCH);
                         snid = S.snid;
-                        float uu = 0.f;
-                        if (A.has_local) uu = local_policy<TSP>(I.loc, lane, S.f0, S.f1, S.f2, S.smask, nullptr);
-                        addval = S.pen + uu * A.inv_ens;
+                        addval = S.pen;
+                        if (A.has_local && lane < ELG_SLOT_STRIDE) {        // slot block for co_local16 (layout of the coop kernel)
+                            float* X = sX + q * CO_XP;
+                            X[CO_XF + lane] = S.f0; X[CO_XF + ELG_SLOT_STRIDE + lane] = S.f1; X[CO_XF + 2 * ELG_SLOT_STRIDE + lane] = S.f2;
+                            reinterpret_cast<int*>(X)[CO_XS + lane] = S.smask ? (S.snid >= 0 ? -2 : -1) : S.snid;
+                        }
                     }
-                } else if (lane == 0) {
+                } else {
+                    if (lane == 0) {
 #pragma unroll
-                    for (int c = 0; c < NCH; ++c) sMaskW[q * NCH + c] = ~0ull;
+                        for (int c = 0; c < NCH; ++c) sMaskW[q * NCH + c] = ~0ull;
+                    }
+                    if (A.has_local && lane < ELG_SLOT_STRIDE) {
+                        float* X = sX + q * CO_XP;
+                        X[CO_XF + lane] = 0.f; X[CO_XF + ELG_SLOT_STRIDE + lane] = 0.f; X[CO_XF + 2 * ELG_SLOT_STRIDE + lane] = 0.f;
+                        reinterpret_cast<int*>(X)[CO_XS + lane] = -1;
+                    }
                 }
                 if (lane < 32) *reinterpret_cast<float4*>(sQ + q * QP + 4 * lane) = q4;
             };
@@ -1422,44 +1446,47 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
             // ================= glimpse: wave = head =================
             {
                 const float4 q4 = *reinterpret_cast<const float4*>(sQ + lo * QP + 16 * wave + 4 * hi);    // trajectory lo
-                const unsigned* mw = reinterpret_cast<const unsigned*>(sMaskW + lo * NCH);
                 const float cs = 0.25f * 1.4426950408889634f;
                 float mrun = -1e30f, lrun = 0.f;
                 f32x4c o = {0.f, 0.f, 0.f, 0.f}, o2 = {0.f, 0.f, 0.f, 0.f};
-                float4 kfa, kfb;
-                float va0, va1, va2, va3, vb0, vb1, vb2, vb3;
-#define MT_LOAD(NT0, KA, KB, A0, A1, A2, A3, B0, B1, B2, B3)                                                         \
-    {                                                                                                                \
-        const int na_ = 16 * (NT0), nb_ = na_ + 16;                                                                  \
-        KA = *reinterpret_cast<const float4*>(gK + (size_t)min(na_ + lo, N1 - 1) * ELG_E + 4 * hi);                 \
-        KB = *reinterpret_cast<const float4*>(gK + (size_t)min(nb_ + lo, N1 - 1) * ELG_E + 4 * hi);                 \
-        A0 = gV[(size_t)min(na_ + 4 * hi, N1 - 1) * ELG_E + lo]; A1 = gV[(size_t)min(na_ + 4 * hi + 1, N1 - 1) * ELG_E + lo]; \
-        A2 = gV[(size_t)min(na_ + 4 * hi + 2, N1 - 1) * ELG_E + lo]; A3 = gV[(size_t)min(na_ + 4 * hi + 3, N1 - 1) * ELG_E + lo]; \
-        B0 = gV[(size_t)min(nb_ + 4 * hi, N1 - 1) * ELG_E + lo]; B1 = gV[(size_t)min(nb_ + 4 * hi + 1, N1 - 1) * ELG_E + lo]; \
-        B2 = gV[(size_t)min(nb_ + 4 * hi + 2, N1 - 1) * ELG_E + lo]; B3 = gV[(size_t)min(nb_ + 4 * hi + 3, N1 - 1) * ELG_E + lo]; \
-    }
-                MT_LOAD(0, kfa, kfb, va0, va1, va2, va3, vb0, vb1, vb2, vb3)
-                for (int nt = 0; nt < NTn; nt += 2) {
-                    float4 kna, knb;
-                    float na0, na1, na2, na3, nb0, nb1, nb2, nb3;
-                    MT_LOAD(min(nt + 2, NTn - 1), kna, knb, na0, na1, na2, na3, nb0, nb1, nb2, nb3)   // next pair in flight
-                    const unsigned dw = mw[nt >> 1];                        // mask bits of nodes 16 nt .. 16 nt + 31
-                    f32x4c Sa = {0.f, 0.f, 0.f, 0.f}, Sb = {0.f, 0.f, 0.f, 0.f};
-                    Sa = __builtin_amdgcn_mfma_f32_16x16x4f32(kfa.x, q4.x, Sa, 0, 0, 0);
-                    Sb = __builtin_amdgcn_mfma_f32_16x16x4f32(kfb.x, q4.x, Sb, 0, 0, 0);
-                    Sa = __builtin_amdgcn_mfma_f32_16x16x4f32(kfa.y, q4.y, Sa, 0, 0, 0);
-                    Sb = __builtin_amdgcn_mfma_f32_16x16x4f32(kfb.y, q4.y, Sb, 0, 0, 0);
-                    Sa = __builtin_amdgcn_mfma_f32_16x16x4f32(kfa.z, q4.z, Sa, 0, 0, 0);
-                    Sb = __builtin_amdgcn_mfma_f32_16x16x4f32(kfb.z, q4.z, Sb, 0, 0, 0);
-                    Sa = __builtin_amdgcn_mfma_f32_16x16x4f32(kfa.w, q4.w, Sa, 0, 0, 0);
-                    Sb = __builtin_amdgcn_mfma_f32_16x16x4f32(kfb.w, q4.w, Sb, 0, 0, 0);
-                    const unsigned niba = (dw >> (4 * hi)) & 0xFu, nibb = (dw >> (16 + 4 * hi)) & 0xFu;
+                // four node tiles (64 nodes) per softmax update: four independent S chains on the matrix cores, one running-max
+                // rescale per 64 nodes; the next four tiles' fragments are in flight meanwhile
+                float4 kf[4], kn[4];
+                float vf[4][4], vn[4][4];
+                auto load4 = [&](int nt0, float4 (&kk)[4], float (&vv)[4][4]) {
+#pragma unroll
+                    for (int u4 = 0; u4 < 4; ++u4) {
+                        const int n0 = 16 * (nt0 + u4);
+                        kk[u4] = *reinterpret_cast<const float4*>(gK + (size_t)min(n0 + lo, N1 - 1) * ELG_E + 4 * hi);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) vv[u4][i] = gV[(size_t)min(n0 + 4 * hi + i, N1 - 1) * ELG_E + lo];
+                    }
+                };
+                load4(0, kf, vf);
+                for (int nt = 0; nt < NTn; nt += 4) {
+                    load4(min(nt + 4, (NTn - 1) & ~3), kn, vn);
+                    __builtin_amdgcn_sched_barrier(0);            // the loads stay here: in flight under this iteration's MFMAs
+                    const unsigned long long dw = sMaskW[lo * NCH + (nt >> 2)];      // mask bits of nodes 16 nt .. 16 nt + 63
+                    f32x4c S[4];
+#pragma unroll
+                    for (int u4 = 0; u4 < 4; ++u4) S[u4] = f32x4c{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int u4 = 0; u4 < 4; ++u4) S[u4] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u4].x, q4.x, S[u4], 0, 0, 0);
+#pragma unroll
+                    for (int u4 = 0; u4 < 4; ++u4) S[u4] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u4].y, q4.y, S[u4], 0, 0, 0);
+#pragma unroll
+                    for (int u4 = 0; u4 < 4; ++u4) S[u4] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u4].z, q4.z, S[u4], 0, 0, 0);
+#pragma unroll
+                    for (int u4 = 0; u4 < 4; ++u4) S[u4] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u4].w, q4.w, S[u4], 0, 0, 0);
+                    const unsigned nib = (unsigned)(dw >> (4 * hi)) & 0x000F000Fu, nib2 = (unsigned)(dw >> (32 + 4 * hi)) & 0x000F000Fu;
                     float tm = ELG_NEG_INF;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        Sa[i] = ((niba >> i) & 1u) ? ELG_NEG_INF : Sa[i];
-                        Sb[i] = ((nibb >> i) & 1u) ? ELG_NEG_INF : Sb[i];
-                        tm = fmaxf(tm, fmaxf(Sa[i], Sb[i]));
+                        S[0][i] = ((nib >> i) & 1u) ? ELG_NEG_INF : S[0][i];
+                        S[1][i] = ((nib >> (16 + i)) & 1u) ? ELG_NEG_INF : S[1][i];
+                        S[2][i] = ((nib2 >> i) & 1u) ? ELG_NEG_INF : S[2][i];
+                        S[3][i] = ((nib2 >> (16 + i)) & 1u) ? ELG_NEG_INF : S[3][i];
+                        tm = fmaxf(fmaxf(tm, fmaxf(S[0][i], S[1][i])), fmaxf(S[2][i], S[3][i]));
                     }
                     tm = quarters_max(tm);
                     const float mnew = fmaxf(mrun, tm);
@@ -1469,54 +1496,71 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { o[i] *= sc; o2[i] *= sc; }
                     const float cm = -mnew * cs;
-                    float ea[4], eb[4];
+#pragma unroll
+                    for (int u4 = 0; u4 < 4; ++u4)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            S[u4][i] = __builtin_amdgcn_exp2f(fmaf(S[u4][i], cs, cm));
+                            lrun += S[u4][i];
+                        }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        ea[i] = __builtin_amdgcn_exp2f(fmaf(Sa[i], cs, cm));
-                        eb[i] = __builtin_amdgcn_exp2f(fmaf(Sb[i], cs, cm));
-                        lrun += ea[i] + eb[i];
+                        o = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[0][i], S[0][i], o, 0, 0, 0);
+                        o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[1][i], S[1][i], o2, 0, 0, 0);
                     }
-                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(va0, ea[0], o, 0, 0, 0);
-                    o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vb0, eb[0], o2, 0, 0, 0);
-                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(va1, ea[1], o, 0, 0, 0);
-                    o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vb1, eb[1], o2, 0, 0, 0);
-                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(va2, ea[2], o, 0, 0, 0);
-                    o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vb2, eb[2], o2, 0, 0, 0);
-                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(va3, ea[3], o, 0, 0, 0);
-                    o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vb3, eb[3], o2, 0, 0, 0);
-                    kfa = kna; kfb = knb;
-                    va0 = na0; va1 = na1; va2 = na2; va3 = na3; vb0 = nb0; vb1 = nb1; vb2 = nb2; vb3 = nb3;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        o = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[2][i], S[2][i], o, 0, 0, 0);
+                        o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[3][i], S[3][i], o2, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int u4 = 0; u4 < 4; ++u4) {
+                        kf[u4] = kn[u4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) vf[u4][i] = vn[u4][i];
+                    }
                 }
-#undef MT_LOAD
                 lrun = quarters_sum(lrun);
                 const float inv = lrun > 0.f ? 1.0f / lrun : 0.f;
                 *reinterpret_cast<float4*>(sQ + lo * QP + 16 * wave + 4 * hi) =
                     make_float4((o[0] + o2[0]) * inv, (o[1] + o2[1]) * inv, (o[2] + o2[2]) * inv, (o[3] + o2[3]) * inv);
             }
             __syncthreads();
-            // ================= pointer: node tiles over the waves =================
-            for (int nt = wave; nt < NTn; nt += 8) {
-                const float* prow = gPK + (size_t)min(16 * nt + lo, N1 - 1) * ELG_E + 4 * hi;
-                float4 pk0 = *reinterpret_cast<const float4*>(prow), pk1 = *reinterpret_cast<const float4*>(prow + 16);
-                float4 pk2 = *reinterpret_cast<const float4*>(prow + 32), pk3 = *reinterpret_cast<const float4*>(prow + 48);
-                float4 pk4 = *reinterpret_cast<const float4*>(prow + 64), pk5 = *reinterpret_cast<const float4*>(prow + 80);
-                float4 pk6 = *reinterpret_cast<const float4*>(prow + 96), pk7 = *reinterpret_cast<const float4*>(prow + 112);
-                f32x4c a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-                const float* orow = sQ + lo * QP + 4 * hi;
-#define MT_PK(PKV, S4)                                                                         \
-    {                                                                                          \
-        const float4 ov = *reinterpret_cast<const float4*>(orow + 16 * (S4));                  \
-        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(PKV.x, ov.x, a0, 0, 0, 0);                   \
-        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(PKV.y, ov.y, a1, 0, 0, 0);                   \
-        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(PKV.z, ov.z, a0, 0, 0, 0);                   \
-        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(PKV.w, ov.w, a1, 0, 0, 0);                   \
-    }
-                MT_PK(pk0, 0) MT_PK(pk1, 1) MT_PK(pk2, 2) MT_PK(pk3, 3) MT_PK(pk4, 4) MT_PK(pk5, 5) MT_PK(pk6, 6) MT_PK(pk7, 7)
-#undef MT_PK
-                const int nb = 16 * nt + 4 * hi;
-                const float p0 = I.pb[min(nb, N1 - 1)], p1 = I.pb[min(nb + 1, N1 - 1)], p2 = I.pb[min(nb + 2, N1 - 1)], p3 = I.pb[min(nb + 3, N1 - 1)];
-                *reinterpret_cast<float4*>(sSc + lo * SP + nb) =
-                    make_float4(a0[0] + a1[0] + p0, a0[1] + a1[1] + p1, a0[2] + a1[2] + p2, a0[3] + a1[3] + p3);
+            // ================= pointer: node tiles over the waves; local policy of the 16 trajectories: wave 7 =================
+            // (co_local16 costs about what three node tiles do: wave 7 joins the tile round-robin three rounds late)
+            if (A.has_local && wave == 7) co_local16_call(sT, A.loc, sX, lo, hi);
+            const int skip = A.has_local ? 21 : 0;           // tiles 0 .. 20 go to waves 0 .. 6 only
+            {
+                float4 pk[8], pkn[8];
+                auto loadpk = [&](int nt, float4 (&d)[8]) {
+                    const float* prow = gPK + (size_t)min(16 * nt + lo, N1 - 1) * ELG_E + 4 * hi;
+#pragma unroll
+                    for (int s4 = 0; s4 < 8; ++s4) d[s4] = *reinterpret_cast<const float4*>(prow + 16 * s4);
+                };
+                int nt = (wave < 7 ? wave : skip + 7);
+                if (nt < NTn) loadpk(nt, pk);
+                while (nt < NTn) {
+                    const int nxt = nt + (nt < skip ? 7 : 8);
+                    loadpk(min(nxt, NTn - 1), pkn);              // the wave's next tile, in flight under this tile's MFMAs
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x4c a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+                    const float* orow = sQ + lo * QP + 4 * hi;
+#pragma unroll
+                    for (int s4 = 0; s4 < 8; ++s4) {
+                        const float4 ov = *reinterpret_cast<const float4*>(orow + 16 * s4);
+                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pk[s4].x, ov.x, a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pk[s4].y, ov.y, a1, 0, 0, 0);
+                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pk[s4].z, ov.z, a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pk[s4].w, ov.w, a1, 0, 0, 0);
+                    }
+                    const int nb = 16 * nt + 4 * hi;
+                    const float p0 = I.pb[min(nb, N1 - 1)], p1 = I.pb[min(nb + 1, N1 - 1)], p2 = I.pb[min(nb + 2, N1 - 1)], p3 = I.pb[min(nb + 3, N1 - 1)];
+                    *reinterpret_cast<float4*>(sSc + lo * SP + nb) =
+                        make_float4(a0[0] + a1[0] + p0, a0[1] + a1[1] + p1, a0[2] + a1[2] + p2, a0[3] + a1[3] + p3);
+#pragma unroll
+                    for (int s4 = 0; s4 < 8; ++s4) pk[s4] = pkn[s4];
+                    nt = nxt;
+                }
             }
             __syncthreads();
             // ================= owners: clip, mask, softmax, choice =================
@@ -1543,6 +1587,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                 if (A.mode == ELG_MODE_SAMPLE)
                     uni = A.uniforms ? A.uniforms[bm * A.Tmax + t] : philox_uniform(A.seed, (unsigned)bm, (unsigned)t);
                 float* frow = (A.full_probs && t < A.dump_T) ? A.full_probs + (bm * A.dump_T + t) * N1 : nullptr;
+                if (A.has_local && lane < ELG_SLOT_STRIDE) addval += sX[q * CO_XP + CO_XU + lane] * A.inv_ens;
                 // finish_step scatters through a node-indexed scratch row: the score row itself (the scores are in registers now)
                 const FwdOut fo = finish_step<NCH, TSP, false>(A, N1, lane, srow, mk, s, snid, addval, fsel, uni, frow, (size_t)b, 0, 0);
                 sel = __builtin_amdgcn_readfirstlane(fo.sel);
@@ -1574,7 +1619,8 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
 
 template <int NCH, bool TSP>
 static int launch_fwd_mt(const elg_rollout_args& A, hipStream_t stream) {
-    const size_t lds = ((size_t)16 * 132 + (size_t)16 * (64 * NCH + 4) + (size_t)16 * NCH * 2 + ((A.N1 + 3) & ~3) + (size_t)8 * ELG_SB_MIN) * 4;
+    const size_t lds = ((size_t)16 * 132 + (size_t)16 * (64 * NCH + 4) + (size_t)16 * NCH * 2 + (A.has_local ? 16 * CO_XP + CL_SIZE : 0) +
+                        ((A.N1 + 3) & ~3) + (size_t)8 * ELG_SB_MIN) * 4;
     auto kern = rollout_fwd_mt_kernel<NCH, TSP>;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
