@@ -94,7 +94,8 @@ EXPORTS = ["elg_version", "elg_last_error", "elg_aug8", "elg_dist_matrix", "elg_
            "elg_pomo_loss", "elg_adam_step", "elg_local_bwd_rows",
            "elg_add_instnorm_fwd", "elg_add_instnorm_bwd",
            "elg_encoder_ws_floats", "elg_encoder_fwd", "elg_encoder_bwd_ws_floats", "elg_encoder_bwd",
-           "elg_local_fold_fwd", "elg_local_fold_bwd", "elg_check_feasible", "elg_rollout_stats", "elg_decoder_bwd"]
+           "elg_local_fold_fwd", "elg_local_fold_bwd", "elg_check_feasible", "elg_rollout_stats", "elg_decoder_bwd",
+           "elg_rollout_scratch_floats"]
 
 _lib = None
 
@@ -133,6 +134,8 @@ def lib() -> C.CDLL:
         L.elg_adam_step.argtypes = [f, f, f, i, f, f, f, i64, fl, fl, fl, fl, fl, i64, fl, f]
         L.elg_encoder_ws_floats.argtypes = [i, i, i, i, i]
         L.elg_encoder_ws_floats.restype = i64
+        L.elg_rollout_scratch_floats.argtypes = [i, i, i, i]
+        L.elg_rollout_scratch_floats.restype = i64
         L.elg_encoder_bwd_ws_floats.argtypes = [i, i, i, i]
         L.elg_encoder_bwd_ws_floats.restype = i64
         L.elg_encoder_fwd.argtypes = [C.POINTER(EncoderArgs), f]

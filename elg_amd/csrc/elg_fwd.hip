@@ -1321,6 +1321,43 @@ __device__ __forceinline__ void glimpse_tile(const float* __restrict__ sK, const
 
 
 // =============================================================================================
+// Fragment-major copies of an instance's K / V / PK for rollout_fwd_mt_kernel: every MFMA operand fragment of a 16-node
+// tile is one 16-byte load per lane out of a contiguous 1 KB block, so the per-step stream out of L2 moves whole cache
+// lines (the row-major tables give 64-byte pieces of 512-byte rows).  NP = 64 NCH padded nodes, NT = NP / 16 tiles;
+// lane = 16 hi + lo.  Per instance, floats:
+//   Kf [h][tile][lane][j] = K [16 tile + lo][16 h + 4 hi + j]             at 0
+//   Vf [h][tile][lane][j] = V [16 tile + 4 hi + j][16 h + lo]             at NP * 128
+//   PKf[tile][s4][lane][j] = PK[16 tile + lo][16 s4 + 4 hi + j]           at 2 * NP * 128
+// Rows past N1 are zero (their nodes are masked).
+// =============================================================================================
+__global__ __launch_bounds__(256) void mt_repack_kernel(const float* __restrict__ K, const float* __restrict__ V,
+                                                        const float* __restrict__ PK, float* __restrict__ F, int N1, int NP) {
+    const int b = blockIdx.y;
+    const int per = NP * 32;                                  // float4s per table
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= 3 * per) return;
+    const int which = o / per, r = o % per;
+    const int lane = r & 63, lo = lane & 15, hi = lane >> 4;
+    const size_t NE = (size_t)N1 * ELG_E;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (which == 0) {
+        const int NT = NP >> 4, h = (r >> 6) / NT, tile = (r >> 6) % NT, n = 16 * tile + lo;
+        if (n < N1) v = *reinterpret_cast<const float4*>(K + b * NE + (size_t)n * ELG_E + 16 * h + 4 * hi);
+    } else if (which == 1) {
+        const int NT = NP >> 4, h = (r >> 6) / NT, tile = (r >> 6) % NT, n = 16 * tile + 4 * hi;
+        const float* src = V + b * NE + 16 * h + lo;
+        if (n < N1) v.x = src[(size_t)n * ELG_E];
+        if (n + 1 < N1) v.y = src[(size_t)(n + 1) * ELG_E];
+        if (n + 2 < N1) v.z = src[(size_t)(n + 2) * ELG_E];
+        if (n + 3 < N1) v.w = src[(size_t)(n + 3) * ELG_E];
+    } else {
+        const int tile = r >> 9, s4 = (r >> 6) & 7, n = 16 * tile + lo;
+        if (n < N1) v = *reinterpret_cast<const float4*>(PK + b * NE + (size_t)n * ELG_E + 16 * s4 + 4 * hi);
+    }
+    reinterpret_cast<float4*>(F + (size_t)b * 3 * NP * ELG_E)[o] = v;
+}
+
+// =============================================================================================
 // rollout_fwd_mt_kernel: 128 < N1 <= 1024 (TSP-200/500, VRPLIB X).  16 lockstep trajectories per workgroup.
 //   owners   (wave w owns trajectories w and w + 8; one wavefront per trajectory, the code of rollout_fwd_kernel):
 //            feasibility mask, query row, k-NN slots, local policy  ->  exchange rows in LDS
@@ -1372,9 +1409,11 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
     I.ndist = A.nbr_dist + (size_t)b * N1 * N1;
     I.ntheta = A.nbr_theta + (size_t)b * N1 * N1;
     I.loc = A.loc;
-    const float* gK = A.Kmat + b * NE + wave * 16;
-    const float* gV = A.Vmat + b * NE + wave * 16;
-    const float* gPK = A.PK + b * NE;
+    constexpr int NP = 64 * NCH, NT = 4 * NCH;              // padded nodes / tiles of the fragment-major tables
+    const float* gF = A.scratch + (size_t)b * 3 * NP * ELG_E;
+    const float4* gK = reinterpret_cast<const float4*>(gF) + (size_t)wave * NT * 64 + lane;                  // head = wave
+    const float4* gV = reinterpret_cast<const float4*>(gF + (size_t)NP * ELG_E) + (size_t)wave * NT * 64 + lane;
+    const float4* gPK = reinterpret_cast<const float4*>(gF + (size_t)2 * NP * ELG_E) + lane;
     const int step_cap = TSP ? N1 : 2 * N1 + 2;
 
     // the wave's two trajectories as separate objects (an array of Traj lands in scratch memory)
@@ -1451,20 +1490,18 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                 f32x4c o = {0.f, 0.f, 0.f, 0.f}, o2 = {0.f, 0.f, 0.f, 0.f};
                 // four node tiles (64 nodes) per softmax update: four independent S chains on the matrix cores, one running-max
                 // rescale per 64 nodes; the next four tiles' fragments are in flight meanwhile
-                float4 kf[4], kn[4];
-                float vf[4][4], vn[4][4];
-                auto load4 = [&](int nt0, float4 (&kk)[4], float (&vv)[4][4]) {
+                float4 kf[4], kn[4], vf[4], vn[4];
+                auto load4 = [&](int nt0, float4 (&kk)[4], float4 (&vv)[4]) {
 #pragma unroll
                     for (int u4 = 0; u4 < 4; ++u4) {
-                        const int n0 = 16 * (nt0 + u4);
-                        kk[u4] = *reinterpret_cast<const float4*>(gK + (size_t)min(n0 + lo, N1 - 1) * ELG_E + 4 * hi);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) vv[u4][i] = gV[(size_t)min(n0 + 4 * hi + i, N1 - 1) * ELG_E + lo];
+                        kk[u4] = gK[(nt0 + u4) * 64];
+                        vv[u4] = gV[(nt0 + u4) * 64];
                     }
                 };
                 load4(0, kf, vf);
+#pragma unroll 1
                 for (int nt = 0; nt < NTn; nt += 4) {
-                    load4(min(nt + 4, (NTn - 1) & ~3), kn, vn);
+                    load4(min(nt + 4, NT - 4), kn, vn);
                     __builtin_amdgcn_sched_barrier(0);            // the loads stay here: in flight under this iteration's MFMAs
                     const unsigned long long dw = sMaskW[lo * NCH + (nt >> 2)];      // mask bits of nodes 16 nt .. 16 nt + 63
                     f32x4c S[4];
@@ -1503,22 +1540,15 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                             S[u4][i] = __builtin_amdgcn_exp2f(fmaf(S[u4][i], cs, cm));
                             lrun += S[u4][i];
                         }
+#define MT_PV(U, ACC)                                                                       \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[U].x, S[U][0], ACC, 0, 0, 0);                \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[U].y, S[U][1], ACC, 0, 0, 0);                \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[U].z, S[U][2], ACC, 0, 0, 0);                \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[U].w, S[U][3], ACC, 0, 0, 0);
+                    MT_PV(0, o) MT_PV(1, o2) MT_PV(2, o) MT_PV(3, o2)
+#undef MT_PV
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        o = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[0][i], S[0][i], o, 0, 0, 0);
-                        o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[1][i], S[1][i], o2, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        o = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[2][i], S[2][i], o, 0, 0, 0);
-                        o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[3][i], S[3][i], o2, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int u4 = 0; u4 < 4; ++u4) {
-                        kf[u4] = kn[u4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) vf[u4][i] = vn[u4][i];
-                    }
+                    for (int u4 = 0; u4 < 4; ++u4) { kf[u4] = kn[u4]; vf[u4] = vn[u4]; }
                 }
                 lrun = quarters_sum(lrun);
                 const float inv = lrun > 0.f ? 1.0f / lrun : 0.f;
@@ -1533,12 +1563,12 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
             {
                 float4 pk[8], pkn[8];
                 auto loadpk = [&](int nt, float4 (&d)[8]) {
-                    const float* prow = gPK + (size_t)min(16 * nt + lo, N1 - 1) * ELG_E + 4 * hi;
 #pragma unroll
-                    for (int s4 = 0; s4 < 8; ++s4) d[s4] = *reinterpret_cast<const float4*>(prow + 16 * s4);
+                    for (int s4 = 0; s4 < 8; ++s4) d[s4] = gPK[(nt * 8 + s4) * 64];
                 };
                 int nt = (wave < 7 ? wave : skip + 7);
                 if (nt < NTn) loadpk(nt, pk);
+#pragma unroll 1
                 while (nt < NTn) {
                     const int nxt = nt + (nt < skip ? 7 : 8);
                     loadpk(min(nxt, NTn - 1), pkn);              // the wave's next tile, in flight under this tile's MFMAs
@@ -1629,9 +1659,12 @@ static int launch_fwd_mt(const elg_rollout_args& A, hipStream_t stream) {
         if (e != hipSuccess) return fail(ELG_ELAUNCH, std::string("mt rollout: hipFuncSetAttribute: ") + hipGetErrorString(e));
         attr_lds = lds;
     }
+    if (!A.scratch) return fail(ELG_EINVAL, "rollout: 128 < N1 <= 1024 needs the scratch workspace (elg_rollout_scratch_floats)");
     elg_rollout_args B2 = A;
     B2.tiles = (A.M + 15) / 16;                            // this kernel's geometry: 16 trajectories per workgroup
     (void)hipGetLastError();
+    constexpr int NP = 64 * NCH;
+    hipLaunchKernelGGL(mt_repack_kernel, dim3((3 * NP * 32 + 255) / 256, A.B), dim3(256), 0, stream, A.Kmat, A.Vmat, A.PK, A.scratch, A.N1, NP);
     hipLaunchKernelGGL(kern, dim3(B2.B * B2.tiles), dim3(512), lds, stream, B2);
     return launch_status("rollout_fwd_mt");
 }
@@ -2035,6 +2068,16 @@ static int dispatch_fwd(const elg_rollout_args& A, hipStream_t stream) {
 using namespace elg;
 
 extern "C" {
+int64_t elg_rollout_scratch_floats(int32_t B, int32_t M, int32_t N1, int32_t variant) {
+    if (B <= 0 || M <= 0 || N1 <= 0) return 0;
+    if (variant == 2 || N1 > 1024) return (int64_t)B * M * N1;                     // score rows of rollout_fwd_xl_kernel
+    if (N1 > 128 && variant == 0) {                                                // fragment-major K / V / PK copies
+        const int nch = (N1 + 63) / 64, NP = 64 * (nch <= 4 ? 4 : nch <= 8 ? 8 : 16);
+        return (int64_t)B * 3 * NP * ELG_E;
+    }
+    return 0;
+}
+
 
 const char* elg_version(void) { return "elg-hip 0.1 (gfx950)"; }
 const char* elg_last_error(void) { return elg::last_error(); }

@@ -379,8 +379,9 @@ def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mo
     a.actions, a.probs, a.reward, a.tlen = _ptr(actions), _ptr(probs), _ptr(reward), _ptr(tlen)
     a.full_probs, a.dump_T = _ptr(full), dump_T
     scratch = None
-    if variant == 2 or N1 > 1024:
-        scratch = torch.empty(B, M, N1, device=dev)            # score rows of the N1 > 1024 kernel
+    n_scratch = int(L.lib().elg_rollout_scratch_floats(B, M, N1, variant))
+    if n_scratch:
+        scratch = torch.empty(n_scratch, device=dev)           # score rows (N1 > 1024) / fragment-major tables (N1 > 128)
         a.scratch = _ptr(scratch)
     rows = None
     if train and N1 <= 128:

@@ -85,8 +85,8 @@ typedef struct elg_rollout_args {
     float xi;               /* model_params.xi                                                  */
     float clip;             /* model_params.logit_clipping                                      */
     float inv_ens;          /* 1 / ensemble_size                                                */
-    int32_t variant;        /* 0: pick the kernel by shape (cooperative MFMA kernel for N1 <= 112, node-tiled kernel for
-                               N1 > 128); 1: the one-wavefront-per-trajectory kernel for any N1 (what the step-wise
+    int32_t variant;        /* 0: pick the kernel by shape (cooperative MFMA kernel for N1 <= 112, node-streaming MFMA kernel
+                               for 128 < N1 <= 1024); 1: the one-wavefront-per-trajectory kernel for any N1 (what the step-wise
                                protocol and 112 < N1 <= 128 always use; the A/B reference of the parity tests);
                                2: the N1 > 1024 kernel (Vrp-Set-XXL; runtime node loops, needs `scratch`) for any N1 */
     int32_t dump_logits;    /* what full_probs receives: 0 probabilities, 1 the clipped + masked logits
@@ -134,7 +134,7 @@ typedef struct elg_rollout_args {
     float* trF;             /* (B,Rcap,3,48)  local-policy features of every slot (NULL: not saved)   */
     uint64_t* trMask;       /* (B,Rcap,2)     feasibility mask words of the row (bit n = node n closed); with it the
                                cooperative kernel (N1 <= 112) may skip trA: the backward recomputes a_h from q, K   */
-    float* scratch;         /* (B,M,N1)       score rows of the N1 > 1024 kernel (variant 2), else NULL               */
+    float* scratch;         /* elg_rollout_scratch_floats() floats of workspace (fused rollouts with N1 > 128), else NULL */
     float* trLse;           /* (B,Rcap,8)     with trMask: log2 of the glimpse softmax denominator per head, in the units of
                                s log2(e) / 4, so that a_h[n] = exp2(q_h.K_h[n] log2(e) / 4 - trLse) (NULL: not saved) */
 } elg_rollout_args;
@@ -142,6 +142,9 @@ typedef struct elg_rollout_args {
 /* POMO construction: CVRPEnv.reset/step + CVRPModel.one_step_rollout + utils.rollout fused into one
  * persistent launch (CVRP/utils.py:7-29), or single steps of it (use_state / max_steps). */
 int elg_rollout_fwd(const elg_rollout_args* args, void* stream);
+/* Floats of elg_rollout_args.scratch a fused rollout of this shape needs (0: none): the score rows of the N1 > 1024 kernel,
+   or the fragment-major K / V / PK copies the 128 < N1 <= 1024 kernel streams its matrix-core operands from. */
+int64_t elg_rollout_scratch_floats(int32_t B, int32_t M, int32_t N1, int32_t variant);
 
 /* Backward of the chosen-node probabilities w.r.t. the per-instance tables and the folded local
  * tables (replaces autograd's tape over CVRP/utils.py:14-21 + models.py:322-423; train.py:112-125).
