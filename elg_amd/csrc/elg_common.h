@@ -164,7 +164,9 @@ __device__ __forceinline__ float dot4(const float4 a, const float4 b, float acc)
 // (no fma contraction) -- CVRPEnv.py:148 / :261.
 __device__ __forceinline__ float dist2d(float ax, float ay, float bx, float by) {
     float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by);
-    return __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+    // sqrtf, not __fsqrt_rn: this toolchain lowers __fsqrt_rn to the bare v_sqrt_f32 (1 ulp), sqrtf to the correctly rounded
+    // sequence -- and a 1-ulp distance reorders near-equidistant neighbours (a different k-NN set than the reference's)
+    return sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
 }
 
 // Philox-4x32-10 counter RNG: one uniform in [0,1) per (seed, trajectory, step).

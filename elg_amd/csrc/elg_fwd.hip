@@ -1370,10 +1370,82 @@ __global__ __launch_bounds__(256) void mt_repack_kernel(const float* __restrict_
 // The node-tiled kernel this replaces shared LDS-staged K / V / PK tiles between 8 one-wavefront trajectories and did the
 // glimpse and pointer products on the VALU: two barriers + a global->LDS round trip per tile, 65 us per step of 8.
 // =============================================================================================
+// wave-uniform scalar state of a trajectory of rollout_fwd_mt_kernel (Traj<> without the visited words, which live in LDS)
+struct MtTraj {
+    int cur, first, cnt, fin;
+    float load, len, cx, cy;
+};
+
+// build_mask() with the visited words in LDS
 template <int NCH, bool TSP>
+__device__ __forceinline__ void mt_build_mask(const MtTraj& st, const unsigned long long* vis, const Inst& I, int N1, int lane,
+                                              unsigned long long (&mk)[NCH]) {
+    const float lim = __fadd_rn(st.load, 1e-6f);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int n = lane + 64 * ch;
+        bool m = true;
+        if (n < N1) {
+            m = (vis[ch] >> lane) & 1ull;
+            if (!TSP) {
+                m = m || (lim < I.dem[n]);
+                if (n == 0 && st.fin) m = false;
+            }
+        }
+        mk[ch] = __ballot(m);
+    }
+}
+
+// env_update() with the visited words in LDS (same roundings: one fp32 subtraction for the load, dist2d for the length)
+template <int NCH, bool TSP>
+__device__ __forceinline__ void mt_env_update(MtTraj& st, unsigned long long* vis, const Inst& I, int N1, int sel, int lane) {
+    const float2 sxy = *reinterpret_cast<const float2*>(I.xy + 2 * sel);
+    const float sx = i2f(__builtin_amdgcn_readfirstlane(f2i(sxy.x))), sy = i2f(__builtin_amdgcn_readfirstlane(f2i(sxy.y)));
+    if (st.cnt > 0) st.len += dist2d(st.cx, st.cy, sx, sy);
+    st.cx = sx; st.cy = sy;
+    if (TSP) {
+        if (st.cnt == 0) st.first = sel;
+    } else {
+        st.load = (sel == 0) ? 1.0f : __fsub_rn(st.load, I.dem[sel]);
+    }
+    if (lane == 0) {
+        if (TSP) {
+            vis[sel >> 6] |= 1ull << (sel & 63);
+        } else {
+            // depot counts as visited exactly while the trajectory stands on it (CVRPEnv.py:214-216)
+            if (sel >= 64) vis[sel >> 6] |= 1ull << (sel & 63);
+            unsigned long long w0 = vis[0];
+            if (sel < 64) w0 |= 1ull << sel;
+            if (sel == 0) w0 |= 1ull; else w0 &= ~1ull;
+            vis[0] = w0;
+        }
+    }
+    st.cur = sel;
+    st.cnt += 1;
+    if (TSP) {
+        if (st.cnt == N1) {                    // close the tour (TSPEnv.py:166 roll(-1))
+            const float fx = I.xy[2 * st.first], fy = I.xy[2 * st.first + 1];
+            st.len += dist2d(sx, sy, fx, fy);
+            st.fin = 1;
+        }
+    } else {
+        wave_lds_fence();
+        bool ok = true;
+        if (lane < NCH) {
+            const int rem = N1 - 64 * lane;
+            if (rem > 0) {
+                const unsigned long long full = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+                ok = (vis[lane] & full) == full;
+            }
+        }
+        if (__ballot(ok) == ~0ull) st.fin = 1;  // CVRPEnv.py:226-228
+    }
+}
+
+template <int NCH, bool TSP, int NG>
 __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_args A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NTR = 16, QP = 132, SP = 64 * NCH + 4;
+    constexpr int NTR = 16 * NG, NOWN = 2 * NG, QP = 132, SP = 64 * NCH + 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lo = lane & 15, hi = lane >> 4;
@@ -1384,16 +1456,19 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
     if ((G & 7) == 0) u = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
     const int b = u / A.tiles, tile = u % A.tiles;
     const int m_base = tile * NTR;
-    // LDS: query / glimpse-output rows | score rows | mask words | demand | per-wave slot scratch
+    // LDS: query / glimpse-output rows | score rows | mask words | visited words | slot blocks | local tables | demand |
+    //      per-wave slot scratch
     float* sQ = lds;
     float* sSc = sQ + NTR * QP;                            // score rows (pointer -> choice)
     unsigned long long* sMaskW = reinterpret_cast<unsigned long long*>(sSc + NTR * SP);
-    float* sX = reinterpret_cast<float*>(sMaskW + NTR * NCH);           // slot blocks (owners -> local policy -> owners)
+    unsigned long long* sVis = sMaskW + NTR * NCH;
+    float* sX = reinterpret_cast<float*>(sVis + NTR * NCH);             // slot blocks (owners -> local policy -> owners)
     float* sT = sX + (A.has_local ? NTR * CO_XP : 0);                   // folded local-policy tables
     float* sdem = sT + (A.has_local ? CL_SIZE : 0);
     float* sb = sdem + ((N1 + 3) & ~3) + wave * ELG_SB_MIN;
     if (!TSP)
         for (int i = tid; i < N1; i += 512) sdem[i] = A.demand[(size_t)b * N1 + i];
+    for (int i = tid; i < NTR * NCH; i += 512) sVis[i] = 0ull;
     if (A.has_local) co_stage_local(A.loc, sT, tid, 512);
     __syncthreads();
     const size_t NE = (size_t)N1 * ELG_E;
@@ -1416,40 +1491,49 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
     const float4* gPK = reinterpret_cast<const float4*>(gF + (size_t)2 * NP * ELG_E) + lane;
     const int step_cap = TSP ? N1 : 2 * N1 + 2;
 
-    // the wave's two trajectories as separate objects (an array of Traj lands in scratch memory)
-    Traj<NCH> st0, st1;
-    const bool has0 = m_base + wave < A.M, has1 = m_base + wave + 8 < A.M;
-    const size_t bm0 = (size_t)b * A.M + (has0 ? m_base + wave : 0), bm1 = (size_t)b * A.M + (has1 ? m_base + wave + 8 : 0);
-    auto reset = [&](Traj<NCH>& st, bool has) {
-        st.cur = 0; st.first = 0; st.cnt = 0; st.fin = has ? 0 : 1; st.load = 1.0f; st.len = 0.f; st.cx = 0.f; st.cy = 0.f;
+    // the wave's trajectories: q = wave + 8 j (row q % 16 of MFMA group q / 16); every loop over j is unrolled, so st[] stays
+    // in (scalar) registers
+    MtTraj st[NOWN];
+    bool has[NOWN];
+    size_t bm[NOWN];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) st.vis[c] = 0ull;
-    };
-    reset(st0, has0);
-    reset(st1, has1);
+    for (int j = 0; j < NOWN; ++j) {
+        has[j] = m_base + wave + 8 * j < A.M;
+        bm[j] = (size_t)b * A.M + (has[j] ? m_base + wave + 8 * j : 0);
+        st[j].cur = 0; st[j].first = 0; st[j].cnt = 0; st[j].fin = has[j] ? 0 : 1;
+        st[j].load = 1.0f; st[j].len = 0.f; st[j].cx = 0.f; st[j].cy = 0.f;
+    }
     for (int t = 0; t < step_cap && t < A.Tmax; ++t) {
         const bool first_move = (!TSP && t <= 1) || (TSP && t == 0);
-        const bool act0 = has0 && !st0.fin, act1 = has1 && !st1.fin;
-        const bool dec0 = act0 && !first_move, dec1 = act1 && !first_move;
-        if (!__syncthreads_or((act0 || act1) ? 1 : 0)) break;
-        int sel0 = 0, sel1 = 0, snid0 = -1, snid1 = -1;
-        float pr0 = 1.0f, pr1 = 1.0f, add0 = 0.f, add1 = 0.f;
+        bool act[NOWN], dec[NOWN];
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < NOWN; ++j) {
+            act[j] = has[j] && !st[j].fin;
+            dec[j] = act[j] && !first_move;
+            any = any || act[j];
+        }
+        if (!__syncthreads_or(any ? 1 : 0)) break;
+        int sel[NOWN], snid[NOWN];
+        float pr[NOWN], addv[NOWN];
+#pragma unroll
+        for (int j = 0; j < NOWN; ++j) { sel[j] = 0; snid[j] = -1; pr[j] = 1.0f; addv[j] = 0.f; }
         if (!first_move) {
-            // ================= owners: masks, query rows, k-NN slots, local policy =================
-            auto prepare = [&](const Traj<NCH>& st, bool dec, int q, float& addval, int& snid) {
+            // ================= owners: masks, query rows, k-NN slots =================
+            auto prepare = [&](const MtTraj& s1, bool dc, int q, float& addval, int& sn) {
                 float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (dec) {
+                if (dc) {
                     unsigned long long mk[NCH];
-                    build_mask<NCH, TSP>(st, I, N1, lane, mk);
+                    mt_build_mask<NCH, TSP>(s1, sVis + q * NCH, I, N1, lane, mk);
                     const int cb = (lane & 31) * 4;
-                    q4 = *reinterpret_cast<const float4*>(I.Q1 + (size_t)st.cur * ELG_E + cb);
+                    q4 = *reinterpret_cast<const float4*>(I.Q1 + (size_t)s1.cur * ELG_E + cb);
                     if (TSP) {
-                        const float4 qf = *reinterpret_cast<const float4*>(I.Q2 + (size_t)st.first * ELG_E + cb);
+                        const float4 qf = *reinterpret_cast<const float4*>(I.Q2 + (size_t)s1.first * ELG_E + cb);
                         q4.x += qf.x; q4.y += qf.y; q4.z += qf.z; q4.w += qf.w;
                     } else {
                         const float4 w = *reinterpret_cast<const float4*>(I.wl + cb);
-                        q4.x = fmaf(st.load, w.x, q4.x); q4.y = fmaf(st.load, w.y, q4.y);
-                        q4.z = fmaf(st.load, w.z, q4.z); q4.w = fmaf(st.load, w.w, q4.w);
+                        q4.x = fmaf(s1.load, w.x, q4.x); q4.y = fmaf(s1.load, w.y, q4.y);
+                        q4.z = fmaf(s1.load, w.z, q4.z); q4.w = fmaf(s1.load, w.w, q4.w);
                     }
                     if (lane == 0) {
 #pragma unroll
@@ -1457,8 +1541,8 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                     }
                     if (A.has_penalty || A.has_local) {
                         wave_lds_fence();
-                        const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb, sMaskW + q * NCH);
-                        snid = S.snid;
+                        const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, s1, lane, mk, sb, sMaskW + q * NCH);
+                        sn = S.snid;
                         addval = S.pen;
                         if (A.has_local && lane < ELG_SLOT_STRIDE) {        // slot block for co_local16 (layout of the coop kernel)
                             float* X = sX + q * CO_XP;
@@ -1479,16 +1563,22 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                 }
                 if (lane < 32) *reinterpret_cast<float4*>(sQ + q * QP + 4 * lane) = q4;
             };
-            prepare(st0, dec0, wave, add0, snid0);
-            prepare(st1, dec1, wave + 8, add1, snid1);
+#pragma unroll
+            for (int j = 0; j < NOWN; ++j) prepare(st[j], dec[j], wave + 8 * j, addv[j], snid[j]);
             __syncthreads();
-            // ================= glimpse: wave = head =================
+            // ================= glimpse: wave = head; every K / V fragment serves the NG groups of 16 trajectories =================
             {
-                const float4 q4 = *reinterpret_cast<const float4*>(sQ + lo * QP + 16 * wave + 4 * hi);    // trajectory lo
                 const float cs = 0.25f * 1.4426950408889634f;
-                float mrun = -1e30f, lrun = 0.f;
-                f32x4c o = {0.f, 0.f, 0.f, 0.f}, o2 = {0.f, 0.f, 0.f, 0.f};
-                // four node tiles (64 nodes) per softmax update: four independent S chains on the matrix cores, one running-max
+                float4 q4[NG];
+                float mrun[NG], lrun[NG];
+                f32x4c o[NG], o2[NG];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    q4[g] = *reinterpret_cast<const float4*>(sQ + (16 * g + lo) * QP + 16 * wave + 4 * hi);     // trajectory 16 g + lo
+                    mrun[g] = -1e30f; lrun[g] = 0.f;
+                    o[g] = f32x4c{0.f, 0.f, 0.f, 0.f}; o2[g] = f32x4c{0.f, 0.f, 0.f, 0.f};
+                }
+                // four node tiles (64 nodes) per softmax update: independent S chains on the matrix cores, one running-max
                 // rescale per 64 nodes; the next four tiles' fragments are in flight meanwhile
                 float4 kf[4], kn[4], vf[4], vn[4];
                 auto load4 = [&](int nt0, float4 (&kk)[4], float4 (&vv)[4]) {
@@ -1503,90 +1593,113 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                 for (int nt = 0; nt < NTn; nt += 4) {
                     load4(min(nt + 4, NT - 4), kn, vn);
                     __builtin_amdgcn_sched_barrier(0);            // the loads stay here: in flight under this iteration's MFMAs
-                    const unsigned long long dw = sMaskW[lo * NCH + (nt >> 2)];      // mask bits of nodes 16 nt .. 16 nt + 63
-                    f32x4c S[4];
+                    f32x4c S[NG][4];
 #pragma unroll
-                    for (int u4 = 0; u4 < 4; ++u4) S[u4] = f32x4c{0.f, 0.f, 0.f, 0.f};
+                    for (int g = 0; g < NG; ++g)
 #pragma unroll
-                    for (int u4 = 0; u4 < 4; ++u4) S[u4] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u4].x, q4.x, S[u4], 0, 0, 0);
+                        for (int u4 = 0; u4 < 4; ++u4) S[g][u4] = f32x4c{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int u4 = 0; u4 < 4; ++u4) S[u4] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u4].y, q4.y, S[u4], 0, 0, 0);
+                    for (int g = 0; g < NG; ++g)
 #pragma unroll
-                    for (int u4 = 0; u4 < 4; ++u4) S[u4] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u4].z, q4.z, S[u4], 0, 0, 0);
+                        for (int u4 = 0; u4 < 4; ++u4) S[g][u4] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u4].x, q4[g].x, S[g][u4], 0, 0, 0);
 #pragma unroll
-                    for (int u4 = 0; u4 < 4; ++u4) S[u4] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u4].w, q4.w, S[u4], 0, 0, 0);
-                    const unsigned nib = (unsigned)(dw >> (4 * hi)) & 0x000F000Fu, nib2 = (unsigned)(dw >> (32 + 4 * hi)) & 0x000F000Fu;
-                    float tm = ELG_NEG_INF;
+                    for (int g = 0; g < NG; ++g)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        S[0][i] = ((nib >> i) & 1u) ? ELG_NEG_INF : S[0][i];
-                        S[1][i] = ((nib >> (16 + i)) & 1u) ? ELG_NEG_INF : S[1][i];
-                        S[2][i] = ((nib2 >> i) & 1u) ? ELG_NEG_INF : S[2][i];
-                        S[3][i] = ((nib2 >> (16 + i)) & 1u) ? ELG_NEG_INF : S[3][i];
-                        tm = fmaxf(fmaxf(tm, fmaxf(S[0][i], S[1][i])), fmaxf(S[2][i], S[3][i]));
-                    }
-                    tm = quarters_max(tm);
-                    const float mnew = fmaxf(mrun, tm);
-                    const float sc = __builtin_amdgcn_exp2f((mrun - mnew) * cs);
-                    mrun = mnew;
-                    lrun *= sc;
+                        for (int u4 = 0; u4 < 4; ++u4) S[g][u4] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u4].y, q4[g].y, S[g][u4], 0, 0, 0);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { o[i] *= sc; o2[i] *= sc; }
-                    const float cm = -mnew * cs;
+                    for (int g = 0; g < NG; ++g)
 #pragma unroll
-                    for (int u4 = 0; u4 < 4; ++u4)
+                        for (int u4 = 0; u4 < 4; ++u4) S[g][u4] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u4].z, q4[g].z, S[g][u4], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+#pragma unroll
+                        for (int u4 = 0; u4 < 4; ++u4) S[g][u4] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u4].w, q4[g].w, S[g][u4], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        const unsigned long long dw = sMaskW[(16 * g + lo) * NCH + (nt >> 2)];   // mask bits of nodes 16 nt .. 16 nt + 63
+                        const unsigned nib = (unsigned)(dw >> (4 * hi)) & 0x000F000Fu, nib2 = (unsigned)(dw >> (32 + 4 * hi)) & 0x000F000Fu;
+                        float tm = ELG_NEG_INF;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            S[u4][i] = __builtin_amdgcn_exp2f(fmaf(S[u4][i], cs, cm));
-                            lrun += S[u4][i];
+                            S[g][0][i] = ((nib >> i) & 1u) ? ELG_NEG_INF : S[g][0][i];
+                            S[g][1][i] = ((nib >> (16 + i)) & 1u) ? ELG_NEG_INF : S[g][1][i];
+                            S[g][2][i] = ((nib2 >> i) & 1u) ? ELG_NEG_INF : S[g][2][i];
+                            S[g][3][i] = ((nib2 >> (16 + i)) & 1u) ? ELG_NEG_INF : S[g][3][i];
+                            tm = fmaxf(fmaxf(tm, fmaxf(S[g][0][i], S[g][1][i])), fmaxf(S[g][2][i], S[g][3][i]));
                         }
-#define MT_PV(U, ACC)                                                                       \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[U].x, S[U][0], ACC, 0, 0, 0);                \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[U].y, S[U][1], ACC, 0, 0, 0);                \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[U].z, S[U][2], ACC, 0, 0, 0);                \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[U].w, S[U][3], ACC, 0, 0, 0);
-                    MT_PV(0, o) MT_PV(1, o2) MT_PV(2, o) MT_PV(3, o2)
+                        tm = quarters_max(tm);
+                        const float mnew = fmaxf(mrun[g], tm);
+                        const float sc = __builtin_amdgcn_exp2f((mrun[g] - mnew) * cs);
+                        mrun[g] = mnew;
+                        lrun[g] *= sc;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { o[g][i] *= sc; o2[g][i] *= sc; }
+                        const float cm = -mnew * cs;
+#pragma unroll
+                        for (int u4 = 0; u4 < 4; ++u4)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                S[g][u4][i] = __builtin_amdgcn_exp2f(fmaf(S[g][u4][i], cs, cm));
+                                lrun[g] += S[g][u4][i];
+                            }
+                    }
+#define MT_PV(GG, U, ACC)                                                                             \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[U].x, S[GG][U][0], ACC, 0, 0, 0);                    \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[U].y, S[GG][U][1], ACC, 0, 0, 0);                    \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[U].z, S[GG][U][2], ACC, 0, 0, 0);                    \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[U].w, S[GG][U][3], ACC, 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) { MT_PV(g, 0, o[g]) MT_PV(g, 1, o2[g]) MT_PV(g, 2, o[g]) MT_PV(g, 3, o2[g]) }
 #undef MT_PV
 #pragma unroll
                     for (int u4 = 0; u4 < 4; ++u4) { kf[u4] = kn[u4]; vf[u4] = vn[u4]; }
                 }
-                lrun = quarters_sum(lrun);
-                const float inv = lrun > 0.f ? 1.0f / lrun : 0.f;
-                *reinterpret_cast<float4*>(sQ + lo * QP + 16 * wave + 4 * hi) =
-                    make_float4((o[0] + o2[0]) * inv, (o[1] + o2[1]) * inv, (o[2] + o2[2]) * inv, (o[3] + o2[3]) * inv);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const float l = quarters_sum(lrun[g]);
+                    const float inv = l > 0.f ? 1.0f / l : 0.f;
+                    *reinterpret_cast<float4*>(sQ + (16 * g + lo) * QP + 16 * wave + 4 * hi) =
+                        make_float4((o[g][0] + o2[g][0]) * inv, (o[g][1] + o2[g][1]) * inv, (o[g][2] + o2[g][2]) * inv, (o[g][3] + o2[g][3]) * inv);
+                }
             }
             __syncthreads();
-            // ================= pointer: node tiles over the waves; local policy of the 16 trajectories: wave 7 =================
-            // (co_local16 costs about what three node tiles do: wave 7 joins the tile round-robin three rounds late)
-            if (A.has_local && wave == 7) co_local16_call(sT, A.loc, sX, lo, hi);
-            const int skip = A.has_local ? 21 : 0;           // tiles 0 .. 20 go to waves 0 .. 6 only
+            // ================= pointer: node tiles over the waves; local policy of group g: wave 7 - g =================
+            // (co_local16 costs about what three node tiles do: its wave joins the tile round-robin three rounds late)
+            const int nloc = A.has_local ? NG : 0, W0 = 8 - nloc, skip = nloc ? 3 * W0 : 0;
+            if (wave >= W0) co_local16_call(sT, A.loc, sX + (7 - wave) * 16 * CO_XP, lo, hi);
             {
                 float4 pk[8], pkn[8];
                 auto loadpk = [&](int nt, float4 (&d)[8]) {
 #pragma unroll
                     for (int s4 = 0; s4 < 8; ++s4) d[s4] = gPK[(nt * 8 + s4) * 64];
                 };
-                int nt = (wave < 7 ? wave : skip + 7);
+                int nt = (wave < W0 ? wave : skip + wave);
                 if (nt < NTn) loadpk(nt, pk);
 #pragma unroll 1
                 while (nt < NTn) {
-                    const int nxt = nt + (nt < skip ? 7 : 8);
+                    const int nxt = nt + (nt < skip ? W0 : 8);
                     loadpk(min(nxt, NTn - 1), pkn);              // the wave's next tile, in flight under this tile's MFMAs
                     __builtin_amdgcn_sched_barrier(0);
-                    f32x4c a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-                    const float* orow = sQ + lo * QP + 4 * hi;
+                    f32x4c a0[NG], a1[NG];
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) { a0[g] = f32x4c{0.f, 0.f, 0.f, 0.f}; a1[g] = f32x4c{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
                     for (int s4 = 0; s4 < 8; ++s4) {
-                        const float4 ov = *reinterpret_cast<const float4*>(orow + 16 * s4);
-                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pk[s4].x, ov.x, a0, 0, 0, 0);
-                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pk[s4].y, ov.y, a1, 0, 0, 0);
-                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pk[s4].z, ov.z, a0, 0, 0, 0);
-                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pk[s4].w, ov.w, a1, 0, 0, 0);
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) {
+                            const float4 ov = *reinterpret_cast<const float4*>(sQ + (16 * g + lo) * QP + 4 * hi + 16 * s4);
+                            a0[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(pk[s4].x, ov.x, a0[g], 0, 0, 0);
+                            a1[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(pk[s4].y, ov.y, a1[g], 0, 0, 0);
+                            a0[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(pk[s4].z, ov.z, a0[g], 0, 0, 0);
+                            a1[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(pk[s4].w, ov.w, a1[g], 0, 0, 0);
+                        }
                     }
                     const int nb = 16 * nt + 4 * hi;
                     const float p0 = I.pb[min(nb, N1 - 1)], p1 = I.pb[min(nb + 1, N1 - 1)], p2 = I.pb[min(nb + 2, N1 - 1)], p3 = I.pb[min(nb + 3, N1 - 1)];
-                    *reinterpret_cast<float4*>(sSc + lo * SP + nb) =
-                        make_float4(a0[0] + a1[0] + p0, a0[1] + a1[1] + p1, a0[2] + a1[2] + p2, a0[3] + a1[3] + p3);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+                        *reinterpret_cast<float4*>(sSc + (16 * g + lo) * SP + nb) =
+                            make_float4(a0[g][0] + a1[g][0] + p0, a0[g][1] + a1[g][1] + p1, a0[g][2] + a1[g][2] + p2, a0[g][3] + a1[g][3] + p3);
 #pragma unroll
                     for (int s4 = 0; s4 < 8; ++s4) pk[s4] = pkn[s4];
                     nt = nxt;
@@ -1594,8 +1707,8 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
             }
             __syncthreads();
             // ================= owners: clip, mask, softmax, choice =================
-            auto choose = [&](bool dec, int q, size_t bm, int snid, float addval, int& sel, float& pr) {
-                if (!dec) return;
+            auto choose = [&](bool dc, int q, size_t bmq, int sn, float addval, int& sl, float& pp) {
+                if (!dc) return;
                 unsigned long long mk[NCH];
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
@@ -1612,46 +1725,49 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                 }
                 wave_lds_fence();
                 int fsel = 0;
-                if (A.forced && t < A.Tforced) fsel = __builtin_amdgcn_readfirstlane(A.forced[bm * A.Tforced + t]);
+                if (A.forced && t < A.Tforced) fsel = __builtin_amdgcn_readfirstlane(A.forced[bmq * A.Tforced + t]);
                 float uni = 0.f;
                 if (A.mode == ELG_MODE_SAMPLE)
-                    uni = A.uniforms ? A.uniforms[bm * A.Tmax + t] : philox_uniform(A.seed, (unsigned)bm, (unsigned)t);
-                float* frow = (A.full_probs && t < A.dump_T) ? A.full_probs + (bm * A.dump_T + t) * N1 : nullptr;
+                    uni = A.uniforms ? A.uniforms[bmq * A.Tmax + t] : philox_uniform(A.seed, (unsigned)bmq, (unsigned)t);
+                float* frow = (A.full_probs && t < A.dump_T) ? A.full_probs + (bmq * A.dump_T + t) * N1 : nullptr;
                 if (A.has_local && lane < ELG_SLOT_STRIDE) addval += sX[q * CO_XP + CO_XU + lane] * A.inv_ens;
                 // finish_step scatters through a node-indexed scratch row: the score row itself (the scores are in registers now)
-                const FwdOut fo = finish_step<NCH, TSP, false>(A, N1, lane, srow, mk, s, snid, addval, fsel, uni, frow, (size_t)b, 0, 0);
-                sel = __builtin_amdgcn_readfirstlane(fo.sel);
-                pr = i2f(__builtin_amdgcn_readfirstlane(f2i(fo.p)));
+                const FwdOut fo = finish_step<NCH, TSP, false>(A, N1, lane, srow, mk, s, sn, addval, fsel, uni, frow, (size_t)b, 0, 0);
+                sl = __builtin_amdgcn_readfirstlane(fo.sel);
+                pp = i2f(__builtin_amdgcn_readfirstlane(f2i(fo.p)));
             };
-            choose(dec0, wave, bm0, snid0, add0, sel0, pr0);
-            choose(dec1, wave + 8, bm1, snid1, add1, sel1, pr1);
+#pragma unroll
+            for (int j = 0; j < NOWN; ++j) choose(dec[j], wave + 8 * j, bm[j], snid[j], addv[j], sel[j], pr[j]);
         }
-        auto advance = [&](Traj<NCH>& st, bool act, size_t bm, int m, int sel, float pr) {
-            if (!act) return;
+        auto advance = [&](MtTraj& s1, bool ac, int q, size_t bmq, int sl, float pp) {
+            if (!ac) return;
+            const int m = m_base + q;
             if (first_move) {
-                if (A.mode == ELG_MODE_FORCED) sel = (A.forced && t < A.Tforced) ? __builtin_amdgcn_readfirstlane(A.forced[bm * A.Tforced + t]) : 0;
-                else sel = (!TSP && t == 0) ? 0 : __builtin_amdgcn_readfirstlane(A.starts[m]);
+                if (A.mode == ELG_MODE_FORCED) sl = (A.forced && t < A.Tforced) ? __builtin_amdgcn_readfirstlane(A.forced[bmq * A.Tforced + t]) : 0;
+                else sl = (!TSP && t == 0) ? 0 : __builtin_amdgcn_readfirstlane(A.starts[m]);
             }
             if (lane == 0) {
-                if (A.actions) A.actions[bm * A.Tmax + t] = sel;
-                if (A.probs) A.probs[((size_t)b * A.Tmax + t) * A.M + m] = pr;
+                if (A.actions) A.actions[bmq * A.Tmax + t] = sl;
+                if (A.probs) A.probs[((size_t)b * A.Tmax + t) * A.M + m] = pp;
             }
-            env_update<NCH, TSP>(st, I, N1, sel);
+            mt_env_update<NCH, TSP>(s1, sVis + q * NCH, I, N1, sl, lane);
         };
-        advance(st0, act0, bm0, m_base + wave, sel0, pr0);
-        advance(st1, act1, bm1, m_base + wave + 8, sel1, pr1);
+#pragma unroll
+        for (int j = 0; j < NOWN; ++j) advance(st[j], act[j], wave + 8 * j, bm[j], sel[j], pr[j]);
     }
     if (lane == 0) {
-        if (has0) { if (A.reward) A.reward[bm0] = -st0.len; if (A.tlen) A.tlen[bm0] = st0.cnt; }
-        if (has1) { if (A.reward) A.reward[bm1] = -st1.len; if (A.tlen) A.tlen[bm1] = st1.cnt; }
+#pragma unroll
+        for (int j = 0; j < NOWN; ++j)
+            if (has[j]) { if (A.reward) A.reward[bm[j]] = -st[j].len; if (A.tlen) A.tlen[bm[j]] = st[j].cnt; }
     }
 }
 
-template <int NCH, bool TSP>
-static int launch_fwd_mt(const elg_rollout_args& A, hipStream_t stream) {
-    const size_t lds = ((size_t)16 * 132 + (size_t)16 * (64 * NCH + 4) + (size_t)16 * NCH * 2 + (A.has_local ? 16 * CO_XP + CL_SIZE : 0) +
+template <int NCH, bool TSP, int NG>
+static int launch_fwd_mt_g(const elg_rollout_args& A, hipStream_t stream) {
+    constexpr int NTR = 16 * NG;
+    const size_t lds = ((size_t)NTR * 132 + (size_t)NTR * (64 * NCH + 4) + (size_t)NTR * NCH * 4 + (A.has_local ? NTR * CO_XP + CL_SIZE : 0) +
                         ((A.N1 + 3) & ~3) + (size_t)8 * ELG_SB_MIN) * 4;
-    auto kern = rollout_fwd_mt_kernel<NCH, TSP>;
+    auto kern = rollout_fwd_mt_kernel<NCH, TSP, NG>;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         (void)hipGetLastError();
@@ -1661,12 +1777,20 @@ static int launch_fwd_mt(const elg_rollout_args& A, hipStream_t stream) {
     }
     if (!A.scratch) return fail(ELG_EINVAL, "rollout: 128 < N1 <= 1024 needs the scratch workspace (elg_rollout_scratch_floats)");
     elg_rollout_args B2 = A;
-    B2.tiles = (A.M + 15) / 16;                            // this kernel's geometry: 16 trajectories per workgroup
+    B2.tiles = (A.M + NTR - 1) / NTR;                      // this kernel's geometry: 16 NG trajectories per workgroup
     (void)hipGetLastError();
     constexpr int NP = 64 * NCH;
     hipLaunchKernelGGL(mt_repack_kernel, dim3((3 * NP * 32 + 255) / 256, A.B), dim3(256), 0, stream, A.Kmat, A.Vmat, A.PK, A.scratch, A.N1, NP);
     hipLaunchKernelGGL(kern, dim3(B2.B * B2.tiles), dim3(512), lds, stream, B2);
     return launch_status("rollout_fwd_mt");
+}
+
+// 32 trajectories per workgroup (every K / V / PK fragment read from L2 serves two MFMA column groups) once 16 per workgroup
+// would put more than one workgroup on a CU anyway; the score rows of 32 trajectories fit LDS up to 512 nodes
+template <int NCH, bool TSP>
+static int launch_fwd_mt(const elg_rollout_args& A, hipStream_t stream) {
+    if (NCH <= 8 && (long long)A.B * ((A.M + 15) / 16) > 256) return launch_fwd_mt_g<NCH, TSP, (NCH <= 8 ? 2 : 1)>(A, stream);
+    return launch_fwd_mt_g<NCH, TSP, 1>(A, stream);
 }
 
 // =============================================================================================

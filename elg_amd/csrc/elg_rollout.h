@@ -175,8 +175,8 @@ struct Slots {
     bool smask;       // slot masked / absent for the local attention
 };
 
-template <int NCH, bool TSP>
-__device__ __forceinline__ Slots slot_setup(const Inst& I, int N1, int K, bool has_penalty, const Traj<NCH>& st,
+template <int NCH, bool TSP, class ST>     // ST: anything with .cur and .load
+__device__ __forceinline__ Slots slot_setup(const Inst& I, int N1, int K, bool has_penalty, const ST& st,
                                             int lane, const unsigned long long (&mk)[NCH], float* sb,
                                             const unsigned long long* lds_mk = nullptr) {
     constexpr int S0 = TSP ? 0 : 1;

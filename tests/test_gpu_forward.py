@@ -33,7 +33,7 @@ def test_aug8_and_dist_and_route_length():
     assert np.array_equal(out.cpu().numpy(), fx["y"])
     xy = torch.rand(3, 37, 2)
     d = eng.dist_matrix(xy.to(gc.DEV)).cpu()
-    np.testing.assert_allclose(d.numpy(), orc.dist_matrix(xy).numpy(), rtol=1e-6, atol=1e-7)
+    assert torch.equal(d, orc.dist_matrix(xy))            # every op rounded once, correctly rounded sqrt: bit-exact
     tour = torch.stack([torch.stack([torch.randperm(37) for _ in range(5)]) for _ in range(3)])
     got = eng.route_length(xy.to(gc.DEV), tour.to(gc.DEV)).cpu()
     np.testing.assert_allclose(got.numpy(), orc.route_length(xy, tour).numpy(), rtol=1e-6)
@@ -42,22 +42,20 @@ def test_aug8_and_dist_and_route_length():
 def test_nbr_tables():
     gc, L, eng = _imports()
     torch.manual_seed(0)
-    for N in (21, 101, 200):
+    for N in (21, 101, 200, 500):
         xy = torch.rand(2, N, 2)
         xy[0, 5] = xy[0, 3]          # exact tie: order must fall back to the node index
         nb = eng.nbr_tables(xy.to(gc.DEV))
         d = orc.dist_matrix(xy)
-        key = d.double() * 4e9 // 1          # not used: compare through sorting with a stable argsort
         order = torch.argsort(d, dim=-1, stable=True)
         got_idx = nb.idx.cpu().long()
         got_d = nb.dist.cpu()
         # distances ascending and consistent with the indices
         assert (got_d[:, :, 1:] >= got_d[:, :, :-1]).all()
-        np.testing.assert_allclose(torch.gather(d, 2, got_idx).numpy(), got_d.numpy(), rtol=1e-6, atol=1e-7)
-        # a permutation of the nodes, ties by index
-        assert (torch.sort(got_idx, dim=-1)[0] == torch.arange(N)[None, None]).all()
-        same = (got_idx == order).float().mean().item()
-        assert same > 0.999, same
+        # bit-exact distances (a 1-ulp difference reorders near-equidistant neighbours and changes a k-NN set), hence the
+        # reference's order exactly: (distance, node index)
+        assert torch.equal(torch.gather(d, 2, got_idx), got_d)
+        assert torch.equal(got_idx, order)
         th = orc.make_theta_fn(xy)(torch.arange(N)[None].expand(2, N))
         np.testing.assert_allclose(nb.theta.cpu().numpy(), torch.gather(th, 2, got_idx).numpy(), rtol=1e-5, atol=2e-6)
 
