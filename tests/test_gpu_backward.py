@@ -113,3 +113,62 @@ def test_cvrp_backward_n100(train):
 @pytest.mark.parametrize("train", [False, True], ids=["replay", "saved_rows"])
 def test_tsp_backward(tag, train):
     _run("tsp", tag, "pomo", train=train)
+
+
+@pytest.mark.parametrize("problem,N,M", [("cvrp", 200, 8), ("tsp", 150, 6)])
+def test_backward_large_instance_replay(problem, N, M):
+    """N1 > 128 (no saved-row training forward for these sizes): the engine's own sampled tours, gradients through the
+    replay backward (rollout_bwd_kernel + the row contractions) against the oracle's autograd on the same forced tours."""
+    gc, L, eng = _imports()
+    B = 1
+    if problem == "cvrp":
+        mp = dict(gu.CVRP_MODEL_PARAMS)
+        cfg = orc.ModelCfg.from_model_params(mp, "cvrp")
+        depot, loc_xy, demand = gu.golden_cvrp_problem(61 + N, B, N, 50.0)
+        xy = torch.from_numpy(np.concatenate([depot, loc_xy], 1))
+        dem = torch.from_numpy(np.concatenate([np.zeros((B, 1), np.float32), demand], 1))
+        kind, starts = L.PROBLEM_CVRP, torch.arange(1, M + 1)
+        lp_prefix, nfeat, nslots = "decoder.local_policies.0.", 3, cfg.local_size + 1
+    else:
+        mp = dict(gu.TSP_MODEL_PARAMS)
+        cfg = orc.ModelCfg.from_model_params(mp, "tsp")
+        xy, dem = torch.from_numpy(gu.golden_tsp_problem(61 + N, B, N)), None
+        kind, starts = L.PROBLEM_TSP, torch.arange(M)
+        lp_prefix, nfeat, nslots = "decoder.local_policy_0.", 2, cfg.local_size
+    P = gc.weights(problem, 21, mp, 1.0)
+    with torch.no_grad():
+        enc0 = orc.encoder_forward(P, cfg, xy, dem)
+    prob = gc.make_problem(xy, dem, kind)
+    Pg = {k: v.clone().to(gc.DEV).requires_grad_(k.startswith("decoder.")) for k, v in P.items()}
+    enc_g = enc0.clone().to(gc.DEV).requires_grad_(True)
+    tables = gc.fold_decoder_tables(gc.sub(Pg, "decoder."), enc_g, kind)
+    loc = gc.fold_local_tables(gc.sub(Pg, lp_prefix), nfeat, nslots)
+    pol = eng.Policy(tables, loc, cfg.local_size, cfg.xi, cfg.logit_clipping, 1.0 / cfg.ensemble_size, True, True)
+    with torch.no_grad():
+        res = eng.rollout_forward(prob, pol, M, starts, L.MODE_SAMPLE, seed=9)
+    T = int(res.tlen.max().item())
+    acts = res.actions[:, :, :T].cpu().long()
+    torch.manual_seed(4)
+    rew = res.reward.cpu() + 0.3 * torch.randn(B, M)
+
+    def loss_fn(probs):
+        return orc.pomo_loss(probs, rew.to(probs.device), guard_zero=(problem == "tsp"))
+    Po = {k: v.clone().requires_grad_(k.startswith("decoder.")) for k, v in P.items()}
+    enc_o = enc0.clone().requires_grad_(True)
+    if problem == "cvrp":
+        out = orc.rollout_cvrp(Po, cfg, xy, dem, M, starts=starts, forced=acts, enc=enc_o)
+    else:
+        out = orc.rollout_tsp(Po, cfg, xy, M, starts=starts, forced=acts, enc=enc_o)
+    Jo = loss_fn(out["probs"])
+    Jo.backward()
+    ref = {k: v.grad.clone() for k, v in Po.items() if v.grad is not None}
+    ref["enc"] = enc_o.grad.clone()
+    pr = eng.chosen_probs(prob, pol, M, res, T)
+    np.testing.assert_allclose(pr.detach().cpu().numpy(), out["probs"].detach().numpy(), rtol=5e-4)
+    Jg = loss_fn(pr)
+    assert abs(Jg.item() - Jo.item()) <= 2e-4 * max(1.0, abs(Jo.item()))
+    Jg.backward()
+    got = {k: v.grad for k, v in Pg.items() if v.grad is not None}
+    got["enc"] = enc_g.grad
+    assert set(got) == set(ref)
+    _grad_check(got, ref)
