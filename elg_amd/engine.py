@@ -255,8 +255,7 @@ def launch_geometry(B: int, M: int, N1: int):
     tiles = max(1, min(M, (n_cu + B - 1) // B))
     if not lds and N1 <= 128:
         tiles = max(tiles, min(M, (4 * n_cu + B - 1) // B))
-    # N1 > 128: node-tiled kernel, 128 KiB of K/V tiles per workgroup -> one workgroup per CU,
-    # trajectories advance in rounds of `waves`
+    # N1 > 128: the fused rollout picks its own geometry (16 or 32 trajectories per workgroup, launch_fwd_mt)
     return waves, tiles, lds
 
 
