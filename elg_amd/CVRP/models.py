@@ -38,8 +38,6 @@ class local_policy_att(nn.Module):
         self.multi_head_combine = nn.Linear(hd, self.emb_dim)
         if (self.emb_dim, self.head_num, self.qkv_dim) != (eng.LE, eng.LH, eng.LDK):
             raise NotImplementedError("HIP kernels are built for local_att 32/4/8")
-        if model_params.get('euclidean', False):
-            raise NotImplementedError("euclidean local features are not built (SURVEY 8f rank 4)")
 
     def folded_tables(self, n_slots: int) -> torch.Tensor:
         lp = {k: v for k, v in self.named_parameters()}
@@ -133,7 +131,8 @@ class CVRP_Decoder(nn.Module):
         mp = self.model_params
         has_local = bool(mp['ensemble'] and self.local)
         self.policy = eng.Policy(tables, loc, int(mp['local_size'][0]), float(mp['xi']), float(mp['logit_clipping']),
-                                 1.0 / float(mp['ensemble_size']), has_local, bool(mp['distance_penalty']))
+                                 1.0 / float(mp['ensemble_size']), has_local, bool(mp['distance_penalty']),
+                                 bool(mp.get('euclidean', False)))
         # attributes the reference exposes after set_kv
         self.k, self.v = tables["K"], tables["V"]
         self.single_head_key = encoded_nodes.transpose(1, 2)

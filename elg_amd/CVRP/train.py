@@ -126,9 +126,8 @@ if __name__ == "__main__":
     with open('config.yml', 'r', encoding='utf-8') as fh:
         config = yaml.load(fh.read(), Loader=yaml.FullLoader)
     rank, world, local = parallel.init_distributed()
-    if config['training'] not in ('joint', 'only_global'):
-        # the reference's own entry point names a class it never defines for this mode (train.py:199-200)
-        raise NotImplementedError("training: {} is not built (the reference's 'only_local' model class does not exist either)".format(config['training']))
+    if config['training'] not in ('joint', 'only_global', 'only_local'):
+        raise ValueError("training: {} (config.yml:9 allows joint, only_local, only_global)".format(config['training']))
     p = config['params']
     device = "cuda:{}".format(local if world > 1 else config['cuda_device_num']) if config['use_cuda'] else 'cpu'
     seed_everything(config['seed'] + rank)
@@ -141,6 +140,8 @@ if __name__ == "__main__":
         os.makedirs('log', exist_ok=True)
         fileLogger = Logger('log/{}_{}'.format(config['name'], ts_name), config)
     model = CVRPModel(**config['model_params'])
+    if config['training'] == 'only_local':                         # reference train.py:198-200
+        model = CVRPModel_local(**config['model_params'])
     if config['load_checkpoint'] is not None:
         checkpoint = torch.load(config['load_checkpoint'], map_location=device)
         if any(k.startswith('decoder.local_policies') for k in checkpoint['model_state_dict']):

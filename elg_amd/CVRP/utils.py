@@ -19,7 +19,7 @@ def rollout(model, env, eval_type='greedy'):
     returned probabilities carry a grad_fn whose backward is the replay kernel pair of csrc/elg_bwd.hip."""
     env.reset()
     B, M, N = env.batch_size, env.multi_width, env.problem_size
-    pol = model.decoder.policy
+    pol = model.policy if hasattr(model, 'policy') else model.decoder.policy      # CVRPModel_local owns its policy
     if pol is None:
         raise RuntimeError("call model.pre_forward(reset_state) before rollout")
     starts = torch.tensor(model.draw_starts(N, M), dtype=torch.int32)

@@ -75,7 +75,7 @@ class TSP_Decoder(nn.Module):
         mp = self.model_params
         has_local = bool(mp['ensemble'] and self.local)
         self.policy = eng.Policy(tables, loc, int(mp['local_size'][0]), float(mp['xi']), float(mp['logit_clipping']), 1.0,
-                                 has_local, bool(mp['distance_penalty']))
+                                 has_local, bool(mp['distance_penalty']), bool(mp.get('euclidean', False)))
         self.k, self.v = tables["K"], tables["V"]
         self.single_head_key = encoded_nodes.transpose(1, 2)
 

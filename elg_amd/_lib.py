@@ -27,7 +27,7 @@ class RolloutArgs(C.Structure):
         ("use_state", C.c_int32), ("waves", C.c_int32), ("tiles", C.c_int32), ("lds_stage", C.c_int32),
         ("dump_T", C.c_int32),
         ("xi", C.c_float), ("clip", C.c_float), ("inv_ens", C.c_float), ("variant", C.c_int32),
-        ("dump_logits", C.c_int32), ("pad0", C.c_int32),
+        ("dump_logits", C.c_int32), ("euclidean", C.c_int32),
         ("seed", C.c_uint64),
         ("Kmat", _vp), ("Vmat", _vp), ("PK", _vp), ("pb", _vp), ("Q1", _vp), ("Q2", _vp), ("wl", _vp),
         ("xy", _vp), ("demand", _vp), ("nbr_idx", _vp), ("nbr_dist", _vp), ("nbr_theta", _vp), ("loc", _vp),

@@ -98,7 +98,7 @@ __device__ __forceinline__ void bwd_step(const elg_bwd_args& BA, const Inst& I, 
     float addval = 0.f;
     int snid = -1;
     if (A.has_penalty || A.has_local) {
-        const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb);
+        const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb, nullptr, A.euclidean != 0);
         snid = S.snid;
         float u = 0.f;
         if (A.has_local) u = local_policy<TSP>(I.loc, lane, S.f0, S.f1, S.f2, S.smask, nullptr);
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(WAVES * 64) void local_bwd_kernel(const elg_bwd_arg
                 if (__ballot(du != 0.f)) {
                     unsigned long long mk[NCH];
                     build_mask<NCH, TSP>(st, I, N1, lane, mk);
-                    const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb);
+                    const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb, nullptr, A.euclidean != 0);
                     local_bwd_step<TSP>(I.loc, LA, lane, S, du);
                 }
             }

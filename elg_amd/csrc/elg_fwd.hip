@@ -270,7 +270,7 @@ __device__ __forceinline__ FwdOut decode_step(const elg_rollout_args& A, const I
     int ssave = -1;              // what the backward needs to know about the slot
     float sf0 = 0.f, sf1 = 0.f, sf2 = 0.f;
     if (A.has_penalty || A.has_local) {
-        const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb);
+        const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb, nullptr, A.euclidean != 0);
         snid = S.snid;
         ssave = (S.smask && S.snid >= 0) ? -2 : S.snid;              // present but masked (the CVRP depot slot)
         sf0 = S.f0; sf1 = S.f1; sf2 = S.f2;
@@ -953,6 +953,10 @@ __device__ __forceinline__ void co_advance4(const elg_rollout_args& A, const Ins
         if (cust) {
             f0 = sd / nf;
             f1 = sth;
+            if (A.euclidean) {                                          // models.py:95-125: relative (x, y) / norm
+                f0 = __fsub_rn(I.xy[2 * snid], st.cx) / nf;
+                f1 = __fsub_rn(I.xy[2 * snid + 1], st.cy) / nf;
+            }
             if (!TSP) f2 = I.dem[snid] / st.load;
         }
         bool smask = !cust;
@@ -1541,7 +1545,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                     }
                     if (A.has_penalty || A.has_local) {
                         wave_lds_fence();
-                        const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, s1, lane, mk, sb, sMaskW + q * NCH);
+                        const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, s1, lane, mk, sb, sMaskW + q * NCH, A.euclidean != 0);
                         sn = S.snid;
                         addval = S.pen;
                         if (A.has_local && lane < ELG_SLOT_STRIDE) {        // slot block for co_local16 (layout of the coop kernel)
@@ -1932,7 +1936,11 @@ __global__ __launch_bounds__(512) void rollout_fwd_xl_kernel(const elg_rollout_a
                         }
                         const float nf = dmax + 1e-6f;
                         float f0 = 0.f, f1 = 0.f, f2 = 0.f;
-                        if (cust) { f0 = sd / nf; f1 = sth; if (!TSP) f2 = sdem[snid] / load; }
+                        if (cust) {
+                            f0 = sd / nf; f1 = sth;
+                            if (A.euclidean) { f0 = __fsub_rn(xy[2 * snid], cx) / nf; f1 = __fsub_rn(xy[2 * snid + 1], cy) / nf; }
+                            if (!TSP) f2 = sdem[snid] / load;
+                        }
                         bool smask = !cust;
                         if (!TSP && j == 0) smask = smk[0] & 1ull;
                         float uu = 0.f;

@@ -178,7 +178,7 @@ struct Slots {
 template <int NCH, bool TSP, class ST>     // ST: anything with .cur and .load
 __device__ __forceinline__ Slots slot_setup(const Inst& I, int N1, int K, bool has_penalty, const ST& st,
                                             int lane, const unsigned long long (&mk)[NCH], float* sb,
-                                            const unsigned long long* lds_mk = nullptr) {
+                                            const unsigned long long* lds_mk = nullptr, bool euclid = false) {
     constexpr int S0 = TSP ? 0 : 1;
     Slots S;
     S.k = knn_slots<NCH, TSP>(I, N1, K, st.cur, lane, mk, sb, lds_mk);
@@ -205,6 +205,11 @@ __device__ __forceinline__ Slots slot_setup(const Inst& I, int N1, int K, bool h
     if (S.cust) {
         S.f0 = sd / nf;
         S.f1 = sth;
+        if (euclid) {                                                 // models.py:95-125: relative (x, y) / norm (CVRPEnv.py:303)
+            const float cx = I.xy[2 * st.cur], cy = I.xy[2 * st.cur + 1];
+            S.f0 = __fsub_rn(I.xy[2 * S.snid], cx) / nf;
+            S.f1 = __fsub_rn(I.xy[2 * S.snid + 1], cy) / nf;
+        }
         if (!TSP) S.f2 = I.dem[S.snid] / st.load;                     // CVRPEnv.py:315-316
     }
     S.smask = !S.cust;

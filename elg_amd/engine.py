@@ -244,6 +244,7 @@ class Policy:
     inv_ens: float
     has_local: bool
     has_penalty: bool
+    euclidean: bool = False        # local features (x, y) / norm instead of (dist / norm, theta)
 
 
 def launch_geometry(B: int, M: int, N1: int):
@@ -268,6 +269,7 @@ def _fill_common(a: L.RolloutArgs, prob: Problem, pol: Policy, M: int, geometry=
     waves, tiles, lds = geometry or launch_geometry(prob.B, M, prob.N1)
     a.problem, a.B, a.M, a.N1, a.K = prob.kind, prob.B, M, prob.N1, pol.K
     a.has_local, a.has_penalty = int(pol.has_local), int(pol.has_penalty)
+    a.euclidean = int(getattr(pol, 'euclidean', False))
     a.waves, a.tiles, a.lds_stage = waves, tiles, lds
     a.xi, a.clip, a.inv_ens = pol.xi, pol.clip, pol.inv_ens
     t = pol.tables

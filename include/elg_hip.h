@@ -91,7 +91,8 @@ typedef struct elg_rollout_args {
                                2: the N1 > 1024 kernel (Vrp-Set-XXL; runtime node loops, needs `scratch`) for any N1 */
     int32_t dump_logits;    /* what full_probs receives: 0 probabilities, 1 the clipped + masked logits
                                clip * tanh(s) (-inf at closed nodes), 2 the scores s before the clip            */
-    int32_t pad0;
+    int32_t euclidean;      /* model_params.euclidean: local-policy slot features (x, y) / norm relative to the current node
+                               instead of (dist / norm, theta)   (models.py:95-125, TSP/models.py:67-75)            */
     uint64_t seed;          /* sampling seed (Philox key)                                       */
     const float* Kmat;      /* (B,N1,128) decoder.Wk enc                                        */
     const float* Vmat;      /* (B,N1,128) decoder.Wv enc                                        */

@@ -107,7 +107,7 @@ def make_policy(P, cfg, enc_gpu, kind, has_local=True):
     nslots = cfg.local_size + (1 if kind == L.PROBLEM_CVRP else 0)
     loc = fold_local_tables(sub(Pg, lp_prefix), nfeat, nslots) if has_local else None
     return eng.Policy(tables, loc, cfg.local_size, cfg.xi, cfg.logit_clipping, 1.0 / cfg.ensemble_size,
-                      has_local and cfg.ensemble, cfg.distance_penalty)
+                      has_local and cfg.ensemble, cfg.distance_penalty, bool(getattr(cfg, 'euclidean', False)))
 
 
 def make_problem(xy, demand, kind):

@@ -1,0 +1,144 @@
+"""Config-reachable model variants through the product path, against fixtures of the real reference
+(tools/make_golden_r02b.py): `training: only_local` = CVRPModel_local (reference CVRPModel.py:78-131) and
+model_params['euclidean'] = True (models.py:95-125, TSP/models.py:67-75).  Logit tolerance as in test_gpu_logits.py."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+import gpu_common as gc
+from oracle import elg_oracle as orc
+from elg_amd import _lib as L
+from elg_amd import engine as eng
+from test_oracle_golden import LOGIT_RTOL, local_only_setup, logit_errors
+
+pytestmark = pytest.mark.gpu
+DEV = gc.DEV
+
+
+def _local_model(mp, P):
+    from elg_amd.CVRP.CVRPModel import CVRPModel_local
+    model = CVRPModel_local(**mp)
+    model.load_state_dict({k: v.clone() for k, v in P.items()}, strict=True)     # the reference's checkpoint keys
+    return model.to(DEV)
+
+
+def _env(mp, xy, dem, M):
+    from elg_amd.CVRP.CVRPEnv import CVRPEnv
+    env = CVRPEnv(multi_width=M, device=DEV)
+    env.load_random_problems(dict(depot=xy[:, :1].clone(), loc=xy[:, 1:].clone(), demand=dem[:, 1:].clone()))
+    return env
+
+
+@pytest.mark.parametrize("tag,variant", [("greedy", 0), ("sample", 0), ("greedy", 1)])
+def test_local_only_model_logits(tag, variant):
+    """The reference's CVRPModel_local tours teacher-forced through the engine: clipped + masked logits of every decode
+    step (1e-4 of the clip), the mask exactly, rewards; sampled tours: chosen probabilities."""
+    fx, mp, cfg, P, xy, dem, B, N, M = local_only_setup()
+    model = _local_model(mp, P).eval()
+    env = _env(mp, xy, dem, M)
+    rs, _, _ = env.reset()
+    acts = torch.from_numpy(fx[f"{tag}_actions"].astype(np.int64))
+    T = acts.shape[2]
+    with torch.no_grad():
+        model.pre_forward(rs)
+        res = eng.rollout_forward(env.problem, model.policy, M, acts[0, :, 1], L.MODE_FORCED, forced=acts, dump_T=T,
+                                  dump="logits", variant=variant)
+    got = res.full_probs.cpu().numpy()                               # (B, M, T, N1)
+    ref = fx[f"{tag}_logits"]                                        # (T-2, B, M, N1)
+    live = (np.arange(T)[None, None, :] < res.tlen.cpu().numpy()[:, :, None])
+    worst = 0.0
+    for i in range(ref.shape[0]):
+        t = i + 2
+        rows = live[:, :, t]
+        g, r = got[:, :, t, :][rows], ref[i][rows]
+        assert np.array_equal(np.isfinite(g), np.isfinite(r)), t
+        worst = max(worst, logit_errors(g, r, np.isfinite(r), cfg.logit_clipping))
+    assert worst <= LOGIT_RTOL, worst
+    np.testing.assert_allclose(res.reward.cpu().numpy(), fx[f"{tag}_reward"], rtol=1e-5)
+    if tag == "sample":
+        p = res.probs[:, :T].cpu().numpy()
+        lv = np.transpose(live, (0, 2, 1))
+        np.testing.assert_allclose(p[lv], fx["sample_probs"][lv], rtol=5e-4, atol=1e-9)
+    gc.record_parity(f"local_only_{tag}_v{variant}_logits_over_clip", worst)
+
+
+def test_local_only_model_free_running_and_protocol():
+    """Greedy free-running rollout (utils.rollout, one launch) and the reference's step-wise loop (one_step_rollout) both
+    reproduce the reference's own greedy tours of CVRPModel_local."""
+    import random
+    from elg_amd.CVRP.utils import rollout
+    fx, mp, cfg, P, xy, dem, B, N, M = local_only_setup()
+    model = _local_model(mp, P).eval()
+    env = _env(mp, xy, dem, M)
+    acts = fx["greedy_actions"].astype(np.int64)
+    starts = [int(a) for a in acts[0, :, 1]]
+    model.draw_starts = staticmethod(lambda n, m: starts)            # the reference drew these with Python's random
+    with torch.no_grad():
+        rs, _, _ = env.reset()
+        model.pre_forward(rs)
+        a, p, r = rollout(model, env, 'greedy')
+    assert np.array_equal(a.cpu().numpy(), acts)
+    np.testing.assert_allclose(r.cpu().numpy(), fx["greedy_reward"], rtol=1e-5)
+
+
+def test_local_only_training_gradients():
+    """`training: only_local`: sampled rollout -> POMO loss -> backward; gradients of every local-policy parameter against
+    the oracle's autograd on the same tours (the decoder tables are zeros and carry no gradient)."""
+    from elg_amd.CVRP.utils import rollout
+    from elg_amd.CVRP.train import pomo_loss
+    fx, mp, cfg, P, xy, dem, B, N, M = local_only_setup()
+    model = _local_model(mp, P).train()
+    env = _env(mp, xy, dem, M)
+    rs, _, _ = env.reset()
+    model.pre_forward(rs)
+    torch.manual_seed(3)
+    acts, probs, rew = rollout(model, env, 'sample')
+    assert probs.requires_grad
+    rew_n = rew + 0.3 * torch.randn(B, M, device=rew.device)        # keep the advantage away from rounding noise
+    J = pomo_loss(probs, rew_n, True)
+    J.backward()
+    Po = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    out = orc.rollout_cvrp(Po, cfg, xy, dem, M, starts=acts[0, :, 1].cpu(), forced=acts.cpu(), local_only=True)
+    To = out["probs"].shape[1]
+    np.testing.assert_allclose(probs.detach().cpu().numpy()[:, :To], out["probs"].detach().numpy(), rtol=5e-4, atol=1e-9)
+    Jo = orc.pomo_loss(out["probs"], rew_n.cpu(), True)
+    Jo.backward()
+    assert abs(float(J.detach()) - float(Jo.detach())) <= 2e-4 * max(1.0, abs(float(Jo.detach())))
+    got = dict(model.named_parameters())
+    for k, v in Po.items():
+        g, r = got[k].grad.cpu(), v.grad
+        err = float((g - r).abs().max())
+        assert err <= 2e-3 * float(r.abs().max()) + 1e-6, (k, err, float(r.abs().max()))
+
+
+@pytest.mark.parametrize("problem,variant", [("cvrp", 0), ("cvrp", 1), ("tsp", 0), ("tsp", 1)])
+def test_euclidean_local_features(problem, variant):
+    """model_params['euclidean'] = True: local-policy output is not observable on its own through the ABI, the score before
+    the clip and the logits are -- both against the reference's, cooperative and per-wavefront kernels."""
+    lg = gu.load_golden(f"r02_{problem}_euclidean.npz")
+    if problem == "cvrp":
+        fx, cfg, P, xy, dem, B, N, M = gc.cvrp_fixture("n20")
+        kind, t_first = L.PROBLEM_CVRP, 1
+    else:
+        fx, cfg, P, xy, B, N, M = gc.tsp_fixture("n20")
+        dem, kind, t_first = None, L.PROBLEM_TSP, 0
+    cfg.euclidean = True
+    acts = torch.from_numpy(fx["actions"].astype(np.int64))
+    T = acts.shape[2]
+    enc = orc.encoder_forward(P, cfg, xy, dem)
+    prob = gc.make_problem(xy, dem, kind)
+    pol = gc.make_policy(P, cfg, enc.to(DEV), kind)
+    assert pol.euclidean
+    worst = {}
+    for dump, key, scale in (("scores", "pre_clip", None), ("logits", "logits", cfg.logit_clipping)):
+        res = eng.rollout_forward(prob, pol, M, acts[0, :, t_first], L.MODE_FORCED, forced=acts, dump_T=T, dump=dump,
+                                  variant=variant)
+        got = res.full_probs.cpu().numpy()
+        for i, t in enumerate(lg["steps"]):
+            ref = lg[key][i]
+            open_ = np.isfinite(lg["logits"][i])
+            e = logit_errors(got[:, :, int(t), :], ref, open_, scale)
+            worst[key] = max(worst.get(key, 0.0), e)
+    assert max(worst.values()) <= LOGIT_RTOL, worst
+    gc.record_parity(f"euclidean_{problem}_v{variant}", max(worst.values()))

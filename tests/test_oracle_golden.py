@@ -301,3 +301,82 @@ def test_oracle_decoder_internals(problem, tag):
             worst[k] = max(worst.get(k, 0.0), e)
             assert e <= LOGIT_RTOL, (k, int(t), e)
     print(problem, tag, {k: f"{v:.2e}" for k, v in worst.items()})
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# config-reachable model variants: fixtures of tools/make_golden_r02b.py
+# ---------------------------------------------------------------------------------------------------------------------
+def local_only_setup(dtype=torch.float32):
+    fx = gu.load_golden("r02_cvrp_local_only.npz")
+    B, N, M, wseed, pseed, K = [int(x) for x in fx["meta"]]
+    mp = dict(gu.CVRP_MODEL_PARAMS)
+    mp["local_size"] = [K]
+    cfg = orc.ModelCfg.from_model_params(mp, "cvrp")
+    w = gu.golden_weights("cvrp", wseed, mp, local=True, gain=float(fx["gain"]))
+    pre = "decoder.local_policies.0."
+    P = {"local_policy." + k[len(pre):]: torch.from_numpy(v).to(dtype) for k, v in w.items() if k.startswith(pre)}
+    depot, loc, demand = gu.golden_cvrp_problem(pseed, B, N, 30.0)
+    xy = torch.from_numpy(np.concatenate([depot, loc], 1)).to(dtype)
+    dem = torch.from_numpy(np.concatenate([np.zeros((B, 1), np.float32), demand], 1)).to(dtype)
+    return fx, mp, cfg, P, xy, dem, B, N, M
+
+
+@pytest.mark.parametrize("tag", ["greedy", "sample"])
+def test_oracle_local_only_model(tag):
+    """CVRPModel_local (reference CVRPModel.py:78-131): logits of every decode step of the reference's own rollout, its
+    greedy tours and the chosen probabilities of its sampled tours."""
+    fx, mp, cfg, P, xy, dem, B, N, M = local_only_setup()
+    acts = torch.from_numpy(fx[f"{tag}_actions"].astype(np.int64))
+    out = orc.rollout_cvrp(P, cfg, xy, dem, M, starts=acts[0, :, 1], forced=acts, keep_parts=True, keep_probs=True,
+                           local_only=True)
+    ref_logits = fx[f"{tag}_logits"]
+    assert len(out["parts"]) == ref_logits.shape[0]
+    worst = 0.0
+    for i in range(ref_logits.shape[0]):
+        open_ = np.isfinite(ref_logits[i])
+        got = cfg.logit_clipping * np.tanh(out["parts"][i]["s"].numpy())
+        e = logit_errors(got, ref_logits[i], open_, cfg.logit_clipping)
+        worst = max(worst, e)
+        assert e <= LOGIT_RTOL, (i, e)
+        assert np.array_equal(np.isfinite(out["full_probs"][i].log().numpy()), open_)       # same mask
+    np.testing.assert_allclose(out["reward"].numpy(), fx[f"{tag}_reward"], rtol=1e-5)
+    if tag == "greedy":
+        free = orc.rollout_cvrp(P, cfg, xy, dem, M, starts=acts[0, :, 1], local_only=True)
+        assert torch.equal(free["actions"], acts)
+    else:
+        np.testing.assert_allclose(out["probs"].numpy(), fx["sample_probs"], rtol=5e-4, atol=1e-9)
+    print("local-only", tag, f"worst logit error {worst:.2e}")
+
+
+@pytest.mark.parametrize("problem", ["cvrp", "tsp"])
+def test_oracle_euclidean_local_features(problem):
+    """model_params['euclidean'] = True (reference models.py:95-125, TSP/models.py:67-75): local-policy output, score before
+    the clip and logits at teacher-forced steps."""
+    lg = gu.load_golden(f"r02_{problem}_euclidean.npz")
+    fx = gu.load_golden(f"{problem}_rollout_n20.npz")
+    acts = torch.from_numpy(fx["actions"].astype(np.int64))
+    if problem == "cvrp":
+        cfg, P, xy, dem, B, N, M = _cvrp_setup(fx, torch.float32)
+        cfg.euclidean = True
+        out = orc.rollout_cvrp(P, cfg, xy, dem, M, starts=acts[0, :, 1], forced=acts, keep_parts=True)
+        t0 = 2
+    else:
+        cfg, P, xy, B, N, M = _tsp_setup(fx, torch.float32)
+        cfg.euclidean = True
+        out = orc.rollout_tsp(P, cfg, xy, M, starts=acts[0, :, 0], forced=acts, keep_parts=True)
+        t0 = 1
+    for i, t in enumerate(lg["steps"]):
+        parts = out["parts"][int(t) - t0]
+        open_ = np.isfinite(lg["logits"][i])
+        s = parts["s"].numpy()
+        for k, g in {"pre_clip": s, "local": parts["u"].numpy(), "logits": cfg.logit_clipping * np.tanh(s)}.items():
+            e = logit_errors(g, lg[k][i], open_, cfg.logit_clipping if k == "logits" else None)
+            assert e <= LOGIT_RTOL, (k, int(t), e)
+    # and it is a different model: the polar features give other local scores
+    cfg.euclidean = False
+    if problem == "cvrp":
+        polar = orc.rollout_cvrp(P, cfg, xy, dem, M, starts=acts[0, :, 1], forced=acts, keep_parts=True)
+    else:
+        polar = orc.rollout_tsp(P, cfg, xy, M, starts=acts[0, :, 0], forced=acts, keep_parts=True)
+    i, t = 1, int(lg["steps"][1])
+    assert np.abs(polar["parts"][t - t0]["u"].numpy() - lg["local"][i]).max() > 1e-2
