@@ -60,7 +60,7 @@ def _one_step(model, policy, state, eval_type):
     if state.selected_count == 0:
         return torch.zeros(B, M, dtype=torch.long, device=dev), torch.ones(B, M, device=dev)
     if state.selected_count == 1:
-        starts = torch.tensor(CVRPModel.draw_starts(env.problem_size, M), device=dev)
+        starts = torch.tensor(model.draw_starts(env.problem_size, M), device=dev)
         return starts[None, :].expand(B, M), torch.ones(B, M, device=dev)
     if torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters()):
         raise RuntimeError("the step-wise protocol is inference-only; train through utils.rollout()")
