@@ -1038,13 +1038,14 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
     _Pragma("unroll") for (int nt = 0; nt < CO_NT; ++nt) {                                                  \
         const int n = 16 * nt + lo_t;                                                                       \
         {   /* one 16-byte load: channels 4 hi .. 4 hi + 3 (the MFMA visits the 16 channels in the order 4 hi + kk) */ \
+            /* rows past N1 re-read row N1 - 1 (finite): their nodes are closed in every mask, so S is replaced by -inf */ \
+            /* and the weight that multiplies the V row is exactly 0 -- no zeroing of the operands needed              */ \
             const float4 k4_ = *reinterpret_cast<const float4*>(gK + (unsigned)(min(n, N1 - 1) * ELG_E + 4 * hi_t));   \
-            const float mk_ = (n < N1) ? 1.f : 0.f;                                                         \
-            kop[nt][0] = k4_.x * mk_; kop[nt][1] = k4_.y * mk_; kop[nt][2] = k4_.z * mk_; kop[nt][3] = k4_.w * mk_; \
+            kop[nt][0] = k4_.x; kop[nt][1] = k4_.y; kop[nt][2] = k4_.z; kop[nt][3] = k4_.w;                 \
         }                                                                                                   \
         _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                                     \
             const int n2 = 16 * nt + 4 * hi_t + v;                                                          \
-            vop[nt][v] = gV[(unsigned)(min(n2, N1 - 1) * ELG_E + lo_t)] * ((n2 < N1) ? 1.f : 0.f);         \
+            vop[nt][v] = gV[(unsigned)(min(n2, N1 - 1) * ELG_E + lo_t)];                                    \
         }                                                                                                   \
     }
     {
@@ -1098,78 +1099,96 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                 // (kop / vop: this head's K_h / V_h operand images, 56 registers, re-read from L2 for every step right
                 // after the owners' phase so the latency hides behind the barrier.  The instance's 103 KB of K / V stay
                 // L2-resident; keeping the images live across the whole step does not fit beside the batched local policy.)
+                // Both trajectory tiles (rt = 0: trajectories 0-15, rt = 1: 16-31) are in flight together so that the VALU of
+                // one hides under the MFMAs of the other (in program order: S(0) | S(1) with exp(0) | O(0) with exp(1) | O(1));
+                // the O accumulators take the unnormalised weights and are scaled by 1 / den once.
+                {
+                    const float cs = 0.25f * 1.4426950408889634f;
+                    float qb[2][4];
+                    uint4 mwords[2];
+                    f32x4c sc[2][CO_NT];
+                    float mx[2], cm[2], den[2] = {0.f, 0.f};
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt) {
-                    if (rt == 1 && !two_rt) break;
-                    const int traj = 16 * rt + lo_t;
-                    const float* qrow = sQ + traj * CO_QP + 16 * wave;
-                    float qb[4];
-                    {
-                        const float4 q4 = *reinterpret_cast<const float4*>(qrow + 4 * hi_t);     // channels 4 hi + kk, as kop
-                        qb[0] = q4.x; qb[1] = q4.y; qb[2] = q4.z; qb[3] = q4.w;
+                    for (int rt = 0; rt < 2; ++rt) {
+                        const int traj = 16 * rt + lo_t;
+                        const float4 q4 = *reinterpret_cast<const float4*>(sQ + traj * CO_QP + 16 * wave + 4 * hi_t);   // channels 4 hi + kk, as kop
+                        qb[rt][0] = q4.x; qb[rt][1] = q4.y; qb[rt][2] = q4.z; qb[rt][3] = q4.w;
+                        // the trajectory's mask as four dwords; this lane's nodes of chunk nt are bits 4 hi .. 4 hi + 3 of the
+                        // chunk's 16-bit slice (nodes past N1 are closed in the mask words themselves)
+                        mwords[rt] = *reinterpret_cast<const uint4*>(sMask + 2 * traj);
+                        mx[rt] = -1e30f;                                // finite floor: a fully closed row gives exp2(-inf) = 0
                     }
-                    // the trajectory's mask as four dwords; this lane's nodes of chunk nt are bits 4 hi .. 4 hi + 3 of the
-                    // chunk's 16-bit slice (nodes past N1 are closed in the mask words themselves)
-                    const uint4 mwords = *reinterpret_cast<const uint4*>(sMask + 2 * traj);
-                    f32x4c sc[CO_NT];
-                    float mx = -1e30f;                                  // finite floor: a fully closed row gives exp2(-inf) = 0
-#pragma unroll
-                    for (int nt = 0; nt < CO_NT; ++nt) {
+                    auto s_tile = [&](int rt, int nt) {                // S^T tile: 4 MFMAs + the mask
                         f32x4c acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kop[nt][kk], qb[kk], acc, 0, 0, 0);
-                        const unsigned dw = (nt >> 1) == 0 ? mwords.x : (nt >> 1) == 1 ? mwords.y : (nt >> 1) == 2 ? mwords.z : mwords.w;
+                        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kop[nt][kk], qb[rt][kk], acc, 0, 0, 0);
+                        const uint4 mw = mwords[rt];
+                        const unsigned dw = (nt >> 1) == 0 ? mw.x : (nt >> 1) == 1 ? mw.y : (nt >> 1) == 2 ? mw.z : mw.w;
                         const unsigned nib = (dw >> (16 * (nt & 1) + 4 * hi_t)) & 0xFu;
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
                             const float x = (nib & (1u << v)) ? ELG_NEG_INF : acc[v];
                             acc[v] = x;
-                            mx = fmaxf(mx, x);
+                            mx[rt] = fmaxf(mx[rt], x);
                         }
-                        sc[nt] = acc;
-                    }
-                    mx = quarters_max(mx);
-                    // softmax of q.k / 4: exp2((s - max) * log2(e) / 4) as one fma + v_exp
-                    const float cs = 0.25f * 1.4426950408889634f, cm = -mx * cs;
-                    float den = 0.f;
-#pragma unroll
-                    for (int nt = 0; nt < CO_NT; ++nt)
+                        sc[rt][nt] = acc;
+                    };
+                    auto e_tile = [&](int rt, int nt) {                // softmax numerators: exp2((s - max) log2(e) / 4), one fma + v_exp
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
-                            const float e = __builtin_amdgcn_exp2f(fmaf(sc[nt][v], cs, cm));
-                            sc[nt][v] = e;
-                            den += e;
+                            const float e = __builtin_amdgcn_exp2f(fmaf(sc[rt][nt][v], cs, cm[rt]));
+                            sc[rt][nt][v] = e;
+                            den[rt] += e;
                         }
-                    den = quarters_sum(den);
-                    const bool live = den > 0.f;                    // a decoding trajectory has an open node
-                    if (TRAIN && A.trLse && hi_t == 0 && live)
-                        A.trLse[((size_t)b * Rcap + (size_t)t * A.M + g_lo + traj) * ELG_H + wave] = __log2f(den) - cm;
-                    const float inv = live ? 1.0f / den : 0.f;
-                    f32x4c o = {0.f, 0.f, 0.f, 0.f}, o2 = {0.f, 0.f, 0.f, 0.f};      // two chains: dependent MFMAs stall
-                    const size_t r = (size_t)t * A.M + g_lo + traj;
+                    };
+                    f32x4c o[2], o2[2];                                // two chains per trajectory tile: dependent MFMAs stall
 #pragma unroll
-                    for (int nt = 0; nt < CO_NT; ++nt) {
+                    for (int rt = 0; rt < 2; ++rt) { o[rt] = f32x4c{0.f, 0.f, 0.f, 0.f}; o2[rt] = f32x4c{0.f, 0.f, 0.f, 0.f}; }
+                    auto o_tile = [&](int rt, int nt) {
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
-                            sc[nt][v] *= inv;
-                            if (v & 1) o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vop[nt][v], sc[nt][v], o2, 0, 0, 0);
-                            else o = __builtin_amdgcn_mfma_f32_16x16x4f32(vop[nt][v], sc[nt][v], o, 0, 0, 0);
+                            if (v & 1) o2[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vop[nt][v], sc[rt][nt][v], o2[rt], 0, 0, 0);
+                            else o[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vop[nt][v], sc[rt][nt][v], o[rt], 0, 0, 0);
                         }
+                    };
+#pragma unroll
+                    for (int nt = 0; nt < CO_NT; ++nt) s_tile(0, nt);
+                    mx[0] = quarters_max(mx[0]);
+                    cm[0] = -mx[0] * cs;
+#pragma unroll
+                    for (int nt = 0; nt < CO_NT; ++nt) { s_tile(1, nt); e_tile(0, nt); }
+                    mx[1] = quarters_max(mx[1]);
+                    cm[1] = -mx[1] * cs;
+#pragma unroll
+                    for (int nt = 0; nt < CO_NT; ++nt) { o_tile(0, nt); e_tile(1, nt); }
+#pragma unroll
+                    for (int nt = 0; nt < CO_NT; ++nt) o_tile(1, nt);
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) {
+                        const int traj = 16 * rt + lo_t;
+                        const float dn = quarters_sum(den[rt]);
+                        const bool live = dn > 0.f;                    // a decoding trajectory has an open node
+                        const size_t r = (size_t)t * A.M + g_lo + traj;
+                        if (TRAIN && A.trLse && hi_t == 0 && live)
+                            A.trLse[((size_t)b * Rcap + r) * ELG_H + wave] = __log2f(dn) - cm[rt];
+                        const float inv = live ? 1.0f / dn : 0.f;
                         if (TRAIN && live && A.trA) {
-                            float* rA = A.trA + (((size_t)b * ELG_H + wave) * Rcap + r) * N1 + 16 * nt + 4 * hi_t;
-                            // (scalar dword stores: rows are only 4-byte aligned, and one unaligned 16-byte store per
-                            // group measured 4 % slower for the whole launch)
 #pragma unroll
-                            for (int v = 0; v < 4; ++v)
-                                if (16 * nt + 4 * hi_t + v < N1) rA[v] = sc[nt][v];
+                            for (int nt = 0; nt < CO_NT; ++nt) {
+                                float* rA = A.trA + (((size_t)b * ELG_H + wave) * Rcap + r) * N1 + 16 * nt + 4 * hi_t;
+                                // (scalar dword stores: rows are only 4-byte aligned, and one unaligned 16-byte store per
+                                // group measured 4 % slower for the whole launch)
+#pragma unroll
+                                for (int v = 0; v < 4; ++v)
+                                    if (16 * nt + 4 * hi_t + v < N1) rA[v] = sc[rt][nt][v] * inv;
+                            }
                         }
+                        const float4 ov = make_float4((o[rt][0] + o2[rt][0]) * inv, (o[rt][1] + o2[rt][1]) * inv,
+                                                      (o[rt][2] + o2[rt][2]) * inv, (o[rt][3] + o2[rt][3]) * inv);
+                        // O^T[d = 4 hi_t + v][traj = lo_t] -> this head's 16 channels of the trajectory's exchange row
+                        *reinterpret_cast<float4*>(sQ + traj * CO_QP + 16 * wave + 4 * hi_t) = ov;
+                        if (TRAIN && live) *reinterpret_cast<float4*>(A.trO + ((size_t)b * Rcap + r) * ELG_E + 16 * wave + 4 * hi_t) = ov;
                     }
-                    o[0] += o2[0]; o[1] += o2[1]; o[2] += o2[2]; o[3] += o2[3];
-                    // O^T[d = 4 hi_t + v][traj = lo_t] -> this head's 16 channels of the trajectory's exchange row
-                    *reinterpret_cast<float4*>(sQ + traj * CO_QP + 16 * wave + 4 * hi_t) = make_float4(o[0], o[1], o[2], o[3]);
-                    if (TRAIN && live)
-                        *reinterpret_cast<float4*>(A.trO + ((size_t)b * Rcap + r) * ELG_E + 16 * wave + 4 * hi_t) =
-                            make_float4(o[0], o[1], o[2], o[3]);
                 }
                 __syncthreads();
                 // =============== pointer (waves 0-5: 7 node tiles x 2 trajectory tiles) || local policy (waves 6, 7) ====
