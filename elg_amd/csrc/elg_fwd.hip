@@ -690,7 +690,7 @@ __device__ __forceinline__ int row16_max_i(int v) {
 template <bool TSP, bool TRAIN>
 __device__ __forceinline__ void co_finish4(const elg_rollout_args& A, int N1, int lane, int wave, int ntraj, int t, int g_lo,
                                            size_t b, size_t Rcap, float* sSc, const unsigned long long* sMask,
-                                           const float* sX, int* sState, int fin_row, int& sel_out, float& p_out) {
+                                           const float* sX, int* sState, int fin_row, int& sel_out, float& p_out, float& ubuf) {
     constexpr int NK = CO_NT;
     const int tq = lane >> 4, lo = lane & 15;
     const int q = 4 * wave + tq;
@@ -770,7 +770,14 @@ __device__ __forceinline__ void co_finish4(const elg_rollout_args& A, int N1, in
         sel = bn;
     } else {
         float uni = 0.f;
-        if (act) uni = A.uniforms ? A.uniforms[bm * A.Tmax + t] : philox_uniform(A.seed, (unsigned)bm, (unsigned)t);
+        if (A.uniforms) {
+            if (act) uni = A.uniforms[bm * A.Tmax + t];
+        } else {
+            // philox_uniform(seed, trajectory, step) as everywhere, but drawn 16 steps at a time: lane lo of the trajectory's
+            // row holds the uniform of step (t & ~15) + lo (one Philox evaluation per 16 steps instead of one per step)
+            if ((t & 15) == 0 || t == (TSP ? 1 : 2)) ubuf = philox_uniform(A.seed, (unsigned)bm, (unsigned)((t & ~15) + lo));
+            uni = __shfl(ubuf, (lane & 48) | (t & 15), ELG_WAVE);
+        }
         const float target = uni * tot;
         float run = 0.f;
         int found = 0x7fffffff, lastpos = -1;
@@ -1079,6 +1086,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
         __syncthreads();
         const int step_cap = TSP ? N1 : 2 * N1 + 2;
         CoRow row;                                                  // batched owners: the row's trajectory (registers)
+        float ubuf = 0.f;                                           // the row's next 16 sampling uniforms, one per lane
         row.cur = 0; row.first = 0; row.cnt = 0; row.fin = (4 * wave + (lane >> 4) < ntraj) ? 0 : 1;
         row.load = 1.0f; row.len = 0.f; row.cx = 0.f; row.cy = 0.f; row.v0 = 0ull; row.v1 = 0ull;
         float kop[CO_NT][4], vop[CO_NT][4];                         // (re)loaded at the end of every owners' phase
@@ -1226,7 +1234,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
             float pr = 1.0f;
             if (decode_step) {
                 co_finish4<TSP, TRAIN>(A, N1, lane_t, wave, ntraj, t, g_lo, (size_t)b, Rcap, sSc, sMask, sX, sState,
-                                       q4 < ntraj ? row.fin : 1, sel, pr);
+                                       q4 < ntraj ? row.fin : 1, sel, pr, ubuf);
             } else if (A.mode == ELG_MODE_FORCED) {
                 sel = (A.forced && t < A.Tforced) ? A.forced[bm4 * A.Tforced + t] : 0;
             } else {
