@@ -188,3 +188,31 @@ def test_many_workgroups_32_trajectory_configuration(problem, N, B, M):
     assert np.quantile(err, 0.999) < PROB_RTOL
     assert err.max() <= max(PROB_RTOL, 4.0 * err32.max()), (err.max(), err32.max())
     np.testing.assert_allclose(res.reward[:2].cpu().numpy(), o64["reward"].numpy(), rtol=1e-5)
+
+
+def test_streaming_kernel_needs_its_workspace():
+    """elg_rollout_scratch_floats sizes the workspace of a fused rollout; without it the launch is refused (no silent
+    fallback to another kernel)."""
+    import ctypes as C
+    gc, L, eng = _imports()
+    lib = L.lib()
+    assert lib.elg_rollout_scratch_floats(4, 10, 101, 0) == 0                      # cooperative kernel: none
+    assert lib.elg_rollout_scratch_floats(4, 10, 200, 0) == 4 * 3 * 256 * 128      # fragment-major K / V / PK, 64 NCH = 256 rows
+    assert lib.elg_rollout_scratch_floats(4, 10, 600, 0) == 4 * 3 * 1024 * 128
+    assert lib.elg_rollout_scratch_floats(4, 10, 200, 1) == 0                      # one-wavefront-per-trajectory kernel: none
+    assert lib.elg_rollout_scratch_floats(2, 10, 3001, 0) == 2 * 10 * 3001         # score rows of the N1 > 1024 kernel
+    N, B, M = 150, 1, 4
+    mp, cfg, xy, dem = _cvrp_case(N, B, 5)
+    P = gc.weights("cvrp", 5, mp, 1.0)
+    enc = orc.encoder_forward(P, cfg, xy, dem)
+    prob = gc.make_problem(xy, dem, L.PROBLEM_CVRP)
+    pol = gc.make_policy(P, cfg, enc.to(gc.DEV), L.PROBLEM_CVRP)
+    a = L.RolloutArgs()
+    eng._fill_common(a, prob, pol, M)
+    a.Tmax, a.mode, a.max_steps, a.do_decode, a.do_update, a.use_state = 40, L.MODE_GREEDY, 0, 1, 1, 0
+    starts = torch.arange(1, M + 1, dtype=torch.int32, device=gc.DEV)
+    acts = torch.zeros(B, M, 40, dtype=torch.int32, device=gc.DEV)
+    a.starts, a.actions = eng._ptr(starts), eng._ptr(acts)
+    a.scratch = None
+    rc = lib.elg_rollout_fwd(C.byref(a), eng._stream())
+    assert rc == L.ELG_EINVAL and b"scratch" in lib.elg_last_error()
