@@ -648,10 +648,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int g = grp_start(nt, hi, N1) + v;
         const bool own = g >= 16 * nt + 4 * hi;
         const float x = Kmat[((size_t)b * N1 + g) * ELG_E + h * 16 + lo];
-        sK[e * 64 + lane] = own ? x : 0.f;
+        sK[(nt * 64 + lane) * 4 + v] = own ? x : 0.f;                 // [chunk][lane][k-step]: one ds_read_b128 per chunk
         if (RECOMP) {      // entry (nt, kk): K[node of position lo][4 kk + hi]
             const int g2 = grp_start(nt, lo >> 2, N1) + (lo & 3);
-            sK2[e * 64 + lane] = Kmat[((size_t)b * N1 + g2) * ELG_E + h * 16 + 4 * v + hi];
+            sK2[(nt * 64 + lane) * 4 + v] = Kmat[((size_t)b * N1 + g2) * ELG_E + h * 16 + 4 * v + hi];
         }
     }
     __syncthreads();
@@ -732,12 +732,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         if (RECOMP && has_lse) {
             const float cs = 0.25f * 1.4426950408889634f;
+            // (the K operands of chunk nt + 1 are read from LDS while chunk nt's MFMAs issue: one ds_read_b128 per chunk; with
+            // a scalar LDS read in front of every MFMA this block was half of the kernel's time)
+            float4 kc = *reinterpret_cast<const float4*>(sK2 + lane * 4);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
+                const float4 kn = *reinterpret_cast<const float4*>(sK2 + ((nt + 1 < NT ? nt + 1 : nt) * 64 + lane) * 4);
                 f32x4 S = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-                    S = __builtin_amdgcn_mfma_f32_16x16x4f32(qA[kk], sK2[(nt * 4 + kk) * 64 + lane], S, 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f32_16x16x4f32(qA[0], kc.x, S, 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f32_16x16x4f32(qA[1], kc.y, S, 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f32_16x16x4f32(qA[2], kc.z, S, 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f32_16x16x4f32(qA[3], kc.w, S, 0, 0, 0);
                 const unsigned node = gl[nt];
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
@@ -745,6 +750,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const bool closed = !own_lo[nt] || ((w >> (node & 63u)) & 1ull);
                     a1[nt][v] = closed ? 0.f : __builtin_amdgcn_exp2f(fmaf(S[v], cs, -lsv[v]));
                 }
+                kc = kn;
             }
         } else if (RECOMP) {
             // a_h[row 4 hi + v][position lo] = softmax over the row's open nodes of q_h . K_h[node] / 4
@@ -754,7 +760,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 f32x4 S = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
-                    S = __builtin_amdgcn_mfma_f32_16x16x4f32(qA[kk], sK2[(nt * 4 + kk) * 64 + lane], S, 0, 0, 0);
+                    S = __builtin_amdgcn_mfma_f32_16x16x4f32(qA[kk], sK2[(nt * 64 + lane) * 4 + kk], S, 0, 0, 0);
                 const unsigned node = gl[nt];
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
@@ -814,16 +820,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             wave_lds_fence();
             if (nt > 0) {
                 const float* pb = sTr + ((nt - 1) & 1) * 320;
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    dq = __builtin_amdgcn_mfma_f32_16x16x4f32(sK[((nt - 1) * 4 + v) * 64 + lane], pb[(4 * hi + v) * 20 + lo], dq, 0, 0, 0);
+                const float4 kq = *reinterpret_cast<const float4*>(sK + ((nt - 1) * 64 + lane) * 4);
+                dq = __builtin_amdgcn_mfma_f32_16x16x4f32(kq.x, pb[(4 * hi + 0) * 20 + lo], dq, 0, 0, 0);
+                dq = __builtin_amdgcn_mfma_f32_16x16x4f32(kq.y, pb[(4 * hi + 1) * 20 + lo], dq, 0, 0, 0);
+                dq = __builtin_amdgcn_mfma_f32_16x16x4f32(kq.z, pb[(4 * hi + 2) * 20 + lo], dq, 0, 0, 0);
+                dq = __builtin_amdgcn_mfma_f32_16x16x4f32(kq.w, pb[(4 * hi + 3) * 20 + lo], dq, 0, 0, 0);
             }
         }
         {
             const float* pb = sTr + ((NT - 1) & 1) * 320;
-#pragma unroll
-            for (int v = 0; v < 4; ++v)
-                dq = __builtin_amdgcn_mfma_f32_16x16x4f32(sK[((NT - 1) * 4 + v) * 64 + lane], pb[(4 * hi + v) * 20 + lo], dq, 0, 0, 0);
+            const float4 kq = *reinterpret_cast<const float4*>(sK + ((NT - 1) * 64 + lane) * 4);
+            dq = __builtin_amdgcn_mfma_f32_16x16x4f32(kq.x, pb[(4 * hi + 0) * 20 + lo], dq, 0, 0, 0);
+            dq = __builtin_amdgcn_mfma_f32_16x16x4f32(kq.y, pb[(4 * hi + 1) * 20 + lo], dq, 0, 0, 0);
+            dq = __builtin_amdgcn_mfma_f32_16x16x4f32(kq.z, pb[(4 * hi + 2) * 20 + lo], dq, 0, 0, 0);
+            dq = __builtin_amdgcn_mfma_f32_16x16x4f32(kq.w, pb[(4 * hi + 3) * 20 + lo], dq, 0, 0, 0);
         }
         wave_lds_fence();
         if (SEG && seg.load) {
