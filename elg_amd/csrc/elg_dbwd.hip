@@ -55,7 +55,8 @@ __global__ __launch_bounds__(512) void pointer_bwd_kernel(const PtrBwd a) {
     constexpr int DLP = 16 * NT + 8;                                    // pitch of a dl row in LDS (floats)
     constexpr int OP = 144;                                             // pitch of an O / dO row
     constexpr int NPT = (16 * NT + 31) / 32;                            // nodes per thread and row
-    __shared__ __attribute__((aligned(16))) float sDL[16 * DLP], sO[16 * OP], sDO[16 * OP];
+    constexpr int TPD = 20;                                             // pitch of the transposed dl tile (conflict-free b128 reads)
+    __shared__ __attribute__((aligned(16))) float sDL[16 * DLP], sDLT[16 * NT * TPD], sO[16 * OP], sDO[16 * OP];
     const int tid = threadIdx.x, lane = tid & 63, h = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lo = lane & 15, hi = lane >> 4;
     const int b = blockIdx.y, N1 = a.N1;
@@ -102,7 +103,11 @@ __global__ __launch_bounds__(512) void pointer_bwd_kernel(const PtrBwd a) {
                 const int n = sl + 32 * k;
                 float v = -rw.x * pc[k];
                 if (n == sel) v += rw.y;
-                if (n < 16 * NT) sDL[srow * DLP + n] = n < N1 ? v : 0.f;
+                if (n < 16 * NT) {
+                    const float x = n < N1 ? v : 0.f;
+                    sDL[srow * DLP + n] = x;                            // [row][node]: operand of dO^T, column sums
+                    sDLT[n * TPD + srow] = x;                           // [node][row]: operand of dPK (one ds_read_b128 per chunk)
+                }
             }
             *reinterpret_cast<float4*>(sO + srow * OP + 4 * sl) = o4;
         }
@@ -135,12 +140,20 @@ __global__ __launch_bounds__(512) void pointer_bwd_kernel(const PtrBwd a) {
         }
         *reinterpret_cast<float4*>(sDO + lo * OP + h * 16 + 4 * hi) = make_float4(dot[0], dot[1], dot[2], dot[3]);
         // dPK[n][d] += sum_row dl[row][n] O[row][d]   (D: lane holds node 16 nt + 4 hi + i, d = lo)
+        // (k-slot (step j, group hi) stands for row 4 hi + j in both operands: a lane's four steps of a chunk are contiguous in
+        // the transposed tile)
+        {
+            float ov[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float ov = sO[(4 * j + hi) * OP + h * 16 + lo];
+            for (int j = 0; j < 4; ++j) ov[j] = sO[(4 * hi + j) * OP + h * 16 + lo];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                dpk[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(sDL[(4 * j + hi) * DLP + 16 * nt + lo], ov, dpk[nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 dT = *reinterpret_cast<const float4*>(sDLT + (16 * nt + lo) * TPD + 4 * hi);
+                dpk[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dT.x, ov[0], dpk[nt], 0, 0, 0);
+                dpk[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dT.y, ov[1], dpk[nt], 0, 0, 0);
+                dpk[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dT.z, ov[2], dpk[nt], 0, 0, 0);
+                dpk[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dT.w, ov[3], dpk[nt], 0, 0, 0);
+            }
         }
         __syncthreads();
         if (r0 + srow < R)
