@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void row_weights_kernel(const PtrBwd a) {
 // of the dl tile (32 threads per row) and one 16-byte piece of the O tile; the next tile's values are fetched into
 // registers before the current tile's MFMAs.
 template <int NT>
-__global__ __launch_bounds__(512) void pointer_bwd_kernel(const PtrBwd a) {
+__global__ __launch_bounds__(512, 4) void pointer_bwd_kernel(const PtrBwd a) {
     constexpr int DLP = 16 * NT + 8;                                    // pitch of a dl row in LDS (floats)
     constexpr int OP = 144;                                             // pitch of an O / dO row
     constexpr int NPT = (16 * NT + 31) / 32;                            // nodes per thread and row
