@@ -1060,8 +1060,14 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
         // too, the batched local policy no longer fits the 256-VGPR budget of 2 waves/SIMD
         const int np = 16 * wave + lo;
         const float* gP = A.PK + b * NE + (size_t)min(np, N1 - 1) * ELG_E;
+        // [tile][channel group g][lane][j] = PK[16 tile + lo][16 g + 4 hi + j]: the four k-steps of a channel group are one
+        // ds_read_b128 (k-slot (g, j, hi) stands for channel 16 g + 4 hi + j in both operands)
         if (wave < CO_NT)
-            for (int s4 = 0; s4 < 32; ++s4) sP[(wave * 32 + s4) * 64 + lane] = (np < N1) ? gP[4 * s4 + hi] : 0.f;
+            for (int g = 0; g < 8; ++g) {
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (np < N1) x = *reinterpret_cast<const float4*>(gP + 16 * g + 4 * hi);
+                *reinterpret_cast<float4*>(sP + ((wave * 8 + g) * 64 + lane) * 4) = x;
+            }
     }
     for (int i = tid; i < 16 * CO_NT; i += 512) sPb[i] = (i < N1) ? I.pb[i] : 0.f;
     __syncthreads();
@@ -1205,14 +1211,18 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                     for (int un = wave; un < (two_rt ? 2 * CO_NT : CO_NT); un += 6) {
                         const int nt = un % CO_NT, rt = un / CO_NT;
                         const int traj = 16 * rt + lo_t;
-                        const float* orow = sQ + traj * CO_QP + hi_t;
-                        const float* pop = sP + nt * 32 * 64 + lane_t;
+                        const float* orow = sQ + traj * CO_QP + 4 * hi_t;
+                        const float* pop = sP + (nt * 8 * 64 + lane_t) * 4;
                         const float4 pb4 = *reinterpret_cast<const float4*>(sPb + 16 * nt + 4 * hi_t);
                         f32x4c a0 = {pb4.x, pb4.y, pb4.z, pb4.w}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int s4 = 0; s4 < 32; s4 += 2) {
-                            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pop[s4 * 64], orow[4 * s4], a0, 0, 0, 0);
-                            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pop[(s4 + 1) * 64], orow[4 * s4 + 4], a1, 0, 0, 0);
+                        for (int g = 0; g < 8; ++g) {
+                            const float4 pk4 = *reinterpret_cast<const float4*>(pop + g * 256);
+                            const float4 ov = *reinterpret_cast<const float4*>(orow + 16 * g);
+                            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pk4.x, ov.x, a0, 0, 0, 0);
+                            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pk4.y, ov.y, a1, 0, 0, 0);
+                            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pk4.z, ov.z, a0, 0, 0, 0);
+                            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pk4.w, ov.w, a1, 0, 0, 0);
                         }
                         *reinterpret_cast<float4*>(sSc + traj * CO_SP + 16 * nt + 4 * hi_t) =
                             make_float4(a0[0] + a1[0], a0[1] + a1[1], a0[2] + a1[2], a0[3] + a1[3]);
