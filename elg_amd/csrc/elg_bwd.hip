@@ -792,8 +792,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // <dO_h, O_h> per row: partial over this lane's 4 channels, summed over the 4 lane groups
         float doto = doA[0] * oA[0];
         doto = fmaf(doA[1], oA[1], doto); doto = fmaf(doA[2], oA[2], doto); doto = fmaf(doA[3], oA[3], doto);
-        doto += shfl_xor(doto, 16);
-        doto += shfl_xor(doto, 32);                                // row lo, in every lane
+        doto = quarters_sum(doto);                                // row lo, in every lane
         float dv[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) dv[v] = __shfl(doto, 4 * hi + v);   // row 4 hi + v

@@ -453,8 +453,7 @@ __global__ __launch_bounds__(256) void enc_attn_fwd_kernel(const float* __restri
             }
             S[c] = s;
         }
-        cmax = fmaxf(cmax, shfl_xor(cmax, 16));
-        cmax = fmaxf(cmax, shfl_xor(cmax, 32));
+        cmax = quarters_max(cmax);
         const float mn = fmaxf(m, cmax);
         const float sc = __expf(m - mn);                 // 0 on the first chunk (m = -inf)
         m = mn;
@@ -470,8 +469,7 @@ __global__ __launch_bounds__(256) void enc_attn_fwd_kernel(const float* __restri
                 o = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c][i], p, o, 0, 0, 0);
             }
     }
-    l += shfl_xor(l, 16);
-    l += shfl_xor(l, 32);
+    l = quarters_sum(l);
     const float inv = 1.0f / l;
     const int row = row0 + lo;
     if (row < N1) {
@@ -681,8 +679,8 @@ __global__ __launch_bounds__(256) void enc_dw_kernel(const DwBatch bt) {
                 atomicAdd(dW + (size_t)(m0 + 2 * row + a) * ldw + n0 + 2 * li + b, acc[a][b][r] * alpha);
             }
     if (db && nt == 0 && (wave & 1) == 0) {
-        bsum0 += shfl_xor(bsum0, 32);
-        bsum1 += shfl_xor(bsum1, 32);
+        bsum0 = x32_sum(bsum0);
+        bsum1 = x32_sum(bsum1);
         if (kq == 0) { atomicAdd(db + m0 + 2 * li, bsum0); atomicAdd(db + m0 + 2 * li + 1, bsum1); }
     }
 }

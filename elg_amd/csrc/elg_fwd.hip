@@ -561,8 +561,7 @@ __device__ __forceinline__ void co_local16(const float* __restrict__ sT, const f
                     al[hh][jt][v] = sc;
                     mx = fmaxf(mx, sc);
                 }
-            mx = fmaxf(mx, shfl_xor(mx, 16));
-            mx = fmaxf(mx, shfl_xor(mx, 32));
+            mx = quarters_max(mx);
             float den = 0.f;
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt)
@@ -572,8 +571,7 @@ __device__ __forceinline__ void co_local16(const float* __restrict__ sT, const f
                     al[hh][jt][v] = e;
                     den += e;
                 }
-            den += shfl_xor(den, 16);
-            den += shfl_xor(den, 32);
+            den = quarters_sum(den);
             float fk[3] = {0.f, 0.f, 0.f};
             const float rden = den > 0.f ? 1.0f / den : 0.f;        // one IEEE division per head instead of twelve
 #pragma unroll
@@ -587,8 +585,7 @@ __device__ __forceinline__ void co_local16(const float* __restrict__ sT, const f
                 }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                fk[k] += shfl_xor(fk[k], 16);
-                fk[k] += shfl_xor(fk[k], 32);
+                fk[k] = quarters_sum(fk[k]);
                 F[hh][k] = fk[k];
             }
         }
@@ -629,7 +626,7 @@ __device__ __forceinline__ void co_local16(const float* __restrict__ sT, const f
             for (int k = 0; k < 3; ++k) w[k] = fmaf(acc[v], sT[CL_LWE + 3 * (16 * dq + 4 * hi + v) + k], w[k]);
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { w[k] += shfl_xor(w[k], 16); w[k] += shfl_xor(w[k], 32); }
+    for (int k = 0; k < 3; ++k) { w[k] = quarters_sum(w[k]); }
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt) {
         f32x4c acc = z4;
@@ -1329,7 +1326,7 @@ __device__ __forceinline__ void glimpse_tile(const float* __restrict__ sK, const
     for (int k = 1; k < NGT; ++k) mb = fmaxf(mb, sc[k]);
     mb = fmaxf(mb, quad_xor1(mb));
     mb = fmaxf(mb, quad_xor2(mb));
-    mb = fmaxf(mb, shfl_xor(mb, 32));
+    mb = x32_max(mb);
     const float m_new = fmaxf(m_run, mb);
     const bool live = m_new > ELG_NEG_INF;
     const float scale = (live && m_run > ELG_NEG_INF) ? __expf(m_run - m_new) : 0.f;
@@ -2003,11 +2000,11 @@ __global__ __launch_bounds__(512) void rollout_fwd_xl_kernel(const elg_rollout_a
                 }
                 if (dec) {
                     float l = l_run;
-                    l += quad_xor1(l); l += quad_xor2(l); l += shfl_xor(l, 32);
+                    l += quad_xor1(l); l += quad_xor2(l); l = x32_sum(l);
                     const float inv = 1.0f / l;
                     float4 o4 = make_float4(acc01.x, acc01.y, acc23.x, acc23.y);
-                    o4.x += shfl_xor(o4.x, 32); o4.y += shfl_xor(o4.y, 32);
-                    o4.z += shfl_xor(o4.z, 32); o4.w += shfl_xor(o4.w, 32);
+                    o4.x = x32_sum(o4.x); o4.y = x32_sum(o4.y);
+                    o4.z = x32_sum(o4.z); o4.w = x32_sum(o4.w);
                     o4.x *= inv; o4.y *= inv; o4.z *= inv; o4.w *= inv;
                     if (lane < 32) *reinterpret_cast<float4*>(so + 4 * lane) = o4;
                 }

@@ -168,8 +168,7 @@ __global__ __launch_bounds__(256) void local_bwd_rows_kernel(const float* __rest
                     al[h][jt][v] = s;
                     mx = fmaxf(mx, s);
                 }
-            mx = fmaxf(mx, shfl_xor(mx, 16));
-            mx = fmaxf(mx, shfl_xor(mx, 32));
+            mx = quarters_max(mx);
             float den = 0.f;
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt)
@@ -179,8 +178,7 @@ __global__ __launch_bounds__(256) void local_bwd_rows_kernel(const float* __rest
                     al[h][jt][v] = e;
                     den += e;
                 }
-            den += shfl_xor(den, 16);
-            den += shfl_xor(den, 32);
+            den = quarters_sum(den);
             const float inv = den > 0.f ? 1.0f / den : 0.f;
             float fk[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -194,8 +192,7 @@ __global__ __launch_bounds__(256) void local_bwd_rows_kernel(const float* __rest
                 }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                fk[k] += shfl_xor(fk[k], 16);
-                fk[k] += shfl_xor(fk[k], 32);
+                fk[k] = quarters_sum(fk[k]);
                 F[h][k] = fk[k];
             }
         }
@@ -207,7 +204,7 @@ __global__ __launch_bounds__(256) void local_bwd_rows_kernel(const float* __rest
 #pragma unroll
                 for (int k = 0; k < 3; ++k) dw[k] = fmaf(du1[jt][v], f1[k][jt][v], dw[k]);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { dw[k] += shfl_xor(dw[k], 16); dw[k] += shfl_xor(dw[k], 32); }
+        for (int k = 0; k < 3; ++k) { dw[k] = quarters_sum(dw[k]); }
 
         const bool up = hi >= 2;                                 // rows 4 hi + v of a d-tile belong to head 2 dt + up
         f32x4 o1[2], g1[2], dg1[2], do1[2];
@@ -278,7 +275,7 @@ __global__ __launch_bounds__(256) void local_bwd_rows_kernel(const float* __rest
                 float part = 0.f;
 #pragma unroll
                 for (int v = 0; v < 4; ++v) part = fmaf(do1[dt][v], sT[S_LAV + 3 * (16 * dt + 4 * hi + v) + k], part);
-                part += shfl_xor(part, 16);                      // the two hi groups of one head
+                part = x16_sum(part);                      // the two hi groups of one head
                 dF[2 * dt][k] = __shfl(part, lo, ELG_WAVE);       // held by hi = 0, 1
                 dF[2 * dt + 1][k] = __shfl(part, lo + 32, ELG_WAVE);   // held by hi = 2, 3
             }
@@ -314,8 +311,7 @@ __global__ __launch_bounds__(256) void local_bwd_rows_kernel(const float* __rest
                 }
                 dal[jt] = acc;
             }
-            ts += shfl_xor(ts, 16);
-            ts += shfl_xor(ts, 32);
+            ts = quarters_sum(ts);
             const bool lane_lo_half = lo < 8;
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt) {
@@ -394,12 +390,12 @@ __global__ __launch_bounds__(256) void local_bwd_rows_kernel(const float* __rest
 #pragma unroll
     for (int h = 0; h < ELG_LH; ++h) {
 #pragma unroll
-        for (int jt = 0; jt < JT; ++jt) { aLt[h][jt] += shfl_xor(aLt[h][jt], 16); aLt[h][jt] += shfl_xor(aLt[h][jt], 32); }
+        for (int jt = 0; jt < JT; ++jt) { aLt[h][jt] = quarters_sum(aLt[h][jt]); }
 #pragma unroll
         for (int k = 0; k < 3; ++k) aLa[h][k] = wave_sum(aLa[h][k]);
     }
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt) { aLbc[dt] += shfl_xor(aLbc[dt], 16); aLbc[dt] += shfl_xor(aLbc[dt], 32); }
+    for (int dt = 0; dt < 2; ++dt) { aLbc[dt] = quarters_sum(aLbc[dt]); }
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
 #pragma unroll

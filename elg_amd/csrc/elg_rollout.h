@@ -244,7 +244,7 @@ __device__ __forceinline__ float reduce_scatter32(float (&c)[32], int lane) {
         const float keep = b0 ? c[1] : c[0], send = b0 ? c[0] : c[1];
         c[0] = keep + quad_xor1(send);
     }
-    return c[0] + shfl_xor(c[0], 32);
+    return x32_sum(c[0]);
 }
 
 // 16 per-lane values -> lane l ends with the wave-wide sum of element (l & 15).
@@ -271,8 +271,7 @@ __device__ __forceinline__ float reduce_scatter16(float (&c)[16], int lane) {
         const float keep = b0 ? c[1] : c[0], send = b0 ? c[0] : c[1];
         c[0] = keep + quad_xor1(send);
     }
-    float r = c[0] + shfl_xor(c[0], 16);
-    return r + shfl_xor(r, 32);
+    return quarters_sum(c[0]);
 }
 
 // Saved intermediates of the local policy for the backward pass.
@@ -457,7 +456,7 @@ __device__ __forceinline__ float4 glimpse(const Inst& I, int N1, int lane, const
         for (int k = 1; k < GB; ++k) mb = fmaxf(mb, sc[k]);
         mb = fmaxf(mb, quad_xor1(mb));
         mb = fmaxf(mb, quad_xor2(mb));
-        mb = fmaxf(mb, shfl_xor(mb, 32));
+        mb = x32_max(mb);
         const float m_new = fmaxf(m_run, mb);
         // m_new == -inf only if every node seen so far is masked (same for all lanes): nothing to add
         const bool live = m_new > ELG_NEG_INF;
@@ -505,11 +504,11 @@ __device__ __forceinline__ float4 glimpse(const Inst& I, int N1, int lane, const
     float l = l_run;
     l += quad_xor1(l);
     l += quad_xor2(l);
-    l += shfl_xor(l, 32);
+    l = x32_sum(l);
     const float inv = 1.0f / l;
     float4 acc = make_float4(acc01.x, acc01.y, acc23.x, acc23.y);
-    acc.x += shfl_xor(acc.x, 32); acc.y += shfl_xor(acc.y, 32);
-    acc.z += shfl_xor(acc.z, 32); acc.w += shfl_xor(acc.w, 32);
+    acc.x = x32_sum(acc.x); acc.y = x32_sum(acc.y);
+    acc.z = x32_sum(acc.z); acc.w = x32_sum(acc.w);
     if (save) {
 #pragma unroll
         for (int k = 0; k < NG; ++k) save->e[k] *= inv;
