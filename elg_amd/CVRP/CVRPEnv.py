@@ -40,6 +40,8 @@ class Step_State:
 
 class CVRPEnv:
     def __init__(self, multi_width, device):
+        self._needs_state = False
+        self._st_store = self._load = self._finished = self._ninf_mask = None
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("elg_amd.CVRPEnv runs on the GPU only (no CPU fallback)")
@@ -140,20 +142,45 @@ class CVRPEnv:
         self.selected_count = 0
         self.current_node = None
         self.selected_node_list = torch.zeros(B, M, 0, dtype=torch.long, device=dev)
-        nw = (N1 + 63) // 64
-        self._st = dict(cur=torch.zeros(B, M, dtype=torch.int32, device=dev),
-                        cnt=torch.zeros(B, M, dtype=torch.int32, device=dev),
-                        fin=torch.zeros(B, M, dtype=torch.int32, device=dev),
-                        first=torch.zeros(B, M, dtype=torch.int32, device=dev),
-                        load=torch.ones(B, M, dtype=torch.float32, device=dev),
-                        len=torch.zeros(B, M, dtype=torch.float32, device=dev),
-                        vis=torch.zeros(B, M, nw, dtype=torch.int64, device=dev))
-        self.load = self._st["load"]
-        self.finished = torch.zeros(B, M, dtype=torch.bool, device=dev)
-        self.ninf_mask = torch.zeros(B, M, N1, device=dev)
+        # the step-wise protocol's device state (load / finished / ninf_mask / kernel state words) is built on first use:
+        # the fused rollout (utils.rollout) never reads it, and ten small fills per reset are 1 % of a training step
+        self._st_store = self._load = self._finished = self._ninf_mask = None
+        self._needs_state = True
         if self.reset_state.dist is None:
             _ = self.dist
         return self.reset_state, None, False
+
+    def _ensure_state(self):
+        if self._needs_state:
+            self._needs_state = False
+            B, M, N1 = self.batch_size, self.multi_width, self.problem_size + 1
+            dev = self.device
+            nw = (N1 + 63) // 64
+            self._st_store = dict(cur=torch.zeros(B, M, dtype=torch.int32, device=dev),
+                                  cnt=torch.zeros(B, M, dtype=torch.int32, device=dev),
+                                  fin=torch.zeros(B, M, dtype=torch.int32, device=dev),
+                                  first=torch.zeros(B, M, dtype=torch.int32, device=dev),
+                                  load=torch.ones(B, M, dtype=torch.float32, device=dev),
+                                  len=torch.zeros(B, M, dtype=torch.float32, device=dev),
+                                  vis=torch.zeros(B, M, nw, dtype=torch.int64, device=dev))
+            self._load = self._st_store["load"]
+            self._finished = torch.zeros(B, M, dtype=torch.bool, device=dev)
+            self._ninf_mask = torch.zeros(B, M, N1, device=dev)
+
+    def _lazy(name):                       # noqa: N805  (property factory)
+        def get(self):
+            self._ensure_state()
+            return getattr(self, name)
+
+        def put(self, v):
+            setattr(self, name, v)
+        return property(get, put)
+
+    _st = _lazy("_st_store")
+    load = _lazy("_load")
+    finished = _lazy("_finished")
+    ninf_mask = _lazy("_ninf_mask")
+    del _lazy
 
     def reset_width(self, new_width):
         self.multi_width = new_width

@@ -42,7 +42,8 @@ class TSPEnv:
         self.current_node = None
         self.selected_node_list = None
         self.problem = None
-        self._st = None
+        self._st_store = None
+        self._needs_state = False
         self._dist = None
 
     def _finish_load(self):
@@ -87,17 +88,32 @@ class TSPEnv:
         self.selected_count = 0
         self.current_node = None
         self.selected_node_list = torch.zeros(B, M, 0, dtype=torch.long, device=dev)
-        nw = (N + 63) // 64
-        self._st = dict(cur=torch.zeros(B, M, dtype=torch.int32, device=dev),
-                        cnt=torch.zeros(B, M, dtype=torch.int32, device=dev),
-                        fin=torch.zeros(B, M, dtype=torch.int32, device=dev),
-                        first=torch.zeros(B, M, dtype=torch.int32, device=dev),
-                        load=torch.ones(B, M, dtype=torch.float32, device=dev),
-                        len=torch.zeros(B, M, dtype=torch.float32, device=dev),
-                        vis=torch.zeros(B, M, nw, dtype=torch.int64, device=dev))
+        self._st_store = None                  # kernel state words of the step-wise protocol: built on first use (the fused
+        self._needs_state = True               # rollout never reads them)
         self.step_state = Step_State(BATCH_IDX=self.BATCH_IDX, POMO_IDX=self.POMO_IDX, _env=self)
         self.step_state.ninf_mask = torch.zeros(B, M, N, device=dev)
         return Reset_State(self.problems), None, False
+
+    @property
+    def _st(self):
+        if self._needs_state:
+            self._needs_state = False
+            B, M, N = self.batch_size, self.pomo_size, self.problem_size
+            dev = self.device
+            nw = (N + 63) // 64
+            self._st_store = dict(cur=torch.zeros(B, M, dtype=torch.int32, device=dev),
+                                  cnt=torch.zeros(B, M, dtype=torch.int32, device=dev),
+                                  fin=torch.zeros(B, M, dtype=torch.int32, device=dev),
+                                  first=torch.zeros(B, M, dtype=torch.int32, device=dev),
+                                  load=torch.ones(B, M, dtype=torch.float32, device=dev),
+                                  len=torch.zeros(B, M, dtype=torch.float32, device=dev),
+                                  vis=torch.zeros(B, M, nw, dtype=torch.int64, device=dev))
+        return self._st_store
+
+    @_st.setter
+    def _st(self, v):
+        self._st_store = v
+        self._needs_state = False
 
     def pre_step(self):
         return self.step_state, None, False
