@@ -33,16 +33,24 @@ int launch_status(const char* what);
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 #define ELG_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-constexpr int LP = 33;                       // padded pitch of the 32-wide tables in LDS
+// Table images in LDS.  Every MFMA operand that comes from a table is one ds_read_b128 (four k-steps / four D rows at once):
+// a table is kept row-major ([row][36]) where a lane's four values are consecutive columns, and transposed ([col][52] /
+// [col][36]) where they are consecutive rows.  Pitches 36 and 52 keep the 16 lanes of a b128 group on distinct banks.  (With one
+// wave per SIMD -- 512 registers -- every LDS round trip in front of an MFMA is exposed: scalar operand reads made this kernel
+// latency bound.)
+constexpr int LP = 36;                       // pitch of the row-major 32-wide tables
+constexpr int LQ = 52;                       // pitch of the transposed 48-wide tables
 constexpr int TP = 20;                       // pitch of a transpose tile
-constexpr int S_LCV = 0;                     // [48][33]
-constexpr int S_LPE = S_LCV + 48 * LP;       // [48][33]
-constexpr int S_LWC = S_LPE + 48 * LP;       // [32][33]
-constexpr int S_LT = S_LWC + 32 * LP;        // [48][4]
-constexpr int S_LAV = S_LT + 48 * 4;         // [32][3]
-constexpr int S_LWE = S_LAV + 96;            // [32][3]
-constexpr int S_LBC = S_LWE + 96;            // [32]
-constexpr int S_TABLES = S_LBC + 32;         // = 4640 floats
+constexpr int S_LCV = 0;                     // [48 slots][36]   lcv[j][d]
+constexpr int S_LCVT = S_LCV + 48 * LP;      // [32 d][52]       lcv[j][d] transposed
+constexpr int S_LPET = S_LCVT + 32 * LQ;     // [32 d][52]       lpe[j][d] transposed
+constexpr int S_LWC = S_LPET + 32 * LQ;      // [32][36]         lwc[d'][d]
+constexpr int S_LWCT = S_LWC + 32 * LP;      // [32][36]         lwc transposed
+constexpr int S_LTT = S_LWCT + 32 * LP;      // [4 heads][48]    lt[j][h] transposed
+constexpr int S_LAV = S_LTT + 4 * 48;        // [32][4]          lAv[d][k], k < 3
+constexpr int S_LWE = S_LAV + 32 * 4;        // [32][4]          lWe[d][k], k < 3
+constexpr int S_LBC = S_LWE + 32 * 4;        // [32]
+constexpr int S_TABLES = S_LBC + 32;         // = 7840 floats
 constexpr int S_TR = 16 * TP;                // one transpose tile (320 floats)
 constexpr int NTRB = 4;                      // transpose buffers per wave
 
@@ -71,12 +79,22 @@ __global__ __launch_bounds__(256) void local_bwd_rows_kernel(const float* __rest
     // ---- stage the tables (padded pitches) and clear the accumulators
     for (int i = tid; i < 48 * 32; i += 256) {
         const int j = i >> 5, d = i & 31;
-        sT[S_LCV + j * LP + d] = loc[ELG_LOC_LCV + i];
-        sT[S_LPE + j * LP + d] = loc[ELG_LOC_LPE + i];
+        const float cv = loc[ELG_LOC_LCV + i];
+        sT[S_LCV + j * LP + d] = cv;
+        sT[S_LCVT + d * LQ + j] = cv;
+        sT[S_LPET + d * LQ + j] = loc[ELG_LOC_LPE + i];
     }
-    for (int i = tid; i < 32 * 32; i += 256) sT[S_LWC + (i >> 5) * LP + (i & 31)] = loc[ELG_LOC_LWC + i];
-    for (int i = tid; i < 48 * 4; i += 256) sT[S_LT + i] = loc[ELG_LOC_LT + i];
-    for (int i = tid; i < 96; i += 256) { sT[S_LAV + i] = loc[ELG_LOC_LAV + i]; sT[S_LWE + i] = loc[ELG_LOC_LWE + i]; }
+    for (int i = tid; i < 32 * 32; i += 256) {
+        const float wv = loc[ELG_LOC_LWC + i];
+        sT[S_LWC + (i >> 5) * LP + (i & 31)] = wv;
+        sT[S_LWCT + (i & 31) * LP + (i >> 5)] = wv;
+    }
+    for (int i = tid; i < 48 * 4; i += 256) sT[S_LTT + (i & 3) * 48 + (i >> 2)] = loc[ELG_LOC_LT + i];
+    for (int i = tid; i < 128; i += 256) {
+        const int d = i >> 2, k = i & 3;
+        sT[S_LAV + i] = k < 3 ? loc[ELG_LOC_LAV + 3 * d + k] : 0.f;
+        sT[S_LWE + i] = k < 3 ? loc[ELG_LOC_LWE + 3 * d + k] : 0.f;
+    }
     for (int i = tid; i < 32; i += 256) sT[S_LBC + i] = loc[ELG_LOC_LBC + i];
     for (int i = tid; i < ELG_LOC_SIZE; i += 256) sAcc[i] = 0.f;
     float la[ELG_LH][3];                                         // uniform
@@ -157,10 +175,12 @@ __global__ __launch_bounds__(256) void local_bwd_rows_kernel(const float* __rest
         for (int h = 0; h < ELG_LH; ++h) {
             float mx = ELG_NEG_INF;
 #pragma unroll
-            for (int jt = 0; jt < JT; ++jt)
+            for (int jt = 0; jt < JT; ++jt) {
+                const float4 lt4 = *reinterpret_cast<const float4*>(sT + S_LTT + h * 48 + 16 * jt + 4 * hi);
+                const float ltv[4] = {lt4.x, lt4.y, lt4.z, lt4.w};
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    float s = sT[S_LT + (16 * jt + 4 * hi + v) * 4 + h];
+                    float s = ltv[v];
                     s = fmaf(la[h][0], f1[0][jt][v], s);
                     s = fmaf(la[h][1], f1[1][jt][v], s);
                     s = fmaf(la[h][2], f1[2][jt][v], s);
@@ -168,6 +188,7 @@ __global__ __launch_bounds__(256) void local_bwd_rows_kernel(const float* __rest
                     al[h][jt][v] = s;
                     mx = fmaxf(mx, s);
                 }
+            }
             mx = quarters_max(mx);
             float den = 0.f;
 #pragma unroll
@@ -212,32 +233,38 @@ __global__ __launch_bounds__(256) void local_bwd_rows_kernel(const float* __rest
         for (int dt = 0; dt < 2; ++dt) {
             f32x4 Pa = z4, Pb = z4;
 #pragma unroll
-            for (int jt = 0; jt < JT; ++jt)
+            for (int jt = 0; jt < JT; ++jt) {
+                const float4 a4 = *reinterpret_cast<const float4*>(sT + S_LCVT + (16 * dt + lo) * LQ + 16 * jt + 4 * hi);
+                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    const float a = sT[S_LCV + (16 * jt + 4 * hi + v) * LP + 16 * dt + lo];
-                    Pa = ELG_MFMA(a, al[2 * dt][jt][v], Pa);
-                    Pb = ELG_MFMA(a, al[2 * dt + 1][jt][v], Pb);
+                    Pa = ELG_MFMA(av[v], al[2 * dt][jt][v], Pa);
+                    Pb = ELG_MFMA(av[v], al[2 * dt + 1][jt][v], Pb);
                 }
+            }
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int d = 16 * dt + 4 * hi + v;
                 float x = up ? Pb[v] : Pa[v];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) x = fmaf(sT[S_LAV + 3 * d + k], up ? F[2 * dt + 1][k] : F[2 * dt][k], x);
+                const float4 lav = *reinterpret_cast<const float4*>(sT + S_LAV + 4 * d);
+                x = fmaf(lav.x, up ? F[2 * dt + 1][0] : F[2 * dt][0], x);
+                x = fmaf(lav.y, up ? F[2 * dt + 1][1] : F[2 * dt][1], x);
+                x = fmaf(lav.z, up ? F[2 * dt + 1][2] : F[2 * dt][2], x);
                 o1[dt][v] = x;
             }
         }
 #pragma unroll
         for (int dq = 0; dq < 2; ++dq) {                         // g'[d'] tile dq
-            f32x4 acc;
+            const float4 bc4 = *reinterpret_cast<const float4*>(sT + S_LBC + 16 * dq + 4 * hi);
+            f32x4 acc = {bc4.x, bc4.y, bc4.z, bc4.w};
 #pragma unroll
-            for (int v = 0; v < 4; ++v) acc[v] = sT[S_LBC + 16 * dq + 4 * hi + v];
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    acc = ELG_MFMA(sT[S_LWC + (16 * dq + lo) * LP + 16 * dt + 4 * hi + v], o1[dt][v], acc);
+            for (int dt = 0; dt < 2; ++dt) {
+                const float4 w4 = *reinterpret_cast<const float4*>(sT + S_LWC + (16 * dq + lo) * LP + 16 * dt + 4 * hi);
+                acc = ELG_MFMA(w4.x, o1[dt][0], acc);
+                acc = ELG_MFMA(w4.y, o1[dt][1], acc);
+                acc = ELG_MFMA(w4.z, o1[dt][2], acc);
+                acc = ELG_MFMA(w4.w, o1[dt][3], acc);
+            }
             g1[dq] = acc;
         }
         // ---- backward chain (L1)
@@ -245,15 +272,19 @@ __global__ __launch_bounds__(256) void local_bwd_rows_kernel(const float* __rest
         for (int dt = 0; dt < 2; ++dt) {
             f32x4 acc = z4;
 #pragma unroll
-            for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    acc = ELG_MFMA(sT[S_LPE + (16 * jt + 4 * hi + v) * LP + 16 * dt + lo], du1[jt][v], acc);
+            for (int jt = 0; jt < JT; ++jt) {
+                const float4 p4 = *reinterpret_cast<const float4*>(sT + S_LPET + (16 * dt + lo) * LQ + 16 * jt + 4 * hi);
+                acc = ELG_MFMA(p4.x, du1[jt][0], acc);
+                acc = ELG_MFMA(p4.y, du1[jt][1], acc);
+                acc = ELG_MFMA(p4.z, du1[jt][2], acc);
+                acc = ELG_MFMA(p4.w, du1[jt][3], acc);
+            }
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int d = 16 * dt + 4 * hi + v;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) acc[v] = fmaf(sT[S_LWE + 3 * d + k], dw[k], acc[v]);
+                const float4 we = *reinterpret_cast<const float4*>(sT + S_LWE + 4 * (16 * dt + 4 * hi + v));
+                acc[v] = fmaf(we.x, dw[0], acc[v]);
+                acc[v] = fmaf(we.y, dw[1], acc[v]);
+                acc[v] = fmaf(we.z, dw[2], acc[v]);
             }
             dg1[dt] = acc;
         }
@@ -261,24 +292,34 @@ __global__ __launch_bounds__(256) void local_bwd_rows_kernel(const float* __rest
         for (int dt = 0; dt < 2; ++dt) {
             f32x4 acc = z4;
 #pragma unroll
-            for (int dq = 0; dq < 2; ++dq)
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    acc = ELG_MFMA(sT[S_LWC + (16 * dq + 4 * hi + v) * LP + 16 * dt + lo], dg1[dq][v], acc);
+            for (int dq = 0; dq < 2; ++dq) {
+                const float4 w4 = *reinterpret_cast<const float4*>(sT + S_LWCT + (16 * dt + lo) * LP + 16 * dq + 4 * hi);
+                acc = ELG_MFMA(w4.x, dg1[dq][0], acc);
+                acc = ELG_MFMA(w4.y, dg1[dq][1], acc);
+                acc = ELG_MFMA(w4.z, dg1[dq][2], acc);
+                acc = ELG_MFMA(w4.w, dg1[dq][3], acc);
+            }
             do1[dt] = acc;
         }
         float dF[ELG_LH][3];
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+        for (int dt = 0; dt < 2; ++dt) {
+            float lav[4][3];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float4 t4 = *reinterpret_cast<const float4*>(sT + S_LAV + 4 * (16 * dt + 4 * hi + v));
+                lav[v][0] = t4.x; lav[v][1] = t4.y; lav[v][2] = t4.z;
+            }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 float part = 0.f;
 #pragma unroll
-                for (int v = 0; v < 4; ++v) part = fmaf(do1[dt][v], sT[S_LAV + 3 * (16 * dt + 4 * hi + v) + k], part);
+                for (int v = 0; v < 4; ++v) part = fmaf(do1[dt][v], lav[v][k], part);
                 part = x16_sum(part);                      // the two hi groups of one head
                 dF[2 * dt][k] = __shfl(part, lo, ELG_WAVE);       // held by hi = 0, 1
                 dF[2 * dt + 1][k] = __shfl(part, lo + 32, ELG_WAVE);   // held by hi = 2, 3
             }
+        }
         // per head: dalpha, dsc; d la in place; dsc / alpha transposed for d lt / d lcv
         f32x4 o2[2], g2[2], dg2[2], do2[2];
 #pragma unroll
@@ -300,9 +341,13 @@ __global__ __launch_bounds__(256) void local_bwd_rows_kernel(const float* __rest
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt) {
                 f32x4 acc = z4;
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    acc = ELG_MFMA(sT[S_LCV + (16 * jt + lo) * LP + 16 * dt + 4 * hi + v], dob[v], acc);
+                {
+                    const float4 c4 = *reinterpret_cast<const float4*>(sT + S_LCV + (16 * jt + lo) * LP + 16 * dt + 4 * hi);
+                    acc = ELG_MFMA(c4.x, dob[0], acc);
+                    acc = ELG_MFMA(c4.y, dob[1], acc);
+                    acc = ELG_MFMA(c4.z, dob[2], acc);
+                    acc = ELG_MFMA(c4.w, dob[3], acc);
+                }
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
 #pragma unroll
