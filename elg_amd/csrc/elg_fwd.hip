@@ -502,19 +502,32 @@ constexpr int CO_MAXTR = 32;    // trajectories in lockstep per workgroup
 constexpr int CO_XP = 6 * ELG_SLOT_STRIDE;
 constexpr int CO_XF = 0, CO_XS = 3 * ELG_SLOT_STRIDE, CO_XPEN = 4 * ELG_SLOT_STRIDE, CO_XU = 5 * ELG_SLOT_STRIDE;
 // ---- folded local-policy tables staged in LDS with conflict-free pitches (same images as csrc/elg_local.hip)
-constexpr int CL_P = 33;
-constexpr int CL_LCV = 0, CL_LPE = CL_LCV + 48 * CL_P, CL_LWC = CL_LPE + 48 * CL_P, CL_LT = CL_LWC + 32 * CL_P;
-constexpr int CL_LAV = CL_LT + 48 * 4, CL_LWE = CL_LAV + 96, CL_LBC = CL_LWE + 96, CL_SIZE = CL_LBC + 32;
+// Every MFMA operand that comes from a table is one ds_read_b128 (four k-steps at once): lcv is kept transposed ([d][52]: a
+// lane's four values are consecutive slots), lpe / lwc row-major with pitch 36 (consecutive channels), lt transposed per head,
+// lAv / lWe padded to four floats per channel.  Pitches 36 / 52 keep the 16 lanes of a b128 group on distinct banks.
+constexpr int CL_P = 36, CL_Q = 52;
+constexpr int CL_LCVT = 0;                              // [32 d][52]   lcv[j][d] transposed
+constexpr int CL_LPE = CL_LCVT + 32 * CL_Q;             // [48 j][36]
+constexpr int CL_LWC = CL_LPE + 48 * CL_P;              // [32][36]
+constexpr int CL_LTT = CL_LWC + 32 * CL_P;              // [4 heads][48]
+constexpr int CL_LAV = CL_LTT + 4 * 48;                 // [32][4]
+constexpr int CL_LWE = CL_LAV + 32 * 4;                 // [32][4]
+constexpr int CL_LBC = CL_LWE + 32 * 4;                 // [32]
+constexpr int CL_SIZE = CL_LBC + 32;                    // = 5024 floats
 
 __device__ __forceinline__ void co_stage_local(const float* __restrict__ loc, float* sT, int tid, int nthreads) {
     for (int i = tid; i < 48 * 32; i += nthreads) {
         const int j = i >> 5, d = i & 31;
-        sT[CL_LCV + j * CL_P + d] = loc[ELG_LOC_LCV + i];
+        sT[CL_LCVT + d * CL_Q + j] = loc[ELG_LOC_LCV + i];
         sT[CL_LPE + j * CL_P + d] = loc[ELG_LOC_LPE + i];
     }
     for (int i = tid; i < 32 * 32; i += nthreads) sT[CL_LWC + (i >> 5) * CL_P + (i & 31)] = loc[ELG_LOC_LWC + i];
-    for (int i = tid; i < 48 * 4; i += nthreads) sT[CL_LT + i] = loc[ELG_LOC_LT + i];
-    for (int i = tid; i < 96; i += nthreads) { sT[CL_LAV + i] = loc[ELG_LOC_LAV + i]; sT[CL_LWE + i] = loc[ELG_LOC_LWE + i]; }
+    for (int i = tid; i < 48 * 4; i += nthreads) sT[CL_LTT + (i & 3) * 48 + (i >> 2)] = loc[ELG_LOC_LT + i];
+    for (int i = tid; i < 128; i += nthreads) {
+        const int d = i >> 2, k = i & 3;
+        sT[CL_LAV + i] = k < 3 ? loc[ELG_LOC_LAV + 3 * d + k] : 0.f;
+        sT[CL_LWE + i] = k < 3 ? loc[ELG_LOC_LWE + 3 * d + k] : 0.f;
+    }
     for (int i = tid; i < 32; i += nthreads) sT[CL_LBC + i] = loc[ELG_LOC_LBC + i];
 }
 
@@ -550,10 +563,12 @@ __device__ __forceinline__ void co_local16(const float* __restrict__ sT, const f
             const int h = 2 * dt + hh;
             float mx = ELG_NEG_INF;
 #pragma unroll
-            for (int jt = 0; jt < JT; ++jt)
+            for (int jt = 0; jt < JT; ++jt) {
+                const float4 lt4 = *reinterpret_cast<const float4*>(sT + CL_LTT + h * 48 + 16 * jt + 4 * hi);
+                const float ltv[4] = {lt4.x, lt4.y, lt4.z, lt4.w};
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    float sc = sT[CL_LT + (16 * jt + 4 * hi + v) * 4 + h];
+                    float sc = ltv[v];
                     sc = fmaf(la[h][0], f1[0][jt][v], sc);
                     sc = fmaf(la[h][1], f1[1][jt][v], sc);
                     sc = fmaf(la[h][2], f1[2][jt][v], sc);
@@ -561,6 +576,7 @@ __device__ __forceinline__ void co_local16(const float* __restrict__ sT, const f
                     al[hh][jt][v] = sc;
                     mx = fmaxf(mx, sc);
                 }
+            }
             mx = quarters_max(mx);
             float den = 0.f;
 #pragma unroll
@@ -591,39 +607,45 @@ __device__ __forceinline__ void co_local16(const float* __restrict__ sT, const f
         }
         f32x4c Pa = z4, Pb = z4;
 #pragma unroll
-        for (int jt = 0; jt < JT; ++jt)
+        for (int jt = 0; jt < JT; ++jt) {
+            const float4 a4 = *reinterpret_cast<const float4*>(sT + CL_LCVT + (16 * dt + lo) * CL_Q + 16 * jt + 4 * hi);
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const float a = sT[CL_LCV + (16 * jt + 4 * hi + v) * CL_P + 16 * dt + lo];
-                Pa = __builtin_amdgcn_mfma_f32_16x16x4f32(a, al[0][jt][v], Pa, 0, 0, 0);
-                Pb = __builtin_amdgcn_mfma_f32_16x16x4f32(a, al[1][jt][v], Pb, 0, 0, 0);
+                Pa = __builtin_amdgcn_mfma_f32_16x16x4f32(av[v], al[0][jt][v], Pa, 0, 0, 0);
+                Pb = __builtin_amdgcn_mfma_f32_16x16x4f32(av[v], al[1][jt][v], Pb, 0, 0, 0);
             }
+        }
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int d = 16 * dt + 4 * hi + v;
             float x = up ? Pb[v] : Pa[v];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) x = fmaf(sT[CL_LAV + 3 * d + k], up ? F[1][k] : F[0][k], x);
+            const float4 lav = *reinterpret_cast<const float4*>(sT + CL_LAV + 4 * d);
+            x = fmaf(lav.x, up ? F[1][0] : F[0][0], x);
+            x = fmaf(lav.y, up ? F[1][1] : F[0][1], x);
+            x = fmaf(lav.z, up ? F[1][2] : F[0][2], x);
             o1[dt][v] = x;
         }
     }
     float w[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int dq = 0; dq < 2; ++dq) {
-        f32x4c acc;
+        const float4 bc4 = *reinterpret_cast<const float4*>(sT + CL_LBC + 16 * dq + 4 * hi);
+        f32x4c acc = {bc4.x, bc4.y, bc4.z, bc4.w};
 #pragma unroll
-        for (int v = 0; v < 4; ++v) acc[v] = sT[CL_LBC + 16 * dq + 4 * hi + v];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int v = 0; v < 4; ++v)
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[CL_LWC + (16 * dq + lo) * CL_P + 16 * dt + 4 * hi + v],
-                                                           o1[dt][v], acc, 0, 0, 0);
+        for (int dt = 0; dt < 2; ++dt) {
+            const float4 w4 = *reinterpret_cast<const float4*>(sT + CL_LWC + (16 * dq + lo) * CL_P + 16 * dt + 4 * hi);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, o1[dt][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, o1[dt][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, o1[dt][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, o1[dt][3], acc, 0, 0, 0);
+        }
         g1[dq] = acc;
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) w[k] = fmaf(acc[v], sT[CL_LWE + 3 * (16 * dq + 4 * hi + v) + k], w[k]);
+        for (int v = 0; v < 4; ++v) {
+            const float4 we = *reinterpret_cast<const float4*>(sT + CL_LWE + 4 * (16 * dq + 4 * hi + v));
+            w[0] = fmaf(acc[v], we.x, w[0]); w[1] = fmaf(acc[v], we.y, w[1]); w[2] = fmaf(acc[v], we.z, w[2]);
+        }
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) { w[k] = quarters_sum(w[k]); }
@@ -631,11 +653,13 @@ __device__ __forceinline__ void co_local16(const float* __restrict__ sT, const f
     for (int jt = 0; jt < JT; ++jt) {
         f32x4c acc = z4;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int v = 0; v < 4; ++v)
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[CL_LPE + (16 * jt + lo) * CL_P + 16 * dt + 4 * hi + v],
-                                                           g1[dt][v], acc, 0, 0, 0);
+        for (int dt = 0; dt < 2; ++dt) {
+            const float4 p4 = *reinterpret_cast<const float4*>(sT + CL_LPE + (16 * jt + lo) * CL_P + 16 * dt + 4 * hi);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p4.x, g1[dt][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p4.y, g1[dt][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p4.z, g1[dt][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p4.w, g1[dt][3], acc, 0, 0, 0);
+        }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float4 t = *reinterpret_cast<const float4*>(X + CO_XF + k * ELG_SLOT_STRIDE + 16 * jt + 4 * hi);
