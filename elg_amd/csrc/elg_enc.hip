@@ -650,11 +650,14 @@ __global__ __launch_bounds__(256) void enc_dw_kernel(const DwBatch bt) {
         AV[u] = a_;                                                                                    \
         BV[u] = *reinterpret_cast<const float2*>(bp + (size_t)rc_ * ldx);                              \
     }
+    float2 an[U], bn[U];
     DW_LOAD(kbeg, av, bv)
+    DW_LOAD(min(kbeg + 2 * U, kend - 1), an, bn)
     for (int k = kbeg; k < kend; k += 2 * U) {
-        float2 an[U], bn[U];
-        const int kn = min(k + 2 * U, kend - 1);       // the last prefetch re-reads in-range rows, unused
-        DW_LOAD(kn, an, bn)
+        // two batches in flight: the batch after next is requested before this one is consumed
+        float2 a2[U], b2[U];
+        const int kn = min(k + 4 * U, kend - 1);       // the last prefetches re-read in-range rows, unused
+        DW_LOAD(kn, a2, b2)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].x, acc[0][0], 0, 0, 0);
@@ -664,7 +667,7 @@ __global__ __launch_bounds__(256) void enc_dw_kernel(const DwBatch bt) {
             bsum0 += av[u].x; bsum1 += av[u].y;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) { av[u] = an[u]; bv[u] = bn[u]; }
+        for (int u = 0; u < U; ++u) { av[u] = an[u]; bv[u] = bn[u]; an[u] = a2[u]; bn[u] = b2[u]; }
     }
 #undef DW_LOAD
     // C/D layout of 32x32: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); tile (a, b) holds
