@@ -22,4 +22,4 @@ for name, fn in (("fwd", lambda: fwd()), ("fwd+bwd", both)):
     e0.record()
     for _ in range(20): fn()
     e1.record(); torch.cuda.synchronize()
-    print(f"{name}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us  (ELG_ENC_DBG={os.environ.get('ELG_ENC_DBG', '0')})")
+    print(f"{name}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us  (B={B})")
