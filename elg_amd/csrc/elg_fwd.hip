@@ -513,7 +513,8 @@ constexpr int CL_LTT = CL_LWC + 32 * CL_P;              // [4 heads][48]
 constexpr int CL_LAV = CL_LTT + 4 * 48;                 // [32][4]
 constexpr int CL_LWE = CL_LAV + 32 * 4;                 // [32][4]
 constexpr int CL_LBC = CL_LWE + 32 * 4;                 // [32]
-constexpr int CL_SIZE = CL_LBC + 32;                    // = 5024 floats
+constexpr int CL_LA = CL_LBC + 32;                      // [4 heads][4]  la[h][k], k < 3
+constexpr int CL_SIZE = CL_LA + 16;                     // = 5040 floats
 
 __device__ __forceinline__ void co_stage_local(const float* __restrict__ loc, float* sT, int tid, int nthreads) {
     for (int i = tid; i < 48 * 32; i += nthreads) {
@@ -529,6 +530,7 @@ __device__ __forceinline__ void co_stage_local(const float* __restrict__ loc, fl
         sT[CL_LWE + i] = k < 3 ? loc[ELG_LOC_LWE + 3 * d + k] : 0.f;
     }
     for (int i = tid; i < 32; i += nthreads) sT[CL_LBC + i] = loc[ELG_LOC_LBC + i];
+    for (int i = tid; i < 16; i += nthreads) sT[CL_LA + i] = (i & 3) < 3 ? loc[ELG_LOC_LA + 3 * (i >> 2) + (i & 3)] : 0.f;
 }
 
 // Local policy of 16 lockstep trajectories at once (models.py:133-166, folded as in elg_rollout.h::local_policy):
@@ -626,6 +628,149 @@ __device__ __forceinline__ void co_local16(const float* __restrict__ sT, const f
             x = fmaf(lav.z, up ? F[1][2] : F[0][2], x);
             o1[dt][v] = x;
         }
+    }
+    float w[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dq = 0; dq < 2; ++dq) {
+        const float4 bc4 = *reinterpret_cast<const float4*>(sT + CL_LBC + 16 * dq + 4 * hi);
+        f32x4c acc = {bc4.x, bc4.y, bc4.z, bc4.w};
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const float4 w4 = *reinterpret_cast<const float4*>(sT + CL_LWC + (16 * dq + lo) * CL_P + 16 * dt + 4 * hi);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, o1[dt][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, o1[dt][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, o1[dt][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, o1[dt][3], acc, 0, 0, 0);
+        }
+        g1[dq] = acc;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float4 we = *reinterpret_cast<const float4*>(sT + CL_LWE + 4 * (16 * dq + 4 * hi + v));
+            w[0] = fmaf(acc[v], we.x, w[0]); w[1] = fmaf(acc[v], we.y, w[1]); w[2] = fmaf(acc[v], we.z, w[2]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { w[k] = quarters_sum(w[k]); }
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        f32x4c acc = z4;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const float4 p4 = *reinterpret_cast<const float4*>(sT + CL_LPE + (16 * jt + lo) * CL_P + 16 * dt + 4 * hi);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p4.x, g1[dt][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p4.y, g1[dt][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p4.z, g1[dt][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p4.w, g1[dt][3], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float4 t = *reinterpret_cast<const float4*>(X + CO_XF + k * ELG_SLOT_STRIDE + 16 * jt + 4 * hi);
+            acc[0] = fmaf(w[k], t.x, acc[0]); acc[1] = fmaf(w[k], t.y, acc[1]);
+            acc[2] = fmaf(w[k], t.z, acc[2]); acc[3] = fmaf(w[k], t.w, acc[3]);
+        }
+        *reinterpret_cast<float4*>(sUrows + lo * upitch + 16 * jt + 4 * hi) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// co_local16 in two stages for the cooperative kernel, where the single-wave chain (~12 K cycles) was the critical path of the
+// pointer phase:
+//   co_local_head   one (head h, 16-trajectory group) unit: attention of head h over the slots and its 8 channels of o'
+//                   (12 MFMAs).  The eight units of a workgroup run on the eight waves at the start of the GLIMPSE phase (each
+//                   wave's own head-glimpse follows; the unit's VALU fills the shadow of those MFMAs), o' goes to LDS.
+//   co_local_tail   g' = Wc o' + bc, w = g' . Lwe, u_j = Lpe_j . g' + w . f_j for one group (40 MFMAs): one wave per group in
+//                   the pointer phase, ~1/3 of the old chain.
+// sO1 layout per group (floats): [dt][lane][4] = o'[16 dt + 4 hi + v][trajectory lo]  (the tail's B operands, one b128 each).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void co_local_head(const float* __restrict__ sT, const float* sXrows, float* sO1, int h, int lo, int hi) {
+    constexpr int JT = 3;
+    const float* X = sXrows + lo * CO_XP;                           // this lane's trajectory
+    const int dt = h >> 1;
+    const f32x4c z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4c f1[3][JT], al[JT];
+    bool msk[JT][4];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        const int4 sl = *reinterpret_cast<const int4*>(X + CO_XS + 16 * jt + 4 * hi);
+        msk[jt][0] = sl.x < 0; msk[jt][1] = sl.y < 0; msk[jt][2] = sl.z < 0; msk[jt][3] = sl.w < 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float4 t = *reinterpret_cast<const float4*>(X + CO_XF + k * ELG_SLOT_STRIDE + 16 * jt + 4 * hi);
+            f1[k][jt] = f32x4c{t.x, t.y, t.z, t.w};
+        }
+    }
+    const float4 la4 = *reinterpret_cast<const float4*>(sT + CL_LA + 4 * h);
+    float mx = ELG_NEG_INF;
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        const float4 lt4 = *reinterpret_cast<const float4*>(sT + CL_LTT + h * 48 + 16 * jt + 4 * hi);
+        const float ltv[4] = {lt4.x, lt4.y, lt4.z, lt4.w};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            float sc = ltv[v];
+            sc = fmaf(la4.x, f1[0][jt][v], sc);
+            sc = fmaf(la4.y, f1[1][jt][v], sc);
+            sc = fmaf(la4.z, f1[2][jt][v], sc);
+            sc = msk[jt][v] ? ELG_NEG_INF : sc;
+            al[jt][v] = sc;
+            mx = fmaxf(mx, sc);
+        }
+    }
+    mx = quarters_max(mx);
+    float den = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float e = msk[jt][v] ? 0.f : __expf(al[jt][v] - mx);
+            al[jt][v] = e;
+            den += e;
+        }
+    den = quarters_sum(den);
+    const float rden = den > 0.f ? 1.0f / den : 0.f;
+    float F[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float a = al[jt][v] * rden;
+            al[jt][v] = a;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) F[k] = fmaf(a, f1[k][jt][v], F[k]);
+        }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) F[k] = quarters_sum(F[k]);
+    f32x4c P = z4;
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        const float4 a4 = *reinterpret_cast<const float4*>(sT + CL_LCVT + (16 * dt + lo) * CL_Q + 16 * jt + 4 * hi);
+        P = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, al[jt][0], P, 0, 0, 0);
+        P = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, al[jt][1], P, 0, 0, 0);
+        P = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, al[jt][2], P, 0, 0, 0);
+        P = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, al[jt][3], P, 0, 0, 0);
+    }
+    // rows 4 hi + v of the 16-channel tile dt: channels 8 (h & 1) .. + 7 belong to this head
+    if ((hi >= 2) == bool(h & 1)) {
+        float x[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float4 lav = *reinterpret_cast<const float4*>(sT + CL_LAV + 4 * (16 * dt + 4 * hi + v));
+            x[v] = fmaf(lav.z, F[2], fmaf(lav.y, F[1], fmaf(lav.x, F[0], P[v])));
+        }
+        *reinterpret_cast<float4*>(sO1 + (dt * 64 + 16 * hi + lo) * 4) = make_float4(x[0], x[1], x[2], x[3]);
+    }
+}
+
+__device__ __forceinline__ void co_local_tail(const float* __restrict__ sT, const float* sXrows, const float* sO1, float* sUrows,
+                                              int upitch, int lo, int hi) {
+    constexpr int JT = 3;
+    const float* X = sXrows + lo * CO_XP;
+    const f32x4c z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4c o1[2], g1[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const float4 t = *reinterpret_cast<const float4*>(sO1 + (dt * 64 + 16 * hi + lo) * 4);
+        o1[dt] = f32x4c{t.x, t.y, t.z, t.w};
     }
     float w[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -1033,14 +1178,10 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
     float* sP = sT + CL_SIZE;                                         // [7][32][64] PK operand image
     float* sPb = sP + CO_NT * 32 * 64;                                // [112] pointer bias
     float* sb = sPb + 16 * CO_NT + wave * SbSize<2>::value;
+    float* sO1 = sPb + 16 * CO_NT + 8 * SbSize<2>::value;             // [2 groups][2][64][4] o' of the local policy (head units -> tail)
     if (!TSP)
         for (int i = tid; i < N1; i += 512) sdem[i] = A.demand[(size_t)b * N1 + i];
     for (int i = tid; i < 2 * N1; i += 512) sxy[i] = A.xy[(size_t)b * N1 * 2 + i];
-    float la[ELG_LH][3];
-#pragma unroll
-    for (int h = 0; h < ELG_LH; ++h)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) la[h][k] = A.has_local ? A.loc[ELG_LOC_LA + 3 * h + k] : 0.f;
     if (A.has_local) co_stage_local(A.loc, sT, tid, 512);
 
     Inst I;
@@ -1134,6 +1275,9 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                 // (kop / vop: this head's K_h / V_h operand images, 56 registers, re-read from L2 for every step right
                 // after the owners' phase so the latency hides behind the barrier.  The instance's 103 KB of K / V stay
                 // L2-resident; keeping the images live across the whole step does not fit beside the batched local policy.)
+                // local policy, stage 1: wave w = (group w >> 2, head w & 3) -- independent of the glimpse, under whose MFMAs it runs
+                if (A.has_local && (wave < 4 || two_rt))
+                    co_local_head(sT, sX + (wave >> 2) * 16 * CO_XP, sO1 + (wave >> 2) * 512, wave & 3, lo_t, hi_t);
                 // Both trajectory tiles (rt = 0: trajectories 0-15, rt = 1: 16-31) are in flight together so that the VALU of
                 // one hides under the MFMAs of the other (in program order: S(0) | S(1) with exp(0) | O(0) with exp(1) | O(1));
                 // the O accumulators take the unnormalised weights and are scaled by 1 / den once.
@@ -1249,8 +1393,9 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                             make_float4(a0[0] + a1[0], a0[1] + a1[1], a0[2] + a1[2], a0[3] + a1[3]);
                     }
                 } else if (A.has_local && (wave == 6 || two_rt)) {
-                    // wave 6: trajectories 0-15, wave 7: trajectories 16-31
-                    co_local16(sT, la, sX + (wave - 6) * 16 * CO_XP, sX + (wave - 6) * 16 * CO_XP + CO_XU, CO_XP, lo_t, hi_t);
+                    // local policy, stage 2: wave 6: trajectories 0-15, wave 7: trajectories 16-31
+                    co_local_tail(sT, sX + (wave - 6) * 16 * CO_XP, sO1 + (wave - 6) * 512, sX + (wave - 6) * 16 * CO_XP + CO_XU, CO_XP,
+                                  lo_t, hi_t);
                 }
                 __syncthreads();
             }
@@ -1297,7 +1442,7 @@ template <bool TSP, bool TRAIN>
 static int launch_fwd_coop(const elg_rollout_args& A, hipStream_t stream) {
     const size_t lds = ((size_t)CO_MAXTR * CO_QP + (size_t)CO_MAXTR * CO_SP + 4 * CO_MAXTR + 16 * CO_MAXTR +
                         ((A.N1 + 3) & ~3) + ((2 * A.N1 + 3) & ~3) + (size_t)CO_MAXTR * CO_XP + CL_SIZE + CO_NT * 32 * 64 + 16 * CO_NT +
-                        8 * SbSize<2>::value) * 4 + 64;
+                        8 * SbSize<2>::value + 2 * 512) * 4 + 64;
     auto kern = rollout_fwd_coop_kernel<TSP, TRAIN>;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
