@@ -675,92 +675,14 @@ __device__ __forceinline__ void co_local16(const float* __restrict__ sT, const f
 // ---------------------------------------------------------------------------------------------------------------------
 // co_local16 in two stages for the cooperative kernel, where the single-wave chain (~12 K cycles) was the critical path of the
 // pointer phase:
-//   co_local_head   one (head h, 16-trajectory group) unit: attention of head h over the slots and its 8 channels of o'
-//                   (12 MFMAs).  The eight units of a workgroup run on the eight waves at the start of the GLIMPSE phase (each
-//                   wave's own head-glimpse follows; the unit's VALU fills the shadow of those MFMAs), o' goes to LDS.
+//   head units      one (head h, 16-trajectory group) unit: attention of head h over the slots and its 8 channels of o'
+//                   (12 MFMAs).  The eight units of a workgroup run on the eight waves inside the GLIMPSE phase, their stages
+//                   written between the glimpse's MFMA loops (rollout_fwd_coop_kernel: lh_score / lh_exp / lh_norm / lh_mfma),
+//                   o' goes to LDS.
 //   co_local_tail   g' = Wc o' + bc, w = g' . Lwe, u_j = Lpe_j . g' + w . f_j for one group (40 MFMAs): one wave per group in
 //                   the pointer phase, ~1/3 of the old chain.
 // sO1 layout per group (floats): [dt][lane][4] = o'[16 dt + 4 hi + v][trajectory lo]  (the tail's B operands, one b128 each).
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void co_local_head(const float* __restrict__ sT, const float* sXrows, float* sO1, int h, int lo, int hi) {
-    constexpr int JT = 3;
-    const float* X = sXrows + lo * CO_XP;                           // this lane's trajectory
-    const int dt = h >> 1;
-    const f32x4c z4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4c f1[3][JT], al[JT];
-    bool msk[JT][4];
-#pragma unroll
-    for (int jt = 0; jt < JT; ++jt) {
-        const int4 sl = *reinterpret_cast<const int4*>(X + CO_XS + 16 * jt + 4 * hi);
-        msk[jt][0] = sl.x < 0; msk[jt][1] = sl.y < 0; msk[jt][2] = sl.z < 0; msk[jt][3] = sl.w < 0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float4 t = *reinterpret_cast<const float4*>(X + CO_XF + k * ELG_SLOT_STRIDE + 16 * jt + 4 * hi);
-            f1[k][jt] = f32x4c{t.x, t.y, t.z, t.w};
-        }
-    }
-    const float4 la4 = *reinterpret_cast<const float4*>(sT + CL_LA + 4 * h);
-    float mx = ELG_NEG_INF;
-#pragma unroll
-    for (int jt = 0; jt < JT; ++jt) {
-        const float4 lt4 = *reinterpret_cast<const float4*>(sT + CL_LTT + h * 48 + 16 * jt + 4 * hi);
-        const float ltv[4] = {lt4.x, lt4.y, lt4.z, lt4.w};
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            float sc = ltv[v];
-            sc = fmaf(la4.x, f1[0][jt][v], sc);
-            sc = fmaf(la4.y, f1[1][jt][v], sc);
-            sc = fmaf(la4.z, f1[2][jt][v], sc);
-            sc = msk[jt][v] ? ELG_NEG_INF : sc;
-            al[jt][v] = sc;
-            mx = fmaxf(mx, sc);
-        }
-    }
-    mx = quarters_max(mx);
-    float den = 0.f;
-#pragma unroll
-    for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const float e = msk[jt][v] ? 0.f : __expf(al[jt][v] - mx);
-            al[jt][v] = e;
-            den += e;
-        }
-    den = quarters_sum(den);
-    const float rden = den > 0.f ? 1.0f / den : 0.f;
-    float F[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const float a = al[jt][v] * rden;
-            al[jt][v] = a;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) F[k] = fmaf(a, f1[k][jt][v], F[k]);
-        }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) F[k] = quarters_sum(F[k]);
-    f32x4c P = z4;
-#pragma unroll
-    for (int jt = 0; jt < JT; ++jt) {
-        const float4 a4 = *reinterpret_cast<const float4*>(sT + CL_LCVT + (16 * dt + lo) * CL_Q + 16 * jt + 4 * hi);
-        P = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, al[jt][0], P, 0, 0, 0);
-        P = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, al[jt][1], P, 0, 0, 0);
-        P = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, al[jt][2], P, 0, 0, 0);
-        P = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, al[jt][3], P, 0, 0, 0);
-    }
-    // rows 4 hi + v of the 16-channel tile dt: channels 8 (h & 1) .. + 7 belong to this head
-    if ((hi >= 2) == bool(h & 1)) {
-        float x[4];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const float4 lav = *reinterpret_cast<const float4*>(sT + CL_LAV + 4 * (16 * dt + 4 * hi + v));
-            x[v] = fmaf(lav.z, F[2], fmaf(lav.y, F[1], fmaf(lav.x, F[0], P[v])));
-        }
-        *reinterpret_cast<float4*>(sO1 + (dt * 64 + 16 * hi + lo) * 4) = make_float4(x[0], x[1], x[2], x[3]);
-    }
-}
-
 __device__ __forceinline__ void co_local_tail(const float* __restrict__ sT, const float* sXrows, const float* sO1, float* sUrows,
                                               int upitch, int lo, int hi) {
     constexpr int JT = 3;
@@ -1276,8 +1198,63 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                 // after the owners' phase so the latency hides behind the barrier.  The instance's 103 KB of K / V stay
                 // L2-resident; keeping the images live across the whole step does not fit beside the batched local policy.)
                 // local policy, stage 1: wave w = (group w >> 2, head w & 3) -- independent of the glimpse, under whose MFMAs it runs
-                if (A.has_local && (wave < 4 || two_rt))
-                    co_local_head(sT, sX + (wave >> 2) * 16 * CO_XP, sO1 + (wave >> 2) * 512, wave & 3, lo_t, hi_t);
+                // (its five stages are spread over the four MFMA loops of the glimpse below, in program order, so that the scheduler has
+                // independent VALU to put into the MFMA shadows; a wave without a unit -- one trajectory group only -- computes on
+                // its own group's blocks and stores nothing)
+                const bool lh_on = A.has_local && (wave < 4 || two_rt);
+                const int lh_h = wave & 3, lh_dt = lh_h >> 1;
+                const float* LX = sX + ((lh_on ? (wave >> 2) : 0) * 16 + lo_t) * CO_XP;
+                f32x4c lf[3][3], lal[3];
+                bool lmsk[3][4];
+                float lmx = ELG_NEG_INF, lden = 0.f, lF[3] = {0.f, 0.f, 0.f};
+                f32x4c lP = {0.f, 0.f, 0.f, 0.f};
+                const float4 la4 = *reinterpret_cast<const float4*>(sT + CL_LA + 4 * lh_h);
+                auto lh_score = [&](int jt) {
+                    const int4 sl = *reinterpret_cast<const int4*>(LX + CO_XS + 16 * jt + 4 * hi_t);
+                    lmsk[jt][0] = sl.x < 0; lmsk[jt][1] = sl.y < 0; lmsk[jt][2] = sl.z < 0; lmsk[jt][3] = sl.w < 0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float4 tq = *reinterpret_cast<const float4*>(LX + CO_XF + k * ELG_SLOT_STRIDE + 16 * jt + 4 * hi_t);
+                        lf[k][jt] = f32x4c{tq.x, tq.y, tq.z, tq.w};
+                    }
+                    const float4 lt4 = *reinterpret_cast<const float4*>(sT + CL_LTT + lh_h * 48 + 16 * jt + 4 * hi_t);
+                    const float ltv[4] = {lt4.x, lt4.y, lt4.z, lt4.w};
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        float x = ltv[v];
+                        x = fmaf(la4.x, lf[0][jt][v], x);
+                        x = fmaf(la4.y, lf[1][jt][v], x);
+                        x = fmaf(la4.z, lf[2][jt][v], x);
+                        x = lmsk[jt][v] ? ELG_NEG_INF : x;
+                        lal[jt][v] = x;
+                        lmx = fmaxf(lmx, x);
+                    }
+                };
+                auto lh_exp = [&](int jt) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const float e = lmsk[jt][v] ? 0.f : __expf(lal[jt][v] - lmx);
+                        lal[jt][v] = e;
+                        lden += e;
+                    }
+                };
+                float lrden = 0.f;
+                auto lh_norm = [&](int jt) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const float a = lal[jt][v] * lrden;
+                        lal[jt][v] = a;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) lF[k] = fmaf(a, lf[k][jt][v], lF[k]);
+                    }
+                };
+                auto lh_mfma = [&](int jt) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(sT + CL_LCVT + (16 * lh_dt + lo_t) * CL_Q + 16 * jt + 4 * hi_t);
+                    lP = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, lal[jt][0], lP, 0, 0, 0);
+                    lP = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, lal[jt][1], lP, 0, 0, 0);
+                    lP = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, lal[jt][2], lP, 0, 0, 0);
+                    lP = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, lal[jt][3], lP, 0, 0, 0);
+                };
                 // Both trajectory tiles (rt = 0: trajectories 0-15, rt = 1: 16-31) are in flight together so that the VALU of
                 // one hides under the MFMAs of the other (in program order: S(0) | S(1) with exp(0) | O(0) with exp(1) | O(1));
                 // the O accumulators take the unnormalised weights and are scaled by 1 / den once.
@@ -1331,17 +1308,32 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                         }
                     };
 #pragma unroll
-                    for (int nt = 0; nt < CO_NT; ++nt) s_tile(0, nt);
+                    for (int nt = 0; nt < CO_NT; ++nt) { s_tile(0, nt); if (nt < 3) lh_score(nt); }
                     mx[0] = quarters_max(mx[0]);
                     cm[0] = -mx[0] * cs;
+                    lmx = quarters_max(lmx);
 #pragma unroll
-                    for (int nt = 0; nt < CO_NT; ++nt) { s_tile(1, nt); e_tile(0, nt); }
+                    for (int nt = 0; nt < CO_NT; ++nt) { s_tile(1, nt); e_tile(0, nt); if (nt < 3) lh_exp(nt); }
                     mx[1] = quarters_max(mx[1]);
                     cm[1] = -mx[1] * cs;
+                    lden = quarters_sum(lden);
+                    lrden = lden > 0.f ? 1.0f / lden : 0.f;
 #pragma unroll
-                    for (int nt = 0; nt < CO_NT; ++nt) { o_tile(0, nt); e_tile(1, nt); }
+                    for (int nt = 0; nt < CO_NT; ++nt) { o_tile(0, nt); e_tile(1, nt); if (nt < 3) lh_norm(nt); }
 #pragma unroll
-                    for (int nt = 0; nt < CO_NT; ++nt) o_tile(1, nt);
+                    for (int k = 0; k < 3; ++k) lF[k] = quarters_sum(lF[k]);
+#pragma unroll
+                    for (int nt = 0; nt < CO_NT; ++nt) { o_tile(1, nt); if (nt < 3) lh_mfma(nt); }
+                    // rows 4 hi + v of the 16-channel tile lh_dt: channels 8 (h & 1) .. + 7 belong to head lh_h
+                    if (lh_on && ((hi_t >= 2) == bool(lh_h & 1))) {
+                        float xo[4];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const float4 lav = *reinterpret_cast<const float4*>(sT + CL_LAV + 4 * (16 * lh_dt + 4 * hi_t + v));
+                            xo[v] = fmaf(lav.z, lF[2], fmaf(lav.y, lF[1], fmaf(lav.x, lF[0], lP[v])));
+                        }
+                        *reinterpret_cast<float4*>(sO1 + (wave >> 2) * 512 + (lh_dt * 64 + 16 * hi_t + lo_t) * 4) = make_float4(xo[0], xo[1], xo[2], xo[3]);
+                    }
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt) {
                         const int traj = 16 * rt + lo_t;
