@@ -99,13 +99,17 @@ class _EncodeFold(torch.autograd.Function):
         if train:
             ws.gen += 1
             ctx.args, ctx.ws, ctx.gen, ctx.tsp = a, ws, ws.gen, tsp
-            ctx.keep = (xy, demand, enc, K, V, PK, Q1, Q2, pb, wl)       # buffers the args point to
-            ctx.save_for_backward(*params)
+            # Buffers of `a` that the backward reads (elg_encoder_bwd: xy, demand, enc).  The INPUTS may sit in ctx; the
+            # output `enc` must go through save_for_backward: an output stored on ctx is a reference cycle (tensor ->
+            # grad_fn -> ctx -> tensor) that only Python's cyclic collector frees -- 16.5 MB of tables per training step
+            # piled up until a long run died with an out-of-memory error.
+            ctx.keep = (xy, demand)
+            ctx.save_for_backward(*params, enc)
         return enc, K, V, PK, pb, Q1, Q2, wl
 
     @staticmethod
     def backward(ctx, g_enc, gK, gV, gPK, gpb, gQ1, gQ2, gwl):
-        params = ctx.saved_tensors
+        params = ctx.saved_tensors[:-1]                                 # (+ enc, kept alive for the kernel)
         ws = ctx.ws
         if ws.gen != ctx.gen:
             raise RuntimeError("elg_amd.encoder: the activation workspace was overwritten by a later training forward of "

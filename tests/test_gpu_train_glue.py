@@ -239,3 +239,37 @@ def test_add_instance_norm_matches_torch(B, N, C):
     gg = torch.autograd.grad((got * w).sum(), [a, b, norm.weight, norm.bias])
     for x, y in zip(gg, gr):
         np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=0, atol=1e-5 * max(1.0, y.abs().max().item()))
+
+
+def test_training_steps_do_not_accumulate_device_memory():
+    """No reference cycles through the autograd nodes: with Python's cyclic collector switched off, the allocated device
+    memory after step 12 equals the one after step 4 (an output tensor stored on a Function's ctx used to leak the decoder
+    tables of every step, 16.5 MB at the bench shape, until a long run ran out of memory)."""
+    import gc
+    import yaml
+    import os
+    from elg_amd.CVRP.CVRPEnv import CVRPEnv
+    from elg_amd.CVRP.CVRPModel import CVRPModel
+    from elg_amd.CVRP.generate_data import generate_vrp_data
+    from elg_amd.CVRP.train import train_step
+    from elg_amd.optim import Adam
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "elg_amd", "CVRP", "config.yml")))
+    dev = "cuda:0"
+    model = CVRPModel(**cfg["model_params"])
+    model.decoder.add_local_policy(dev)
+    model.to(dev).train()
+    env = CVRPEnv(50, dev)
+    opt = Adam(model.parameters(), lr=1e-4, weight_decay=1e-6)
+    dist = dict(cfg["distribution"], data_type="uniform")
+    gc.collect()
+    gc.disable()
+    try:
+        mem = []
+        for i in range(12):
+            train_step(model, env, opt, generate_vrp_data(16, 50, dist), True)
+            torch.cuda.synchronize()
+            mem.append(torch.cuda.memory_allocated())
+        assert mem[11] - mem[3] < (1 << 20), [m >> 20 for m in mem]
+    finally:
+        gc.enable()
