@@ -21,7 +21,7 @@ from elg_amd.optim import Adam as Optimizer      # one-launch Adam, torch.optim.
 from elg_amd import engine as eng
 from elg_amd import parallel
 from elg_amd.CVRP.CVRPEnv import CVRPEnv
-from elg_amd.CVRP.CVRPModel import CVRPModel
+from elg_amd.CVRP.CVRPModel import CVRPModel, CVRPModel_local
 from elg_amd.CVRP.generate_data import VRPDataset, generate_vrp_data
 from elg_amd.CVRP.utils import Logger, check_feasible, rollout, seed_everything
 

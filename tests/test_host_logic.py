@@ -152,6 +152,36 @@ def test_entry_points_import_from_their_own_directory():
             assert r.returncode == 0, (sub, m, r.stderr[-1500:])
 
 
+def test_entry_points_have_no_undefined_globals():
+    """Every global name a function of the entry-point modules loads exists in the module (or builtins): the config-only
+    branches (`training: only_local`, checkpoints with local policies ...) are not all exercised on the CPU."""
+    import builtins
+    import dis
+    import importlib
+    import types
+    missing = []
+    for name in ("elg_amd.CVRP.train", "elg_amd.CVRP.test", "elg_amd.CVRP.test_vrplib", "elg_amd.CVRP.utils",
+                 "elg_amd.CVRP.CVRPModel", "elg_amd.CVRP.models", "elg_amd.CVRP.CVRPEnv", "elg_amd.TSP.train", "elg_amd.TSP.test",
+                 "elg_amd.TSP.test_tsplib", "elg_amd.TSP.utils", "elg_amd.TSP.TSPModel", "elg_amd.TSP.models", "elg_amd.TSP.TSPEnv",
+                 "elg_amd.engine", "elg_amd.encoder", "elg_amd.parallel", "elg_amd.optim"):
+        mod = importlib.import_module(name)
+
+        with open(mod.__file__) as f:
+            top = compile(f.read(), mod.__file__, "exec")
+        stored = {i.argval for i in dis.get_instructions(top) if i.opname in ("STORE_NAME", "STORE_GLOBAL", "IMPORT_NAME")}
+
+        def walk(code):
+            for ins in dis.get_instructions(code):
+                if (ins.opname == "LOAD_GLOBAL" or (ins.opname == "LOAD_NAME" and code is top)) \
+                        and not hasattr(mod, ins.argval) and not hasattr(builtins, ins.argval) and ins.argval not in stored:
+                    missing.append((name, code.co_name, ins.argval))
+            for c in code.co_consts:
+                if isinstance(c, types.CodeType):
+                    walk(c)
+        walk(top)
+    assert not missing, missing
+
+
 def test_train_batch_must_divide_over_the_ranks(monkeypatch):
     from elg_amd import parallel
     from elg_amd.CVRP import train as ctrain
