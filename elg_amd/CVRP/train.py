@@ -23,7 +23,7 @@ from elg_amd import parallel
 from elg_amd.CVRP.CVRPEnv import CVRPEnv
 from elg_amd.CVRP.CVRPModel import CVRPModel, CVRPModel_local
 from elg_amd.CVRP.generate_data import VRPDataset, generate_vrp_data
-from elg_amd.CVRP.utils import Logger, check_feasible, rollout, seed_everything
+from elg_amd.CVRP.utils import Logger, check_feasible, rollout, rollout_train, seed_everything
 
 
 def softmax(x):
@@ -42,16 +42,28 @@ def train_step(model, env, optimizer, batch, scale_norm=True, bucket=None, world
     env.load_random_problems(batch)
     reset_state, _, _ = env.reset()
     model.pre_forward(reset_state)
-    solutions, probs, rewards = rollout(model=model, env=env, eval_type='sample')
-    if check:
-        check_feasible(solutions[0:1], reset_state.node_demand[0:1])
+    if env.problem.N1 > 128 or env.vrplib:
+        # sizes whose training forward saves no rows: the reference's sequence with the host sync inside rollout()
+        solutions, probs, rewards = rollout(model=model, env=env, eval_type='sample')
+        if check:
+            check_feasible(solutions[0:1], reset_state.node_demand[0:1])
+        optimizer.zero_grad()
+        J = pomo_loss(probs, rewards, scale_norm)
+        J.backward()
+        if bucket is not None:
+            bucket.allreduce(world)
+        optimizer.step()
+        return J.detach(), rewards
+    # same operations; the rollout's length and the feasibility flags are read AFTER the backward and the update are queued
+    ro = rollout_train(model, env, reset_state.node_demand[0] if check else None)
     optimizer.zero_grad()
-    J = pomo_loss(probs, rewards, scale_norm)
+    J = pomo_loss(ro.probs, ro.reward, scale_norm)
     J.backward()
     if bucket is not None:
         bucket.allreduce(world)
     optimizer.step()
-    return J.detach(), rewards
+    ro.finish()                     # the step's host sync + the feasibility assertions
+    return J.detach(), ro.reward
 
 
 def test_rollout(loader, env, model):

@@ -44,6 +44,55 @@ def rollout(model, env, eval_type='greedy'):
     return actions, probs, reward
 
 
+class TrainRollout:
+    """A sampled training rollout whose one host sync is deferred (rollout_train).  `probs` (B, Tcap, M) is differentiable and
+    padded with ones past each trajectory's end (log 1 = 0: the loss does not see the padding); `reward` (B, M).  finish()
+    waits for the rollout's length and the feasibility flags, which were copied to the host right behind the rollout -- by
+    then the backward is already queued, so the GPU never idles on the host -- and returns the actions (B, M, T)."""
+
+    def __init__(self, env, res, probs, fetch, checked):
+        self.env, self.res, self.probs, self.reward = env, res, probs, res.reward
+        self._fetch, self._checked = fetch, checked
+
+    def finish(self):
+        vals = self._fetch.get()
+        T = int(vals[0])
+        actions = self.res.actions[:, :, :T].long()
+        env = self.env
+        env.selected_count = T
+        env.selected_node_list = actions
+        env.current_node = actions[:, :, -1]
+        if self._checked:                                   # utils.check_feasible's assertions (reference utils.py:90-119)
+            assert not vals[2], "Invalid tour"
+            assert not vals[3], "Used more than capacity"
+        return actions
+
+
+def rollout_train(model, env, check_demand=None):
+    """The sampled rollout of a training step (reference train.py:108-111 = rollout(..., 'sample') + check_feasible of
+    instance 0) without a host round trip before the backward: the rollout's length stays on the device
+    (elg_decoder_bwd_args.T_dev), the +1e-6 of CVRPModel.py:67-68 is applied per step from device flags, the feasibility
+    kernel runs over the padded tours.  Needs the rows a training forward saves (N + 1 <= 128)."""
+    env.reset()
+    B, M, N = env.batch_size, env.multi_width, env.problem_size
+    pol = model.policy if hasattr(model, 'policy') else model.decoder.policy
+    if pol is None:
+        raise RuntimeError("call model.pre_forward(reset_state) before rollout")
+    starts = torch.tensor(model.draw_starts(N, M), dtype=torch.int32)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    res = eng.rollout_forward(env.problem, pol, M, starts, L.MODE_SAMPLE, seed=seed, train=True)
+    stats, zsteps = eng.rollout_stats_launch(res)
+    vals = stats
+    if check_demand is not None:
+        flags = eng.feasibility_flags_launch(res.actions[0].long(), check_demand.reshape(-1))
+        vals = torch.cat((stats, flags))
+    fetch = eng.HostFetch(vals)
+    Tcap = res.probs.shape[1]
+    probs = eng.chosen_probs(env.problem, pol, M, res, Tcap, T_dev=stats)
+    probs = probs + 1e-6 * zsteps[None, :, None].to(probs.dtype)     # exact + 0.0 unless a chosen probability was 0
+    return TrainRollout(env, res, probs, fetch, check_demand is not None)
+
+
 def augment_xy_data_by_8_fold(problems):
     """reference utils.py:69-87 (elg_aug8 kernel)."""
     return eng.aug8(problems)

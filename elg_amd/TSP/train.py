@@ -33,13 +33,17 @@ def train_step(model, env, optimizer, batch, scale_norm=True, bucket=None, world
     reset_state, _, _ = env.reset()
     model.pre_forward(reset_state)
     solutions, probs, rewards = rollout(model=model, env=env, eval_type='sample')
-    check_feasible(solutions[0:1])
+    # the feasibility flags are computed right behind the rollout but read after the backward and the update are queued:
+    # the tour length is known (N), so this would be the step's only host round trip before the backward
+    pi = solutions[0]
+    flags = eng.HostFetch(eng.feasibility_flags_launch(pi if pi.stride(1) == 1 else pi.contiguous(), None))
     optimizer.zero_grad()
     J = pomo_loss(probs, rewards, scale_norm)
     J.backward()
     if bucket is not None:
         bucket.allreduce(world)
     optimizer.step()
+    flags.get()                     # TSP/train.py:105 calls check_feasible and drops its result; the wait bounds the run-ahead
     return J.detach(), rewards
 
 

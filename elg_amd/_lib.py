@@ -69,7 +69,8 @@ class DecoderBwdArgs(C.Structure):
                 ("gprob", _vp), ("pval", _vp), ("tlen", _vp), ("actions", _vp), ("trPC", _vp), ("trCsel", _vp), ("trQ", _vp),
                 ("trO", _vp), ("trLoad", _vp), ("trSlot", _vp), ("trA", _vp), ("trMask", _vp), ("trLse", _vp), ("Kmat", _vp), ("Vmat", _vp),
                 ("PK", _vp), ("dK", _vp), ("dV", _vp), ("dPK", _vp), ("dpb", _vp), ("dQ1", _vp), ("dQ2", _vp), ("dwl", _vp),
-                ("rowDU", _vp), ("dO", _vp), ("idx_prev", _vp), ("idx_first", _vp), ("rowW", _vp)]
+                ("rowDU", _vp), ("dO", _vp), ("idx_prev", _vp), ("idx_first", _vp), ("rowW", _vp),
+                ("T_dev", _vp), ("gprob_T", C.c_int32)]
 
 
 class LocalWeights(C.Structure):
@@ -130,7 +131,7 @@ def lib() -> C.CDLL:
         L.elg_pomo_loss.argtypes = [f, f, i, i, i, i64, i64, f, f, f, f, f, f]
         L.elg_add_instnorm_fwd.argtypes = [f, f, f, f, f, f, f, i, i, i, fl, f]
         L.elg_add_instnorm_bwd.argtypes = [f, f, f, f, f, f, f, i, i, i, f]
-        L.elg_local_bwd_rows.argtypes = [f, f, f, f, f, i, i, i64, i, f]
+        L.elg_local_bwd_rows.argtypes = [f, f, f, f, f, i, i, i64, i, f, i, f]
         L.elg_adam_step.argtypes = [f, f, f, i, f, f, f, i64, fl, fl, fl, fl, fl, i64, fl, f]
         L.elg_encoder_ws_floats.argtypes = [i, i, i, i, i]
         L.elg_encoder_ws_floats.restype = i64
@@ -143,7 +144,7 @@ def lib() -> C.CDLL:
         L.elg_local_fold_fwd.argtypes = [C.POINTER(LocalWeights), i, i, i, f, f]
         L.elg_local_fold_bwd.argtypes = [C.POINTER(LocalWeights), i, i, i, f, C.POINTER(LocalWeights), f]
         L.elg_check_feasible.argtypes = [f, i64, f, i, i, i, f, f]
-        L.elg_rollout_stats.argtypes = [f, f, i, i, i, f, f]
+        L.elg_rollout_stats.argtypes = [f, f, i, i, i, f, f, f]
         L.elg_decoder_bwd.argtypes = [C.POINTER(DecoderBwdArgs), f]
         L.elg_decoder_bwd.restype = C.c_int
         L.elg_check_feasible.restype = C.c_int

@@ -604,6 +604,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float* __restrict__ dQ, float* __restrict__ dKp, float* __restrict__ dVp, int B, int R, int N1,
     size_t rowA_rows, size_t rowO_rows, size_t rowQ_rows, int splits, const GlimpseSeg seg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (SEG && seg.T_dev) R = min(R, seg.T_dev[0] * seg.M);           // the host has not read the rollout's length yet
     // LDS: [K operand image: NT*4 x 64] then the 4 x 2 x NT*256 reduction buffer
     float* sK = lds;
     float* sRed = lds + NT * 256;                                          // [2][2 NT 256] reduction buffer

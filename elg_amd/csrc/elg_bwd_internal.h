@@ -18,6 +18,8 @@ struct GlimpseSeg {
     long long load_rows;
     const float* lse;       // (B,rowQ_rows,8) log2-sum-exp of the glimpse scores per (row, head) (mask-row mode), or NULL
     int accumulate;         // 1: dK / dV are added to dKp / dVp (B,N1,128, caller zeroes) instead of written per split
+    const int* T_dev;       // device-resident number of decode steps: R = min(R, T_dev[0] * M) inside the kernel, or NULL
+    int M;                  // trajectories per instance (with T_dev)
 };
 
 

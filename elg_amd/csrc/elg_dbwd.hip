@@ -27,18 +27,23 @@ struct PtrBwd {
     int B, T, M, N1, Tcap_act, t0, splits;
     long long Rcap;
     float inv_ens;
+    const int* T_dev;       // device-resident step count (<= T), or NULL
+    int gT;                 // time extent of gprob / pval
 };
+
+// decode steps covered: the host's value, or the rollout's own count when the host has not read it yet
+__device__ __forceinline__ int eff_T(const PtrBwd& a) { return a.T_dev ? min(a.T, a.T_dev[0]) : a.T; }
 
 // per decode row: weight w = gprob * pval * valid, w * c_sel, the chosen node, and the nodes its query was gathered at
 __global__ __launch_bounds__(256) void row_weights_kernel(const PtrBwd a) {
-    const long long R = (long long)a.T * a.M;
+    const long long R = (long long)eff_T(a) * a.M;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)a.B * R) return;
     const int b = (int)(i / R), r = (int)(i - (long long)b * R);
     const int t = r / a.M, m = r - t * a.M;
     const size_t bm = (size_t)b * a.M + m;
     const bool valid = t >= a.t0 && t < a.tlen[bm];
-    const size_t gi = ((size_t)b * a.T + t) * a.M + m;
+    const size_t gi = ((size_t)b * a.gT + t) * a.M + m;
     const float w = valid ? a.gprob[gi] * a.pval[gi] : 0.f;
     const int* act = a.actions + bm * a.Tcap_act;
     const int sel = act[t];
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(512, 4) void pointer_bwd_kernel(const PtrBwd a) {
     const int tid = threadIdx.x, lane = tid & 63, h = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lo = lane & 15, hi = lane >> 4;
     const int b = blockIdx.y, N1 = a.N1;
-    const int R = a.T * a.M;
+    const int R = eff_T(a) * a.M;
     const int ntile = (R + 15) >> 4;
     const int per = (ntile + a.splits - 1) / a.splits;
     const int t_lo = blockIdx.x * per, t_hi = min(ntile, t_lo + per);
@@ -197,6 +202,8 @@ extern "C" int elg_decoder_bwd(const elg_decoder_bwd_args* p, void* stream) {
     a.idx_prev = p->idx_prev; a.idx_first = tsp ? p->idx_first : nullptr; a.rowW = reinterpret_cast<float4*>(p->rowW);
     a.B = B; a.T = T; a.M = M; a.N1 = N1; a.Tcap_act = p->Tcap_actions; a.t0 = p->first_decode_step; a.Rcap = p->Rcap;
     a.inv_ens = p->inv_ens;
+    a.T_dev = p->T_dev; a.gT = p->T_dev ? p->gprob_T : T;
+    if (p->T_dev && p->gprob_T < T) return fail(ELG_EINVAL, "decoder_bwd: gprob_T smaller than T");
     a.splits = (int)max(1LL, min(16LL, min((R + 15) / 16, (long long)((512 + B - 1) / B))));
     const int nt = (N1 + 15) / 16;
     (void)hipGetLastError();
@@ -215,6 +222,7 @@ extern "C" int elg_decoder_bwd(const elg_decoder_bwd_args* p, void* stream) {
     seg.dQ1 = p->dQ1; seg.dQ2 = tsp ? p->dQ2 : nullptr; seg.dwl = tsp ? nullptr : p->dwl; seg.load_rows = p->Rcap;
     seg.accumulate = 1;
     seg.lse = p->trMask ? p->trLse : nullptr;
+    seg.T_dev = p->T_dev; seg.M = M;
     const int splits = max(1, min(8, 1024 / (B * 8)));
     return glimpse_bwd_launch(p->trMask ? nullptr : p->trA, reinterpret_cast<const unsigned long long*>(p->trMask), p->dO, p->trO,
                               p->trQ, p->Kmat, p->Vmat, nullptr, p->dK, p->dV, B, (int)R, N1, p->Rcap, p->Rcap, p->Rcap, splits, seg, s);

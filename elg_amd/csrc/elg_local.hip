@@ -69,8 +69,10 @@ template <int JT>
 __global__ __launch_bounds__(256) void local_bwd_rows_kernel(const float* __restrict__ loc, const float* __restrict__ trF,
                                                              const int* __restrict__ trSlot,
                                                              const float* __restrict__ rowDU, float* __restrict__ gloc,
-                                                             int B, int R, long long Rcap) {
+                                                             int B, int R, long long Rcap, const int* __restrict__ T_dev,
+                                                             int M) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (T_dev) R = min(R, T_dev[0] * M);                        // step count still on the device (elg_decoder_bwd_args.T_dev)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lo = lane & 15, hi = lane >> 4;
     float* sT = lds;                                            // tables
@@ -497,9 +499,11 @@ __global__ __launch_bounds__(256) void local_bwd_rows_kernel(const float* __rest
 using namespace elg;
 
 extern "C" int elg_local_bwd_rows(const float* loc, const float* trF, const int32_t* trSlot, const float* rowDU,
-                                  float* gloc, int B, int R, int64_t Rcap, int n_slots, void* stream) {
+                                  float* gloc, int B, int R, int64_t Rcap, int n_slots, const int32_t* T_dev, int M,
+                                  void* stream) {
     if (!loc || !trF || !trSlot || !rowDU || !gloc) return fail(ELG_EINVAL, "local_bwd_rows: null buffer");
     if (B <= 0 || R <= 0 || Rcap < R) return fail(ELG_EINVAL, "local_bwd_rows: bad sizes");
+    if (T_dev && M <= 0) return fail(ELG_EINVAL, "local_bwd_rows: T_dev needs M");
     if (n_slots <= 0 || n_slots > ELG_SLOT_STRIDE) return fail(ELG_EINVAL, "local_bwd_rows: local_size must be <= 47");
     const size_t lds = (size_t)(S_TABLES + 4 * NTRB * S_TR + ELG_LOC_SIZE) * sizeof(float);
     const long long ntiles = (long long)B * ((R + 15) / 16);
@@ -515,7 +519,7 @@ extern "C" int elg_local_bwd_rows(const float* loc, const float* trF, const int3
             done = true;
         }
         hipLaunchKernelGGL(local_bwd_rows_kernel<2>, dim3(grid), dim3(256), lds, s, loc, trF, trSlot, rowDU, gloc, B, R,
-                           (long long)Rcap);
+                           (long long)Rcap, T_dev, M);
     } else {
         static bool done = false;
         if (!done) {
@@ -525,7 +529,7 @@ extern "C" int elg_local_bwd_rows(const float* loc, const float* trF, const int3
             done = true;
         }
         hipLaunchKernelGGL(local_bwd_rows_kernel<3>, dim3(grid), dim3(256), lds, s, loc, trF, trSlot, rowDU, gloc, B, R,
-                           (long long)Rcap);
+                           (long long)Rcap, T_dev, M);
     }
     return launch_status("local_bwd_rows");
 }

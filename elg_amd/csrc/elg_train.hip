@@ -33,30 +33,45 @@ __device__ __forceinline__ float block_max(float v, float* red, int tid, int nth
 // scaled variant divides by max_m advantage.  Outputs per instance: sum_m J (raw and scaled), the max, and
 // coef[b,m] = d(sum J)/d(log-prob sum) = -advantage (/ max) for both variants; the caller picks the variant
 // (CVRP: always scaled; TSP: scaled only if no instance has a zero max) and applies the 1/(B*M) of the mean.
-__global__ __launch_bounds__(256) void pomo_loss_kernel(const float* __restrict__ probs, const float* __restrict__ reward,
-                                                        int T, int M, long long p_bstride, long long p_tstride,
-                                                        float* __restrict__ Jraw, float* __restrict__ Jscaled,
-                                                        float* __restrict__ amax_out, float* __restrict__ coef_raw,
-                                                        float* __restrict__ coef_scaled) {
-    __shared__ float red[4];
+__global__ __launch_bounds__(1024) void pomo_loss_kernel(const float* __restrict__ probs, const float* __restrict__ reward,
+                                                         int T, int M, long long p_bstride, long long p_tstride,
+                                                         float* __restrict__ Jraw, float* __restrict__ Jscaled,
+                                                         float* __restrict__ amax_out, float* __restrict__ coef_raw,
+                                                         float* __restrict__ coef_scaled) {
+    // 1024 threads = G step groups x MP trajectory columns (MP = power of two >= min(M, 1024)): group g sums log p over
+    // the steps t = g, g + G, ...; the groups' partial sums are added in group order (fixed order: deterministic)
+    __shared__ float red[16];
+    __shared__ float part[1024];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* pb = probs + (size_t)b * p_bstride;
+    int MP = 1;
+    while (MP < M && MP < 1024) MP <<= 1;
+    const int G = 1024 / MP, g = tid / MP, mc = tid - g * MP;
     float rsum = 0.f;
-    for (int m = tid; m < M; m += 256) rsum += reward[(size_t)b * M + m];
-    const float mean = block_sum(rsum, red, tid, 256) / (float)M;
+    for (int m = tid; m < M; m += 1024) rsum += reward[(size_t)b * M + m];
+    const float mean = block_sum(rsum, red, tid, 1024) / (float)M;
     float amax = ELG_NEG_INF;
-    for (int m = tid; m < M; m += 256) amax = fmaxf(amax, reward[(size_t)b * M + m] - mean);
-    amax = block_max(amax, red, tid, 256);
+    for (int m = tid; m < M; m += 1024) amax = fmaxf(amax, reward[(size_t)b * M + m] - mean);
+    amax = block_max(amax, red, tid, 1024);
     float jr = 0.f;
-    for (int m = tid; m < M; m += 256) {
-        const float adv = reward[(size_t)b * M + m] - mean;
+    for (int m0 = 0; m0 < M; m0 += MP) {
+        const int m = m0 + mc;
         float lp = 0.f;
-        for (int t = 0; t < T; ++t) lp += logf(pb[(size_t)t * p_tstride + m]);
-        jr = fmaf(-adv, lp, jr);
-        coef_raw[(size_t)b * M + m] = -adv;
-        coef_scaled[(size_t)b * M + m] = -adv / amax;
+        if (m < M)
+            for (int t = g; t < T; t += G) lp += logf(pb[(size_t)t * p_tstride + m]);
+        __syncthreads();
+        part[tid] = lp;
+        __syncthreads();
+        if (g == 0 && m < M) {
+            float tot = part[mc];
+            for (int k = 1; k < G; ++k) tot += part[k * MP + mc];
+            const float adv = reward[(size_t)b * M + m] - mean;
+            jr = fmaf(-adv, tot, jr);
+            coef_raw[(size_t)b * M + m] = -adv;
+            coef_scaled[(size_t)b * M + m] = -adv / amax;
+        }
     }
-    jr = block_sum(jr, red, tid, 256);
+    jr = block_sum(jr, red, tid, 1024);
     if (tid == 0) {
         Jraw[b] = jr;
         Jscaled[b] = jr / amax;
@@ -134,26 +149,30 @@ __global__ __launch_bounds__(256) void check_feasible_kernel(const long long* __
     }
 }
 
-// stats[0] = max tlen, stats[1] = 1 if some chosen probability of a decoded step is exactly 0 (CVRPModel.py:67-68)
+// stats[0] = max tlen, stats[1] = 1 if some chosen probability of a decoded step is exactly 0 (CVRPModel.py:67-68),
+// zero_steps[t] = 1 for those steps.  grid (B, slices of the time axis): a workgroup scans its (steps x M) block of one
+// instance with the trajectories along the lanes.
 __global__ __launch_bounds__(256) void rollout_stats_kernel(const int* __restrict__ tlen, const float* __restrict__ probs,
-                                                            long long n_traj, int M, int Tcap, int* stats) {
-    __shared__ int smax[4], szero[4];
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    int tl = 0, z = 0;
-    if (i < n_traj) {
-        tl = tlen[i];
-        const long long b = i / M, m = i % M;
-        const float* p = probs + b * (long long)Tcap * M + m;
-        for (int t = 0; t < tl; ++t) z |= p[(long long)t * M] == 0.f;
+                                                            int M, int Tcap, int tper, int* stats, int* __restrict__ zero_steps) {
+    __shared__ int smax[4];
+    const int b = blockIdx.x, t0 = blockIdx.y * tper, t1 = min(Tcap, t0 + tper);
+    const int* tl = tlen + (size_t)b * M;
+    const float* p = probs + (size_t)b * Tcap * M;
+    if (blockIdx.y == 0) {
+        int mx = 0;
+        for (int m = threadIdx.x; m < M; m += 256) mx = max(mx, tl[m]);
+        mx = (int)wave_max((float)mx);
+        if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(stats, max(max(smax[0], smax[1]), max(smax[2], smax[3])));
     }
-    tl = (int)wave_max((float)tl);
-    z = __any(z);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) { smax[w] = tl; szero[w] = z; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicMax(stats, max(max(smax[0], smax[1]), max(smax[2], smax[3])));
-        if (szero[0] | szero[1] | szero[2] | szero[3]) atomicOr(stats + 1, 1);
+    for (int m = threadIdx.x; m < M; m += 256) {
+        const int len = min(tl[m], t1);
+        for (int t = t0; t < len; ++t)
+            if (p[(size_t)t * M + m] == 0.f) {
+                atomicOr(stats + 1, 1);
+                if (zero_steps) atomicOr(zero_steps + t, 1);
+            }
     }
 }
 
@@ -172,12 +191,15 @@ extern "C" int elg_check_feasible(const int64_t* pi, int64_t m_stride, const flo
     return launch_status("check_feasible");
 }
 
-extern "C" int elg_rollout_stats(const int32_t* tlen, const float* probs, int B, int M, int Tcap, int32_t* stats, void* stream) {
+extern "C" int elg_rollout_stats(const int32_t* tlen, const float* probs, int B, int M, int Tcap, int32_t* stats,
+                                 int32_t* zero_steps, void* stream) {
     if (!tlen || !probs || !stats || B <= 0 || M <= 0 || Tcap <= 0) return fail(ELG_EINVAL, "rollout_stats: bad arguments");
-    const long long n = (long long)B * M;
+    // ~1024 workgroups: the time axis in slices of >= 8 steps
+    const int slices = max(1, min((Tcap + 7) / 8, (1024 + B - 1) / B));
+    const int tper = (Tcap + slices - 1) / slices;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(rollout_stats_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tlen, probs, n,
-                       M, Tcap, stats);
+    hipLaunchKernelGGL(rollout_stats_kernel, dim3((unsigned)B, (unsigned)((Tcap + tper - 1) / tper)), dim3(256), 0, (hipStream_t)stream,
+                       tlen, probs, M, Tcap, tper, stats, zero_steps);
     return launch_status("rollout_stats");
 }
 
@@ -188,7 +210,7 @@ extern "C" int elg_pomo_loss(const float* probs, const float* reward, int B, int
     if (!probs || !reward || !J_raw || !J_scaled || !adv_max || !coef_raw || !coef_scaled)
         return fail(ELG_EINVAL, "pomo_loss: null buffer");
     (void)hipGetLastError();
-    hipLaunchKernelGGL(pomo_loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, probs, reward, T, M,
+    hipLaunchKernelGGL(pomo_loss_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, probs, reward, T, M,
                        (long long)probs_bstride, (long long)probs_tstride, J_raw, J_scaled, adv_max, coef_raw, coef_scaled);
     return launch_status("pomo_loss");
 }

@@ -39,6 +39,21 @@ def _side_stream(dev) -> "torch.cuda.Stream":
     return _SIDE[key]
 
 
+class HostFetch:
+    """A few device integers copied to pinned host memory behind the work queued so far; get() waits for that copy only,
+    not for what was queued after it (a plain .tolist() would wait for the whole stream)."""
+
+    def __init__(self, t: torch.Tensor):
+        self.buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        self.buf.copy_(t, non_blocking=True)
+        self.ev = torch.cuda.Event()
+        self.ev.record(torch.cuda.current_stream(t.device))
+
+    def get(self) -> list:
+        self.ev.synchronize()
+        return self.buf.tolist()
+
+
 _PINNED = {}
 
 
@@ -126,9 +141,10 @@ def route_length(xy: torch.Tensor, tour: torch.Tensor, rounding: bool = False) -
     return out
 
 
-def feasibility_flags(pi: torch.Tensor, demand: Optional[torch.Tensor]) -> tuple:
-    """(invalid_tour, over_capacity) of the tours `pi` (multi, T) int64 of ONE instance (elg_check_feasible: the
-    reference's utils.check_feasible as one launch; demand (problem,) of the customers, None for TSP).  One host sync."""
+def feasibility_flags_launch(pi: torch.Tensor, demand: Optional[torch.Tensor]) -> torch.Tensor:
+    """Enqueue elg_check_feasible for the tours `pi` (multi, T) int64 of ONE instance (the reference's utils.check_feasible as
+    one launch; demand (problem,) of the customers, None for TSP) -> device flags [invalid_tour, over_capacity].  No host
+    sync.  For CVRP, trailing depot visits (the padding of unfinished time steps) do not change either flag."""
     _need_cuda(pi, "pi")
     assert pi.dim() == 2 and pi.dtype == torch.int64 and pi.stride(1) == 1
     n = int(demand.numel()) if demand is not None else int(pi.shape[1])
@@ -138,7 +154,12 @@ def feasibility_flags(pi: torch.Tensor, demand: Optional[torch.Tensor]) -> tuple
     with torch.cuda.device(pi.device):
         L.check(L.lib().elg_check_feasible(_ptr(pi), pi.stride(0), _ptr(demand), pi.shape[0], pi.shape[1], n, _ptr(flags),
                                            _stream(pi.device)), "elg_check_feasible")
-    bad, over = flags.tolist()
+    return flags
+
+
+def feasibility_flags(pi: torch.Tensor, demand: Optional[torch.Tensor]) -> tuple:
+    """(invalid_tour, over_capacity) of the tours `pi` (feasibility_flags_launch + one host sync)."""
+    bad, over = feasibility_flags_launch(pi, demand).tolist()
     return bool(bad), bool(over)
 
 
@@ -327,14 +348,23 @@ class TrainRows:
         self.gen += 1
 
 
+def rollout_stats_launch(res: "RolloutResult"):
+    """Enqueue elg_rollout_stats: (stats, zero_steps) stay on the device -- stats = [longest trajectory T, 1 if some chosen
+    probability is exactly 0], zero_steps[t] = 1 for the steps where that happened.  No host sync."""
+    B, M = res.tlen.shape
+    Tcap = res.probs.shape[1]
+    buf = torch.zeros(2 + Tcap, dtype=torch.int32, device=res.tlen.device)
+    stats, zsteps = buf[:2], buf[2:]
+    with torch.cuda.device(res.tlen.device):
+        L.check(L.lib().elg_rollout_stats(_ptr(res.tlen), _ptr(res.probs), B, M, Tcap, _ptr(stats), _ptr(zsteps),
+                                          _stream(res.tlen.device)), "elg_rollout_stats")
+    return stats, zsteps
+
+
 def rollout_stats(res: "RolloutResult") -> tuple:
     """(T, zero_prob): longest trajectory and whether some chosen probability is exactly 0 -- one tiny launch and THE
     host sync of a rollout (elg_rollout_stats)."""
-    B, M = res.tlen.shape
-    stats = torch.zeros(2, dtype=torch.int32, device=res.tlen.device)
-    with torch.cuda.device(res.tlen.device):
-        L.check(L.lib().elg_rollout_stats(_ptr(res.tlen), _ptr(res.probs), B, M, res.probs.shape[1], _ptr(stats),
-                                          _stream(res.tlen.device)), "elg_rollout_stats")
+    stats, _ = rollout_stats_launch(res)
     T, z = stats.tolist()
     return int(T), bool(z)
 
@@ -414,9 +444,10 @@ class _ChosenProbs(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, prob: Problem, pol_meta: Policy, M, actions, probs_val, T, geometry,
-                Kt, Vt, PKt, pbt, Q1t, Q2t, wlt, loct, rows=None, rows_gen=-1, tlen=None):
+                Kt, Vt, PKt, pbt, Q1t, Q2t, wlt, loct, rows=None, rows_gen=-1, tlen=None, T_dev=None):
         ctx.prob, ctx.pol_meta, ctx.M, ctx.T, ctx.geometry = prob, pol_meta, M, T, geometry
         ctx.rows, ctx.rows_gen = rows, rows_gen
+        ctx.T_dev = T_dev                       # device-resident step count (the host only knows the bound T)
         ctx.probs_val = probs_val
         ctx.tlen = tlen
         ctx.save_for_backward(actions, Kt, Vt, PKt, pbt, Q1t, Q2t if Q2t is not None else Kt.new_empty(0),
@@ -439,6 +470,9 @@ class _ChosenProbs(torch.autograd.Function):
         use_saved = rows is not None and rows.gen == ctx.rows_gen and T <= rows.Tcap
         if use_saved:
             return _ChosenProbs._backward_saved_rows(ctx, g, rows)
+        if ctx.T_dev is not None:
+            raise RuntimeError("a rollout with a deferred host sync needs the rows its training forward saved "
+                               "(another training forward has reused them)")
         tables = dict(K=Kt, V=Vt, PK=PKt, pb=pbt, Q1=Q1t, Q2=Q2t if hasQ2 else None, wl=wlt if haswl else None)
         pol = Policy(tables, loct if hasloc else None, meta.K, meta.xi, meta.clip, meta.inv_ens, meta.has_local,
                      meta.has_penalty)
@@ -497,7 +531,7 @@ class _ChosenProbs(torch.autograd.Function):
         if haswl:
             dwl = torch.einsum("br,bre->e", rowLoad, dQ)
         return (None, None, None, None, None, None, None,
-                dK, dV, dPK, dpb, dQ1, dQ2, dwl, gloc if hasloc else None, None, None, None)
+                dK, dV, dPK, dpb, dQ1, dQ2, dwl, gloc if hasloc else None, None, None, None, None)
 
     @staticmethod
     def _backward_saved_rows(ctx, g, rows):
@@ -536,14 +570,16 @@ class _ChosenProbs(torch.autograd.Function):
         a.dwl = _ptr(dwl) if haswl else None
         a.rowDU = _ptr(ws.rowDU) if meta.has_local else None
         a.dO, a.idx_prev, a.idx_first, a.rowW = _ptr(ws.dO), _ptr(ws.idx_prev), _ptr(ws.idx_first), _ptr(ws.rowW)
+        a.T_dev, a.gprob_T = _ptr(ctx.T_dev), g.shape[1]
         L.check(L.lib().elg_decoder_bwd(C.byref(a), _stream()), "elg_decoder_bwd")
         if meta.has_local:
             # rows are independent given the saved slot features: 16 rows per wavefront on the matrix cores
             n_slots = meta.K + (0 if tsp else 1)
             L.check(L.lib().elg_local_bwd_rows(_ptr(loct), _ptr(rows.F), _ptr(rows.Slot), _ptr(ws.rowDU), _ptr(gloc),
-                                               B, R, rows.Rcap, n_slots, _stream()), "elg_local_bwd_rows")
+                                               B, R, rows.Rcap, n_slots, _ptr(ctx.T_dev), M, _stream()),
+                    "elg_local_bwd_rows")
         return (None, None, None, None, None, None, None,
-                dK, dV, dPK, dpb, dQ1, dQ2, dwl if haswl else None, gloc if hasloc else None, None, None, None)
+                dK, dV, dPK, dpb, dQ1, dQ2, dwl if haswl else None, gloc if hasloc else None, None, None, None, None)
 
 
 class _BwdScratch:
@@ -568,13 +604,17 @@ class _BwdScratch:
         return ws
 
 
-def chosen_probs(prob: Problem, pol: Policy, M: int, res: RolloutResult, T: int, geometry=None) -> torch.Tensor:
-    """Differentiable view of res.probs[:, :T, :] (gradients flow to pol.tables / pol.loc)."""
+def chosen_probs(prob: Problem, pol: Policy, M: int, res: RolloutResult, T: int, geometry=None, T_dev=None) -> torch.Tensor:
+    """Differentiable view of res.probs[:, :T, :] (gradients flow to pol.tables / pol.loc).  With `T_dev` (the device
+    tensor holding the rollout's step count, rollout_stats_launch) T is only an upper bound -- normally the capacity of
+    res.probs -- and the backward kernels take the count from the device: no host sync between rollout and backward."""
     t = pol.tables
     rows = getattr(res, "rows", None)
+    if T_dev is not None and rows is None:
+        raise ValueError("chosen_probs: T_dev needs a training forward (saved rows)")
     return _ChosenProbs.apply(prob, pol, M, res.actions, res.probs[:, :T, :], T, geometry,
                               t["K"], t["V"], t["PK"], t["pb"], t["Q1"], t.get("Q2"), t.get("wl"), pol.loc,
-                              rows, getattr(res, "rows_gen", -1), res.tlen)
+                              rows, getattr(res, "rows_gen", -1), res.tlen, T_dev)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -182,9 +182,10 @@ int elg_rollout_bwd(const elg_bwd_args* args, void* stream);
 /* Local-policy backward over independent decode rows on the matrix cores (autograd of models.py:133-166 w.r.t.
  * the folded tables): 16 rows per wavefront tile, every contraction with a shared table as v_mfma_f32_16x16x4_f32.
  * loc (ELG_LOC_SIZE); trF (B,Rcap,3,48) / trSlot (B,Rcap,48) as saved by a training forward; rowDU (B,R,48) from
- * elg_rows_prep; gloc (ELG_LOC_SIZE) accumulated (caller zeroes).  n_slots = local_size (+1 for the CVRP depot). */
+ * elg_rows_prep; gloc (ELG_LOC_SIZE) accumulated (caller zeroes).  n_slots = local_size (+1 for the CVRP depot).
+ * T_dev (or NULL) / M: as elg_decoder_bwd_args.T_dev -- R = min(R, T_dev[0] * M) is taken on the device. */
 int elg_local_bwd_rows(const float* loc, const float* trF, const int32_t* trSlot, const float* rowDU, float* gloc,
-                       int B, int R, int64_t Rcap, int n_slots, void* stream);
+                       int B, int R, int64_t Rcap, int n_slots, const int32_t* T_dev, int M, void* stream);
 
 /* Row-wise part of the glimpse backward (softmax backward of models.py:478-500 on the saved weights):
  * per decode row r and head h:  dS = a (dO_h V_h^T - <dO_h, O_h>) / 4,  dQ_h = dS K_h.
@@ -332,8 +333,10 @@ int elg_check_feasible(const int64_t* pi, int64_t m_stride, const float* demand,
 
 /* After elg_rollout_fwd: stats[0] = max over tlen (the T of utils.rollout's outputs), stats[1] = 1 if a chosen
  * probability of a decoded step is exactly 0 (CVRPModel.py:67-68 then adds 1e-6 to that step).  stats: 2 x int32,
- * caller zeroes.  tlen (B,M), probs (B,Tcap,M). */
-int elg_rollout_stats(const int32_t* tlen, const float* probs, int B, int M, int Tcap, int32_t* stats, void* stream);
+ * caller zeroes.  tlen (B,M), probs (B,Tcap,M).  zero_steps (Tcap x int32, caller zeroes) or NULL: [t] = 1 for the
+ * steps in which that happened. */
+int elg_rollout_stats(const int32_t* tlen, const float* probs, int B, int M, int Tcap, int32_t* stats,
+                      int32_t* zero_steps, void* stream);
 
 /* ---- decoder backward over the rows saved by a training forward (elg_rollout_args.tr*, time-major r = t*M + m) ----
  * Autograd of the chosen-node probabilities (CVRP/models.py:322-423 under train.py:112-125) w.r.t. the decoder tables:
@@ -374,6 +377,10 @@ typedef struct elg_decoder_bwd_args {
     int32_t* idx_prev;          /* (B,R) scratch                                                                  */
     int32_t* idx_first;         /* (B,R) scratch, TSP                                                             */
     float* rowW;                /* (B,R,4) scratch, 16-byte aligned                                               */
+    const int32_t* T_dev;       /* NULL, or the device-resident step count (elg_rollout_stats' stats[0]) when the   *
+                                 * host has not read it yet: `T` is then only an upper bound, the kernels use       *
+                                 * min(T, T_dev[0]) (same value in elg_local_bwd_rows), scratch strides follow it    */
+    int32_t gprob_T;            /* with T_dev: time extent of gprob / pval (>= T); ignored otherwise                */
 } elg_decoder_bwd_args;
 int elg_decoder_bwd(const elg_decoder_bwd_args* args, void* stream);
 

@@ -273,3 +273,86 @@ def test_training_steps_do_not_accumulate_device_memory():
         assert mem[11] - mem[3] < (1 << 20), [m >> 20 for m in mem]
     finally:
         gc.enable()
+
+
+def _glue_model(n=50):
+    import os
+    import yaml
+    from elg_amd.CVRP.CVRPEnv import CVRPEnv
+    from elg_amd.CVRP.CVRPModel import CVRPModel
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "elg_amd", "CVRP", "config.yml")))
+    torch.manual_seed(5)
+    model = CVRPModel(**cfg["model_params"])
+    model.decoder.add_local_policy("cuda:0")
+    model.to("cuda:0").train()
+    return cfg, model, CVRPEnv(n, "cuda:0")
+
+
+def test_deferred_sync_rollout_matches_the_synchronous_sequence():
+    """rollout_train (rollout length left on the device, host sync after the backward is queued) against
+    rollout() -> check_feasible -> pomo_loss -> backward with the same draws: same actions, loss and gradients (the kernels see
+    the same rows; only the order of the f32 atomics differs)."""
+    import random
+    from elg_amd.CVRP.generate_data import generate_vrp_data
+    from elg_amd.CVRP.train import pomo_loss
+    from elg_amd.CVRP.utils import check_feasible, rollout, rollout_train
+    cfg, model, env = _glue_model(50)
+    dist = dict(cfg["distribution"], data_type="uniform")
+    batch = generate_vrp_data(8, 50, dist)
+
+    def run(deferred):
+        random.seed(3)
+        torch.manual_seed(3)
+        env.load_random_problems(batch)
+        rs, _, _ = env.reset()
+        model.zero_grad(set_to_none=True)
+        model.pre_forward(rs)
+        if deferred:
+            ro = rollout_train(model, env, rs.node_demand[0])
+            J = pomo_loss(ro.probs, ro.reward, True)
+            J.backward()
+            sol, rew = ro.finish(), ro.reward
+            assert ro.probs.shape[1] >= sol.shape[2]
+        else:
+            sol, probs, rew = rollout(model, env, 'sample')
+            check_feasible(sol[0:1], rs.node_demand[0:1])
+            J = pomo_loss(probs, rew, True)
+            J.backward()
+        torch.cuda.synchronize()
+        return sol.clone(), rew.clone(), float(J.detach()), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    sol_a, rew_a, J_a, g_a = run(False)
+    sol_b, rew_b, J_b, g_b = run(True)
+    assert torch.equal(sol_a, sol_b) and torch.equal(rew_a, rew_b)
+    assert abs(J_a - J_b) <= 1e-6 * max(1.0, abs(J_a)), (J_a, J_b)
+    assert g_a.keys() == g_b.keys() and len(g_a) > 80
+    gmax = max(float(g.abs().max()) for g in g_a.values())
+    for n in g_a:
+        # (the biases in front of an instance norm have a mathematically zero gradient: rounding noise, measured on the global scale)
+        scale = max(float(g_a[n].abs().max()), 1e-2 * gmax)
+        err = float((g_a[n] - g_b[n]).abs().max()) / scale
+        assert err < 2e-4, (n, err)
+
+
+def test_rollout_stats_marks_the_steps_with_a_zero_probability():
+    """elg_rollout_stats: longest trajectory, the any-zero flag and the per-step flags (only steps a trajectory decoded count)."""
+    from elg_amd import engine as eng
+    B, M, Tcap = 3, 37, 29
+    g = torch.Generator().manual_seed(1)
+    tlen = torch.randint(5, 20, (B, M), generator=g, dtype=torch.int32)
+    probs = torch.rand(B, Tcap, M, generator=g) * 0.9 + 0.05
+    probs[1, 4, 7] = 0.0                                   # inside (tlen >= 5)
+    probs[2, 25, 3] = 0.0                                  # past every trajectory's end: ignored
+    tlen[0, 11] = 23
+    probs[0, 22, 11] = 0.0                                 # last decoded step of the longest trajectory
+    res = eng.RolloutResult(actions=torch.zeros(B, M, Tcap, dtype=torch.int32, device="cuda:0"), probs=probs.cuda(),
+                            reward=torch.zeros(B, M, device="cuda:0"), tlen=tlen.cuda())
+    stats, zsteps = eng.rollout_stats_launch(res)
+    assert stats.tolist() == [23, 1]
+    want = [0] * Tcap
+    want[4] = want[22] = 1
+    assert zsteps.tolist() == want
+    res.probs[1, 4, 7] = 0.5
+    res.probs[0, 22, 11] = 0.5
+    assert eng.rollout_stats(res) == (23, False)
