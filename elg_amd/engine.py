@@ -398,7 +398,8 @@ def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mo
     a.seed = seed & 0xFFFFFFFFFFFFFFFF
     a.variant = variant
     a.dump_logits = {"probs": 0, "logits": 1, "scores": 2}[dump]
-    starts = starts.to(device=dev, dtype=torch.int32).contiguous()
+    # (a pageable host tensor would block the host until the stream has drained: staged through pinned memory instead)
+    starts = h2d(starts.to(torch.int32).contiguous(), dev) if not starts.is_cuda else starts.to(torch.int32).contiguous()
     a.starts = _ptr(starts)
     if forced is not None:
         forced = forced.to(device=dev, dtype=torch.int32).contiguous()
