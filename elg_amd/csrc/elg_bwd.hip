@@ -663,9 +663,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { dKacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dVacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    const int ntile = (R + 15) >> 4;
-    const int per = (ntile + splits - 1) / splits;
-    const int t_lo = split * per, t_hi = min(ntile, t_lo + per);
+    int tile_first = 0, ntile = (R + 15) >> 4;
+    if (SEG && seg.tlen) {
+        // same live range as pointer_bwd_kernel: decode steps t0 .. max_m tlen[b,m] - 1 of this instance
+        __shared__ int sTb;
+        if (threadIdx.x == 0) sTb = 0;
+        __syncthreads();
+        int mx = 0;
+        for (int m = threadIdx.x; m < seg.M; m += 256) mx = max(mx, seg.tlen[(size_t)b * seg.M + m]);
+        mx = (int)wave_max((float)mx);
+        if (lane == 0) atomicMax(&sTb, mx);
+        __syncthreads();
+        tile_first = live_tile_first(seg.t0, seg.M);
+        ntile = (min(R, sTb * seg.M) + 15) >> 4;
+    }
+    const int per = (max(ntile - tile_first, 0) + splits - 1) / splits;
+    const int t_lo = tile_first + split * per, t_hi = min(ntile, t_lo + per);
     const float* Abh = rowA + (size_t)bh * rowA_rows * N1;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     // ---- tile loads.  No load is guarded: the compiler turns `ok ? load : 0` (and any if / else around loads) into

@@ -19,8 +19,13 @@ struct GlimpseSeg {
     const float* lse;       // (B,rowQ_rows,8) log2-sum-exp of the glimpse scores per (row, head) (mask-row mode), or NULL
     int accumulate;         // 1: dK / dV are added to dKp / dVp (B,N1,128, caller zeroes) instead of written per split
     const int* T_dev;       // device-resident number of decode steps: R = min(R, T_dev[0] * M) inside the kernel, or NULL
-    int M;                  // trajectories per instance (with T_dev)
+    int M;                  // trajectories per instance (with T_dev / tlen)
+    const int* tlen;        // (B,M) steps per trajectory, or NULL: with it (time-major rows) only the tiles of the decode steps
+    int t0;                 //   t0 .. max_m tlen[b,m] - 1 are walked -- the rows outside carry dO = 0 and contribute nothing
 };
+
+// first 16-row tile that holds a row of decode step t0 (rows r = t M + m)
+__host__ __device__ inline int live_tile_first(int t0, int M) { return (t0 * M) >> 4; }
 
 
 int glimpse_bwd_launch(const float* rowA, const unsigned long long* mk, const float* dO, const float* rowO, const float* rowQ,

@@ -66,9 +66,30 @@ __global__ __launch_bounds__(512, 4) void pointer_bwd_kernel(const PtrBwd a) {
     const int lo = lane & 15, hi = lane >> 4;
     const int b = blockIdx.y, N1 = a.N1;
     const int R = eff_T(a) * a.M;
-    const int ntile = (R + 15) >> 4;
-    const int per = (ntile + a.splits - 1) / a.splits;
-    const int t_lo = blockIdx.x * per, t_hi = min(ntile, t_lo + per);
+    // live rows of this instance: the rows are time-major, so the decode steps first_decode_step .. max_m tlen[b,m] - 1 are
+    // the contiguous range [t0 M, Tb M); every row outside has weight 0 (its dO / rowDU are exact zeros, written below
+    // without any arithmetic; the glimpse backward walks the same range)
+    __shared__ int sTb;
+    if (tid == 0) sTb = 0;
+    __syncthreads();
+    {
+        int mx = 0;
+        for (int m = tid; m < a.M; m += 512) mx = max(mx, a.tlen[(size_t)b * a.M + m]);
+        mx = (int)wave_max((float)mx);
+        if (lane == 0) atomicMax(&sTb, mx);
+    }
+    __syncthreads();
+    const int Rb = min(R, sTb * a.M);
+    const int tile_first = live_tile_first(a.t0, a.M), ntile = (Rb + 15) >> 4;
+    if (blockIdx.x == 0 && a.rowDU) {
+        // rows [0, 16 tile_first) and [16 ntile, R): elg_local_bwd_rows reads them (and skips their tiles on du == 0)
+        const int head = min(tile_first << 4, R), tail0 = min(ntile << 4, R);
+        float* du = a.rowDU + (size_t)b * R * 48;
+        for (int i = tid; i < head * 48; i += 512) du[i] = 0.f;
+        for (int i = tail0 * 48 + tid; i < R * 48; i += 512) du[i] = 0.f;
+    }
+    const int per = (max(ntile - tile_first, 0) + a.splits - 1) / a.splits;
+    const int t_lo = tile_first + blockIdx.x * per, t_hi = min(ntile, t_lo + per);
     if (t_lo >= t_hi) return;
     // PK operand image: value (nt, j) of lane (lo, hi) = PK[node 16 nt + 4 hi + j][16 h + lo] (0 past the last node)
     float pk[NT][4];
@@ -222,7 +243,7 @@ extern "C" int elg_decoder_bwd(const elg_decoder_bwd_args* p, void* stream) {
     seg.dQ1 = p->dQ1; seg.dQ2 = tsp ? p->dQ2 : nullptr; seg.dwl = tsp ? nullptr : p->dwl; seg.load_rows = p->Rcap;
     seg.accumulate = 1;
     seg.lse = p->trMask ? p->trLse : nullptr;
-    seg.T_dev = p->T_dev; seg.M = M;
+    seg.T_dev = p->T_dev; seg.M = M; seg.tlen = p->tlen; seg.t0 = p->first_decode_step;
     const int splits = max(1, min(8, 1024 / (B * 8)));
     return glimpse_bwd_launch(p->trMask ? nullptr : p->trA, reinterpret_cast<const unsigned long long*>(p->trMask), p->dO, p->trO,
                               p->trQ, p->Kmat, p->Vmat, nullptr, p->dK, p->dV, B, (int)R, N1, p->Rcap, p->Rcap, p->Rcap, splits, seg, s);
