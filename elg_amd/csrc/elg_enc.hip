@@ -31,7 +31,7 @@ int launch_status(const char* what);
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-enum { EPI_STORE = 0, EPI_RELU = 1, EPI_NORM = 2, EPI_ADD = 3, EPI_RELUMASK = 4, EPI_ADDBIAS = 5 };
+enum { EPI_STORE = 0, EPI_RELU = 1, EPI_NORM = 2, EPI_ADD = 3, EPI_RELUMASK = 4, EPI_ADDBIAS = 5, EPI_ADD_NORMBWD = 6 };
 enum { W_NK = 0, W_KN = 1, W_NK_SCALAR = 2 };
 
 struct EncGemm {
@@ -44,6 +44,8 @@ struct EncGemm {
     int epi; float alpha;
     const float* gamma; const float* beta; float* xhat; float* rstd; float eps;   // EPI_NORM
     const float* rv; const float* cv; float alpha2;                               // EPI_ADD: + alpha2 rv[row] cv[n]
+    float* dgamma; float* dbeta;        // EPI_ADD_NORMBWD: d = residual + x W; C = backward of the add & norm that produced the
+                                        // GEMM's consumer (xhat, rstd, gamma as saved by the forward), dgamma / dbeta accumulated
 };
 
 // wave-uniform pick from a kernel-argument pointer table (a select chain: a dynamic index would move the whole
@@ -272,6 +274,70 @@ __global__ __launch_bounds__(256) void enc_gemm_kernel(const EncGemm g) {
             }
         }
         if (rl == 0 && g.rstd) *reinterpret_cast<float4*>(g.rstd + (size_t)blockIdx.y * g.N + gc) = rs;
+        return;
+    }
+    if (g.epi == EPI_ADD_NORMBWD) {
+        // d = residual + x W is the cotangent of an add & instance norm output y = xhat gamma + beta (per instance and
+        // channel over the block's rows): ds = gamma rstd (d - mean(d) - xhat mean(d xhat)), dbeta += sum d, dgamma += sum d xhat.
+        // The workgroup owns whole columns of the instance, so the stand-alone norm-backward launch (one per norm) folds
+        // into this epilogue.
+        float* stat = T + ROWS * TP;                      // [4 waves][TC]
+        auto colsum = [&](float4 v) -> float4 {
+#pragma unroll
+            for (int m = CG; m < 64; m <<= 1) {
+                v.x += shfl_xor(v.x, m); v.y += shfl_xor(v.y, m); v.z += shfl_xor(v.z, m); v.w += shfl_xor(v.w, m);
+            }
+            if (lane < CG) *reinterpret_cast<float4*>(stat + wave * TC + 4 * lane) = v;
+            __syncthreads();
+            float4 r = *reinterpret_cast<const float4*>(stat + 4 * cg);
+#pragma unroll
+            for (int w2 = 1; w2 < 4; ++w2) {
+                const float4 o = *reinterpret_cast<const float4*>(stat + w2 * TC + 4 * cg);
+                r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+            }
+            __syncthreads();
+            return r;
+        };
+        float4 xh[NP];
+        float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int r = rl + p * RPP;
+            xh[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < nrows) {
+                float4 v = *reinterpret_cast<const float4*>(T + r * TP + 4 * cg);
+                const float4 res = *reinterpret_cast<const float4*>(g.R + (size_t)(row0 + r) * g.ldr + gc);
+                v.x += res.x; v.y += res.y; v.z += res.z; v.w += res.w;
+                *reinterpret_cast<float4*>(T + r * TP + 4 * cg) = v;
+                xh[p] = *reinterpret_cast<const float4*>(g.xhat + (size_t)(row0 + r) * g.N + gc);
+                s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                s2.x = fmaf(v.x, xh[p].x, s2.x); s2.y = fmaf(v.y, xh[p].y, s2.y);
+                s2.z = fmaf(v.z, xh[p].z, s2.z); s2.w = fmaf(v.w, xh[p].w, s2.w);
+            }
+        }
+        s1 = colsum(s1);
+        s2 = colsum(s2);
+        if (rl == 0) {
+            atomicAdd(g.dbeta + gc, s1.x); atomicAdd(g.dbeta + gc + 1, s1.y); atomicAdd(g.dbeta + gc + 2, s1.z); atomicAdd(g.dbeta + gc + 3, s1.w);
+            atomicAdd(g.dgamma + gc, s2.x); atomicAdd(g.dgamma + gc + 1, s2.y); atomicAdd(g.dgamma + gc + 2, s2.z); atomicAdd(g.dgamma + gc + 3, s2.w);
+        }
+        const float fn = (float)nrows;                    // (true divisions: the means of ~1e2 values must be as exact as f32 allows,
+                                                          //  the bias gradients upstream are sums of the ds that cancel to 0)
+        const float4 ga = *reinterpret_cast<const float4*>(g.gamma + gc);
+        const float4 rs = *reinterpret_cast<const float4*>(g.rstd + (size_t)blockIdx.y * g.N + gc);
+        const float4 k = make_float4(ga.x * rs.x, ga.y * rs.y, ga.z * rs.z, ga.w * rs.w);
+        const float4 m1 = make_float4(s1.x / fn, s1.y / fn, s1.z / fn, s1.w / fn);
+        const float4 m2 = make_float4(s2.x / fn, s2.y / fn, s2.z / fn, s2.w / fn);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int r = rl + p * RPP;
+            if (r < nrows) {
+                const float4 v = *reinterpret_cast<const float4*>(T + r * TP + 4 * cg);
+                *reinterpret_cast<float4*>(cbase + (size_t)(row0 + r) * g.ldc) =
+                    make_float4(k.x * (v.x - m1.x - xh[p].x * m2.x), k.y * (v.y - m1.y - xh[p].y * m2.y),
+                                k.z * (v.z - m1.z - xh[p].z * m2.z), k.w * (v.w - m1.w - xh[p].w * m2.w));
+            }
+        }
         return;
     }
     float4 cv4 = make_float4(0.f, 0.f, 0.f, 0.f), bias4 = cv4;
@@ -998,8 +1064,9 @@ extern "C" int elg_encoder_bwd(const elg_encoder_bwd_args* ba, void* stream) {
         const float *QKV = lb + w.oQKV, *O = lb + w.oO, *LSE = lb + w.oLSE, *XH1 = lb + w.oXH1, *RS1 = lb + w.oRS1;
         const float *X1 = lb + w.oX1, *H = lb + w.oH, *XH2 = lb + w.oXH2, *RS2 = lb + w.oRS2;
         const float* Xin = (l == 0) ? ws + w.X0 : ws + w.layer0 + w.layer_stride * (l - 1) + w.oXout;
-        // second add & norm
-        ENC_TRY(elg_add_instnorm_bwd(gX, XH2, RS2, L.g2, gS, (float*)GL.g2, (float*)GL.b2, B, N1, ELG_E, stream))
+        // second add & norm (the top layer's: the layers below get theirs from the epilogue of the GEMM that produces d x)
+        if (l == a->n_layers - 1)
+            ENC_TRY(elg_add_instnorm_bwd(gX, XH2, RS2, L.g2, gS, (float*)GL.g2, (float*)GL.b2, B, N1, ELG_E, stream))
         ENC_TRY(dw.add(gS, ELG_E, H, FF, (float*)GL.W2, FF, ELG_E, FF, (float*)GL.bf2, 1.f))
         {   // dH = (dS2 W2) * [h > 0]
             EncGemm g = gemm_base(gS, ELG_E, FF, ELG_E, R, N1, aligned);
@@ -1007,13 +1074,13 @@ extern "C" int elg_encoder_bwd(const elg_encoder_bwd_args* ba, void* stream) {
             ENC_TRY(launch_gemm(g, s))
         }
         ENC_TRY(dw.add(gH, FF, X1, ELG_E, (float*)GL.W1, ELG_E, FF, ELG_E, (float*)GL.bf1, 1.f))
-        {   // d x1 = dS2 + dH W1
+        {   // d x1 = dS2 + dH W1, then the first add & norm's backward in the epilogue: dY
             EncGemm g = gemm_base(gH, FF, ELG_E, FF, R, N1, aligned);
-            g.W[0] = L.W1; g.ldw = ELG_E; g.wmode = W_KN; g.wblk = FF; g.C[0] = gT; g.ldc = ELG_E; g.epi = EPI_ADD; g.R = gS; g.ldr = ELG_E;
+            g.W[0] = L.W1; g.ldw = ELG_E; g.wmode = W_KN; g.wblk = FF; g.C[0] = gY; g.ldc = ELG_E; g.epi = EPI_ADD_NORMBWD; g.R = gS; g.ldr = ELG_E;
+            g.xhat = const_cast<float*>(XH1); g.rstd = const_cast<float*>(RS1); g.gamma = L.g1;
+            g.dgamma = (float*)GL.g1; g.dbeta = (float*)GL.b1;
             ENC_TRY(launch_gemm(g, s))
         }
-        // first add & norm
-        ENC_TRY(elg_add_instnorm_bwd(gT, XH1, RS1, L.g1, gY, (float*)GL.g1, (float*)GL.b1, B, N1, ELG_E, stream))
         ENC_TRY(dw.add(gY, ELG_E, O, ELG_E, (float*)GL.Wc, ELG_E, ELG_E, ELG_E, (float*)GL.bc, 1.f))
         {   // d att = dY Wc
             EncGemm g = gemm_base(gY, ELG_E, ELG_E, ELG_E, R, N1, aligned);
@@ -1032,10 +1099,17 @@ extern "C" int elg_encoder_bwd(const elg_encoder_bwd_args* ba, void* stream) {
         ENC_TRY(dw.add(dQKV, 3 * ELG_E, Xin, ELG_E, (float*)GL.Wq, ELG_E, ELG_E, ELG_E, nullptr, 1.f))
         ENC_TRY(dw.add(dQKV + ELG_E, 3 * ELG_E, Xin, ELG_E, (float*)GL.Wk, ELG_E, ELG_E, ELG_E, nullptr, 1.f))
         ENC_TRY(dw.add(dQKV + 2 * ELG_E, 3 * ELG_E, Xin, ELG_E, (float*)GL.Wv, ELG_E, ELG_E, ELG_E, nullptr, 1.f))
-        {   // d x = dY + dQ Wq + dK Wk + dV Wv
+        {   // d x = dY + dQ Wq + dK Wk + dV Wv; below the first layer d x is the cotangent of layer l - 1's second add & norm,
+            // whose backward runs in the epilogue (-> that layer's dS2)
             EncGemm g = gemm_base(dQKV, 3 * ELG_E, ELG_E, 3 * ELG_E, R, N1, aligned);
             g.W[0] = L.Wq; g.W[1] = L.Wk; g.W[2] = L.Wv; g.ldw = ELG_E; g.wmode = W_KN; g.wblk = ELG_E; g.C[0] = gX; g.ldc = ELG_E;
             g.epi = EPI_ADD; g.R = gY; g.ldr = ELG_E;
+            if (l > 0) {
+                const float* lbp = ws + w.layer0 + w.layer_stride * (l - 1);
+                g.epi = EPI_ADD_NORMBWD; g.C[0] = lay2 + lay2_stride * (l - 1);
+                g.xhat = const_cast<float*>(lbp + w.oXH2); g.rstd = const_cast<float*>(lbp + w.oRS2); g.gamma = a->W.layer[l - 1].g2;
+                g.dgamma = (float*)G.layer[l - 1].g2; g.dbeta = (float*)G.layer[l - 1].b2;
+            }
             ENC_TRY(launch_gemm(g, s))
         }
     }
