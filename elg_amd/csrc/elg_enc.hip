@@ -112,6 +112,22 @@ __global__ __launch_bounds__(256) void enc_gemm_kernel(const EncGemm g) {
             }                                                                                                     \
         }                                                                                                         \
     }
+    // epilogue operands (residual / mask rows, the saved xhat of a fused norm backward) are requested before the main loop:
+    // these launches are latency-bound, a load issued in the epilogue is a full memory round trip added to every kernel.
+    // (g.R may alias the output: every element is read and written by the same thread)
+    constexpr int TC = 16 * NWC, TP = TC + 4, CG = TC / 4, RPP = 256 / CG;
+    constexpr int NP = (ROWS + RPP - 1) / RPP;
+    const int cg = tid % CG, rl = tid / CG;
+    const int c0 = blockIdx.x * TC;                       // first output column of the workgroup
+    const int gc = c0 + 4 * cg;                           // global column of this thread's 4 values
+    float4 rpre[NP], xpre[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int rr = min(rl + p * RPP, nrows - 1);
+        rpre[p] = g.R ? *reinterpret_cast<const float4*>(g.R + (size_t)(row0 + rr) * g.ldr + gc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        xpre[p] = g.epi == EPI_ADD_NORMBWD ? *reinterpret_cast<const float4*>(g.xhat + (size_t)(row0 + rr) * g.N + gc)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     f32x4 acc[RT];
 #pragma unroll
     for (int t = 0; t < RT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -170,7 +186,6 @@ __global__ __launch_bounds__(256) void enc_gemm_kernel(const EncGemm g) {
     // ---- epilogue.  The D tiles (lane = one column, four rows) would be written as 64-byte row pieces (measured: 0.4 TB/s,
     // the dominant cost of the first version); instead the workgroup's TC = 16 NWC output columns are transposed through LDS
     // and written / combined with the residual as whole 16-byte-per-lane row segments (128 or 256 contiguous bytes per row).
-    constexpr int TC = 16 * NWC, TP = TC + 4, CG = TC / 4, RPP = 256 / CG;
     float* red = lds;                                     // the slabs are dead: reuse
     float* T = lds + ((KS > 1) ? (KS - 1) * NWC * RT * 4 * 64 : 0);
     if (KS > 1) {
@@ -206,12 +221,8 @@ __global__ __launch_bounds__(256) void enc_gemm_kernel(const EncGemm g) {
             }
     }
     __syncthreads();
-    const int cg = tid % CG, rl = tid / CG;
-    const int c0 = blockIdx.x * TC;                       // first output column of the workgroup
     const int ncb = __builtin_amdgcn_readfirstlane(c0 / g.cblk);
     float* cbase = pick6(g.C, ncb) + (c0 - ncb * g.cblk) + 4 * cg;
-    const int gc = c0 + 4 * cg;                           // global column of this thread's 4 values
-    constexpr int NP = (ROWS + RPP - 1) / RPP;
     if (g.epi == EPI_NORM) {
         // s = residual + (x W^T + b); InstanceNorm1d statistics per channel over the block's rows (two passes, like the
         // stand-alone kernel): column partials per thread, summed over the threads of a column group
@@ -238,7 +249,7 @@ __global__ __launch_bounds__(256) void enc_gemm_kernel(const EncGemm g) {
             const int r = rl + p * RPP;
             if (r < nrows) {
                 float4 v = *reinterpret_cast<const float4*>(T + r * TP + 4 * cg);
-                const float4 res = *reinterpret_cast<const float4*>(g.R + (size_t)(row0 + r) * g.ldr + gc);
+                const float4 res = rpre[p];
                 v.x += res.x; v.y += res.y; v.z += res.z; v.w += res.w;
                 *reinterpret_cast<float4*>(T + r * TP + 4 * cg) = v;
                 sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
@@ -306,10 +317,10 @@ __global__ __launch_bounds__(256) void enc_gemm_kernel(const EncGemm g) {
             xh[p] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < nrows) {
                 float4 v = *reinterpret_cast<const float4*>(T + r * TP + 4 * cg);
-                const float4 res = *reinterpret_cast<const float4*>(g.R + (size_t)(row0 + r) * g.ldr + gc);
+                const float4 res = rpre[p];
                 v.x += res.x; v.y += res.y; v.z += res.z; v.w += res.w;
                 *reinterpret_cast<float4*>(T + r * TP + 4 * cg) = v;
-                xh[p] = *reinterpret_cast<const float4*>(g.xhat + (size_t)(row0 + r) * g.N + gc);
+                xh[p] = xpre[p];
                 s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
                 s2.x = fmaf(v.x, xh[p].x, s2.x); s2.y = fmaf(v.y, xh[p].y, s2.y);
                 s2.z = fmaf(v.z, xh[p].z, s2.z); s2.w = fmaf(v.w, xh[p].w, s2.w);
@@ -353,14 +364,14 @@ __global__ __launch_bounds__(256) void enc_gemm_kernel(const EncGemm g) {
             const size_t grow = (size_t)(row0 + r);
             float4 v = *reinterpret_cast<const float4*>(T + r * TP + 4 * cg);
             if (g.epi == EPI_ADD || g.epi == EPI_ADDBIAS) {
-                const float4 res = *reinterpret_cast<const float4*>(g.R + grow * g.ldr + gc);
+                const float4 res = rpre[p];
                 v.x += res.x; v.y += res.y; v.z += res.z; v.w += res.w;
                 if (g.epi == EPI_ADD && g.cv) {
                     const float rvv = g.rv[grow];
                     v.x = fmaf(rvv, cv4.x, v.x); v.y = fmaf(rvv, cv4.y, v.y); v.z = fmaf(rvv, cv4.z, v.z); v.w = fmaf(rvv, cv4.w, v.w);
                 }
             } else if (g.epi == EPI_RELUMASK) {
-                const float4 m = *reinterpret_cast<const float4*>(g.R + grow * g.ldr + gc);
+                const float4 m = rpre[p];
                 v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
             }
             *reinterpret_cast<float4*>(cbase + grow * g.ldc) = v;
