@@ -562,8 +562,12 @@ __global__ __launch_bounds__(256) void enc_attn_bwd_kernel(const float* __restri
                                                            const float* __restrict__ Og, const float* __restrict__ lse,
                                                            float* __restrict__ dqkv, int N1) {
     constexpr int P = 20, ROWS = NT * 16, LD = 3 * ELG_E;
+    // channel-major copies [channel][row] (pitch PT = 20 mod 32: conflict-free b128 reads): the operands "rows 4 hi .. 4 hi + 3 of
+    // channel lo" of the dQ / dK / dV products are one ds_read_b128 instead of four scalar reads in front of four MFMAs
+    constexpr int PT = ROWS + 4;
     __shared__ __attribute__((aligned(16))) float sQ[ROWS * P], sK[ROWS * P], sV[ROWS * P], sD[ROWS * P];
-    __shared__ float sL[ROWS], sDel[ROWS];
+    __shared__ __attribute__((aligned(16))) float sQT[16 * PT], sKT[16 * PT], sDT[16 * PT];
+    __shared__ __attribute__((aligned(16))) float sL[ROWS], sDel[ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lo = lane & 15, hi = lane >> 4;
     const int b = blockIdx.x >> 3, h = blockIdx.x & 7;
@@ -584,6 +588,9 @@ __global__ __launch_bounds__(256) void enc_attn_bwd_kernel(const float* __restri
         *reinterpret_cast<float4*>(sK + row * P + c4) = k;
         *reinterpret_cast<float4*>(sV + row * P + c4) = v;
         *reinterpret_cast<float4*>(sD + row * P + c4) = d;
+        sQT[(c4 + 0) * PT + row] = q.x; sQT[(c4 + 1) * PT + row] = q.y; sQT[(c4 + 2) * PT + row] = q.z; sQT[(c4 + 3) * PT + row] = q.w;
+        sKT[(c4 + 0) * PT + row] = k.x; sKT[(c4 + 1) * PT + row] = k.y; sKT[(c4 + 2) * PT + row] = k.z; sKT[(c4 + 3) * PT + row] = k.w;
+        sDT[(c4 + 0) * PT + row] = d.x; sDT[(c4 + 1) * PT + row] = d.y; sDT[(c4 + 2) * PT + row] = d.z; sDT[(c4 + 3) * PT + row] = d.w;
     }
     if (tid < ROWS) {
         const int rr = min(tid, N1 - 1);
@@ -617,12 +624,14 @@ __global__ __launch_bounds__(256) void enc_attn_bwd_kernel(const float* __restri
             dP = __builtin_amdgcn_mfma_f32_16x16x4f32(vA.z, dB.z, dP, 0, 0, 0);
             S = __builtin_amdgcn_mfma_f32_16x16x4f32(kA.w, qB.w, S, 0, 0, 0);
             dP = __builtin_amdgcn_mfma_f32_16x16x4f32(vA.w, dB.w, dP, 0, 0, 0);
+            const float4 kT = *reinterpret_cast<const float4*>(sKT + lo * PT + 16 * kt + 4 * hi);
+            const float kTv[4] = {kT.x, kT.y, kT.z, kT.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int key = 16 * kt + 4 * hi + i;
                 const float p = key < N1 ? __expf(S[i] * 0.25f - lr) : 0.f;
                 const float ds = p * (dP[i] - del) * 0.25f;
-                dq = __builtin_amdgcn_mfma_f32_16x16x4f32(sK[key * P + lo], ds, dq, 0, 0, 0);
+                dq = __builtin_amdgcn_mfma_f32_16x16x4f32(kTv[i], ds, dq, 0, 0, 0);
             }
         }
         const int row = 16 * rt + lo;
@@ -648,13 +657,18 @@ __global__ __launch_bounds__(256) void enc_attn_bwd_kernel(const float* __restri
             dP = __builtin_amdgcn_mfma_f32_16x16x4f32(dA.z, vB.z, dP, 0, 0, 0);
             S = __builtin_amdgcn_mfma_f32_16x16x4f32(qA.w, kB.w, S, 0, 0, 0);
             dP = __builtin_amdgcn_mfma_f32_16x16x4f32(dA.w, vB.w, dP, 0, 0, 0);
+            const float4 l4 = *reinterpret_cast<const float4*>(sL + 16 * rt + 4 * hi);
+            const float4 e4 = *reinterpret_cast<const float4*>(sDel + 16 * rt + 4 * hi);
+            const float4 dT = *reinterpret_cast<const float4*>(sDT + lo * PT + 16 * rt + 4 * hi);
+            const float4 qT = *reinterpret_cast<const float4*>(sQT + lo * PT + 16 * rt + 4 * hi);
+            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, ev[4] = {e4.x, e4.y, e4.z, e4.w};
+            const float dTv[4] = {dT.x, dT.y, dT.z, dT.w}, qTv[4] = {qT.x, qT.y, qT.z, qT.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = 16 * rt + 4 * hi + i;
-                const float p = kok ? __expf(S[i] * 0.25f - sL[row]) : 0.f;
-                const float ds = p * (dP[i] - sDel[row]) * 0.25f;
-                dv = __builtin_amdgcn_mfma_f32_16x16x4f32(sD[row * P + lo], p, dv, 0, 0, 0);
-                dk = __builtin_amdgcn_mfma_f32_16x16x4f32(sQ[row * P + lo], ds, dk, 0, 0, 0);
+                const float p = kok ? __expf(S[i] * 0.25f - lv[i]) : 0.f;
+                const float ds = p * (dP[i] - ev[i]) * 0.25f;
+                dv = __builtin_amdgcn_mfma_f32_16x16x4f32(dTv[i], p, dv, 0, 0, 0);
+                dk = __builtin_amdgcn_mfma_f32_16x16x4f32(qTv[i], ds, dk, 0, 0, 0);
             }
         }
         const int key = 16 * kt + lo;
