@@ -556,9 +556,10 @@ __global__ __launch_bounds__(256) void enc_attn_fwd_kernel(const float* __restri
     }
 }
 
-// self-attention backward, N1 <= 16 NT <= 128.  grid (B * 8), 4 waves.
+// self-attention backward, N1 <= 16 NT <= 128.  grid (B * 8), 8 waves (one row tile / key tile each: with 4 waves the 7 tiles of
+// N1 = 101 took two rounds).
 template <int NT>
-__global__ __launch_bounds__(256) void enc_attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dOg,
+__global__ __launch_bounds__(512) void enc_attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dOg,
                                                            const float* __restrict__ Og, const float* __restrict__ lse,
                                                            float* __restrict__ dqkv, int N1) {
     constexpr int P = 20, ROWS = NT * 16, LD = 3 * ELG_E;
@@ -574,7 +575,7 @@ __global__ __launch_bounds__(256) void enc_attn_bwd_kernel(const float* __restri
     const float* base = qkv + (size_t)b * N1 * LD + h * 16;
     const float* dOb = dOg + (size_t)b * N1 * ELG_E + h * 16;
     const float* Ob = Og + (size_t)b * N1 * ELG_E + h * 16;
-    for (int idx = tid; idx < ROWS * 4; idx += 256) {
+    for (int idx = tid; idx < ROWS * 4; idx += 512) {
         const int row = idx >> 2, c4 = (idx & 3) * 4;
         const int rr = min(row, N1 - 1);
         const float mk = row < N1 ? 1.f : 0.f;
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(256) void enc_attn_bwd_kernel(const float* __restri
     }
     __syncthreads();
     // ---- rows on lanes: dQ of the wave's row tiles
-    for (int rt = wave; rt < NT; rt += 4) {
+    for (int rt = wave; rt < NT; rt += 8) {
         const float4 qB = *reinterpret_cast<const float4*>(sQ + (16 * rt + lo) * P + 4 * hi);
         const float4 dB = *reinterpret_cast<const float4*>(sD + (16 * rt + lo) * P + 4 * hi);
         const float lr = sL[16 * rt + lo], del = sDel[16 * rt + lo];
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(256) void enc_attn_bwd_kernel(const float* __restri
             *reinterpret_cast<float4*>(dqkv + ((size_t)b * N1 + row) * LD + h * 16 + 4 * hi) = make_float4(dq[0], dq[1], dq[2], dq[3]);
     }
     // ---- keys on lanes: dK, dV of the wave's key tiles
-    for (int kt = wave; kt < NT; kt += 4) {
+    for (int kt = wave; kt < NT; kt += 8) {
         const float4 kB = *reinterpret_cast<const float4*>(sK + (16 * kt + lo) * P + 4 * hi);
         const float4 vB = *reinterpret_cast<const float4*>(sV + (16 * kt + lo) * P + 4 * hi);
         const bool kok = 16 * kt + lo < N1;
@@ -1115,10 +1116,10 @@ extern "C" int elg_encoder_bwd(const elg_encoder_bwd_args* ba, void* stream) {
         (void)hipGetLastError();
         {
             const int nt = (N1 + 15) / 16;
-            if (nt <= 2) hipLaunchKernelGGL((enc_attn_bwd_kernel<2>), dim3(B * 8), dim3(256), 0, s, QKV, gO, O, LSE, dQKV, N1);
-            else if (nt <= 4) hipLaunchKernelGGL((enc_attn_bwd_kernel<4>), dim3(B * 8), dim3(256), 0, s, QKV, gO, O, LSE, dQKV, N1);
-            else if (nt <= 7) hipLaunchKernelGGL((enc_attn_bwd_kernel<7>), dim3(B * 8), dim3(256), 0, s, QKV, gO, O, LSE, dQKV, N1);
-            else hipLaunchKernelGGL((enc_attn_bwd_kernel<8>), dim3(B * 8), dim3(256), 0, s, QKV, gO, O, LSE, dQKV, N1);
+            if (nt <= 2) hipLaunchKernelGGL((enc_attn_bwd_kernel<2>), dim3(B * 8), dim3(512), 0, s, QKV, gO, O, LSE, dQKV, N1);
+            else if (nt <= 4) hipLaunchKernelGGL((enc_attn_bwd_kernel<4>), dim3(B * 8), dim3(512), 0, s, QKV, gO, O, LSE, dQKV, N1);
+            else if (nt <= 7) hipLaunchKernelGGL((enc_attn_bwd_kernel<7>), dim3(B * 8), dim3(512), 0, s, QKV, gO, O, LSE, dQKV, N1);
+            else hipLaunchKernelGGL((enc_attn_bwd_kernel<8>), dim3(B * 8), dim3(512), 0, s, QKV, gO, O, LSE, dQKV, N1);
         }
         ENC_TRY(launch_status("enc_attn_bwd"))
         ENC_TRY(dw.add(dQKV, 3 * ELG_E, Xin, ELG_E, (float*)GL.Wq, ELG_E, ELG_E, ELG_E, nullptr, 1.f))
