@@ -447,22 +447,32 @@ __global__ __launch_bounds__(256) void enc_embed_kernel(const float* __restrict_
 }
 
 // d embedding weights: grid over row chunks, thread = channel; partial sums flushed with one atomic each
-__global__ __launch_bounds__(128) void enc_embed_bwd_kernel(const float* __restrict__ xy, const float* __restrict__ demand,
+__global__ __launch_bounds__(512) void enc_embed_bwd_kernel(const float* __restrict__ xy, const float* __restrict__ demand,
                                                             const float* __restrict__ dX, float* gWd, float* gbd, float* gWn,
                                                             float* gbn, int N1, long rows, int rows_per_block) {
-    const int c = threadIdx.x;
+    // 512 threads = 128 channels x 4 row phases, partial sums meet in LDS
+    __shared__ float part[3][7][ELG_E];
+    const int c = threadIdx.x & (ELG_E - 1), q = threadIdx.x >> 7;
     const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-    float nw0 = 0.f, nw1 = 0.f, nw2 = 0.f, nb = 0.f, dw0 = 0.f, dw1 = 0.f, db = 0.f;
-    for (long r = r0; r < r1; ++r) {
+    float v[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // node w0 w1 w2 b | depot w0 w1 b
+    for (long r = r0 + q; r < r1; r += 4) {
         const float gx = dX[r * ELG_E + c];
         const float x = xy[r * 2], y = xy[r * 2 + 1];
-        if (gWd && (r % N1) == 0) { dw0 = fmaf(gx, x, dw0); dw1 = fmaf(gx, y, dw1); db += gx; }
-        else { nw0 = fmaf(gx, x, nw0); nw1 = fmaf(gx, y, nw1); if (demand) nw2 = fmaf(gx, demand[r], nw2); nb += gx; }
+        if (gWd && (r % N1) == 0) { v[4] = fmaf(gx, x, v[4]); v[5] = fmaf(gx, y, v[5]); v[6] += gx; }
+        else { v[0] = fmaf(gx, x, v[0]); v[1] = fmaf(gx, y, v[1]); if (demand) v[2] = fmaf(gx, demand[r], v[2]); v[3] += gx; }
     }
-    if (demand) { atomicAdd(gWn + c * 3, nw0); atomicAdd(gWn + c * 3 + 1, nw1); atomicAdd(gWn + c * 3 + 2, nw2); }
-    else { atomicAdd(gWn + c * 2, nw0); atomicAdd(gWn + c * 2 + 1, nw1); }
-    atomicAdd(gbn + c, nb);
-    if (gWd) { atomicAdd(gWd + c * 2, dw0); atomicAdd(gWd + c * 2 + 1, dw1); atomicAdd(gbd + c, db); }
+    if (q) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) part[q - 1][k][c] = v[k];
+    }
+    __syncthreads();
+    if (q) return;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) v[k] += part[0][k][c] + part[1][k][c] + part[2][k][c];
+    if (demand) { atomicAdd(gWn + c * 3, v[0]); atomicAdd(gWn + c * 3 + 1, v[1]); atomicAdd(gWn + c * 3 + 2, v[2]); }
+    else { atomicAdd(gWn + c * 2, v[0]); atomicAdd(gWn + c * 2 + 1, v[1]); }
+    atomicAdd(gbn + c, v[3]);
+    if (gWd) { atomicAdd(gWd + c * 2, v[4]); atomicAdd(gWd + c * 2 + 1, v[5]); atomicAdd(gbd + c, v[6]); }
 }
 
 // pb[r] = enc[r] . bc / sqrt(E)  (one wave per row) ; wl = Wq_last[:, 128] (CVRP load column)
@@ -480,16 +490,20 @@ __global__ __launch_bounds__(256) void enc_pb_wl_kernel(const float* __restrict_
 }
 
 // d bc[e] += sum_r enc[r][e] gpb[r] * scale ; d Wq_last[:, 128] += gwl
-__global__ __launch_bounds__(128) void enc_fold_small_bwd_kernel(const float* __restrict__ enc, const float* __restrict__ gpb,
+__global__ __launch_bounds__(512) void enc_fold_small_bwd_kernel(const float* __restrict__ enc, const float* __restrict__ gpb,
                                                                  const float* __restrict__ gwl, float* gbc, float* gWq_last,
                                                                  long rows, int rows_per_block, float scale) {
-    const int c = threadIdx.x;
-    if (blockIdx.x == 0 && gwl && gWq_last) atomicAdd(gWq_last + c * (ELG_E + 1) + ELG_E, gwl[c]);
+    // 512 threads = 128 channels x 4 row phases (a thread walks every fourth row of the block; partial sums meet in LDS)
+    __shared__ float part[3][ELG_E];
+    const int c = threadIdx.x & (ELG_E - 1), q = threadIdx.x >> 7;
+    if (blockIdx.x == 0 && q == 0 && gwl && gWq_last) atomicAdd(gWq_last + c * (ELG_E + 1) + ELG_E, gwl[c]);
     if (!gpb) return;
     const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     float acc = 0.f;
-    for (long r = r0; r < r1; ++r) acc = fmaf(enc[r * ELG_E + c], gpb[r], acc);
-    atomicAdd(gbc + c, acc * scale);
+    for (long r = r0 + q; r < r1; r += 4) acc = fmaf(enc[r * ELG_E + c], gpb[r], acc);
+    if (q) part[q - 1][c] = acc;
+    __syncthreads();
+    if (q == 0) atomicAdd(gbc + c, (acc + part[0][c] + part[1][c] + part[2][c]) * scale);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1073,7 +1087,7 @@ extern "C" int elg_encoder_bwd(const elg_encoder_bwd_args* ba, void* stream) {
         if (ba->gpb) ENC_TRY(need(G.dec_bc, "d bc"))
         const int rpb = 64;
         (void)hipGetLastError();
-        hipLaunchKernelGGL(enc_fold_small_bwd_kernel, dim3(ba->gpb ? (unsigned)((R + rpb - 1) / rpb) : 1u), dim3(128), 0, s, a->enc,
+        hipLaunchKernelGGL(enc_fold_small_bwd_kernel, dim3(ba->gpb ? (unsigned)((R + rpb - 1) / rpb) : 1u), dim3(512), 0, s, a->enc,
                            ba->gpb, tsp ? nullptr : ba->gwl, (float*)G.dec_bc, (float*)G.dec_Wq_last, R, rpb, inv_sqrt_e);
         ENC_TRY(launch_status("enc_fold_small_bwd"))
     }
@@ -1143,7 +1157,7 @@ extern "C" int elg_encoder_bwd(const elg_encoder_bwd_args* ba, void* stream) {
     {
         const int rpb = 32;
         (void)hipGetLastError();
-        hipLaunchKernelGGL(enc_embed_bwd_kernel, dim3((unsigned)((R + rpb - 1) / rpb)), dim3(128), 0, s, a->xy,
+        hipLaunchKernelGGL(enc_embed_bwd_kernel, dim3((unsigned)((R + rpb - 1) / rpb)), dim3(512), 0, s, a->xy,
                            tsp ? nullptr : a->demand, gX, tsp ? nullptr : (float*)G.emb_depot_w, tsp ? nullptr : (float*)G.emb_depot_b,
                            (float*)G.emb_w, (float*)G.emb_b, N1, R, rpb);
         ENC_TRY(launch_status("enc_embed_bwd"))
