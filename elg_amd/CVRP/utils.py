@@ -81,15 +81,13 @@ def rollout_train(model, env, check_demand=None):
     starts = torch.tensor(model.draw_starts(N, M), dtype=torch.int32)
     seed = int(torch.randint(0, 2 ** 62, (1,)).item())
     res = eng.rollout_forward(env.problem, pol, M, starts, L.MODE_SAMPLE, seed=seed, train=True)
-    stats, zsteps = eng.rollout_stats_launch(res)
-    vals = stats
+    stats, zsteps, block = eng.rollout_stats_launch(res)     # block = [T, zero_prob, invalid_tour, over_capacity]
     if check_demand is not None:
-        flags = eng.feasibility_flags_launch(res.actions[0].long(), check_demand.reshape(-1))
-        vals = torch.cat((stats, flags))
-    fetch = eng.HostFetch(vals)
+        eng.feasibility_flags_launch(res.actions[0].long(), check_demand.reshape(-1), out=block[2:4])
+    fetch = eng.HostFetch(block)
     Tcap = res.probs.shape[1]
     probs = eng.chosen_probs(env.problem, pol, M, res, Tcap, T_dev=stats)
-    probs = probs + 1e-6 * zsteps[None, :, None].to(probs.dtype)     # exact + 0.0 unless a chosen probability was 0
+    probs = torch.add(probs, zsteps[None, :, None], alpha=1e-6)      # exact + 0.0 unless a chosen probability was 0
     return TrainRollout(env, res, probs, fetch, check_demand is not None)
 
 

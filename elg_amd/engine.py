@@ -141,7 +141,7 @@ def route_length(xy: torch.Tensor, tour: torch.Tensor, rounding: bool = False) -
     return out
 
 
-def feasibility_flags_launch(pi: torch.Tensor, demand: Optional[torch.Tensor]) -> torch.Tensor:
+def feasibility_flags_launch(pi: torch.Tensor, demand: Optional[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Enqueue elg_check_feasible for the tours `pi` (multi, T) int64 of ONE instance (the reference's utils.check_feasible as
     one launch; demand (problem,) of the customers, None for TSP) -> device flags [invalid_tour, over_capacity].  No host
     sync.  For CVRP, trailing depot visits (the padding of unfinished time steps) do not change either flag."""
@@ -150,7 +150,7 @@ def feasibility_flags_launch(pi: torch.Tensor, demand: Optional[torch.Tensor]) -
     n = int(demand.numel()) if demand is not None else int(pi.shape[1])
     if demand is not None:
         demand = demand.contiguous().float()
-    flags = torch.zeros(2, dtype=torch.int32, device=pi.device)
+    flags = out if out is not None else torch.zeros(2, dtype=torch.int32, device=pi.device)    # `out`: zeroed by the caller
     with torch.cuda.device(pi.device):
         L.check(L.lib().elg_check_feasible(_ptr(pi), pi.stride(0), _ptr(demand), pi.shape[0], pi.shape[1], n, _ptr(flags),
                                            _stream(pi.device)), "elg_check_feasible")
@@ -349,22 +349,23 @@ class TrainRows:
 
 
 def rollout_stats_launch(res: "RolloutResult"):
-    """Enqueue elg_rollout_stats: (stats, zero_steps) stay on the device -- stats = [longest trajectory T, 1 if some chosen
-    probability is exactly 0], zero_steps[t] = 1 for the steps where that happened.  No host sync."""
+    """Enqueue elg_rollout_stats: (stats, zero_steps, block) stay on the device -- stats = [longest trajectory T, 1 if some
+    chosen probability is exactly 0], zero_steps[t] = 1 for the steps where that happened; block = stats followed by two
+    zeroed int32 (room for the feasibility flags: one zero fill and one read-back for both).  No host sync."""
     B, M = res.tlen.shape
     Tcap = res.probs.shape[1]
-    buf = torch.zeros(2 + Tcap, dtype=torch.int32, device=res.tlen.device)
-    stats, zsteps = buf[:2], buf[2:]
+    buf = torch.zeros(4 + Tcap, dtype=torch.int32, device=res.tlen.device)     # stats | room for two feasibility flags | steps
+    stats, zsteps = buf[:2], buf[4:]
     with torch.cuda.device(res.tlen.device):
         L.check(L.lib().elg_rollout_stats(_ptr(res.tlen), _ptr(res.probs), B, M, Tcap, _ptr(stats), _ptr(zsteps),
                                           _stream(res.tlen.device)), "elg_rollout_stats")
-    return stats, zsteps
+    return stats, zsteps, buf[:4]
 
 
 def rollout_stats(res: "RolloutResult") -> tuple:
     """(T, zero_prob): longest trajectory and whether some chosen probability is exactly 0 -- one tiny launch and THE
     host sync of a rollout (elg_rollout_stats)."""
-    stats, _ = rollout_stats_launch(res)
+    stats, _, _ = rollout_stats_launch(res)
     T, z = stats.tolist()
     return int(T), bool(z)
 

@@ -348,8 +348,8 @@ def test_rollout_stats_marks_the_steps_with_a_zero_probability():
     probs[0, 22, 11] = 0.0                                 # last decoded step of the longest trajectory
     res = eng.RolloutResult(actions=torch.zeros(B, M, Tcap, dtype=torch.int32, device="cuda:0"), probs=probs.cuda(),
                             reward=torch.zeros(B, M, device="cuda:0"), tlen=tlen.cuda())
-    stats, zsteps = eng.rollout_stats_launch(res)
-    assert stats.tolist() == [23, 1]
+    stats, zsteps, block = eng.rollout_stats_launch(res)
+    assert stats.tolist() == [23, 1] and block.tolist() == [23, 1, 0, 0]
     want = [0] * Tcap
     want[4] = want[22] = 1
     assert zsteps.tolist() == want
