@@ -228,7 +228,7 @@ def main():
     env = CVRPEnv(multi_width=POMO, device=dev)
     from elg_amd.optim import Adam
     opt = Adam(model.parameters(), lr=cfg["params"]["learning_rate"], weight_decay=1e-6)
-    bucket = parallel.GradBucket(model.parameters(), opt) if world > 1 else None
+    bucket = parallel.make_bucket(model.parameters(), opt)
     dist_cfg = dict(cfg["distribution"], data_type="uniform")
 
     # time the persistent rollout kernel with HIP events on the launch stream (torch's current stream)
@@ -263,9 +263,10 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if parallel.active():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
+    ranks_seen = parallel.ranks_seen()          # world size as the collectives see it (an all-reduce of ones)
 
     if rank == 0:
         kern_ms = sum(a.elapsed_time(b) for a, b in fwd_events) / len(fwd_events)
@@ -288,7 +289,10 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic uniform CVRP-100, random-init weights",
             "config": {"workload": "CVRP-100 batch=64/GPU pomo=100 joint (local policy on), BASELINE configs[1]",
                        "global_batch": LOCAL_BATCH * world, "pomo": POMO, "problem_size": N_NODES,
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}", "n_ranks_seen": ranks_seen,
+                       "grad_allreduce": (None if bucket is None else
+                                          {"backend": torch.distributed.get_backend(), "calls": bucket.calls,
+                                           "elements": bucket.numel})},
             "roofline": {"kernel": "rollout_fwd_coop_kernel (persistent decode: all steps of all trajectories)",
                          "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

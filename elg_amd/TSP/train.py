@@ -89,7 +89,7 @@ def train(model, training, T, start_steps, train_steps, mixed, train_batch_size,
     distribution_ = dict(distribution)
     gaps = np.array([1, 1, 1])
     optimizer = Optimizer(model.parameters(), lr=lr, weight_decay=1e-6)
-    bucket = parallel.GradBucket(model.parameters(), optimizer) if world > 1 else None
+    bucket = parallel.make_bucket(model.parameters(), optimizer)
     for i in range(train_steps - start_steps + 1):
         model.train()
         if (i == T - start_steps) and training == 'joint':
@@ -97,7 +97,7 @@ def train(model, training, T, start_steps, train_steps, mixed, train_batch_size,
             model.decoder.add_local_policy(device)
             parallel.broadcast_parameters(model)
             optimizer = Optimizer(model.parameters(), lr=lr, weight_decay=1e-6)
-            bucket = parallel.GradBucket(model.parameters(), optimizer) if world > 1 else None
+            bucket = parallel.make_bucket(model.parameters(), optimizer)
         if mixed:                                                   # curriculum: families weighted by their validation gaps
             kind = str(np.random.choice(['uniform', 'cluster', 'mixed'], size=1, p=softmax(gaps))[0])
             kind = parallel.broadcast_object(kind)                   # every rank must draw the same family

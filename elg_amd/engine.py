@@ -700,11 +700,8 @@ def add_instance_norm(a: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, bet
 # still alive (module globals are otherwise destroyed in arbitrary order at interpreter exit)
 # ----------------------------------------------------------------------------------------------
 def _teardown():
-    try:
-        if torch.cuda.is_available() and torch.cuda.is_initialized():
-            torch.cuda.synchronize()
-    except Exception:
-        pass
+    # no device synchronisation here: freeing a buffer orders itself behind the work that uses it, and an exit path must
+    # never be able to block on the GPU (another process may hold it)
     for cache in (_PINNED, TrainRows._cache, _BwdScratch._cache, _SIDE):
         cache.clear()
 

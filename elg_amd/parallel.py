@@ -2,9 +2,14 @@
 RCCL on ROCm, over xGMI), one flat fp32 gradient bucket all-reduced per step.
 
 The reference has no distributed code at all; instances never interact in the forward pass and the loss is
-a mean over instances, so every rank rolls out its own shard and only the 5 MB gradient is exchanged."""
+a mean over instances, so every rank rolls out its own shard and only the 5 MB gradient is exchanged.
+
+Collectives on device memory are issued on the `nccl` backend only.  On any other backend (gloo: the CPU tests and
+the two-ranks-on-one-GPU test) the flat buffer is staged through pinned host memory and the collective runs on the
+host copy -- gloo's own device path is not exercised anywhere in this package."""
 from __future__ import annotations
 
+import datetime
 import os
 from typing import Iterable, List, Optional
 
@@ -16,17 +21,66 @@ def world_info():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 
 
-def init_distributed(backend: Optional[str] = None) -> tuple:
+def force_group() -> bool:
+    """ELG_FORCE_DIST=1: build the process group and run the gradient all-reduce even at world size 1 (the RCCL branch
+    of a training step on a single GPU: `python -m torch.distributed.run --nproc-per-node 1 ...`)."""
+    return os.environ.get("ELG_FORCE_DIST", "0") not in ("", "0")
+
+
+def active() -> bool:
+    """True when a training step has to go through the gradient bucket."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_group())
+
+
+def init_distributed(backend: Optional[str] = None, timeout_s: float = 600.0) -> tuple:
     rank, world, local = world_info()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_group()) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
+        if backend == "gloo":
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node: never go looking for the host's name
+        kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            kw["device_id"] = torch.device("cuda", local)          # eager communicator: a bad RCCL setup fails here
+        dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=timeout_s), **kw)
     return rank, world, local
+
+
+def _device_collectives() -> bool:
+    return (not dist.is_initialized()) or dist.get_backend() == "nccl"
+
+
+class _HostStage:
+    """Pinned mirror of a flat device buffer for backends without a device path."""
+
+    def __init__(self, numel: int, dtype):
+        self.buf = torch.empty(numel, dtype=dtype, pin_memory=torch.cuda.is_available())
+
+    def down(self, t: torch.Tensor) -> torch.Tensor:
+        self.buf.copy_(t, non_blocking=True)
+        if t.is_cuda:
+            torch.cuda.current_stream(t.device).synchronize()
+        return self.buf
+
+    def up(self, t: torch.Tensor):
+        t.copy_(self.buf, non_blocking=True)
+
+
+def all_reduce_sum(flat: torch.Tensor, stage: Optional[_HostStage] = None):
+    """In-place SUM over the ranks of a flat buffer.  nccl: on the buffer itself, ordered on the current stream by
+    ProcessGroupNCCL (its collective waits for the current stream, and the current stream waits for the collective)."""
+    if not flat.is_cuda or _device_collectives():
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        return
+    stage = stage or _HostStage(flat.numel(), flat.dtype)
+    dist.all_reduce(stage.down(flat), op=dist.ReduceOp.SUM)
+    stage.up(flat)
 
 
 class GradBucket:
@@ -45,13 +99,21 @@ class GradBucket:
             self.flat = self.optimizer.grad_flat
         else:
             self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self._stage = None
+        self.calls = 0                        # all-reduces issued (bench.py / tests: proof that the branch ran)
+
+    def _reduce(self):
+        if self.flat.is_cuda and not _device_collectives() and self._stage is None:
+            self._stage = _HostStage(self.numel, self.flat.dtype)
+        all_reduce_sum(self.flat, self._stage)
+        self.calls += 1
 
     def allreduce(self, world: int):
-        if world <= 1:
+        if world <= 1 and not force_group():
             return
         if self.optimizer is not None:
             self.optimizer.gather_grads()
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self._reduce()
             self.optimizer.grad_scale = 1.0 / world
             return
         off = 0
@@ -62,7 +124,7 @@ class GradBucket:
             else:
                 self.flat[off:off + n].copy_(p.grad.reshape(-1))
             off += n
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        self._reduce()
         self.flat.mul_(1.0 / world)
         off = 0
         for p in self.params:
@@ -74,10 +136,31 @@ class GradBucket:
             off += n
 
 
+def make_bucket(params, optimizer=None) -> Optional[GradBucket]:
+    """The bucket a training loop needs: None for a plain single-process run."""
+    return GradBucket(params, optimizer) if active() else None
+
+
 def broadcast_parameters(module: torch.nn.Module, src: int = 0):
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src=src)
+    """Rank `src`'s parameters and buffers on every rank: ONE broadcast of the packed values."""
+    if not active():
+        return
+    ts = [t.data for t in list(module.parameters()) + list(module.buffers())]
+    if not ts:
+        return
+    for dtype in sorted({t.dtype for t in ts}, key=str):
+        group = [t for t in ts if t.dtype == dtype]
+        flat = torch.cat([t.reshape(-1) for t in group])
+        if flat.is_cuda and not _device_collectives():
+            host = flat.cpu()
+            dist.broadcast(host, src=src)
+            flat = host.to(flat.device)
+        else:
+            dist.broadcast(flat, src=src)
+        off = 0
+        for t in group:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
 
 
 def broadcast_object(obj, src: int = 0):
@@ -89,6 +172,18 @@ def broadcast_object(obj, src: int = 0):
     return obj
 
 
+def ranks_seen() -> int:
+    """World size as the data path sees it: an all-reduce of ones (1 without a process group)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    one = torch.ones(1, device="cuda" if _device_collectives() else "cpu")
+    dist.all_reduce(one)
+    return int(one.item())
+
+
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+    if dist.is_initialized() and (dist.get_world_size() > 1 or force_group()):
+        if _device_collectives():
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()

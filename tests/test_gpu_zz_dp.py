@@ -1,0 +1,123 @@
+"""The data-parallel path the product uses (parallel.GradBucket on elg_amd.optim.Adam's packed gradient buffer, 1/world
+folded into the Adam kernel) in fresh child processes:
+* two real ranks, both on cuda:0, gloo backend (RCCL refuses two ranks on one device);
+* the RCCL branch itself: backend nccl at world size 1 (ELG_FORCE_DIST=1);
+* bench.py under the launcher the driver uses (`python -m torch.distributed.run`), with the RCCL all-reduce forced.
+The file sorts last (`zz`, and tests/conftest.py orders it last): nothing that starts processes or opens sockets runs in
+front of a parity test.  Children are killed on every exit path; their logs land in gpurun_out/dp_logs/ when a test fails."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+import time
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dp_worker.py")
+CHILD_LIMIT_S = 150
+
+
+def _env(extra):
+    e = dict(os.environ)
+    e.update({"MASTER_ADDR": "127.0.0.1", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "GLOO_SOCKET_IFNAME": "lo",
+              "OMP_NUM_THREADS": "4", "ELG_DP_WATCHDOG": str(CHILD_LIMIT_S - 30)})
+    e.update(extra)
+    return e
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
+def _run_children(cmds_envs, tmp_path, tag, limit_s=CHILD_LIMIT_S, cwd=None):
+    """Start the commands, wait at most limit_s for all of them, ALWAYS kill and reap what is left.  Output goes to files
+    (no pipe can fill).  Returns [(returncode, log text)]."""
+    procs, logs = [], []
+    try:
+        for i, (cmd, env) in enumerate(cmds_envs):
+            path = tmp_path / f"{tag}{i}.log"
+            logs.append(path)
+            fh = open(path, "w")
+            procs.append((subprocess.Popen(cmd, env=env, stdout=fh, stderr=subprocess.STDOUT, cwd=cwd,
+                                           start_new_session=True), fh))
+        deadline = time.time() + limit_s
+        while time.time() < deadline and any(p.poll() is None for p, _ in procs):
+            time.sleep(0.2)
+    finally:
+        for p, fh in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, 9)              # the child leads its own session: launcher + its workers
+                except (ProcessLookupError, PermissionError):
+                    p.kill()
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                pass
+            fh.close()
+    out = [(p.returncode, open(path).read()) for (p, _), path in zip(procs, logs)]
+    if any(rc != 0 for rc, _ in out):
+        keep = os.path.join(ROOT, "gpurun_out", "dp_logs")
+        os.makedirs(keep, exist_ok=True)
+        for path in logs:
+            shutil.copy(path, os.path.join(keep, os.path.basename(str(path))))
+    return out
+
+
+def _check(results):
+    for rc, log in results:
+        assert rc == 0, f"child exit code {rc} (-9 = killed at the {CHILD_LIMIT_S} s limit)\n" + log[-4000:]
+
+
+def test_two_ranks_share_one_gradient(tmp_path):
+    port = _free_port()
+    outs = [tmp_path / f"rank{r}.json" for r in range(2)]
+    _check(_run_children(
+        [([sys.executable, WORKER, str(outs[r]), "two_ranks"],
+          _env({"RANK": str(r), "WORLD_SIZE": "2", "LOCAL_RANK": "0", "MASTER_PORT": port})) for r in range(2)],
+        tmp_path, "two_ranks_rank"))
+    res = [json.load(open(o)) for o in outs]
+    for r in res:
+        assert r["world"] == 2 and r["grad_scale"] == 0.5 and r["bucket_calls"] == 1
+        assert r["staged_on_host"]                                        # gloo never sees device memory
+        assert r["local_differs"] > 0                                     # the ranks really had different shards
+        assert r["allreduce_err"] <= 1e-6 * r["grad_abs_max"]               # bucket = sum of the local packed gradients
+        assert r["step_moved"] > 0
+        assert r["vs_single_process_adam"] == 0.0                          # = Adam on the averaged gradient, bit for bit
+    assert res[0]["param_checksum"] == res[1]["param_checksum"]             # replicas identical after the step
+
+
+def test_rccl_allreduce_in_the_training_step(tmp_path):
+    """Backend nccl (RCCL) on this box's one GPU: process group, communicator, all-reduce on the optimiser's buffer,
+    stream ordering against the ctypes-launched Adam kernel."""
+    out = tmp_path / "rccl.json"
+    _check(_run_children(
+        [([sys.executable, WORKER, str(out), "rccl_world1"],
+          _env({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_PORT": _free_port(), "ELG_FORCE_DIST": "1"}))],
+        tmp_path, "rccl_world1_"))
+    r = json.load(open(out))
+    assert r["backend"] == "nccl" and r["world"] == 1 and r["ranks_seen"] == 1
+    assert r["bucket_calls"] == 3 and r["finite_after_3_steps"] and r["moved"] > 0
+    assert r["reduced_vs_local"] == 0.0                       # a sum over one rank
+    assert r["vs_single_process_adam"] == 0.0                 # Adam saw the reduced buffer, bit for bit
+    assert r["bucket_vs_plain_grad"] <= 1e-5 * r["grad_abs_max"]
+
+
+def test_bench_under_the_launcher(tmp_path):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2",
+           "--no-cpu-baseline", "--no-secondary"]
+    (rc, log), = _run_children([(cmd, _env({"ELG_FORCE_DIST": "1"}))], tmp_path, "bench_launcher_", limit_s=240, cwd=ROOT)
+    assert rc == 0, log[-4000:]
+    line = [ln for ln in log.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["value"] > 0 and out["scaling"] == "weak"
+    cfg = out["config"]
+    assert cfg["parallelism"] == "dp1" and cfg["n_ranks_seen"] == 1
+    assert cfg["grad_allreduce"]["backend"] == "nccl" and cfg["grad_allreduce"]["calls"] == 5     # 2 warm-up + 3 timed
