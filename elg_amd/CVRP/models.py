@@ -115,9 +115,11 @@ class CVRP_Decoder(nn.Module):
         self.policy = None           # engine.Policy of the current batch
 
     def add_local_policy(self, device):
-        n = self.model_params['ensemble_size']
-        if n != 1:
-            raise NotImplementedError("ensemble_size > 1 is not built (SURVEY 8f rank 4)")
+        n = int(self.model_params['ensemble_size'])
+        if not 1 <= n <= L.MAX_ENS:
+            raise NotImplementedError(f"ensemble_size {n}: the HIP kernels are built for 1 .. {L.MAX_ENS} local policies")
+        if len(self.model_params['local_size']) < n:
+            raise IndexError("model_params['local_size'] needs one entry per ensemble member (reference models.py:14)")
         self.local_policies = nn.ModuleList([local_policy_att(self.model_params, idx=i).to(device) for i in range(n)])
         self.local = True
 
@@ -125,14 +127,18 @@ class CVRP_Decoder(nn.Module):
         """Folded local-policy tables (engine.fold_local_tables), or None without the ensemble head."""
         mp = self.model_params
         has_local = bool(mp['ensemble'] and self.local)
-        return self.local_policies[0].folded_tables(int(mp['local_size'][0]) + 1) if has_local else None
+        if not has_local:
+            return None
+        locs = [lp.folded_tables(int(lp.local_size) + 1) for lp in self.local_policies]     # reference models.py:296-298
+        return locs[0] if len(locs) == 1 else torch.cat(locs)
 
     def set_tables(self, encoded_nodes, tables, loc):
         mp = self.model_params
         has_local = bool(mp['ensemble'] and self.local)
         self.policy = eng.Policy(tables, loc, int(mp['local_size'][0]), float(mp['xi']), float(mp['logit_clipping']),
                                  1.0 / float(mp['ensemble_size']), has_local, bool(mp['distance_penalty']),
-                                 bool(mp.get('euclidean', False)))
+                                 bool(mp.get('euclidean', False)),
+                                 tuple(int(lp.local_size) for lp in self.local_policies) if (has_local and len(self.local_policies) > 1) else ())
         # attributes the reference exposes after set_kv
         self.k, self.v = tables["K"], tables["V"]
         self.single_head_key = encoded_nodes.transpose(1, 2)

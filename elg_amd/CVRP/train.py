@@ -42,8 +42,9 @@ def train_step(model, env, optimizer, batch, scale_norm=True, bucket=None, world
     env.load_random_problems(batch)
     reset_state, _, _ = env.reset()
     model.pre_forward(reset_state)
-    if env.problem.N1 > 128 or env.vrplib:
-        # sizes whose training forward saves no rows: the reference's sequence with the host sync inside rollout()
+    pol = model.policy if hasattr(model, 'policy') else model.decoder.policy
+    if env.problem.N1 > 128 or env.vrplib or pol.ens > 1:
+        # sizes / variants whose training forward saves no rows: the reference's sequence with the host sync inside rollout()
         solutions, probs, rewards = rollout(model=model, env=env, eval_type='sample')
         if check:
             check_feasible(solutions[0:1], reset_state.node_demand[0:1])

@@ -16,6 +16,7 @@ LOC_ROWS = 64
 LOC_LA, LOC_LT, LOC_LAV, LOC_LCV, LOC_LWC, LOC_LBC, LOC_LWE, LOC_LPE, LOC_SIZE = \
     0, 16, 272, 368, 2416, 3440, 3472, 3568, 5616
 
+MAX_ENS = 4
 _vp = C.c_void_p
 
 
@@ -28,6 +29,7 @@ class RolloutArgs(C.Structure):
         ("dump_T", C.c_int32),
         ("xi", C.c_float), ("clip", C.c_float), ("inv_ens", C.c_float), ("variant", C.c_int32),
         ("dump_logits", C.c_int32), ("euclidean", C.c_int32),
+        ("ens", C.c_int32), ("Kens", C.c_int32 * MAX_ENS), ("pad_ens", C.c_int32),
         ("seed", C.c_uint64),
         ("Kmat", _vp), ("Vmat", _vp), ("PK", _vp), ("pb", _vp), ("Q1", _vp), ("Q2", _vp), ("wl", _vp),
         ("xy", _vp), ("demand", _vp), ("nbr_idx", _vp), ("nbr_dist", _vp), ("nbr_theta", _vp), ("loc", _vp),
@@ -41,7 +43,7 @@ class RolloutArgs(C.Structure):
 
 class BwdArgs(C.Structure):
     _fields_ = [
-        ("fwd", RolloutArgs), ("T", C.c_int32), ("pad1", C.c_int32),
+        ("fwd", RolloutArgs), ("T", C.c_int32), ("member", C.c_int32),
         ("gprob", _vp), ("rowA", _vp), ("rowDL", _vp), ("rowQ", _vp), ("rowO", _vp), ("rowLoad", _vp),
         ("rowDU", _vp), ("gloc", _vp), ("time_major", C.c_int32), ("local_only", C.c_int32),
         ("row_stride", C.c_int64),

@@ -98,11 +98,11 @@ __device__ __forceinline__ void bwd_step(const elg_bwd_args& BA, const Inst& I, 
     float addval = 0.f;
     int snid = -1;
     if (A.has_penalty || A.has_local) {
-        const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb, nullptr, A.euclidean != 0);
+        const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb, nullptr, A.euclidean != 0, A.ens, A.Kens);
         snid = S.snid;
         float u = 0.f;
-        if (A.has_local) u = local_policy<TSP>(I.loc, lane, S.f0, S.f1, S.f2, S.smask, nullptr);
-        addval = S.pen + u * A.inv_ens;
+        if (A.has_local) u = local_ensemble<TSP>(A, I.loc, lane, S);
+        addval = slot_penalty(A, S) + u * A.inv_ens;
     }
     GlimpseSave<NG> gs;
     const float4 o4 = glimpse<NCH, LDSK, NG>(I, N1, lane, q4, mk, &gs);
@@ -385,8 +385,13 @@ __global__ __launch_bounds__(WAVES * 64) void local_bwd_kernel(const elg_bwd_arg
                 if (__ballot(du != 0.f)) {
                     unsigned long long mk[NCH];
                     build_mask<NCH, TSP>(st, I, N1, lane, mk);
-                    const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb, nullptr, A.euclidean != 0);
-                    local_bwd_step<TSP>(I.loc, LA, lane, S, du);
+                    Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb, nullptr, A.euclidean != 0, A.ens, A.Kens);
+                    float dui = du;
+                    if (A.ens > 1) {        // this launch's member: its features, its slots' cotangents
+                        const bool in = member_slot<TSP>(S, BA.member, lane, A.euclidean != 0, S.f0, S.f1, S.f2, S.smask);
+                        dui = in ? du : 0.f;
+                    }
+                    local_bwd_step<TSP>(I.loc + (size_t)BA.member * ELG_LOC_SIZE, LA, lane, S, dui);
                 }
             }
             if (!st.fin) env_update<NCH, TSP>(st, I, N1, sel);
@@ -416,7 +421,7 @@ __global__ __launch_bounds__(WAVES * 64) void local_bwd_kernel(const elg_bwd_arg
     __syncthreads();
     for (int i = threadIdx.x; i < ELG_LOC_SIZE; i += WAVES * 64) {
         const float v = acc[i];
-        if (v != 0.f) atomicAdd(BA.gloc + i, v);
+        if (v != 0.f) atomicAdd(BA.gloc + (size_t)BA.member * ELG_LOC_SIZE + i, v);
     }
 }
 
@@ -547,9 +552,13 @@ static int launch_bwd_impl(const elg_bwd_args& BA, hipStream_t stream) {
                 return fail(ELG_ELAUNCH, "hipFuncSetAttribute failed");
             attr2 = true;
         }
-        (void)hipGetLastError();
-    hipLaunchKernelGGL(k2, dim3(A.B * A.tiles), dim3(LW * 64), l2, stream, BA);
-        if (launch_status("local_bwd") != ELG_OK) return ELG_ELAUNCH;
+        elg_bwd_args BM = BA;          // one replay launch per ensemble member (register-resident table gradients)
+        for (int i = 0; i < (A.ens > 1 ? A.ens : 1); ++i) {
+            BM.member = i;
+            (void)hipGetLastError();
+            hipLaunchKernelGGL(k2, dim3(A.B * A.tiles), dim3(LW * 64), l2, stream, BM);
+            if (launch_status("local_bwd") != ELG_OK) return ELG_ELAUNCH;
+        }
     }
     return ELG_OK;
 }
@@ -1045,6 +1054,11 @@ extern "C" int elg_rollout_bwd(const elg_bwd_args* a, void* stream) {
         return fail(ELG_EINVAL, "rollout_bwd: missing row buffers");
     if (A.has_local && (!A.loc || !BA.rowDU || !BA.gloc)) return fail(ELG_EINVAL, "rollout_bwd: local buffers missing");
     if (A.K + 1 > ELG_SLOT_STRIDE) return fail(ELG_EINVAL, "rollout_bwd: local_size must be <= 47");
+    if (A.ens > 1) {
+        if (A.ens > ELG_MAX_ENS || A.problem != ELG_PROBLEM_CVRP || A.Kens[0] != A.K) return fail(ELG_EINVAL, "rollout_bwd: bad ensemble");
+        for (int i = 0; i < A.ens; ++i)
+            if (A.Kens[i] < 0 || A.Kens[i] + 1 > ELG_SLOT_STRIDE) return fail(ELG_EINVAL, "rollout_bwd: local_size must be <= 47");
+    }
     if (A.problem == ELG_PROBLEM_CVRP) return dispatch_bwd<false>(BA, (hipStream_t)stream);
     if (A.problem == ELG_PROBLEM_TSP) return dispatch_bwd<true>(BA, (hipStream_t)stream);
     return fail(ELG_EINVAL, "rollout_bwd: unknown problem");

@@ -695,6 +695,127 @@ __global__ __launch_bounds__(512) void enc_attn_bwd_kernel(const float* __restri
     }
 }
 
+// self-attention backward for N1 > 128 (training at CVRP/TSP-200 ... 1000: TSP/train.py:101-122 trains any size through one
+// tape).  Same products and operand maps as enc_attn_bwd_kernel, but the (instance, head)'s Q, K, V, dO no longer fit LDS:
+// a wave owns one 16-row tile (dQ) or one 16-key tile (dK, dV) and walks the other index in tiles of 16 whose operands it
+// reads from global memory (the instance's 3 x N1 x 128 floats are L2-resident).  delta[row] = dO_h[row] . O_h[row] comes
+// from enc_attn_delta_kernel.  grid (ceil(N1 / 64), B * 8), one wave per tile.
+__global__ __launch_bounds__(256) void enc_attn_delta_kernel(const float* __restrict__ dOg, const float* __restrict__ Og,
+                                                             float* __restrict__ delta, int N1, long rows) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;          // (row, head)
+    if (idx >= rows * 8) return;
+    const long row = idx >> 3;
+    const int h = (int)(idx & 7);
+    const float* d = dOg + row * ELG_E + h * 16;
+    const float* o = Og + row * ELG_E + h * 16;
+    float acc = 0.f;
+#pragma unroll
+    for (int c4 = 0; c4 < 16; c4 += 4)
+        acc = dot4(*reinterpret_cast<const float4*>(d + c4), *reinterpret_cast<const float4*>(o + c4), acc);
+    const long b = row / N1, n = row - b * N1;
+    delta[(b * 8 + h) * N1 + n] = acc;
+}
+
+template <bool KV>
+__global__ __launch_bounds__(256) void enc_attn_bwd_large_kernel(const float* __restrict__ qkv, const float* __restrict__ dOg,
+                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                 float* __restrict__ dqkv, int N1) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lo = lane & 15, hi = lane >> 4;
+    const int b = blockIdx.y >> 3, h = blockIdx.y & 7;
+    const int t0 = (blockIdx.x * 4 + wave) * 16;                    // first row (dQ) / key (dK, dV) of this wave's tile
+    if (t0 >= N1) return;
+    constexpr int LD = 3 * ELG_E;
+    const float* base = qkv + (size_t)b * N1 * LD + h * 16;
+    const float* dOb = dOg + (size_t)b * N1 * ELG_E + h * 16;
+    const float* lb = lse + (size_t)blockIdx.y * N1;
+    const float* db = delta + (size_t)blockIdx.y * N1;
+    const int nt = (N1 + 15) >> 4;
+    if (!KV) {
+        // ---- rows on lanes: dQ of the tile
+        const int row = t0 + lo, rc = min(row, N1 - 1);
+        const float mk = row < N1 ? 1.f : 0.f;
+        float4 qB = *reinterpret_cast<const float4*>(base + (size_t)rc * LD + 4 * hi);
+        float4 dB = *reinterpret_cast<const float4*>(dOb + (size_t)rc * ELG_E + 4 * hi);
+        qB.x *= mk; qB.y *= mk; qB.z *= mk; qB.w *= mk;
+        dB.x *= mk; dB.y *= mk; dB.z *= mk; dB.w *= mk;
+        const float lr = row < N1 ? lb[rc] : __builtin_huge_valf(), del = row < N1 ? db[rc] : 0.f;
+        f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nt; ++kt) {
+            const int kc = min(16 * kt + lo, N1 - 1);
+            const float4 kA = *reinterpret_cast<const float4*>(base + (size_t)kc * LD + ELG_E + 4 * hi);
+            const float4 vA = *reinterpret_cast<const float4*>(base + (size_t)kc * LD + 2 * ELG_E + 4 * hi);
+            float kTv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) kTv[i] = base[(size_t)min(16 * kt + 4 * hi + i, N1 - 1) * LD + ELG_E + lo];
+            f32x4 S = {0.f, 0.f, 0.f, 0.f}, dP = {0.f, 0.f, 0.f, 0.f};
+            S = __builtin_amdgcn_mfma_f32_16x16x4f32(kA.x, qB.x, S, 0, 0, 0);
+            dP = __builtin_amdgcn_mfma_f32_16x16x4f32(vA.x, dB.x, dP, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_16x16x4f32(kA.y, qB.y, S, 0, 0, 0);
+            dP = __builtin_amdgcn_mfma_f32_16x16x4f32(vA.y, dB.y, dP, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_16x16x4f32(kA.z, qB.z, S, 0, 0, 0);
+            dP = __builtin_amdgcn_mfma_f32_16x16x4f32(vA.z, dB.z, dP, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_16x16x4f32(kA.w, qB.w, S, 0, 0, 0);
+            dP = __builtin_amdgcn_mfma_f32_16x16x4f32(vA.w, dB.w, dP, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int key = 16 * kt + 4 * hi + i;
+                const float p = key < N1 ? __expf(S[i] * 0.25f - lr) : 0.f;
+                const float ds = p * (dP[i] - del) * 0.25f;
+                dq = __builtin_amdgcn_mfma_f32_16x16x4f32(kTv[i], ds, dq, 0, 0, 0);
+            }
+        }
+        if (row < N1)
+            *reinterpret_cast<float4*>(dqkv + ((size_t)b * N1 + row) * LD + h * 16 + 4 * hi) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+    } else {
+        // ---- keys on lanes: dK, dV of the tile
+        const int key = t0 + lo, kc = min(key, N1 - 1);
+        const bool kok = key < N1;
+        const float4 kB = *reinterpret_cast<const float4*>(base + (size_t)kc * LD + ELG_E + 4 * hi);
+        const float4 vB = *reinterpret_cast<const float4*>(base + (size_t)kc * LD + 2 * ELG_E + 4 * hi);
+        f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+        for (int rt = 0; rt < nt; ++rt) {
+            const int r = 16 * rt + lo, rc = min(r, N1 - 1);
+            const float mk = r < N1 ? 1.f : 0.f;
+            float4 qA = *reinterpret_cast<const float4*>(base + (size_t)rc * LD + 4 * hi);
+            float4 dA = *reinterpret_cast<const float4*>(dOb + (size_t)rc * ELG_E + 4 * hi);
+            qA.x *= mk; qA.y *= mk; qA.z *= mk; qA.w *= mk;
+            dA.x *= mk; dA.y *= mk; dA.z *= mk; dA.w *= mk;
+            float lv[4], ev[4], dTv[4], qTv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r2 = 16 * rt + 4 * hi + i, r2c = min(r2, N1 - 1);
+                const bool ok = r2 < N1;
+                lv[i] = ok ? lb[r2c] : __builtin_huge_valf();
+                ev[i] = ok ? db[r2c] : 0.f;
+                dTv[i] = ok ? dOb[(size_t)r2c * ELG_E + lo] : 0.f;
+                qTv[i] = ok ? base[(size_t)r2c * LD + lo] : 0.f;
+            }
+            f32x4 S = {0.f, 0.f, 0.f, 0.f}, dP = {0.f, 0.f, 0.f, 0.f};
+            S = __builtin_amdgcn_mfma_f32_16x16x4f32(qA.x, kB.x, S, 0, 0, 0);
+            dP = __builtin_amdgcn_mfma_f32_16x16x4f32(dA.x, vB.x, dP, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_16x16x4f32(qA.y, kB.y, S, 0, 0, 0);
+            dP = __builtin_amdgcn_mfma_f32_16x16x4f32(dA.y, vB.y, dP, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_16x16x4f32(qA.z, kB.z, S, 0, 0, 0);
+            dP = __builtin_amdgcn_mfma_f32_16x16x4f32(dA.z, vB.z, dP, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_16x16x4f32(qA.w, kB.w, S, 0, 0, 0);
+            dP = __builtin_amdgcn_mfma_f32_16x16x4f32(dA.w, vB.w, dP, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float p = kok ? __expf(S[i] * 0.25f - lv[i]) : 0.f;
+                const float ds = p * (dP[i] - ev[i]) * 0.25f;
+                dv = __builtin_amdgcn_mfma_f32_16x16x4f32(dTv[i], p, dv, 0, 0, 0);
+                dk = __builtin_amdgcn_mfma_f32_16x16x4f32(qTv[i], ds, dk, 0, 0, 0);
+            }
+        }
+        if (kok) {
+            float* o = dqkv + ((size_t)b * N1 + key) * LD + h * 16 + 4 * hi;
+            *reinterpret_cast<float4*>(o + ELG_E) = make_float4(dk[0], dk[1], dk[2], dk[3]);
+            *reinterpret_cast<float4*>(o + 2 * ELG_E) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // All weight gradients of the encoder in ONE launch: dW_j[M,N] += alpha_j dY_j^T X_j over the batch*nodes rows, for every
 // nn.Linear of every layer (and the decoder tables' projections), bias gradients = column sums of dY_j.
@@ -883,7 +1004,8 @@ extern "C" int64_t elg_encoder_ws_floats(int B, int N1, int n_layers, int ff_hid
 extern "C" int64_t elg_encoder_bwd_ws_floats(int B, int N1, int n_layers, int ff_hidden) {
     if (B <= 0 || N1 <= 0 || n_layers <= 0 || ff_hidden <= 0) return 0;
     // d x / d att / d x1 (shared) + per layer: dS2, dH, dS1, dQKV (kept until the grouped weight-gradient launch)
-    return (int64_t)B * N1 * (3 * ELG_E + (int64_t)n_layers * (5 * ELG_E + ff_hidden));
+    // + delta[b, h, n] of the N1 > 128 attention backward
+    return (int64_t)B * N1 * (3 * ELG_E + (int64_t)n_layers * (5 * ELG_E + ff_hidden)) + (N1 > 128 ? (int64_t)B * 8 * N1 : 0);
 }
 
 static int check_enc_args(const elg_encoder_args* a) {
@@ -1013,7 +1135,6 @@ extern "C" int elg_encoder_bwd(const elg_encoder_bwd_args* ba, void* stream) {
     const elg_encoder_args* a = &ba->fwd;
     ENC_TRY(check_enc_args(a))
     if (!a->save || a->n_layers < 1) return fail(ELG_EINVAL, "encoder bwd: the forward must have run with save = 1");
-    if (a->N1 > 128) return fail(ELG_ENOTIMPL, "encoder bwd: N1 > 128 not built");
     hipStream_t s = (hipStream_t)stream;
     const int B = a->B, N1 = a->N1, FF = a->ff_hidden;
     const bool tsp = a->problem == ELG_PROBLEM_TSP;
@@ -1029,7 +1150,10 @@ extern "C" int elg_encoder_bwd(const elg_encoder_bwd_args* ba, void* stream) {
     float* ws = a->ws;
     DwList dw(R, s);
     const float inv_sqrt_e = 0.08838834764831845f;
-    const bool aligned = true;
+    // N1 <= 128: row block = instance, the norm backwards ride in GEMM epilogues.  N1 > 128: 128-row blocks, the add & norm
+    // backwards are the stand-alone kernel (per (instance, channel) over the node axis), attention backward from global memory
+    const bool aligned = N1 <= 128;
+    float* delta = lay2 + lay2_stride * a->n_layers;
     // ---- d enc from the decoder tables (autograd of set_kv / fold_decoder_tables)
     bool have = false;          // gX holds a value
     if (ba->g_enc) {
@@ -1119,7 +1243,9 @@ extern "C" int elg_encoder_bwd(const elg_encoder_bwd_args* ba, void* stream) {
             g.W[0] = L.W1; g.ldw = ELG_E; g.wmode = W_KN; g.wblk = FF; g.C[0] = gY; g.ldc = ELG_E; g.epi = EPI_ADD_NORMBWD; g.R = gS; g.ldr = ELG_E;
             g.xhat = const_cast<float*>(XH1); g.rstd = const_cast<float*>(RS1); g.gamma = L.g1;
             g.dgamma = (float*)GL.g1; g.dbeta = (float*)GL.b1;
+            if (!aligned) { g.epi = EPI_ADD; g.C[0] = gT; }
             ENC_TRY(launch_gemm(g, s))
+            if (!aligned) ENC_TRY(elg_add_instnorm_bwd(gT, XH1, RS1, L.g1, gY, (float*)GL.g1, (float*)GL.b1, B, N1, ELG_E, stream))
         }
         ENC_TRY(dw.add(gY, ELG_E, O, ELG_E, (float*)GL.Wc, ELG_E, ELG_E, ELG_E, (float*)GL.bc, 1.f))
         {   // d att = dY Wc
@@ -1128,7 +1254,11 @@ extern "C" int elg_encoder_bwd(const elg_encoder_bwd_args* ba, void* stream) {
             ENC_TRY(launch_gemm(g, s))
         }
         (void)hipGetLastError();
-        {
+        if (!aligned) {
+            hipLaunchKernelGGL(enc_attn_delta_kernel, dim3((unsigned)((R * 8 + 255) / 256)), dim3(256), 0, s, gO, O, delta, N1, R);
+            hipLaunchKernelGGL((enc_attn_bwd_large_kernel<false>), dim3((N1 + 63) / 64, B * 8), dim3(256), 0, s, QKV, gO, LSE, delta, dQKV, N1);
+            hipLaunchKernelGGL((enc_attn_bwd_large_kernel<true>), dim3((N1 + 63) / 64, B * 8), dim3(256), 0, s, QKV, gO, LSE, delta, dQKV, N1);
+        } else {
             const int nt = (N1 + 15) / 16;
             if (nt <= 2) hipLaunchKernelGGL((enc_attn_bwd_kernel<2>), dim3(B * 8), dim3(512), 0, s, QKV, gO, O, LSE, dQKV, N1);
             else if (nt <= 4) hipLaunchKernelGGL((enc_attn_bwd_kernel<4>), dim3(B * 8), dim3(512), 0, s, QKV, gO, O, LSE, dQKV, N1);
@@ -1144,13 +1274,18 @@ extern "C" int elg_encoder_bwd(const elg_encoder_bwd_args* ba, void* stream) {
             EncGemm g = gemm_base(dQKV, 3 * ELG_E, ELG_E, 3 * ELG_E, R, N1, aligned);
             g.W[0] = L.Wq; g.W[1] = L.Wk; g.W[2] = L.Wv; g.ldw = ELG_E; g.wmode = W_KN; g.wblk = ELG_E; g.C[0] = gX; g.ldc = ELG_E;
             g.epi = EPI_ADD; g.R = gY; g.ldr = ELG_E;
-            if (l > 0) {
+            if (l > 0 && aligned) {
                 const float* lbp = ws + w.layer0 + w.layer_stride * (l - 1);
                 g.epi = EPI_ADD_NORMBWD; g.C[0] = lay2 + lay2_stride * (l - 1);
                 g.xhat = const_cast<float*>(lbp + w.oXH2); g.rstd = const_cast<float*>(lbp + w.oRS2); g.gamma = a->W.layer[l - 1].g2;
                 g.dgamma = (float*)G.layer[l - 1].g2; g.dbeta = (float*)G.layer[l - 1].b2;
             }
             ENC_TRY(launch_gemm(g, s))
+            if (l > 0 && !aligned) {
+                const float* lbp = ws + w.layer0 + w.layer_stride * (l - 1);
+                ENC_TRY(elg_add_instnorm_bwd(gX, lbp + w.oXH2, lbp + w.oRS2, a->W.layer[l - 1].g2, lay2 + lay2_stride * (l - 1),
+                                             (float*)G.layer[l - 1].g2, (float*)G.layer[l - 1].b2, B, N1, ELG_E, stream))
+            }
         }
     }
     // ---- input embeddings

@@ -270,13 +270,13 @@ __device__ __forceinline__ FwdOut decode_step(const elg_rollout_args& A, const I
     int ssave = -1;              // what the backward needs to know about the slot
     float sf0 = 0.f, sf1 = 0.f, sf2 = 0.f;
     if (A.has_penalty || A.has_local) {
-        const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb, nullptr, A.euclidean != 0);
+        const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, st, lane, mk, sb, nullptr, A.euclidean != 0, A.ens, A.Kens);
         snid = S.snid;
         ssave = (S.smask && S.snid >= 0) ? -2 : S.snid;              // present but masked (the CVRP depot slot)
         sf0 = S.f0; sf1 = S.f1; sf2 = S.f2;
         float u = 0.f;
-        if (A.has_local) u = local_policy<TSP>(I.loc, lane, S.f0, S.f1, S.f2, S.smask, nullptr);
-        addval = S.pen + u * A.inv_ens;
+        if (A.has_local) u = local_ensemble<TSP>(A, I.loc, lane, S);
+        addval = slot_penalty(A, S) + u * A.inv_ens;
     }
     if (TRAIN && A.trSlot && lane < ELG_SLOT_STRIDE) {
         A.trSlot[(b * Rcap + r) * ELG_SLOT_STRIDE + lane] = ssave;
@@ -2346,6 +2346,15 @@ static int dispatch_fwd(const elg_rollout_args& A, hipStream_t stream) {
     // LDS copies of the one-wavefront-per-trajectory kernel (N1 <= 104; 105..112 fall back to its L2 variant)
     const bool lds = A.lds_stage != 0 && A.N1 <= 104;
 #define ELG_GO(NCHV, L, W) return launch_fwd<NCHV, TSP, L, W>(A, stream)
+    if (A.ens > 1) {        // ensemble_size > 1: the one-wavefront-per-trajectory kernel walks the members
+        if (A.trA || A.trMask) return fail(ELG_ENOTIMPL, "rollout: training rows are not built for ensemble_size > 1 (replay backward)");
+        if (nch > 16) return fail(ELG_ENOTIMPL, "rollout: ensemble_size > 1 is built for N1 <= 1024");
+        if (nch == 1) { if (lds) ELG_GO(1, true, 8); else ELG_GO(1, false, 8); }
+        if (nch == 2) { if (lds) ELG_GO(2, true, 8); else ELG_GO(2, false, 8); }
+        if (nch <= 4) { ELG_GO(4, false, 8); }
+        if (nch <= 8) { ELG_GO(8, false, 8); }
+        ELG_GO(16, false, 8);
+    }
     if (A.lds_stage && A.waves == 8 && A.N1 >= 4 && A.N1 <= 16 * CO_NT && !A.use_state && A.do_decode && A.do_update &&
         A.max_steps <= 0 && A.variant == 0) {
         // fused rollout at the training scale: lockstep trajectories, tables as MFMA operands in registers
@@ -2452,6 +2461,13 @@ int elg_rollout_fwd(const elg_rollout_args* a, void* stream) {
     if (A.B <= 0 || A.M <= 0 || A.N1 <= 1 || A.tiles <= 0) return fail(ELG_EINVAL, "rollout: bad sizes");
     if (A.K < 0 || A.K + 1 > ELG_SLOT_STRIDE) return fail(ELG_EINVAL, "rollout: local_size must be <= 47");
     if (A.has_local && !A.loc) return fail(ELG_EINVAL, "rollout: has_local without tables");
+    if (A.ens > 1) {
+        if (A.ens > ELG_MAX_ENS) return fail(ELG_ENOTIMPL, "rollout: ensemble_size > 4 not built");
+        if (A.problem != ELG_PROBLEM_CVRP) return fail(ELG_EINVAL, "rollout: the TSP decoder has one local policy (TSP/models.py:223-225)");
+        if (A.Kens[0] != A.K) return fail(ELG_EINVAL, "rollout: Kens[0] must equal K (local_size[0])");
+        for (int i = 0; i < A.ens; ++i)
+            if (A.Kens[i] < 0 || A.Kens[i] + 1 > ELG_SLOT_STRIDE) return fail(ELG_EINVAL, "rollout: local_size must be <= 47");
+    }
     if (A.mode == ELG_MODE_FORCED && !A.forced) return fail(ELG_EINVAL, "rollout: forced mode without actions");
     if (A.problem == ELG_PROBLEM_CVRP) return dispatch_fwd<false>(A, (hipStream_t)stream);
     if (A.problem == ELG_PROBLEM_TSP) return dispatch_fwd<true>(A, (hipStream_t)stream);

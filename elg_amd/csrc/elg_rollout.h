@@ -166,25 +166,40 @@ __device__ __forceinline__ int knn_slots(const Inst& I, int N1, int K, int cur, 
 
 // Everything the slot lanes need for one step: k-NN slot contents, penalty, local features, mask.
 struct Slots {
-    int k;            // valid neighbour slots (uniform)
-    float dmax;       // distance of the k-th neighbour (uniform value)
-    bool cust;        // this lane holds a real neighbour slot
+    int k;            // valid neighbour slots of the walk (uniform)
+    float dmax;       // distance of the k-th neighbour of the penalty / first local policy (uniform value)
+    bool cust;        // this lane holds a real neighbour slot of the walk
+    bool pcust;       // ... and the slot belongs to the first min(k, K) of them (always == cust without an ensemble)
     int snid;         // node of this lane's slot (-1: none; CVRP lane 0: depot)
     float pen;        // distance penalty of the slot (0 if none)
-    float f0, f1, f2; // local-policy features
-    bool smask;       // slot masked / absent for the local attention
+    float f0, f1, f2; // local-policy features (first member)
+    bool smask;       // slot masked / absent for the local attention (first member)
+    // ensemble_size > 1 (models.py:296-298): what the other members' features are made of
+    float sd, sth, rx, ry, f2raw;
+    int km[ELG_MAX_ENS];      // min(k, local_size[i])   (uniform)
+    float dm[ELG_MAX_ENS];    // distance of member i's km[i]-th neighbour (uniform value)
 };
 
+// `K` = local_size[0]: the distance penalty's and the first local policy's neighbourhood.  With ens > 1 the walk keeps the first
+// max_i Kens[i] open customers; member i's set is the first min(k, Kens[i]) of them (a prefix: the list is sorted).
 template <int NCH, bool TSP, class ST>     // ST: anything with .cur and .load
 __device__ __forceinline__ Slots slot_setup(const Inst& I, int N1, int K, bool has_penalty, const ST& st,
                                             int lane, const unsigned long long (&mk)[NCH], float* sb,
-                                            const unsigned long long* lds_mk = nullptr, bool euclid = false) {
+                                            const unsigned long long* lds_mk = nullptr, bool euclid = false,
+                                            int ens = 1, const int32_t* Kens = nullptr) {
     constexpr int S0 = TSP ? 0 : 1;
     Slots S;
-    S.k = knn_slots<NCH, TSP>(I, N1, K, st.cur, lane, mk, sb, lds_mk);
+    int Kw = K;
+    if (ens > 1) {
+#pragma unroll
+        for (int i = 0; i < ELG_MAX_ENS; ++i) if (i < ens) Kw = max(Kw, Kens[i]);
+    }
+    S.k = knn_slots<NCH, TSP>(I, N1, Kw, st.cur, lane, mk, sb, lds_mk);
     wave_lds_fence();
     const int j = lane;
+    const int kp = min(S.k, K);
     S.cust = (j >= S0) && (j < S0 + S.k);
+    S.pcust = (j >= S0) && (j < S0 + kp);
     float sd = 0.f, sth = 0.f;
     S.snid = -1;
     if (S.cust) {
@@ -192,29 +207,61 @@ __device__ __forceinline__ Slots slot_setup(const Inst& I, int N1, int K, bool h
         sth = sb[ELG_SLOT_STRIDE + j];
         S.snid = f2i(sb[2 * ELG_SLOT_STRIDE + j]);
     }
-    S.dmax = (S.k > 0) ? sb[S0 + S.k - 1] : 0.f;
+    S.dmax = (kp > 0) ? sb[S0 + kp - 1] : 0.f;
+#pragma unroll
+    for (int i = 0; i < ELG_MAX_ENS; ++i) {
+        S.km[i] = 0; S.dm[i] = 0.f;
+        if (ens > 1 && i < ens) {
+            S.km[i] = min(S.k, Kens[i]);
+            S.dm[i] = (S.km[i] > 0) ? sb[S0 + S.km[i] - 1] : 0.f;
+        }
+    }
     wave_lds_fence();
     if (!TSP && j == 0) S.snid = 0;                                   // depot slot
     S.pen = 0.f;
-    if (has_penalty && S.cust) {
+    if (has_penalty && S.pcust) {
         if (TSP) S.pen = -(sd / (S.dmax + 1e-6f));                    // TSP/models.py:290
         else S.pen = (S.dmax != 0.f) ? -(sd / S.dmax) : -sd;          // models.py:379-405 (no epsilon)
     }
     const float nf = S.dmax + 1e-6f;                                  // models.py:79 / TSP :72
     S.f0 = S.f1 = S.f2 = 0.f;
+    S.sd = sd; S.sth = sth; S.rx = S.ry = S.f2raw = 0.f;
     if (S.cust) {
-        S.f0 = sd / nf;
-        S.f1 = sth;
         if (euclid) {                                                 // models.py:95-125: relative (x, y) / norm (CVRPEnv.py:303)
             const float cx = I.xy[2 * st.cur], cy = I.xy[2 * st.cur + 1];
-            S.f0 = __fsub_rn(I.xy[2 * S.snid], cx) / nf;
-            S.f1 = __fsub_rn(I.xy[2 * S.snid + 1], cy) / nf;
+            S.rx = __fsub_rn(I.xy[2 * S.snid], cx);
+            S.ry = __fsub_rn(I.xy[2 * S.snid + 1], cy);
         }
-        if (!TSP) S.f2 = I.dem[S.snid] / st.load;                     // CVRPEnv.py:315-316
+        if (!TSP) S.f2raw = I.dem[S.snid] / st.load;                  // CVRPEnv.py:315-316
     }
-    S.smask = !S.cust;
+    if (S.pcust) {
+        S.f0 = euclid ? S.rx / nf : sd / nf;
+        S.f1 = euclid ? S.ry / nf : sth;
+        S.f2 = S.f2raw;
+    }
+    S.smask = !S.pcust;
     if (!TSP && j == 0) S.smask = mk[0] & 1ull;                       // depot slot carries the depot's mask
     return S;
+}
+
+// Features / mask of ensemble member i on this lane's slot, and whether the member's output lands on a node at all
+// (its depot slot and its own min(k, Kens[i]) neighbours; models.py:64-76,168-172).
+template <bool TSP>
+__device__ __forceinline__ bool member_slot(const Slots& S, int i, int lane, bool euclid, float& f0, float& f1, float& f2,
+                                            bool& smask) {
+    constexpr int S0 = TSP ? 0 : 1;
+    int km = S.km[0];
+    float dm = S.dm[0];
+#pragma unroll
+    for (int q = 1; q < ELG_MAX_ENS; ++q) if (i == q) { km = S.km[q]; dm = S.dm[q]; }
+    const bool c = S.cust && (lane < S0 + km);
+    const float nf = dm + 1e-6f;
+    f0 = c ? (euclid ? S.rx / nf : S.sd / nf) : 0.f;
+    f1 = c ? (euclid ? S.ry / nf : S.sth) : 0.f;
+    f2 = c ? S.f2raw : 0.f;
+    const bool depot = !TSP && lane == 0;
+    smask = depot ? S.smask : !c;
+    return c || depot;
 }
 
 // 32 per-lane values -> lane l ends with the wave-wide sum of element (l & 31)
@@ -383,6 +430,30 @@ __device__ __forceinline__ float local_policy(const float* __restrict__ loc, int
         save->op = op; save->g = g; save->Ftot = Ftot;
     }
     return u;
+}
+
+// Local-policy term of this lane's slot: one policy, or the sum over the ensemble's members (models.py:409-413; the caller
+// scales by 1 / ensemble_size).  A member contributes only to its own slots.
+template <bool TSP>
+__device__ __forceinline__ float local_ensemble(const elg_rollout_args& A, const float* __restrict__ loc, int lane,
+                                                const Slots& S) {
+    if (A.ens <= 1) return local_policy<TSP>(loc, lane, S.f0, S.f1, S.f2, S.smask, nullptr);
+    float u = 0.f;
+#pragma unroll 1
+    for (int i = 0; i < A.ens; ++i) {
+        float f0, f1, f2;
+        bool sm;
+        const bool in = member_slot<TSP>(S, i, lane, A.euclidean != 0, f0, f1, f2, sm);
+        const float ui = local_policy<TSP>(loc + (size_t)i * ELG_LOC_SIZE, lane, f0, f1, f2, sm, nullptr);
+        u += in ? ui : 0.f;
+    }
+    return u;
+}
+
+// Additive slot term (distance penalty + local score).  With an ensemble whose members look further than the penalty's
+// local_size[0], the slots past the penalty's set keep the default xi (models.py:405-407).
+__device__ __forceinline__ float slot_penalty(const elg_rollout_args& A, const Slots& S) {
+    return (A.ens > 1 && A.has_penalty && S.cust && !S.pcust) ? A.xi : S.pen;
 }
 
 // Saved intermediates of the glimpse for the backward pass (quad layout).

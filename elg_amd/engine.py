@@ -266,6 +266,11 @@ class Policy:
     has_local: bool
     has_penalty: bool
     euclidean: bool = False        # local features (x, y) / norm instead of (dist / norm, theta)
+    Ks: tuple = ()                 # ensemble_size > 1: local_size of every member (Ks[0] == K); loc is (len(Ks), LOC_SIZE)
+
+    @property
+    def ens(self) -> int:
+        return len(self.Ks) if len(self.Ks) > 1 else 1
 
 
 def launch_geometry(B: int, M: int, N1: int):
@@ -291,6 +296,15 @@ def _fill_common(a: L.RolloutArgs, prob: Problem, pol: Policy, M: int, geometry=
     a.problem, a.B, a.M, a.N1, a.K = prob.kind, prob.B, M, prob.N1, pol.K
     a.has_local, a.has_penalty = int(pol.has_local), int(pol.has_penalty)
     a.euclidean = int(getattr(pol, 'euclidean', False))
+    Ks = tuple(getattr(pol, 'Ks', ()))
+    if len(Ks) > 1:
+        if len(Ks) > L.MAX_ENS:
+            raise NotImplementedError(f"ensemble_size {len(Ks)} > {L.MAX_ENS} is not built")
+        if pol.loc is not None and pol.loc.numel() != len(Ks) * L.LOC_SIZE:
+            raise ValueError("ensemble: loc must hold one folded table per member")
+        a.ens = len(Ks)
+        for i, k in enumerate(Ks):
+            a.Kens[i] = int(k)
     a.waves, a.tiles, a.lds_stage = waves, tiles, lds
     a.xi, a.clip, a.inv_ens = pol.xi, pol.clip, pol.inv_ens
     t = pol.tables
@@ -417,7 +431,7 @@ def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mo
         scratch = torch.empty(n_scratch, device=dev)           # score rows (N1 > 1024) / fragment-major tables (N1 > 128)
         a.scratch = _ptr(scratch)
     rows = None
-    if train and N1 <= 128:
+    if train and N1 <= 128 and pol.ens == 1:      # (an ensemble trains through the replay backward)
         rows = TrainRows.get(B, M, N1, Tcap, dev)
         rows.prepare()
         # the cooperative kernel (what dispatch_fwd picks for this launch shape) saves the rows' 128-bit mask words and the
@@ -477,7 +491,7 @@ class _ChosenProbs(torch.autograd.Function):
                                "(another training forward has reused them)")
         tables = dict(K=Kt, V=Vt, PK=PKt, pb=pbt, Q1=Q1t, Q2=Q2t if hasQ2 else None, wl=wlt if haswl else None)
         pol = Policy(tables, loct if hasloc else None, meta.K, meta.xi, meta.clip, meta.inv_ens, meta.has_local,
-                     meta.has_penalty)
+                     meta.has_penalty, getattr(meta, 'euclidean', False), tuple(getattr(meta, 'Ks', ())))
         forced = actions[:, :, :T].contiguous()
         fl = forced.long()
         # ---- replay path (rollouts that were not run as a training forward, N1 > 128): the recorded actions are replayed
@@ -487,7 +501,7 @@ class _ChosenProbs(torch.autograd.Function):
         ba.fwd.Tmax, ba.fwd.mode, ba.fwd.max_steps, ba.fwd.do_decode, ba.fwd.do_update = T, L.MODE_FORCED, 0, 1, 1
         ba.fwd.forced, ba.fwd.Tforced = _ptr(forced), T
         ba.T = T
-        gloc = torch.zeros(L.LOC_SIZE, device=dev)
+        gloc = torch.zeros(pol.ens * L.LOC_SIZE, device=dev)
         ba.gloc = _ptr(gloc)
         rowA = torch.empty(B, H, R, N1, device=dev)
         rowDL = torch.empty(B, R, N1, device=dev)

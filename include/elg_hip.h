@@ -40,6 +40,7 @@ extern "C" {
 #define ELG_LOC_LWE 3472    /* [32][3]  We / sqrt(32)                                         */
 #define ELG_LOC_LPE 3568    /* [64][32] (be + PE[j]) / sqrt(32)                               */
 #define ELG_LOC_SIZE 5616
+#define ELG_MAX_ENS 4       /* model_params['ensemble_size'] <= 4 local policies (models.py:296-298)   */
 
 const char* elg_version(void);
 const char* elg_last_error(void);
@@ -93,6 +94,13 @@ typedef struct elg_rollout_args {
                                clip * tanh(s) (-inf at closed nodes), 2 the scores s before the clip            */
     int32_t euclidean;      /* model_params.euclidean: local-policy slot features (x, y) / norm relative to the current node
                                instead of (dist / norm, theta)   (models.py:95-125, TSP/models.py:67-75)            */
+    int32_t ens;            /* model_params.ensemble_size (0 or 1: one local policy with local_size K).  > 1 (CVRP,
+                               models.py:296-298,409-413): member i has its own folded tables loc + i * ELG_LOC_SIZE and its own
+                               local_size Kens[i] (Kens[0] == K, which also stays the distance penalty's k); the members'
+                               slot scores are summed and scaled by inv_ens.  Runs the one-wavefront-per-trajectory kernel
+                               (N1 <= 1024); training goes through elg_rollout_bwd's replay (N1 <= 256)                */
+    int32_t Kens[ELG_MAX_ENS];
+    int32_t pad_ens;
     uint64_t seed;          /* sampling seed (Philox key)                                       */
     const float* Kmat;      /* (B,N1,128) decoder.Wk enc                                        */
     const float* Vmat;      /* (B,N1,128) decoder.Wv enc                                        */
@@ -106,7 +114,7 @@ typedef struct elg_rollout_args {
     const int32_t* nbr_idx; /* (B,N1,N1) from elg_nbr_tables                                    */
     const float* nbr_dist;
     const float* nbr_theta;
-    const float* loc;       /* (ELG_LOC_SIZE) folded local-policy tables, NULL if !has_local    */
+    const float* loc;       /* (max(ens,1) x ELG_LOC_SIZE) folded local-policy tables, NULL if !has_local */
     const int32_t* starts;  /* (M) POMO start nodes (CVRPModel.py:46-51 / TSPModel.py:30-34)    */
     const int32_t* forced;  /* (B,M,Tforced) or NULL                                            */
     const float* uniforms;  /* (B,M,Tmax) externally drawn U[0,1) or NULL (Philox)              */
@@ -164,7 +172,7 @@ int64_t elg_rollout_scratch_floats(int32_t B, int32_t M, int32_t N1, int32_t var
 typedef struct elg_bwd_args {
     elg_rollout_args fwd;   /* same tables; fwd.forced = recorded actions (B,M,T), fwd.Tforced = T  */
     int32_t T;              /* steps to replay                                                      */
-    int32_t pad1;
+    int32_t member;         /* internal (set by elg_rollout_bwd): ensemble member of a local-policy replay launch */
     const float* gprob;     /* (B,T,M) dJ/d prob[b,t,m]                                             */
     float* rowA;            /* (B,8,R,N1)  glimpse attention weights a_h[n],  R = M*T               */
     float* rowDL;           /* (B,R,N1)    d pointer score s[n]                                     */
@@ -172,7 +180,7 @@ typedef struct elg_bwd_args {
     float* rowO;            /* (B,R,128)   glimpse output o                                         */
     float* rowLoad;         /* (B,R)       load at the step (CVRP), may be NULL                     */
     float* rowDU;           /* (B,R,48)    d u_slot (already includes 1/ensemble_size)              */
-    float* gloc;            /* (ELG_LOC_SIZE) accumulated d loc, caller zeroes                      */
+    float* gloc;            /* (max(fwd.ens,1) x ELG_LOC_SIZE) accumulated d loc, caller zeroes      */
     int32_t time_major;     /* 0: r = m*T + t (replay rows); 1: r = t*M + m (rows saved by the forward) */
     int32_t local_only;     /* 1: skip launch 1 (rows came from the forward), run the local replay only */
     int64_t row_stride;     /* rows per instance in rowDU (R, or Rcap for forward-saved rows)        */

@@ -65,16 +65,20 @@ def model_param_shapes(problem: str, mp: dict, local: bool = True) -> "OrderedDi
     s["decoder.multi_head_combine.weight"] = (E, H * dk)
     s["decoder.multi_head_combine.bias"] = (E,)
     if local:
-        lp = "decoder.local_policies.0." if problem == "cvrp" else "decoder.local_policy_0."
-        nfeat = 3 if problem == "cvrp" else 2
-        s[lp + "cur_token_emb"] = (le,)
-        s[lp + "init_emb.weight"] = (le, nfeat)
-        s[lp + "init_emb.bias"] = (le,)
-        s[lp + "Wq.weight"] = (lh * ldk, le)
-        s[lp + "Wk.weight"] = (lh * ldk, le)
-        s[lp + "Wv.weight"] = (lh * ldk, le)
-        s[lp + "multi_head_combine.weight"] = (le, lh * ldk)
-        s[lp + "multi_head_combine.bias"] = (le,)
+        # one local policy per ensemble member for CVRP (reference models.py:296-298); member 0 first, so that the
+        # weight stream of the ensemble_size = 1 fixtures is unchanged
+        members = int(mp.get("ensemble_size", 1)) if problem == "cvrp" else 1
+        for i in range(members):
+            lp = f"decoder.local_policies.{i}." if problem == "cvrp" else "decoder.local_policy_0."
+            nfeat = 3 if problem == "cvrp" else 2
+            s[lp + "cur_token_emb"] = (le,)
+            s[lp + "init_emb.weight"] = (le, nfeat)
+            s[lp + "init_emb.bias"] = (le,)
+            s[lp + "Wq.weight"] = (lh * ldk, le)
+            s[lp + "Wk.weight"] = (lh * ldk, le)
+            s[lp + "Wv.weight"] = (lh * ldk, le)
+            s[lp + "multi_head_combine.weight"] = (le, lh * ldk)
+            s[lp + "multi_head_combine.bias"] = (le,)
     return s
 
 

@@ -380,3 +380,55 @@ def test_oracle_euclidean_local_features(problem):
         polar = orc.rollout_tsp(P, cfg, xy, M, starts=acts[0, :, 0], forced=acts, keep_parts=True)
     i, t = 1, int(lg["steps"][1])
     assert np.abs(polar["parts"][t - t0]["u"].numpy() - lg["local"][i]).max() > 1e-2
+
+
+def ensemble_setup(tag, dtype=torch.float32, requires_grad=False):
+    """The r03_cvrp_ensemble.npz configuration `tag` (tools/make_golden_r03.py): oracle config, weights, problem."""
+    fx = gu.load_golden("r03_cvrp_ensemble.npz")
+    B, N, M, wseed, pseed = [int(x) for x in fx["meta"]]
+    mp = dict(gu.CVRP_MODEL_PARAMS)
+    mp["local_size"] = [int(k) for k in fx[f"{tag}_sizes"]]
+    mp["ensemble_size"] = len(mp["local_size"])
+    cfg = orc.ModelCfg.from_model_params(mp, "cvrp")
+    P = _weights("cvrp", wseed, mp, float(fx["gain"]), dtype)
+    if requires_grad:
+        P = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    depot, loc, demand = gu.golden_cvrp_problem(pseed, B, N, 30.0)
+    xy = torch.from_numpy(np.concatenate([depot, loc], 1)).to(dtype)
+    dem = torch.from_numpy(np.concatenate([np.zeros((B, 1), np.float32), demand], 1)).to(dtype)
+    return fx, mp, cfg, P, xy, dem, B, N, M
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_oracle_ensemble_of_local_policies(tag):
+    """ensemble_size = 2 (reference models.py:296-298,409-413), local_size [12, 6] and [6, 12]: the members' summed output,
+    the score before the clip and the logits at teacher-forced steps of the reference's own greedy tours; then the gradients
+    of one REINFORCE step (train.py:112-121) on the reference's sampled tours."""
+    fx, mp, cfg, P, xy, dem, B, N, M = ensemble_setup(tag)
+    acts = torch.from_numpy(fx[f"{tag}_greedy_actions"].astype(np.int64))
+    out = orc.rollout_cvrp(P, cfg, xy, dem, M, starts=acts[0, :, 1], forced=acts, keep_parts=True, keep_probs=True)
+    for i, t in enumerate(fx[f"{tag}_steps"]):
+        parts = out["parts"][int(t) - 2]
+        open_ = np.isfinite(fx[f"{tag}_logits"][i])
+        s = parts["s"].numpy()
+        for k, g in {"pre_clip": s, "local_sum": parts["u"].numpy(), "logits": cfg.logit_clipping * np.tanh(s)}.items():
+            e = logit_errors(g, fx[f"{tag}_{k}"][i], open_, cfg.logit_clipping if k == "logits" else None)
+            assert e <= LOGIT_RTOL, (k, int(t), e)
+    # the reference's greedy choices are the oracle's arg-max at every decoded step
+    agree = np.mean([(p.argmax(-1) == acts[:, :, i + 2]).float().mean().item() for i, p in enumerate(out["full_probs"])])
+    assert agree == 1.0
+    np.testing.assert_allclose(out["reward"].numpy(), fx[f"{tag}_greedy_reward"], rtol=1e-5)
+    # ---- one REINFORCE step on the reference's sampled tours: probabilities, loss, every decoder / local gradient
+    fx, mp, cfg, P, xy, dem, B, N, M = ensemble_setup(tag, torch.float64, requires_grad=True)
+    sacts = torch.from_numpy(fx[f"{tag}_sample_actions"].astype(np.int64))
+    out = orc.rollout_cvrp(P, cfg, xy, dem, M, starts=sacts[0, :, 1], forced=sacts)
+    np.testing.assert_allclose(out["probs"].detach().numpy(), fx[f"{tag}_sample_probs"], rtol=2e-4, atol=1e-7)
+    J = orc.pomo_loss(out["probs"], torch.from_numpy(fx[f"{tag}_sample_reward"]).double())
+    assert abs(J.item() - float(fx[f"{tag}_loss"])) <= 1e-4 * max(1.0, abs(float(fx[f"{tag}_loss"])))
+    J.backward()
+    names = [k[len(f"{tag}_grad_"):] for k in fx.files if k.startswith(f"{tag}_grad_")]
+    assert any(n.startswith("decoder.local_policies.1.") for n in names)
+    for n in names:
+        ref = fx[f"{tag}_grad_{n}"]
+        got = P[n].grad.numpy()
+        assert np.abs(got - ref).max() <= 1e-3 * max(np.abs(ref).max(), 1e-6), n
