@@ -207,11 +207,7 @@ def fold_only(kind: int, enc: torch.Tensor, dec_params: Sequence[torch.Tensor]) 
 
 
 def _teardown():
-    try:
-        if torch.cuda.is_available() and torch.cuda.is_initialized():
-            torch.cuda.synchronize()
-    except Exception:
-        pass
+    # (no device synchronisation on an exit path: see engine._teardown)
     _Workspace._cache.clear()
 
 

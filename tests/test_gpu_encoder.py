@@ -80,8 +80,10 @@ def test_encoder_forward_large_instances(problem, B, N1):
 
 
 @pytest.mark.parametrize("problem,B,N1", [("cvrp", 2, 21), ("cvrp", 2, 51), ("cvrp", 3, 101), ("tsp", 2, 100),
-                                          ("tsp", 2, 128)])
+                                          ("tsp", 2, 128), ("cvrp", 2, 151), ("tsp", 2, 200), ("cvrp", 1, 301)])
 def test_encoder_backward_matches_oracle_autograd(problem, B, N1):
+    """N1 <= 128: row block = instance, norm backwards in GEMM epilogues, LDS attention backward.  N1 > 128 (151, 200,
+    301): 128-row blocks, stand-alone norm backward, enc_attn_bwd_large_kernel (operands from global memory)."""
     mp, cfg, P, xy, dem, kind, names = _setup(problem, B, N1, 7)
     g = torch.Generator().manual_seed(11)
     keys = ["enc", "K", "V", "PK", "pb", "Q1"] + (["Q2"] if problem == "tsp" else ["wl"])

@@ -1,0 +1,94 @@
+"""Training at N + 1 > 128 nodes through the PRODUCT path (reference CVRP/train.py:103-125, TSP/train.py:101-122 train any
+size through one tape): model.pre_forward (native encoder + its backward for N1 > 128) -> sampled rollout -> POMO loss ->
+backward, every parameter gradient -- encoder included -- against the oracle's autograd on the same sampled tours."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+import gpu_common as gc
+from oracle import elg_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = gc.DEV
+
+
+def _grad_check(got, ref, rtol=2e-3):
+    rms = max(float(v.norm()) / np.sqrt(v.numel()) for v in ref.values())
+    worst = 0.0
+    for k, r in ref.items():
+        g = got[k].detach().cpu()
+        err = float((g - r).abs().max())
+        lim = rtol * float(r.abs().max()) + 2e-3 * rms
+        worst = max(worst, err / lim)
+        assert err <= lim, f"{k}: max abs err {err:.3e} > {lim:.3e} (ref max {float(r.abs().max()):.3e})"
+    return worst
+
+
+@pytest.mark.parametrize("problem,N,M,B", [("cvrp", 150, 8, 2), ("tsp", 200, 6, 2), ("cvrp", 255, 4, 1)])
+def test_large_instance_training_step_end_to_end(problem, N, M, B):
+    if problem == "cvrp":
+        from elg_amd.CVRP.CVRPEnv import CVRPEnv as Env
+        from elg_amd.CVRP.train import pomo_loss
+        from elg_amd.CVRP.utils import rollout
+        mp = dict(gu.CVRP_MODEL_PARAMS)
+        depot, loc_xy, demand = gu.golden_cvrp_problem(31 + N, B, N, 80.0)
+        xy = torch.from_numpy(np.concatenate([depot, loc_xy], 1))
+        dem = torch.from_numpy(np.concatenate([np.zeros((B, 1), np.float32), demand], 1))
+        batch = dict(depot=torch.from_numpy(depot), loc=torch.from_numpy(loc_xy), demand=torch.from_numpy(demand))
+    else:
+        from elg_amd.TSP.TSPEnv import TSPEnv as Env
+        from elg_amd.TSP.train import pomo_loss
+        from elg_amd.TSP.utils import rollout
+        mp = dict(gu.TSP_MODEL_PARAMS)
+        xy, dem = torch.from_numpy(gu.golden_tsp_problem(31 + N, B, N)), None
+        batch = xy.clone()
+    cfg = orc.ModelCfg.from_model_params(mp, problem)
+    model = gc.load_model(problem, 17, mp, gain=1.0).train()
+    env = Env(multi_width=M, device=DEV)
+    env.load_random_problems(batch)
+    rs, _, _ = env.reset()
+    model.pre_forward(rs)                                            # product encoder: its backward must exist at this size
+    torch.manual_seed(5)
+    acts, probs, rew = rollout(model, env, 'sample')
+    assert probs.requires_grad
+    rew_n = rew + 0.3 * torch.randn(B, M, device=rew.device)         # keep the advantage away from rounding noise
+    J = pomo_loss(probs, rew_n, True)
+    J.backward()
+    got = {k: v.grad for k, v in model.named_parameters()}
+    assert all(g is not None for g in got.values())
+    # ---- the oracle on the same tours
+    P = {k: v.clone().requires_grad_(True) for k, v in gc.weights(problem, 17, mp, 1.0).items()}
+    a = acts.cpu()
+    if problem == "cvrp":
+        out = orc.rollout_cvrp(P, cfg, xy, dem, M, starts=a[0, :, 1], forced=a)
+    else:
+        out = orc.rollout_tsp(P, cfg, xy, M, starts=a[0, :, 0], forced=a)
+    To = out["probs"].shape[1]
+    np.testing.assert_allclose(probs.detach().cpu().numpy()[:, :To], out["probs"].detach().numpy(), rtol=5e-4, atol=1e-9)
+    Jo = orc.pomo_loss(out["probs"], rew_n.cpu(), True, guard_zero=(problem == "tsp"))
+    assert abs(float(J.detach()) - float(Jo.detach())) <= 2e-4 * max(1.0, abs(float(Jo.detach())))
+    Jo.backward()
+    worst = _grad_check(got, {k: v.grad for k, v in P.items()})
+    gc.record_parity(f"train_large_{problem}{N}_grad_over_limit", worst)
+
+
+def test_train_step_function_at_n150():
+    """elg_amd.CVRP.train.train_step itself (the branch for N + 1 > 128) with the one-launch Adam: runs, finite, moves
+    encoder and decoder parameters."""
+    from elg_amd.CVRP.CVRPEnv import CVRPEnv
+    from elg_amd.CVRP.train import train_step
+    from elg_amd.optim import Adam
+    mp = dict(gu.CVRP_MODEL_PARAMS)
+    model = gc.load_model("cvrp", 3, mp).train()
+    env = CVRPEnv(multi_width=10, device=DEV)
+    opt = Adam(model.parameters(), lr=1e-4, weight_decay=1e-6)
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    torch.manual_seed(1)
+    depot, loc_xy, demand = gu.golden_cvrp_problem(5, 3, 150, 80.0)
+    batch = dict(depot=torch.from_numpy(depot), loc=torch.from_numpy(loc_xy), demand=torch.from_numpy(demand))
+    J, rew = train_step(model, env, opt, batch)
+    assert torch.isfinite(J).item() and torch.isfinite(rew).all().item()
+    moved = {k: float((v.detach() - before[k]).abs().max()) for k, v in model.named_parameters()}
+    assert moved["encoder.layers.0.Wq.weight"] > 0 and moved["decoder.Wq_last.weight"] > 0
+    assert all(np.isfinite(m) for m in moved.values())
