@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libelg_hip.so")
+# ELG_HIP_LIB: another build of the same ABI (A/B timing of kernel versions, tools/time_coop_variants.py); default: the in-tree library
+LIB_PATH = os.environ.get("ELG_HIP_LIB") or os.path.join(HERE, "libelg_hip.so")
 
 ELG_OK, ELG_EINVAL, ELG_ELAUNCH, ELG_ENOTIMPL = 0, -1, -2, -3
 PROBLEM_CVRP, PROBLEM_TSP = 0, 1

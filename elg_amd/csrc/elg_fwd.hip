@@ -493,6 +493,24 @@ static int launch_fwd_impl(const elg_rollout_args& A, hipStream_t stream) {
 //            words (row slices of ballots), query row and k-NN slots (rank = DPP row scan over the sorted neighbours).
 // Trajectory state lives in LDS between phases (12 dwords), wave-uniform in SGPRs while a wave works on it.
 // =============================================================================================
+// In-kernel phase clock of the cooperative kernel: only in the diagnostic build (-DELG_STAMPS, tools/stamp_coop.py); the
+// shipped library executes no stamp.  Segment sums leave through elg_rollout_args.scratch (unused at this size).
+#ifdef ELG_STAMPS
+struct StampCtx { unsigned long long last; float acc[16]; };
+__device__ __forceinline__ void stamp_at(StampCtx& c, float& slot) {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    slot += (float)(unsigned)(t - c.last);
+    c.last = t;
+}
+#define ELG_STAMP(c, i) stamp_at(c, (c).acc[i])
+#else
+struct StampCtx {};
+#define ELG_STAMP(c, i)
+#endif
+
 constexpr int CO_QP = 132;      // pitch of the query / glimpse-output exchange rows (conflict-free column reads)
 constexpr int CO_SP = 116;      // pitch of the score exchange rows
 constexpr int CO_NT = 7;        // node tiles of 16
@@ -778,23 +796,35 @@ __device__ __forceinline__ int row16_max_i(int v) {
 template <bool TSP, bool TRAIN>
 __device__ __forceinline__ void co_finish4(const elg_rollout_args& A, int N1, int lane, int wave, int ntraj, int t, int g_lo,
                                            size_t b, size_t Rcap, float* sSc, const unsigned long long* sMask,
-                                           const float* sX, int* sState, int fin_row, int& sel_out, float& p_out, float& ubuf) {
+                                           const float* sX, int* sState, int fin_row, int& sel_out, float& p_out, float& ubuf,
+                                           StampCtx& sc) {
     constexpr int NK = CO_NT;
     const int tq = lane >> 4, lo = lane & 15;
     const int q = 4 * wave + tq;
     const float dflt = A.has_penalty ? A.xi : 0.f;
-    // ---- slot terms (penalty + local policy) scattered into the score rows: one trajectory per pass, lane = slot
+    // ---- slot terms (penalty + local policy) scattered into the score rows: every row's 16 lanes take three slots each of
+    // the row's own trajectory; all reads are issued before the writes (the slots of a trajectory are distinct nodes), so the
+    // read-modify-write costs one LDS round trip instead of four serialised ones
+    {
+        const float* X = sX + q * CO_XP;
+        const bool qok = q < ntraj;
+        int sn[3];
+        float add[3], cur[3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int qq = 4 * wave + i;
-        if (qq < ntraj && lane < ELG_SLOT_STRIDE) {
-            const float* X = sX + qq * CO_XP;
-            const int code = reinterpret_cast<const int*>(X)[CO_XS + lane];
-            const int snid = (code == -2) ? 0 : code;
-            if (snid >= 0) sSc[qq * CO_SP + snid] += X[CO_XPEN + lane] + X[CO_XU + lane] * A.inv_ens - dflt;
+        for (int c3 = 0; c3 < 3; ++c3) {
+            const int j = lo + 16 * c3;
+            const int code = qok ? reinterpret_cast<const int*>(X)[CO_XS + j] : -1;
+            sn[c3] = (code == -2) ? 0 : code;
+            add[c3] = qok ? X[CO_XPEN + j] + X[CO_XU + j] * A.inv_ens - dflt : 0.f;
         }
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) cur[c3] = sn[c3] >= 0 ? sSc[q * CO_SP + sn[c3]] : 0.f;
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3)
+            if (sn[c3] >= 0) sSc[q * CO_SP + sn[c3]] = cur[c3] + add[c3];
     }
     wave_lds_fence();
+    ELG_STAMP(sc, 4);
     const bool act = q < ntraj && (fin_row >= 0 ? fin_row == 0 : sState[16 * q + 3] == 0);   // decoding this step (row-uniform)
     const unsigned long long w0 = sMask[2 * q], w1 = sMask[2 * q + 1];
     const int m = g_lo + q;
@@ -822,6 +852,7 @@ __device__ __forceinline__ void co_finish4(const elg_rollout_args& A, int N1, in
     }
     const float tot = row16_sum(part);
     const float inv = tot > 0.f ? 1.0f / tot : 0.f;
+    ELG_STAMP(sc, 5);
     if (A.full_probs && t < A.dump_T && act) {
         float* frow = A.full_probs + (bm * A.dump_T + t) * N1;
 #pragma unroll
@@ -885,6 +916,7 @@ __device__ __forceinline__ void co_finish4(const elg_rollout_args& A, int N1, in
         lastpos = row16_max_i(lastpos);
         sel = (found != 0x7fffffff) ? found : max(lastpos, 0);
     }
+    ELG_STAMP(sc, 6);
     // probability (and clip Jacobian) of the chosen node: held by lane (sel & 15), register sel >> 4
     const bool mine = (sel & 15) == lo;
     float pe = 0.f, pj = 0.f;
@@ -906,6 +938,7 @@ __device__ __forceinline__ void co_finish4(const elg_rollout_args& A, int N1, in
     wave_lds_fence();
     sel_out = sel;
     p_out = pe;
+    ELG_STAMP(sc, 7);
 }
 
 // State of the trajectory a 16-lane row works on (identical in the row's lanes, different between rows).
@@ -922,10 +955,41 @@ __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v,
 template <bool TSP, bool TRAIN>
 __device__ __forceinline__ void co_advance4(const elg_rollout_args& A, const Inst& I, int N1, int lane, int wave, int ntraj,
                                             int t, int g_lo, size_t b, size_t Rcap, CoRow& st, int sel, bool active,
-                                            unsigned long long* sMask, float* sQ, float* sX) {
+                                            unsigned long long* sMask, float* sQ, float* sX, StampCtx& sc) {
     const int tq = lane >> 4, lo = lane & 15;
     const int q = 4 * wave + tq;
     const int m = g_lo + q;
+    // ---------------- every global load of the phase depends on the chosen node only: request them all up front (the query
+    // row of the node, its sorted neighbour row), one exposed L2 round trip for the whole phase instead of two in series
+    const int cur_n = active ? sel : st.cur;
+    const int first_n = (TSP && active && st.cnt == 0) ? sel : st.first;
+    const bool want_nbr = A.has_penalty || A.has_local;
+    float4 q1a, q1c, q2a = make_float4(0.f, 0.f, 0.f, 0.f), q2c = q2a;
+    {
+        const float* q1 = I.Q1 + (size_t)cur_n * ELG_E + 8 * lo;
+        q1a = *reinterpret_cast<const float4*>(q1);
+        q1c = *reinterpret_cast<const float4*>(q1 + 4);
+        if (TSP) {
+            const float* q2 = I.Q2 + (size_t)first_n * ELG_E + 8 * lo;
+            q2a = *reinterpret_cast<const float4*>(q2);
+            q2c = *reinterpret_cast<const float4*>(q2 + 4);
+        }
+    }
+    int nb_id[CO_NT];
+    float nb_d[CO_NT], nb_th[CO_NT];
+    if (want_nbr) {
+        const size_t row = (size_t)cur_n * N1;
+#pragma unroll
+        for (int k = 0; k < CO_NT; ++k) {
+            const int ic = min(lo + 16 * k, N1 - 1);
+            nb_id[k] = I.nidx[row + ic];
+            nb_d[k] = I.ndist[row + ic];
+            nb_th[k] = I.ntheta[row + ic];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < CO_NT; ++k) { nb_id[k] = 0; nb_d[k] = 0.f; nb_th[k] = 0.f; }
+    }
     // ---------------- transition
     if (active) {
         const float sx = I.xy[2 * sel], sy = I.xy[2 * sel + 1];
@@ -975,14 +1039,12 @@ __device__ __forceinline__ void co_advance4(const elg_rollout_args& A, const Ins
         if (TRAIN && nxt && A.trMask) { A.trMask[(b * Rcap + r1) * 2] = w0; A.trMask[(b * Rcap + r1) * 2 + 1] = w1; }
         if (TRAIN && nxt && A.trLoad) A.trLoad[b * Rcap + r1] = st.load;
     }
+    ELG_STAMP(sc, 8);
     // ---------------- query row: 8 channels per lane
     {
-        const float* q1 = I.Q1 + (size_t)st.cur * ELG_E + 8 * lo;
-        float4 a = *reinterpret_cast<const float4*>(q1), c = *reinterpret_cast<const float4*>(q1 + 4);
+        float4 a = q1a, c = q1c;
         if (TSP) {
-            const float* q2 = I.Q2 + (size_t)st.first * ELG_E + 8 * lo;
-            const float4 a2 = *reinterpret_cast<const float4*>(q2), c2 = *reinterpret_cast<const float4*>(q2 + 4);
-            a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w; c.x += c2.x; c.y += c2.y; c.z += c2.z; c.w += c2.w;
+            a.x += q2a.x; a.y += q2a.y; a.z += q2a.z; a.w += q2a.w; c.x += q2c.x; c.y += q2c.y; c.z += q2c.z; c.w += q2c.w;
         } else {
             const float4 wa = *reinterpret_cast<const float4*>(I.wl + 8 * lo), wc = *reinterpret_cast<const float4*>(I.wl + 8 * lo + 4);
             a.x = fmaf(st.load, wa.x, a.x); a.y = fmaf(st.load, wa.y, a.y); a.z = fmaf(st.load, wa.z, a.z); a.w = fmaf(st.load, wa.w, a.w);
@@ -996,39 +1058,48 @@ __device__ __forceinline__ void co_advance4(const elg_rollout_args& A, const Ins
             *reinterpret_cast<float4*>(A.trQ + (b * Rcap + r1) * ELG_E + 8 * lo + 4) = c;
         }
     }
+    ELG_STAMP(sc, 9);
     // ---------------- k-NN slots: first K open customers of cur's sorted neighbour row, rank = row scan
     constexpr int S0 = TSP ? 0 : 1;
     float* X = sX + q * CO_XP;
     int* Xi = reinterpret_cast<int*>(X);
     int kk = 0;
-    if (A.has_penalty || A.has_local) {
-        int found = 0;
-        const size_t row = (size_t)st.cur * N1;
+    if (want_nbr) {
+        // candidate flags, their in-row ranks (DPP scan) and the row totals of all seven chunks are independent of each other:
+        // only the running offset `found` chains them (two integer adds per chunk)
+        int cI[CO_NT], inc[CO_NT], tot[CO_NT];
 #pragma unroll
         for (int k = 0; k < CO_NT; ++k) {
             const int i = lo + 16 * k;
             const bool valid = i < N1 && nxt;
-            const int ic = min(i, N1 - 1);
-            const int nid = I.nidx[row + ic];
-            const float nd = I.ndist[row + ic], nth = I.ntheta[row + ic];
+            const int nid = nb_id[k];
             bool cand = valid && !(((nid < 64 ? w0 : w1) >> (nid & 63)) & 1ull);
             if (!TSP) cand = cand && (nid != 0);
-            const int cI = cand ? 1 : 0;
-            int inc = cI;
-            inc += dpp_i<0x111>(inc); inc += dpp_i<0x112>(inc); inc += dpp_i<0x114>(inc); inc += dpp_i<0x118>(inc);
-            const int rank = found + inc - cI;
-            if (cand && rank < A.K) {
-                X[CO_XF + S0 + rank] = nd;
-                X[CO_XF + ELG_SLOT_STRIDE + S0 + rank] = nth;
-                Xi[CO_XS + S0 + rank] = nid;
+            cI[k] = cand ? 1 : 0;
+            int sc_ = cI[k];
+            sc_ += dpp_i<0x111>(sc_); sc_ += dpp_i<0x112>(sc_); sc_ += dpp_i<0x114>(sc_); sc_ += dpp_i<0x118>(sc_);
+            inc[k] = sc_;
+            int tt = cI[k];
+            tt += dpp_i<0xB1>(tt); tt += dpp_i<0x4E>(tt); tt += dpp_i<0x141>(tt); tt += dpp_i<0x140>(tt);   // row all-reduce
+            tot[k] = tt;
+        }
+        int found = 0;
+#pragma unroll
+        for (int k = 0; k < CO_NT; ++k) {
+            const int rank = found + inc[k] - cI[k];
+            if (cI[k] && rank < A.K) {
+                X[CO_XF + S0 + rank] = nb_d[k];
+                X[CO_XF + ELG_SLOT_STRIDE + S0 + rank] = nb_th[k];
+                Xi[CO_XS + S0 + rank] = nb_id[k];
             }
-            found += __shfl(inc, (lane & 48) | 15, ELG_WAVE);          // row total = the scan's value in lane 15 of the row
+            found += tot[k];
         }
         kk = min(found, A.K);
     }
     wave_lds_fence();
     const float dmax = (kk > 0) ? X[CO_XF + S0 + kk - 1] : 0.f;
     wave_lds_fence();
+    ELG_STAMP(sc, 10);
     const float nf = dmax + 1e-6f;
     const bool depot_closed = w0 & 1ull;
 #pragma unroll
@@ -1179,6 +1250,11 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
         float ubuf = 0.f;                                           // the row's next 16 sampling uniforms, one per lane
         row.cur = 0; row.first = 0; row.cnt = 0; row.fin = (4 * wave + (lane >> 4) < ntraj) ? 0 : 1;
         row.load = 1.0f; row.len = 0.f; row.cx = 0.f; row.cy = 0.f; row.v0 = 0ull; row.v1 = 0ull;
+        StampCtx sc;
+#ifdef ELG_STAMPS
+        for (int i = 0; i < 16; ++i) sc.acc[i] = 0.f;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sc.last) :: "memory");
+#endif
         float kop[CO_NT][4], vop[CO_NT][4];                         // (re)loaded at the end of every owners' phase
 #pragma unroll
         for (int nt = 0; nt < CO_NT; ++nt)
@@ -1361,7 +1437,9 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                         if (TRAIN && live) *reinterpret_cast<float4*>(A.trO + ((size_t)b * Rcap + r) * ELG_E + 16 * wave + 4 * hi_t) = ov;
                     }
                 }
+                ELG_STAMP(sc, 0);
                 __syncthreads();
+                ELG_STAMP(sc, 1);
                 // =============== pointer (waves 0-5: 7 node tiles x 2 trajectory tiles) || local policy (waves 6, 7) ====
                 if (wave < 6) {
 #pragma unroll 1
@@ -1389,7 +1467,9 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                     co_local_tail(sT, sX + (wave - 6) * 16 * CO_XP, sO1 + (wave - 6) * 512, sX + (wave - 6) * 16 * CO_XP + CO_XU, CO_XP,
                                   lo_t, hi_t);
                 }
+                ELG_STAMP(sc, 2);
                 __syncthreads();
+                ELG_STAMP(sc, 3);
             }
             // =============== owners: finish this step, advance, prepare the next ===============
             int any_left = 0;
@@ -1400,23 +1480,35 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
             const bool active = q4 < ntraj && !row.fin;
             int sel = 0;
             float pr = 1.0f;
-            if (decode_step) {
-                co_finish4<TSP, TRAIN>(A, N1, lane_t, wave, ntraj, t, g_lo, (size_t)b, Rcap, sSc, sMask, sX, sState,
-                                       q4 < ntraj ? row.fin : 1, sel, pr, ubuf);
-            } else if (A.mode == ELG_MODE_FORCED) {
-                sel = (A.forced && t < A.Tforced) ? A.forced[bm4 * A.Tforced + t] : 0;
-            } else {
-                sel = (!TSP && t == 0) ? 0 : A.starts[m4];
+            // (a wave none of whose four trajectories exists -- 25 trajectories leave wave 7 empty -- skips the phase: its
+            // exchange rows keep their reset state (closed masks, zero queries), and its SIMD partner gets the issue slots)
+            if (4 * wave < ntraj) {
+                if (decode_step) {
+                    co_finish4<TSP, TRAIN>(A, N1, lane_t, wave, ntraj, t, g_lo, (size_t)b, Rcap, sSc, sMask, sX, sState,
+                                           q4 < ntraj ? row.fin : 1, sel, pr, ubuf, sc);
+                } else if (A.mode == ELG_MODE_FORCED) {
+                    sel = (A.forced && t < A.Tforced) ? A.forced[bm4 * A.Tforced + t] : 0;
+                } else {
+                    sel = (!TSP && t == 0) ? 0 : A.starts[m4];
+                }
+                if (active && (lane_t & 15) == 0) {
+                    if (A.actions) A.actions[bm4 * A.Tmax + t] = sel;
+                    if (A.probs) A.probs[((size_t)b * A.Tmax + t) * A.M + m4] = pr;
+                }
+                co_advance4<TSP, TRAIN>(A, I, N1, lane_t, wave, ntraj, t, g_lo, (size_t)b, Rcap, row, sel, active, sMask, sQ, sX, sc);
             }
-            if (active && (lane_t & 15) == 0) {
-                if (A.actions) A.actions[bm4 * A.Tmax + t] = sel;
-                if (A.probs) A.probs[((size_t)b * A.Tmax + t) * A.M + m4] = pr;
-            }
-            co_advance4<TSP, TRAIN>(A, I, N1, lane_t, wave, ntraj, t, g_lo, (size_t)b, Rcap, row, sel, active, sMask, sQ, sX);
             any_left = (q4 < ntraj && !row.fin) ? 1 : 0;
+            ELG_STAMP(sc, 11);
             ELG_CO_LOAD_KV()                                         // next step's glimpse operands, in flight over the barrier
-            if (!__syncthreads_or(any_left)) break;                  // also orders the exchange rows for the next step
+            ELG_STAMP(sc, 12);
+            const int go_on = __syncthreads_or(any_left);            // also orders the exchange rows for the next step
+            ELG_STAMP(sc, 13);
+            if (!go_on) break;
         }
+#ifdef ELG_STAMPS
+        if (A.scratch && lane == 0)
+            for (int i = 0; i < 16; ++i) A.scratch[((size_t)blockIdx.x * 8 + wave) * 16 + i] = sc.acc[i];
+#endif
         // ---- results of the group
         {
             const int q4 = 4 * wave + (lane >> 4);
@@ -2358,11 +2450,9 @@ static int dispatch_fwd(const elg_rollout_args& A, hipStream_t stream) {
     if (A.lds_stage && A.waves == 8 && A.N1 >= 4 && A.N1 <= 16 * CO_NT && !A.use_state && A.do_decode && A.do_update &&
         A.max_steps <= 0 && A.variant == 0) {
         // fused rollout at the training scale: lockstep trajectories, tables as MFMA operands in registers
-        if (A.trA || A.trMask) {        // training forward (glimpse weights saved, or recomputed from the mask rows)
-            if (!A.trPC || !A.trCsel || !A.trQ || !A.trO) return fail(ELG_EINVAL, "rollout: incomplete training rows");
-            return launch_fwd_coop<TSP, true>(A, stream);
-        }
-        return launch_fwd_coop<TSP, false>(A, stream);
+        const bool train = A.trA || A.trMask;      // training forward (glimpse weights saved, or recomputed from the mask rows)
+        if (train && (!A.trPC || !A.trCsel || !A.trQ || !A.trO)) return fail(ELG_EINVAL, "rollout: incomplete training rows");
+        return train ? launch_fwd_coop<TSP, true>(A, stream) : launch_fwd_coop<TSP, false>(A, stream);
     }
     if (A.trMask && !A.trA) return fail(ELG_EINVAL, "rollout: this kernel needs trA (mask-only rows: cooperative kernel)");
     if (A.trA) {        // training forward: saves the backward rows; built for N1 <= 128, 8 waves
