@@ -573,7 +573,9 @@ static int dispatch_bwd(const elg_bwd_args& BA, hipStream_t stream) {
     if (nch == 2) { if (lds) return launch_bwd<2, TSP, true, 8>(BA, stream); return launch_bwd<2, TSP, false, 8>(BA, stream); }
     if (lds) return fail(ELG_EINVAL, "lds_stage needs N1 <= 104");
     if (nch <= 4) return launch_bwd<4, TSP, false, 8>(BA, stream);
-    return fail(ELG_ENOTIMPL, "rollout_bwd: N1 > 256 not built");
+    if (nch <= 8) return launch_bwd<8, TSP, false, 8>(BA, stream);
+    if (nch <= 16) return launch_bwd<16, TSP, false, 8>(BA, stream);
+    return fail(ELG_ENOTIMPL, "rollout_bwd: N1 > 1024 not built");
 }
 
 
@@ -1040,7 +1042,8 @@ extern "C" int elg_glimpse_rows_bwd(const float* rowA, const float* dO, const fl
     if (nch == 1) hipLaunchKernelGGL(glimpse_rows_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, rowA, dO, rowO, Kmat, Vmat, dS, dQ, R, N1, rpb, (size_t)rowA_rows, (size_t)rowO_rows);
     else if (nch == 2) hipLaunchKernelGGL(glimpse_rows_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, rowA, dO, rowO, Kmat, Vmat, dS, dQ, R, N1, rpb, (size_t)rowA_rows, (size_t)rowO_rows);
     else if (nch <= 4) hipLaunchKernelGGL(glimpse_rows_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, rowA, dO, rowO, Kmat, Vmat, dS, dQ, R, N1, rpb, (size_t)rowA_rows, (size_t)rowO_rows);
-    else return fail(ELG_ENOTIMPL, "glimpse_rows_bwd: N1 > 256 not built");
+    else return fail(ELG_ENOTIMPL, "glimpse_rows_bwd: N1 > 256 (the K_h / V_h rows of a lane no longer fit its registers): use the "
+                                   "batched products of elg_gemm_f32_batched");
     return launch_status("glimpse_rows_bwd");
 }
 

@@ -516,36 +516,51 @@ class _ChosenProbs(torch.autograd.Function):
         # the query of decode step t was gathered at cur = action[t-1] (and first = action[0] for TSP)
         prev = torch.cat([torch.zeros(B, M, 1, dtype=torch.long, device=dev), fl[:, :, :-1]], dim=2).reshape(B, R)
         first = fl[:, :, :1].expand(B, M, T).reshape(B, R) if hasQ2 else None
+        lib = L.lib()
 
-        def heads(x):                                               # (B,X,128) -> (B,H,X,16)
-            return x.view(B, x.shape[1], H, DK).permute(0, 2, 1, 3)
-        dO = torch.bmm(rowDL, PKt)                                  # (B,R,128)   d o = d s . PK
+        def bgemm(A_, B_, C_, Mm, Nn, Kk, lda, ldb, ldc, tA, tB, n_in, sA, sB, sC, what):
+            """C(b, i) = op(A(b, i)) op(B(b, i)) for b < B, i < n_in through elg_gemm_f32_batched (f32 MFMA); s* = (outer, inner)."""
+            L.check(lib.elg_gemm_f32_batched(_ptr(A_), _ptr(B_), _ptr(C_), Mm, Nn, Kk, lda, ldb, ldc, int(tA), int(tB), B, n_in,
+                                             sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], 1.0, _stream()), what)
+        # every row contraction of the pointer / glimpse backward is a batched f32 MFMA GEMM of csrc/elg_gemm.hip
+        dO = torch.empty(B, R, E, device=dev)                       # d o = d s . PK                (B: R x N1 @ N1 x 128)
+        bgemm(rowDL, PKt, dO, R, E, N1, N1, E, E, 0, 0, 1, (R * N1, 0), (N1 * E, 0), (R * E, 0), "dO = dS PK")
         dQ = torch.empty(B, R, E, device=dev)
         if N1 <= 128:
             splits = max(1, min(8, 1024 // (B * H)))
             dKp = torch.empty(splits, B, N1, E, device=dev)
             dVp = torch.empty(splits, B, N1, E, device=dev)
-            L.check(L.lib().elg_glimpse_bwd_fused(_ptr(rowA), None, _ptr(dO), _ptr(rowO), _ptr(rowQ), _ptr(Kt), _ptr(Vt),
-                                                  _ptr(dQ), _ptr(dKp), _ptr(dVp), B, R, N1, R, R, R, splits, _stream()),
+            L.check(lib.elg_glimpse_bwd_fused(_ptr(rowA), None, _ptr(dO), _ptr(rowO), _ptr(rowQ), _ptr(Kt), _ptr(Vt),
+                                              _ptr(dQ), _ptr(dKp), _ptr(dVp), B, R, N1, R, R, R, splits, _stream()),
                     "elg_glimpse_bwd_fused")
             dK = dKp[0] if splits == 1 else dKp.sum(0)
             dV = dVp[0] if splits == 1 else dVp.sum(0)
         else:
             dS = torch.empty(B, H, R, N1, device=dev)               # d(q.K)
-            L.check(L.lib().elg_glimpse_rows_bwd(_ptr(rowA), _ptr(dO), _ptr(rowO), _ptr(Kt), _ptr(Vt), _ptr(dS),
+            if N1 <= 256:
+                L.check(lib.elg_glimpse_rows_bwd(_ptr(rowA), _ptr(dO), _ptr(rowO), _ptr(Kt), _ptr(Vt), _ptr(dS),
                                                  _ptr(dQ), B, R, N1, R, R, _stream()), "elg_glimpse_rows_bwd")
-            dK = torch.matmul(dS.transpose(2, 3), heads(rowQ)).permute(0, 2, 1, 3).reshape(B, N1, E)
-            dV = torch.matmul(rowA.transpose(2, 3), heads(dO)).permute(0, 2, 1, 3).reshape(B, N1, E)
-        dPK = torch.bmm(rowDL.transpose(1, 2), rowO)
+            else:
+                # dA_h = dO_h V_h^T (per head: R x 16 @ 16 x N1), softmax backward in place, dQ_h = dS_h K_h
+                bgemm(dO, Vt, dS, R, N1, DK, E, E, N1, 0, 1, H, (R * E, DK), (N1 * E, DK), (H * R * N1, R * N1), "dA = dO V^T")
+                doto = (dO * rowO).view(B, R, H, DK).sum(-1).permute(0, 2, 1)                 # <dO_h, O_h>   (B,H,R)
+                dS.sub_(doto[..., None]).mul_(rowA).mul_(0.25)
+                bgemm(dS, Kt, dQ, R, DK, N1, N1, E, E, 0, 0, H, (H * R * N1, R * N1), (N1 * E, DK), (R * E, DK), "dQ = dS K")
+            dK = torch.empty(B, N1, E, device=dev)                  # dK_h = dS_h^T Q_h , dV_h = a_h^T dO_h   (N1 x R @ R x 16)
+            dV = torch.empty(B, N1, E, device=dev)
+            bgemm(dS, rowQ, dK, N1, DK, R, N1, E, E, 1, 0, H, (H * R * N1, R * N1), (R * E, DK), (N1 * E, DK), "dK = dS^T Q")
+            bgemm(rowA, dO, dV, N1, DK, R, N1, E, E, 1, 0, H, (H * R * N1, R * N1), (R * E, DK), (N1 * E, DK), "dV = a^T dO")
+        dPK = torch.empty(B, N1, E, device=dev)                     # dPK = dS_ptr^T O              (B: N1 x R @ R x 128)
+        bgemm(rowDL, rowO, dPK, N1, E, R, N1, E, E, 1, 0, 1, (R * N1, 0), (R * E, 0), (N1 * E, 0), "dPK = dS^T O")
         dpb = rowDL.sum(dim=1)
         dQ2 = dwl = None
-        onehotP = torch.zeros(B, R, N1, device=dev).scatter_(2, prev[:, :, None], 1.0)
-        dQ1 = torch.bmm(onehotP.transpose(1, 2), dQ)
+        # gather backward of the query rows: scatter-add of the row cotangents onto the nodes they were gathered from
+        base = (torch.arange(B, device=dev) * N1)[:, None]
+        dQ1 = torch.zeros(B * N1, E, device=dev).index_add_(0, (prev + base).reshape(-1), dQ.view(B * R, E)).view(B, N1, E)
         if hasQ2:
-            onehotF = torch.zeros(B, R, N1, device=dev).scatter_(2, first[:, :, None], 1.0)
-            dQ2 = torch.bmm(onehotF.transpose(1, 2), dQ)
+            dQ2 = torch.zeros(B * N1, E, device=dev).index_add_(0, (first + base).reshape(-1), dQ.view(B * R, E)).view(B, N1, E)
         if haswl:
-            dwl = torch.einsum("br,bre->e", rowLoad, dQ)
+            dwl = (rowLoad[:, :, None] * dQ).sum(dim=(0, 1))
         return (None, None, None, None, None, None, None,
                 dK, dV, dPK, dpb, dQ1, dQ2, dwl, gloc if hasloc else None, None, None, None, None)
 

@@ -252,6 +252,14 @@ int elg_add_instnorm_bwd(const float* dout, const float* xhat, const float* rstd
 int elg_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                  int lda, int ldb, int ldc, int transA, int transB, int relu, int split_k, float* a_rowsum,
                  void* stream);
+/* The same product for a two-level batch in one launch: C(o, i) = alpha op(A(o, i)) op(B(o, i)), o < n_outer, i < n_inner,
+ * X(o, i) = X + o sX_outer + i sX_inner (element strides; an inner stride may be a column offset of a wider matrix, e.g.
+ * head i of a (rows, 128) buffer: sX_inner = 16 with ldx = 128).  The row contractions of the decoder's replay backward for
+ * N + 1 > 128 nodes (autograd of CVRP/models.py:330-352 over the R = M T decode rows of an instance):
+ * dO = dS PK, dA_h = dO_h V_h^T, dQ_h = dS_h K_h, dK_h = dS_h^T Q_h, dV_h = a_h^T dO_h, dPK = dS^T O. */
+int elg_gemm_f32_batched(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                         int transA, int transB, int n_outer, int n_inner, int64_t sA_outer, int64_t sA_inner,
+                         int64_t sB_outer, int64_t sB_inner, int64_t sC_outer, int64_t sC_inner, float alpha, void* stream);
 
 
 /* ---- attention encoder + decoder tables (CVRPModel.pre_forward: CVRP/CVRPModel.py:21-34 -> CVRP_Encoder.forward,

@@ -28,8 +28,8 @@ def test_build_and_exports():
 
 def test_struct_layout_matches_c():
     from elg_amd import _lib
-    pairs = [("elg_rollout_args", _lib.RolloutArgs, ["problem", "variant", "dump_logits", "seed", "Kmat", "loc", "st_vis", "full_probs", "trMask", "scratch", "trLse"]),
-             ("elg_bwd_args", _lib.BwdArgs, ["T", "gprob", "rowA", "rowLoad", "gloc", "row_stride"]),
+    pairs = [("elg_rollout_args", _lib.RolloutArgs, ["problem", "variant", "dump_logits", "euclidean", "ens", "Kens", "seed", "Kmat", "loc", "st_vis", "full_probs", "trMask", "scratch", "trLse"]),
+             ("elg_bwd_args", _lib.BwdArgs, ["T", "member", "gprob", "rowA", "rowLoad", "gloc", "row_stride"]),
              ("elg_enc_layer", _lib.EncLayer, ["Wq", "bc", "W1", "b2"]),
              ("elg_enc_weights", _lib.EncWeights, ["emb_depot_w", "emb_w", "layer", "dec_Wq_first", "dec_bc"]),
              ("elg_encoder_args", _lib.EncoderArgs, ["problem", "eps", "xy", "W", "enc", "Q2", "wl", "ws", "ws_floats"]),

@@ -115,7 +115,7 @@ def test_tsp_backward(tag, train):
     _run("tsp", tag, "pomo", train=train)
 
 
-@pytest.mark.parametrize("problem,N,M", [("cvrp", 200, 8), ("tsp", 150, 6)])
+@pytest.mark.parametrize("problem,N,M", [("cvrp", 200, 8), ("tsp", 150, 6), ("cvrp", 300, 4), ("tsp", 530, 3)])
 def test_backward_large_instance_replay(problem, N, M):
     """N1 > 128 (no saved-row training forward for these sizes): the engine's own sampled tours, gradients through the
     replay backward (rollout_bwd_kernel + the row contractions) against the oracle's autograd on the same forced tours."""

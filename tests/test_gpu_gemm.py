@@ -25,10 +25,7 @@ def test_gemm_matches_fp64(ta, tb, M, N, K):
     # asymmetric integer-ish data catches swapped / transposed fragment maps exactly
     a = torch.randint(-3, 4, (K, M) if ta else (M, K), device=DEV).float() + 0.25
     b = torch.randint(-3, 4, (N, K) if tb else (K, N), device=DEV).float() - 0.5
-    if (a.shape[1] % 4) or (b.shape[1] % 4):
-        with pytest.raises(ValueError, match="multiples of 4"):      # 16-byte staging loads: refused, not mis-read
-            eng.gemm(a, b, trans_a=ta, trans_b=tb)
-        return
+    # (rows that are not 16-byte aligned -- 130, 52, 77, 36 columns -- are staged with scalar loads)
     c = eng.gemm(a, b, trans_a=ta, trans_b=tb)
     ref = _ref(a, b, ta, tb)
     assert c.shape == (M, N)
@@ -64,3 +61,35 @@ def test_gemm_row_sums_give_the_bias_gradient(rows, out, inp, sk):
     dW = eng.gemm(dy, x, trans_a=True, split_k=sk, a_rowsum=db)
     np.testing.assert_allclose(dW.cpu().numpy(), (dy.double().t() @ x.double()).cpu().numpy(), rtol=1e-3, atol=5e-3)
     np.testing.assert_allclose(db.cpu().numpy(), dy.double().sum(0).cpu().numpy(), rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False)])
+def test_batched_gemm_with_head_strides(ta, tb):
+    """elg_gemm_f32_batched: two-level batch (instance, head) whose inner stride is a 16-column offset into 128-wide rows and
+    whose rows have an odd leading dimension (N + 1 nodes) -- the shapes of the replay backward for N + 1 > 128."""
+    import ctypes as C
+    from elg_amd import _lib as L
+    torch.manual_seed(2)
+    B, H, R, N1 = 2, 8, 77, 301
+    rows = torch.randn(B, H, R, N1, device=DEV)          # a_h / dS_h
+    wide = torch.randn(B, R, 128, device=DEV)            # dO / Q rows, heads side by side
+    tab = torch.randn(B, N1, 128, device=DEV)            # K / V tables
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    if ta:      # dK_h = rows_h^T wide_h : (N1 x R) @ (R x 16)
+        out = torch.empty(B, N1, 128, device=DEV)
+        L.check(L.lib().elg_gemm_f32_batched(p(rows), p(wide), p(out), N1, 16, R, N1, 128, 128, 1, 0, B, H, H * R * N1, R * N1,
+                                             R * 128, 16, N1 * 128, 16, 1.0, st), "batched")
+        ref = torch.einsum("bhrn,brhd->bnhd", rows.double(), wide.double().view(B, R, H, 16)).reshape(B, N1, 128)
+    elif tb:    # dA_h = wide_h tab_h^T : (R x 16) @ (16 x N1)
+        out = torch.empty(B, H, R, N1, device=DEV)
+        L.check(L.lib().elg_gemm_f32_batched(p(wide), p(tab), p(out), R, N1, 16, 128, 128, N1, 0, 1, B, H, R * 128, 16,
+                                             N1 * 128, 16, H * R * N1, R * N1, 1.0, st), "batched")
+        ref = torch.einsum("brhd,bnhd->bhrn", wide.double().view(B, R, H, 16), tab.double().view(B, N1, H, 16))
+    else:       # dQ_h = rows_h tab_h : (R x N1) @ (N1 x 16)
+        out = torch.empty(B, R, 128, device=DEV)
+        L.check(L.lib().elg_gemm_f32_batched(p(rows), p(tab), p(out), R, 16, N1, N1, 128, 128, 0, 0, B, H, H * R * N1, R * N1,
+                                             N1 * 128, 16, R * 128, 16, 1.0, st), "batched")
+        ref = torch.einsum("bhrn,bnhd->brhd", rows.double(), tab.double().view(B, N1, H, 16)).reshape(B, R, 128)
+    err = (out.double() - ref).abs().max().item()
+    assert err < 2e-5 * np.sqrt(max(R, N1)) * 4, err

@@ -25,7 +25,8 @@ def _grad_check(got, ref, rtol=2e-3):
     return worst
 
 
-@pytest.mark.parametrize("problem,N,M,B", [("cvrp", 150, 8, 2), ("tsp", 200, 6, 2), ("cvrp", 255, 4, 1)])
+@pytest.mark.parametrize("problem,N,M,B", [("cvrp", 150, 8, 2), ("tsp", 200, 6, 2), ("cvrp", 255, 4, 1), ("tsp", 400, 4, 1),
+                                              ("cvrp", 600, 3, 1)])
 def test_large_instance_training_step_end_to_end(problem, N, M, B):
     if problem == "cvrp":
         from elg_amd.CVRP.CVRPEnv import CVRPEnv as Env
@@ -67,7 +68,9 @@ def test_large_instance_training_step_end_to_end(problem, N, M, B):
     To = out["probs"].shape[1]
     np.testing.assert_allclose(probs.detach().cpu().numpy()[:, :To], out["probs"].detach().numpy(), rtol=5e-4, atol=1e-9)
     Jo = orc.pomo_loss(out["probs"], rew_n.cpu(), True, guard_zero=(problem == "tsp"))
-    assert abs(float(J.detach()) - float(Jo.detach())) <= 2e-4 * max(1.0, abs(float(Jo.detach())))
+    # (the loss sums ~2 N log-probabilities per trajectory: its fp32 rounding grows with the tour length)
+    tolJ = 2e-4 * max(1.0, abs(float(Jo.detach()))) * max(1.0, To / 100.0)
+    assert abs(float(J.detach()) - float(Jo.detach())) <= tolJ, (float(J.detach()), float(Jo.detach()), tolJ)
     Jo.backward()
     worst = _grad_check(got, {k: v.grad for k, v in P.items()})
     gc.record_parity(f"train_large_{problem}{N}_grad_over_limit", worst)
