@@ -154,6 +154,19 @@ def cpu_baseline(cfg, mean_T, budget_s=150.0):
                       f"build container (BASELINE.md)"}
 
 
+def secondary_roofline(B, M, N1, steps, ms, tsp):
+    """Both ceilings of a secondary greedy rollout, from algorithmic counts only: bytes per decode step as for the
+    headline; executed FLOPs per trajectory-step = glimpse QK^T + AV + pointer (3 x 2 N1 128) + ~9 K of folded local policy."""
+    words = (N1 + 31) // 32
+    per_traj = (4 + 4 * words) + (4 + 4 + 4 * words + 1) if tsp else (4 + 4 + 4 * words) + (4 + 4 + 4 + 4 * words + 1)
+    bytes_step = B * (3 * N1 * 128 * 4 + (8 if tsp else 12) * N1) + B * M * per_traj
+    flops_step = B * M * (3 * 2 * N1 * 128 + 9e3)
+    t = ms * 1e-3
+    return {"algorithmic_MB_per_decode_step": round(bytes_step / 1e6, 2), "decode_steps": steps,
+            "hbm_GBps": round(bytes_step * steps / t / 1e9, 1), "frac_hbm": round(bytes_step * steps / t / 1e9 / HBM_PEAK_GBS, 4),
+            "fp32_TFLOPs": round(flops_step * steps / t / 1e12, 2), "frac_fp32": round(flops_step * steps / t / 1e12 / FP32_PEAK_TFLOPS, 4)}
+
+
 def secondary_workloads(dev):
     """BASELINE.json configs[3] and [4] as secondary entries: one greedy rollout each after a warm-up, random-init weights
     (TSP-500 batch 16 pomo 500; VRPLIB X-n1001-k43, x8 augmentation, pomo 1000), HIP events around the launch."""
@@ -190,6 +203,7 @@ def secondary_workloads(dev):
         ms = timed(lambda: tsp_rollout(tm, tenv, "greedy"))
     out["tsp500_b16_pomo500_greedy_rollout_ms"] = round(ms, 2)
     out["tsp500_trajectory_steps_per_s"] = round(16 * 500 * 499 / (ms * 1e-3), 0)
+    out["tsp500_roofline"] = secondary_roofline(16, 500, 500, 499, ms, tsp=True)
     inst_path = os.path.join(ROOT, "tests", "golden", "vrplib", "X", "X-n1001-k43.vrp")
     if os.path.exists(inst_path):
         with open(os.path.join(ROOT, "elg_amd", "CVRP", "config.yml")) as f:
@@ -208,6 +222,9 @@ def secondary_workloads(dev):
         with torch.no_grad():
             ms = timed(one, reps=2)
         out["vrplib_X-n1001-k43_aug8_pomo1000_greedy_instance_ms"] = round(ms, 1)
+        # (whole instance: encoder + tables + rollout; decode steps = the longest tour of the run is not read back here:
+        # lower bound N + 1 steps per trajectory -- every customer once -- so both fractions are lower bounds too)
+        out["vrplib_X-n1001_roofline"] = secondary_roofline(8, 1000, 1001, 1001, ms, tsp=False)
     return out
 
 

@@ -517,7 +517,11 @@ constexpr int CO_NT = 7;        // node tiles of 16
 constexpr int CO_MAXTR = 32;    // trajectories in lockstep per workgroup
 
 // ---- slot exchange block of a trajectory (floats): f0 | f1 | f2 | slot code | penalty | u   (48 each)
-constexpr int CO_XP = 6 * ELG_SLOT_STRIDE;
+// (block pitch 288 + 4: with 288 = 9 x 32 floats every trajectory's block started on the same LDS bank, and the reads that put
+// the TRAJECTORY on the lane -- the local policy's feature / slot-code fragments, 16 lanes x ds_read_b128 -- were 16-way bank
+// conflicts; 292 = 4 (mod 32) spreads the sixteen 16-byte pieces over all 64 banks.  PMC: SQ_LDS_BANK_CONFLICT was 45 % of
+// SQ_LDS_IDX_ACTIVE in the cooperative kernel.)
+constexpr int CO_XP = 6 * ELG_SLOT_STRIDE + 4;
 constexpr int CO_XF = 0, CO_XS = 3 * ELG_SLOT_STRIDE, CO_XPEN = 4 * ELG_SLOT_STRIDE, CO_XU = 5 * ELG_SLOT_STRIDE;
 // ---- folded local-policy tables staged in LDS with conflict-free pitches (same images as csrc/elg_local.hip)
 // Every MFMA operand that comes from a table is one ds_read_b128 (four k-steps at once): lcv is kept transposed ([d][52]: a

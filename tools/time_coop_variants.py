@@ -23,15 +23,16 @@ pol = model.decoder.policy
 starts = torch.tensor(model.draw_starts(100, 100), dtype=torch.int32)
 out = {}
 for train in (True, False):
-    for variant in (0,):
+    for variant, geo in ((0, None),):
         def run():
-            return eng.rollout_forward(env.problem, pol, 100, starts, L.MODE_SAMPLE, seed=1234, train=train, variant=variant)
+            return eng.rollout_forward(env.problem, pol, 100, starts, L.MODE_SAMPLE, seed=1234, train=train, variant=variant, geometry=geo)
         for _ in range(3): res = run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps): res = run()
         e1.record(); torch.cuda.synchronize()
-        out[(train, variant)] = res
-        print(f"train={train} variant={variant}: {e0.elapsed_time(e1) / reps:.3f} ms  mean T {res.tlen.float().mean().item():.1f}  "
+        if variant == 0: ref = res
+        else: print('   same tours as variant 0:', bool(torch.equal(ref.actions, res.actions)), 'probs max diff', float((ref.probs - res.probs).abs().max()))
+        print(f"train={train} variant={variant} geometry={geo}: {e0.elapsed_time(e1) / reps:.3f} ms  mean T {res.tlen.float().mean().item():.1f}  "
               f"mean cost {(-res.reward).mean().item():.4f}")
