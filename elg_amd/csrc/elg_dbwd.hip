@@ -57,8 +57,10 @@ __global__ __launch_bounds__(256) void row_weights_kernel(const PtrBwd a) {
 // registers before the current tile's MFMAs.
 template <int NT>
 __global__ __launch_bounds__(512, 4) void pointer_bwd_kernel(const PtrBwd a) {
-    constexpr int DLP = 16 * NT + 8;                                    // pitch of a dl row in LDS (floats)
-    constexpr int OP = 144;                                             // pitch of an O / dO row
+    // pitches = 4 x odd (mod 64 floats): the fragment reads / stores that put the ROW on the lane (16 lanes x 16 bytes at one
+    // pitch apart) then cover all 64 banks; 120 and 144 were 2- and 4-way conflicts (PMC: 43 % of the LDS-active cycles)
+    constexpr int DLP = 16 * NT + 4;                                    // pitch of a dl row in LDS (floats)
+    constexpr int OP = 148;                                             // pitch of an O / dO row
     constexpr int NPT = (16 * NT + 31) / 32;                            // nodes per thread and row
     constexpr int TPD = 20;                                             // pitch of the transposed dl tile (conflict-free b128 reads)
     __shared__ __attribute__((aligned(16))) float sDL[16 * DLP], sDLT[16 * NT * TPD], sO[16 * OP], sDO[16 * OP];
