@@ -959,7 +959,7 @@ __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v,
 template <bool TSP, bool TRAIN>
 __device__ __forceinline__ void co_advance4(const elg_rollout_args& A, const Inst& I, int N1, int lane, int wave, int ntraj,
                                             int t, int g_lo, size_t b, size_t Rcap, CoRow& st, int sel, bool active,
-                                            unsigned long long* sMask, float* sQ, float* sX, StampCtx& sc) {
+                                            unsigned long long* sMask, float* sQ, float* sX, float* sSc, StampCtx& sc) {
     const int tq = lane >> 4, lo = lane & 15;
     const int q = 4 * wave + tq;
     const int m = g_lo + q;
@@ -1032,6 +1032,10 @@ __device__ __forceinline__ void co_advance4(const elg_rollout_args& A, const Ins
                 if (n == 0 && st.fin) mm = false;
             }
         }
+        // the glimpse takes the mask as the C operand of its S = K q^T MFMAs (0 for an open node, -inf for a closed one):
+        // written into the trajectory's SCORE row, which is free from here until the pointer phase of the next step
+        // refills it (one select + one LDS store per lane and chunk instead of three VALU per score in every head's wave)
+        sSc[q * CO_SP + n] = mm ? ELG_NEG_INF : 0.f;
         const unsigned long long bal = __ballot(mm);
         const unsigned long long rowbits = (bal >> (16 * tq)) & 0xFFFFull;
         if (k < 4) w0 |= rowbits << (16 * (k & 3)); else w1 |= rowbits << (16 * (k & 3));
@@ -1341,7 +1345,6 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                 {
                     const float cs = 0.25f * 1.4426950408889634f;
                     float qb[2][4];
-                    uint4 mwords[2];
                     f32x4c sc[2][CO_NT];
                     float mx[2], cm[2], den[2] = {0.f, 0.f};
 #pragma unroll
@@ -1349,24 +1352,16 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                         const int traj = 16 * rt + lo_t;
                         const float4 q4 = *reinterpret_cast<const float4*>(sQ + traj * CO_QP + 16 * wave + 4 * hi_t);   // channels 4 hi + kk, as kop
                         qb[rt][0] = q4.x; qb[rt][1] = q4.y; qb[rt][2] = q4.z; qb[rt][3] = q4.w;
-                        // the trajectory's mask as four dwords; this lane's nodes of chunk nt are bits 4 hi .. 4 hi + 3 of the
-                        // chunk's 16-bit slice (nodes past N1 are closed in the mask words themselves)
-                        mwords[rt] = *reinterpret_cast<const uint4*>(sMask + 2 * traj);
                         mx[rt] = -1e30f;                                // finite floor: a fully closed row gives exp2(-inf) = 0
                     }
-                    auto s_tile = [&](int rt, int nt) {                // S^T tile: 4 MFMAs + the mask
-                        f32x4c acc = {0.f, 0.f, 0.f, 0.f};
+                    auto s_tile = [&](int rt, int nt) {                // S^T tile: the additive mask (0 / -inf, left in the score row by
+                        // the owners; nodes past N1 and missing trajectories are -inf) is the accumulator input of the 4 MFMAs
+                        const float4 m4 = *reinterpret_cast<const float4*>(sSc + (16 * rt + lo_t) * CO_SP + 16 * nt + 4 * hi_t);
+                        f32x4c acc = {m4.x, m4.y, m4.z, m4.w};
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kop[nt][kk], qb[rt][kk], acc, 0, 0, 0);
-                        const uint4 mw = mwords[rt];
-                        const unsigned dw = (nt >> 1) == 0 ? mw.x : (nt >> 1) == 1 ? mw.y : (nt >> 1) == 2 ? mw.z : mw.w;
-                        const unsigned nib = (dw >> (16 * (nt & 1) + 4 * hi_t)) & 0xFu;
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const float x = (nib & (1u << v)) ? ELG_NEG_INF : acc[v];
-                            acc[v] = x;
-                            mx[rt] = fmaxf(mx[rt], x);
-                        }
+                        for (int v = 0; v < 4; ++v) mx[rt] = fmaxf(mx[rt], acc[v]);
                         sc[rt][nt] = acc;
                     };
                     auto e_tile = [&](int rt, int nt) {                // softmax numerators: exp2((s - max) log2(e) / 4), one fma + v_exp
@@ -1484,9 +1479,9 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
             const bool active = q4 < ntraj && !row.fin;
             int sel = 0;
             float pr = 1.0f;
-            // (a wave none of whose four trajectories exists -- 25 trajectories leave wave 7 empty -- skips the phase: its
-            // exchange rows keep their reset state (closed masks, zero queries), and its SIMD partner gets the issue slots)
-            if (4 * wave < ntraj) {
+            // (every wave runs the phase, also one without trajectories: it re-closes its rows' additive masks, which the
+            // pointer phase has overwritten with scores)
+            {
                 if (decode_step) {
                     co_finish4<TSP, TRAIN>(A, N1, lane_t, wave, ntraj, t, g_lo, (size_t)b, Rcap, sSc, sMask, sX, sState,
                                            q4 < ntraj ? row.fin : 1, sel, pr, ubuf, sc);
@@ -1499,7 +1494,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                     if (A.actions) A.actions[bm4 * A.Tmax + t] = sel;
                     if (A.probs) A.probs[((size_t)b * A.Tmax + t) * A.M + m4] = pr;
                 }
-                co_advance4<TSP, TRAIN>(A, I, N1, lane_t, wave, ntraj, t, g_lo, (size_t)b, Rcap, row, sel, active, sMask, sQ, sX, sc);
+                co_advance4<TSP, TRAIN>(A, I, N1, lane_t, wave, ntraj, t, g_lo, (size_t)b, Rcap, row, sel, active, sMask, sQ, sX, sSc, sc);
             }
             any_left = (q4 < ntraj && !row.fin) ? 1 : 0;
             ELG_STAMP(sc, 11);
