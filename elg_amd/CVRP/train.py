@@ -55,15 +55,21 @@ def train_step(model, env, optimizer, batch, scale_norm=True, bucket=None, world
             bucket.allreduce(world)
         optimizer.step()
         return J.detach(), rewards
-    # same operations; the rollout's length and the feasibility flags are read AFTER the backward and the update are queued
+    # Same operations; the rollout's length and the feasibility flags are read AFTER the backward and the update are queued.
+    # Intentional difference in ORDER to the reference (train.py:111 asserts before zero_grad / backward): the assertion still
+    # fires in the step that produced the infeasible tour, but that step's update has already been queued -- the run stops
+    # either way (the reference never catches the AssertionError), and the GPU does not idle 0.4 ms per step on the read-back.
+    # finish() runs on every exit path, so the flags are always read.
     ro = rollout_train(model, env, reset_state.node_demand[0] if check else None)
-    optimizer.zero_grad()
-    J = pomo_loss(ro.probs, ro.reward, scale_norm)
-    J.backward()
-    if bucket is not None:
-        bucket.allreduce(world)
-    optimizer.step()
-    ro.finish()                     # the step's host sync + the feasibility assertions
+    try:
+        optimizer.zero_grad()
+        J = pomo_loss(ro.probs, ro.reward, scale_norm)
+        J.backward()
+        if bucket is not None:
+            bucket.allreduce(world)
+        optimizer.step()
+    finally:
+        ro.finish()                 # the step's host sync + the feasibility assertions
     return J.detach(), ro.reward
 
 

@@ -73,7 +73,7 @@ class DecoderBwdArgs(C.Structure):
                 ("trO", _vp), ("trLoad", _vp), ("trSlot", _vp), ("trA", _vp), ("trMask", _vp), ("trLse", _vp), ("Kmat", _vp), ("Vmat", _vp),
                 ("PK", _vp), ("dK", _vp), ("dV", _vp), ("dPK", _vp), ("dpb", _vp), ("dQ1", _vp), ("dQ2", _vp), ("dwl", _vp),
                 ("rowDU", _vp), ("dO", _vp), ("idx_prev", _vp), ("idx_first", _vp), ("rowW", _vp),
-                ("T_dev", _vp), ("gprob_T", C.c_int32)]
+                ("T_dev", _vp), ("gprob_T", C.c_int32), ("tables_frozen", C.c_int32)]
 
 
 class LocalWeights(C.Structure):

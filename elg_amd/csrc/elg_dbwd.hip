@@ -240,6 +240,7 @@ extern "C" int elg_decoder_bwd(const elg_decoder_bwd_args* p, void* stream) {
     else hipLaunchKernelGGL(pointer_bwd_kernel<8>, grid, block, 0, s, a);
     rc = launch_status("pointer_bwd");
     if (rc != ELG_OK) return rc;
+    if (p->tables_frozen) return ELG_OK;          // nothing upstream of the pointer scores needs a gradient
     GlimpseSeg seg{};
     seg.idx_prev = p->idx_prev; seg.idx_first = tsp ? p->idx_first : nullptr; seg.load = tsp ? nullptr : p->trLoad;
     seg.dQ1 = p->dQ1; seg.dQ2 = tsp ? p->dQ2 : nullptr; seg.dwl = tsp ? nullptr : p->dwl; seg.load_rows = p->Rcap;

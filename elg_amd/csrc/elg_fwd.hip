@@ -1786,6 +1786,11 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
     MtTraj st[NOWN];
     bool has[NOWN];
     size_t bm[NOWN];
+    StampCtx sc_;
+#ifdef ELG_STAMPS
+    for (int i = 0; i < 16; ++i) sc_.acc[i] = 0.f;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sc_.last) :: "memory");
+#endif
 #pragma unroll
     for (int j = 0; j < NOWN; ++j) {
         has[j] = m_base + wave + 8 * j < A.M;
@@ -1804,6 +1809,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
             any = any || act[j];
         }
         if (!__syncthreads_or(any ? 1 : 0)) break;
+        ELG_STAMP(sc_, 8);
         int sel[NOWN], snid[NOWN];
         float pr[NOWN], addv[NOWN];
 #pragma unroll
@@ -1855,7 +1861,9 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
             };
 #pragma unroll
             for (int j = 0; j < NOWN; ++j) prepare(st[j], dec[j], wave + 8 * j, addv[j], snid[j]);
+            ELG_STAMP(sc_, 0);
             __syncthreads();
+            ELG_STAMP(sc_, 1);
             // ================= glimpse: wave = head; every K / V fragment serves the NG groups of 16 trajectories =================
             {
                 const float cs = 0.25f * 1.4426950408889634f;
@@ -1952,7 +1960,9 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                         make_float4((o[g][0] + o2[g][0]) * inv, (o[g][1] + o2[g][1]) * inv, (o[g][2] + o2[g][2]) * inv, (o[g][3] + o2[g][3]) * inv);
                 }
             }
+            ELG_STAMP(sc_, 2);
             __syncthreads();
+            ELG_STAMP(sc_, 3);
             // ================= pointer: node tiles over the waves; local policy of group g: wave 7 - g =================
             // (co_local16 costs about what three node tiles do: its wave joins the tile round-robin three rounds late)
             const int nloc = A.has_local ? NG : 0, W0 = 8 - nloc, skip = nloc ? 3 * W0 : 0;
@@ -1995,7 +2005,9 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                     nt = nxt;
                 }
             }
+            ELG_STAMP(sc_, 4);
             __syncthreads();
+            ELG_STAMP(sc_, 5);
             // ================= owners: clip, mask, softmax, choice =================
             auto choose = [&](bool dc, int q, size_t bmq, int sn, float addval, int& sl, float& pp) {
                 if (!dc) return;
@@ -2028,6 +2040,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
             };
 #pragma unroll
             for (int j = 0; j < NOWN; ++j) choose(dec[j], wave + 8 * j, bm[j], snid[j], addv[j], sel[j], pr[j]);
+            ELG_STAMP(sc_, 6);
         }
         auto advance = [&](MtTraj& s1, bool ac, int q, size_t bmq, int sl, float pp) {
             if (!ac) return;
@@ -2044,7 +2057,12 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
         };
 #pragma unroll
         for (int j = 0; j < NOWN; ++j) advance(st[j], act[j], wave + 8 * j, bm[j], sel[j], pr[j]);
+        ELG_STAMP(sc_, 7);
     }
+#ifdef ELG_STAMPS
+    if (A.full_probs == nullptr && A.uniforms && lane == 0)        // diagnostic build only: sums leave through the (unused) uniforms pointer
+        for (int i = 0; i < 16; ++i) const_cast<float*>(A.uniforms)[((size_t)blockIdx.x * 8 + wave) * 16 + i] = sc_.acc[i];
+#endif
     if (lane == 0) {
 #pragma unroll
         for (int j = 0; j < NOWN; ++j)

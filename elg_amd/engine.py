@@ -602,6 +602,8 @@ class _ChosenProbs(torch.autograd.Function):
         a.rowDU = _ptr(ws.rowDU) if meta.has_local else None
         a.dO, a.idx_prev, a.idx_first, a.rowW = _ptr(ws.dO), _ptr(ws.idx_prev), _ptr(ws.idx_first), _ptr(ws.rowW)
         a.T_dev, a.gprob_T = _ptr(ctx.T_dev), g.shape[1]
+        # `training: only_local`: the decoder tables are constants (zeros) -- the glimpse backward would compute gradients nobody reads
+        a.tables_frozen = int(not any(ctx.needs_input_grad[7:14]))
         L.check(L.lib().elg_decoder_bwd(C.byref(a), _stream()), "elg_decoder_bwd")
         if meta.has_local:
             # rows are independent given the saved slot features: 16 rows per wavefront on the matrix cores

@@ -397,6 +397,9 @@ typedef struct elg_decoder_bwd_args {
                                  * host has not read it yet: `T` is then only an upper bound, the kernels use       *
                                  * min(T, T_dev[0]) (same value in elg_local_bwd_rows), scratch strides follow it    */
     int32_t gprob_T;            /* with T_dev: time extent of gprob / pval (>= T); ignored otherwise                */
+    int32_t tables_frozen;      /* 1: the decoder tables carry no gradient (`training: only_local`, CVRPModel.py:78-131: they
+                                 * are zeros): only the softmax / pointer pass runs (it produces rowDU for the local policy);
+                                 * dK, dV, dQ1, dQ2, dwl are left untouched                                            */
 } elg_decoder_bwd_args;
 int elg_decoder_bwd(const elg_decoder_bwd_args* args, void* stream);
 
