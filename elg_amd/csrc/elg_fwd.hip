@@ -1667,9 +1667,11 @@ struct MtTraj {
 };
 
 // build_mask() with the visited words in LDS
+// (also leaves the mask in ADDITIVE form -- 0 open, -inf closed, nodes past N1 closed -- in the trajectory's score row `srow`,
+// which is free until this step's pointer phase refills it: the glimpse takes it as the accumulator input of its S = K q^T MFMAs)
 template <int NCH, bool TSP>
 __device__ __forceinline__ void mt_build_mask(const MtTraj& st, const unsigned long long* vis, const Inst& I, int N1, int lane,
-                                              unsigned long long (&mk)[NCH]) {
+                                              unsigned long long (&mk)[NCH], float* srow) {
     const float lim = __fadd_rn(st.load, 1e-6f);
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
@@ -1682,6 +1684,7 @@ __device__ __forceinline__ void mt_build_mask(const MtTraj& st, const unsigned l
                 if (n == 0 && st.fin) m = false;
             }
         }
+        srow[n] = m ? ELG_NEG_INF : 0.f;
         mk[ch] = __ballot(m);
     }
 }
@@ -1820,7 +1823,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                 float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (dc) {
                     unsigned long long mk[NCH];
-                    mt_build_mask<NCH, TSP>(s1, sVis + q * NCH, I, N1, lane, mk);
+                    mt_build_mask<NCH, TSP>(s1, sVis + q * NCH, I, N1, lane, mk, sSc + q * SP);
                     const int cb = (lane & 31) * 4;
                     q4 = *reinterpret_cast<const float4*>(I.Q1 + (size_t)s1.cur * ELG_E + cb);
                     if (TSP) {
@@ -1851,6 +1854,8 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
 #pragma unroll
                         for (int c = 0; c < NCH; ++c) sMaskW[q * NCH + c] = ~0ull;
                     }
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) sSc[q * SP + lane + 64 * c] = ELG_NEG_INF;       // not decoding: every node closed
                     if (A.has_local && lane < ELG_SLOT_STRIDE) {
                         float* X = sX + q * CO_XP;
                         X[CO_XF + lane] = 0.f; X[CO_XF + ELG_SLOT_STRIDE + lane] = 0.f; X[CO_XF + 2 * ELG_SLOT_STRIDE + lane] = 0.f;
@@ -1895,7 +1900,10 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
 #pragma unroll
                     for (int g = 0; g < NG; ++g)
 #pragma unroll
-                        for (int u4 = 0; u4 < 4; ++u4) S[g][u4] = f32x4c{0.f, 0.f, 0.f, 0.f};
+                        for (int u4 = 0; u4 < 4; ++u4) {               // accumulator input = the additive mask of the tile's nodes
+                            const float4 m4 = *reinterpret_cast<const float4*>(sSc + (16 * g + lo) * SP + 16 * (nt + u4) + 4 * hi);
+                            S[g][u4] = f32x4c{m4.x, m4.y, m4.z, m4.w};
+                        }
 #pragma unroll
                     for (int g = 0; g < NG; ++g)
 #pragma unroll
@@ -1914,17 +1922,10 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                         for (int u4 = 0; u4 < 4; ++u4) S[g][u4] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u4].w, q4[g].w, S[g][u4], 0, 0, 0);
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
-                        const unsigned long long dw = sMaskW[(16 * g + lo) * NCH + (nt >> 2)];   // mask bits of nodes 16 nt .. 16 nt + 63
-                        const unsigned nib = (unsigned)(dw >> (4 * hi)) & 0x000F000Fu, nib2 = (unsigned)(dw >> (32 + 4 * hi)) & 0x000F000Fu;
                         float tm = ELG_NEG_INF;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            S[g][0][i] = ((nib >> i) & 1u) ? ELG_NEG_INF : S[g][0][i];
-                            S[g][1][i] = ((nib >> (16 + i)) & 1u) ? ELG_NEG_INF : S[g][1][i];
-                            S[g][2][i] = ((nib2 >> i) & 1u) ? ELG_NEG_INF : S[g][2][i];
-                            S[g][3][i] = ((nib2 >> (16 + i)) & 1u) ? ELG_NEG_INF : S[g][3][i];
+                        for (int i = 0; i < 4; ++i)
                             tm = fmaxf(fmaxf(tm, fmaxf(S[g][0][i], S[g][1][i])), fmaxf(S[g][2][i], S[g][3][i]));
-                        }
                         tm = quarters_max(tm);
                         const float mnew = fmaxf(mrun[g], tm);
                         const float sc = __builtin_amdgcn_exp2f((mrun[g] - mnew) * cs);
