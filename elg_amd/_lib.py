@@ -73,7 +73,8 @@ class DecoderBwdArgs(C.Structure):
                 ("trO", _vp), ("trLoad", _vp), ("trSlot", _vp), ("trA", _vp), ("trMask", _vp), ("trLse", _vp), ("Kmat", _vp), ("Vmat", _vp),
                 ("PK", _vp), ("dK", _vp), ("dV", _vp), ("dPK", _vp), ("dpb", _vp), ("dQ1", _vp), ("dQ2", _vp), ("dwl", _vp),
                 ("rowDU", _vp), ("dO", _vp), ("idx_prev", _vp), ("idx_first", _vp), ("rowW", _vp),
-                ("T_dev", _vp), ("gprob_T", C.c_int32), ("tables_frozen", C.c_int32)]
+                ("T_dev", _vp), ("gprob_T", C.c_int32), ("tables_frozen", C.c_int32),
+                ("mask_words", C.c_int32), ("pad_large", C.c_int32), ("ws", _vp), ("ws_floats", C.c_int64)]
 
 
 class LocalWeights(C.Structure):
@@ -99,6 +100,7 @@ EXPORTS = ["elg_version", "elg_last_error", "elg_aug8", "elg_dist_matrix", "elg_
            "elg_add_instnorm_fwd", "elg_add_instnorm_bwd",
            "elg_encoder_ws_floats", "elg_encoder_fwd", "elg_encoder_bwd_ws_floats", "elg_encoder_bwd",
            "elg_local_fold_fwd", "elg_local_fold_bwd", "elg_check_feasible", "elg_rollout_stats", "elg_decoder_bwd",
+           "elg_decoder_bwd_ws_floats",
            "elg_rollout_scratch_floats"]
 
 _lib = None
@@ -151,6 +153,8 @@ def lib() -> C.CDLL:
         L.elg_check_feasible.argtypes = [f, i64, f, i, i, i, f, f]
         L.elg_rollout_stats.argtypes = [f, f, i, i, i, f, f, f]
         L.elg_decoder_bwd.argtypes = [C.POINTER(DecoderBwdArgs), f]
+        L.elg_decoder_bwd_ws_floats.argtypes = [i, i64, i]
+        L.elg_decoder_bwd_ws_floats.restype = i64
         L.elg_decoder_bwd.restype = C.c_int
         L.elg_check_feasible.restype = C.c_int
         L.elg_rollout_stats.restype = C.c_int

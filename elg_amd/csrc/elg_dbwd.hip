@@ -199,15 +199,197 @@ __global__ __launch_bounds__(512, 4) void pointer_bwd_kernel(const PtrBwd a) {
     if (tid < N1) atomicAdd(a.dpb + (size_t)b * N1 + tid, dpb_acc);
 }
 
+
+// =============================================================================================
+// 128 < N1 <= 1024: the same backward over the rows the streaming rollout kernel saved, as batched f32 MFMA GEMMs
+// (csrc/elg_gemm.hip) around three row kernels (one wavefront per row, lanes over the nodes).
+// =============================================================================================
+// d s[n] = w (c_sel [n = a] - p c[n]) in place over the saved p c row; d u_slot for the local policy; column sums -> d pb
+__global__ __launch_bounds__(256) void rows_dl_kernel(const PtrBwd a, float* __restrict__ PCrw, int rows_per_block) {
+    extern __shared__ float sAcc[];                                       // [N1] column sums of the block's rows
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y, N1 = a.N1;
+    const int R = a.T * a.M;
+    for (int i = threadIdx.x; i < N1; i += 256) sAcc[i] = 0.f;
+    __syncthreads();
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    for (int r = r0 + wave; r < r1; r += 4) {
+        const float4 rw = a.rowW[(size_t)b * R + r];
+        const float w = rw.x, wc = rw.y;
+        const int sel = f2i(rw.z);
+        float* row = PCrw + ((size_t)b * a.Rcap + r) * N1;
+        if (a.rowDU && lane < 48) {
+            const int s = a.Slot[((size_t)b * a.Rcap + r) * 48 + lane];
+            float du = 0.f;
+            if (s >= 0 && w != 0.f) du = (s == sel ? wc : 0.f) - w * row[s];
+            a.rowDU[((size_t)b * R + r) * 48 + lane] = du * a.inv_ens;
+        }
+        __builtin_amdgcn_wave_barrier();                                    // the slot reads above precede the in-place stores below
+        if (w == 0.f) {                                                     // not a decoded row: exact zeros
+            for (int n = lane; n < N1; n += 64) row[n] = 0.f;
+            continue;
+        }
+        for (int n = lane; n < N1; n += 64) {
+            const float v = (n == sel ? wc : 0.f) - w * row[n];
+            row[n] = v;
+            atomicAdd(sAcc + n, v);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < N1; i += 256) {
+        const float v = sAcc[i];
+        if (v != 0.f) atomicAdd(a.dpb + (size_t)b * N1 + i, v);
+    }
+}
+
+// a_h[n] = closed(n) ? 0 : exp2(s cs - lse) in place over S = q_h K_h^T        grid (rows / 4, B * 8)
+__global__ __launch_bounds__(256) void rows_attn_kernel(float* __restrict__ S, const unsigned long long* __restrict__ mask,
+                                                        const float* __restrict__ lse, int R, long long Rcap, int N1, int W) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= R) return;
+    const int bh = blockIdx.y, b = bh >> 3, h = bh & 7;
+    const float cs = 0.25f * 1.4426950408889634f;
+    const size_t rrow = (size_t)b * Rcap + r;
+    const float l = lse[rrow * 8 + h];
+    float* row = S + ((size_t)bh * R + r) * N1;
+    for (int c = 0; 64 * c < N1; ++c) {
+        const int n = lane + 64 * c;
+        const unsigned long long w = mask[rrow * W + c];
+        if (n < N1) row[n] = ((w >> lane) & 1ull) ? 0.f : __builtin_amdgcn_exp2f(fmaf(row[n], cs, -l));
+    }
+}
+
+// d S = a (dA - <dO_h, O_h>) / 4 in place over dA                              grid (rows / 4, B * 8)
+__global__ __launch_bounds__(256) void rows_ds_kernel(float* __restrict__ dA, const float* __restrict__ Aw,
+                                                      const float* __restrict__ dO, const float* __restrict__ O, int R,
+                                                      long long Rdo, long long Rcap, int N1) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= R) return;
+    const int bh = blockIdx.y, b = bh >> 3, h = bh & 7;
+    float d = 0.f;
+    if (lane < 16) d = dO[((size_t)b * Rdo + r) * ELG_E + h * 16 + lane] * O[((size_t)b * Rcap + r) * ELG_E + h * 16 + lane];
+    const float doto = row16_sum(d);
+    const float dt = readlane(doto, 0);
+    float* row = dA + ((size_t)bh * R + r) * N1;
+    const float* arow = Aw + ((size_t)bh * R + r) * N1;
+    for (int n = lane; n < N1; n += 64) row[n] = 0.25f * arow[n] * (row[n] - dt);
+}
+
+// backward of the query gather: d Q1[prev[r]] += dQ[r], d Q2[first[r]] += dQ[r] (TSP), d wl += load[r] dQ[r] (CVRP)
+__global__ __launch_bounds__(256) void rows_qgather_bwd_kernel(const float* __restrict__ dQ, const int* __restrict__ prev,
+                                                               const int* __restrict__ first, const float* __restrict__ load,
+                                                               float* __restrict__ dQ1, float* __restrict__ dQ2,
+                                                               float* __restrict__ dwl, int R, long long Ridx,
+                                                               long long Rcap, int N1, int rows_per_block) {
+    __shared__ float swl[ELG_E];
+    const int c = threadIdx.x & (ELG_E - 1), half = threadIdx.x >> 7;
+    const int b = blockIdx.y;
+    if (threadIdx.x < ELG_E) swl[threadIdx.x] = 0.f;
+    __syncthreads();
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    float wl = 0.f;
+    for (int r = r0 + half; r < r1; r += 2) {
+        const float v = dQ[((size_t)b * R + r) * ELG_E + c];
+        if (v != 0.f) {
+            atomicAdd(dQ1 + ((size_t)b * N1 + prev[(size_t)b * Ridx + r]) * ELG_E + c, v);
+            if (dQ2) atomicAdd(dQ2 + ((size_t)b * N1 + first[(size_t)b * Ridx + r]) * ELG_E + c, v);
+            if (dwl) wl = fmaf(load[(size_t)b * Rcap + r], v, wl);
+        }
+    }
+    if (dwl) {
+        atomicAdd(swl + c, wl);
+        __syncthreads();
+        if (threadIdx.x < ELG_E && swl[threadIdx.x] != 0.f) atomicAdd(dwl + threadIdx.x, swl[threadIdx.x]);
+    }
+}
+
 }  // namespace elg
 
 using namespace elg;
+
+extern "C" int elg_gemm_f32_batched(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                    int transA, int transB, int n_outer, int n_inner, int64_t sA_outer, int64_t sA_inner,
+                                    int64_t sB_outer, int64_t sB_inner, int64_t sC_outer, int64_t sC_inner, float alpha,
+                                    void* stream);
+
+extern "C" int64_t elg_decoder_bwd_ws_floats(int32_t B, int64_t R, int32_t N1) {
+    if (B <= 0 || R <= 0 || N1 <= 128) return 0;
+    return (int64_t)B * R * (2 * 8 * (int64_t)N1 + ELG_E);
+}
+
+static int decoder_bwd_large(const elg_decoder_bwd_args* p, PtrBwd& a, hipStream_t s) {
+    const int B = p->B, N1 = p->N1, W = p->mask_words;
+    const long long R = (long long)p->T * p->M, Rcap = p->Rcap;
+    const bool tsp = p->problem == ELG_PROBLEM_TSP;
+    if (p->T_dev) return fail(ELG_ENOTIMPL, "decoder_bwd: N1 > 128 needs the step count on the host (T_dev = NULL)");
+    if (!p->trMask || !p->trLse) return fail(ELG_EINVAL, "decoder_bwd: N1 > 128 needs the mask words and the log-sum-exp rows");
+    if (W * 64 < N1 || W > 16) return fail(ELG_EINVAL, "decoder_bwd: mask_words does not cover N1");
+    const int64_t per1 = elg_decoder_bwd_ws_floats(1, R, N1);
+    if (!p->ws || p->ws_floats < per1) return fail(ELG_EINVAL, "decoder_bwd: scratch smaller than one instance (elg_decoder_bwd_ws_floats(1, R, N1))");
+    // rows before the first decode step were never written by the rollout: everything after rows_dl runs over [r_lo, R)
+    const long long r_lo = min(R, (long long)p->first_decode_step * p->M), Rl = R - r_lo;
+    float* PCw = const_cast<float*>(p->trPC);
+    void* st = (void*)s;
+    const int rpb = 64;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(rows_dl_kernel, dim3((unsigned)((R + rpb - 1) / rpb), B), dim3(256), (size_t)N1 * 4, s, a, PCw, rpb);
+    int rc = launch_status("rows_dl");
+    if (rc != ELG_OK || Rl == 0) return rc;
+    // the scratch holds Bc instances: the batch is walked in chunks of Bc
+    const int Bc = (int)min((long long)B, (long long)(p->ws_floats / per1));
+    float* Sbuf = p->ws;                                  // (Bc,8,Rl,N1)  s -> a
+    float* Dbuf = Sbuf + (size_t)Bc * 8 * R * N1;         // (Bc,8,Rl,N1)  dA -> dS
+    float* dQr = Dbuf + (size_t)Bc * 8 * R * N1;          // (Bc,Rl,128)
+#define DB_TRY(x) { rc = (x); if (rc != ELG_OK) return rc; }
+    for (int b0 = 0; b0 < B; b0 += Bc) {
+        const int nb = min(Bc, B - b0);
+        const float* dl = PCw + ((size_t)b0 * Rcap + r_lo) * N1;
+        const float* Ol = p->trO + ((size_t)b0 * Rcap + r_lo) * ELG_E;
+        const float* Ql = p->trQ + ((size_t)b0 * Rcap + r_lo) * ELG_E;
+        float* dOl = p->dO + ((size_t)b0 * R + r_lo) * ELG_E;
+        const size_t tb = (size_t)b0 * N1 * ELG_E;        // this chunk's tables / table gradients
+        // d o = d s PK ;  d PK = d s^T o
+        DB_TRY(elg_gemm_f32_batched(dl, p->PK + tb, dOl, (int)Rl, ELG_E, N1, N1, ELG_E, ELG_E, 0, 0, nb, 1, Rcap * N1, 0,
+                                    (int64_t)N1 * ELG_E, 0, R * ELG_E, 0, 1.f, st))
+        DB_TRY(elg_gemm_f32_batched(dl, Ol, p->dPK + tb, N1, ELG_E, (int)Rl, N1, ELG_E, ELG_E, 1, 0, nb, 1, Rcap * N1, 0, Rcap * ELG_E, 0,
+                                    (int64_t)N1 * ELG_E, 0, 1.f, st))
+        if (p->tables_frozen) continue;
+        // s_h = q_h K_h^T  -> a_h (in place)
+        DB_TRY(elg_gemm_f32_batched(Ql, p->Kmat + tb, Sbuf, (int)Rl, N1, 16, ELG_E, ELG_E, N1, 0, 1, nb, 8, Rcap * ELG_E, 16,
+                                    (int64_t)N1 * ELG_E, 16, 8 * Rl * N1, Rl * N1, 1.f, st))
+        hipLaunchKernelGGL(rows_attn_kernel, dim3((unsigned)((Rl + 3) / 4), nb * 8), dim3(256), 0, s, Sbuf,
+                           reinterpret_cast<const unsigned long long*>(p->trMask) + ((size_t)b0 * Rcap + r_lo) * W,
+                           p->trLse + ((size_t)b0 * Rcap + r_lo) * 8, (int)Rl, Rcap, N1, W);
+        DB_TRY(launch_status("rows_attn"))
+        // dA_h = dO_h V_h^T -> dS_h (in place)
+        DB_TRY(elg_gemm_f32_batched(dOl, p->Vmat + tb, Dbuf, (int)Rl, N1, 16, ELG_E, ELG_E, N1, 0, 1, nb, 8, R * ELG_E, 16,
+                                    (int64_t)N1 * ELG_E, 16, 8 * Rl * N1, Rl * N1, 1.f, st))
+        hipLaunchKernelGGL(rows_ds_kernel, dim3((unsigned)((Rl + 3) / 4), nb * 8), dim3(256), 0, s, Dbuf, Sbuf, dOl, Ol, (int)Rl, R, Rcap, N1);
+        DB_TRY(launch_status("rows_ds"))
+        // d q_h = dS_h K_h ;  d K_h = dS_h^T q_h ;  d V_h = a_h^T dO_h
+        DB_TRY(elg_gemm_f32_batched(Dbuf, p->Kmat + tb, dQr, (int)Rl, 16, N1, N1, ELG_E, ELG_E, 0, 0, nb, 8, 8 * Rl * N1, Rl * N1,
+                                    (int64_t)N1 * ELG_E, 16, Rl * ELG_E, 16, 1.f, st))
+        DB_TRY(elg_gemm_f32_batched(Dbuf, Ql, p->dK + tb, N1, 16, (int)Rl, N1, ELG_E, ELG_E, 1, 0, nb, 8, 8 * Rl * N1, Rl * N1,
+                                    Rcap * ELG_E, 16, (int64_t)N1 * ELG_E, 16, 1.f, st))
+        DB_TRY(elg_gemm_f32_batched(Sbuf, dOl, p->dV + tb, N1, 16, (int)Rl, N1, ELG_E, ELG_E, 1, 0, nb, 8, 8 * Rl * N1, Rl * N1,
+                                    R * ELG_E, 16, (int64_t)N1 * ELG_E, 16, 1.f, st))
+        hipLaunchKernelGGL(rows_qgather_bwd_kernel, dim3((unsigned)((Rl + rpb - 1) / rpb), nb), dim3(256), 0, s, dQr,
+                           p->idx_prev + (size_t)b0 * R + r_lo, tsp ? p->idx_first + (size_t)b0 * R + r_lo : nullptr,
+                           tsp ? nullptr : p->trLoad + (size_t)b0 * Rcap + r_lo, p->dQ1 + tb, tsp ? p->dQ2 + tb : nullptr,
+                           tsp ? nullptr : p->dwl, (int)Rl, R, Rcap, N1, rpb);
+        DB_TRY(launch_status("rows_qgather_bwd"))
+    }
+#undef DB_TRY
+    return ELG_OK;
+}
 
 extern "C" int elg_decoder_bwd(const elg_decoder_bwd_args* p, void* stream) {
     if (!p) return fail(ELG_EINVAL, "decoder_bwd: null args");
     const int B = p->B, M = p->M, N1 = p->N1, T = p->T;
     if (B <= 0 || M <= 0 || T <= 0 || N1 < 4) return fail(ELG_EINVAL, "decoder_bwd: bad sizes");
-    if (N1 > 128) return fail(ELG_ENOTIMPL, "decoder_bwd: N1 > 128 not built (use elg_rollout_bwd)");
+    if (N1 > 1024) return fail(ELG_ENOTIMPL, "decoder_bwd: N1 > 1024 not built");
     const long long R = (long long)T * M;
     if (p->Rcap < R || p->Tcap_actions < T) return fail(ELG_EINVAL, "decoder_bwd: row capacity smaller than T*M");
     if (!p->gprob || !p->pval || !p->tlen || !p->actions || !p->trPC || !p->trCsel || !p->trQ || !p->trO || !p->Kmat ||
@@ -233,6 +415,7 @@ extern "C" int elg_decoder_bwd(const elg_decoder_bwd_args* p, void* stream) {
     hipLaunchKernelGGL(row_weights_kernel, dim3((unsigned)(((long long)B * R + 255) / 256)), dim3(256), 0, s, a);
     int rc = launch_status("row_weights");
     if (rc != ELG_OK) return rc;
+    if (N1 > 128) return decoder_bwd_large(p, a, s);
     dim3 grid(a.splits, B), block(512);
     if (nt <= 2) hipLaunchKernelGGL(pointer_bwd_kernel<2>, grid, block, 0, s, a);
     else if (nt <= 4) hipLaunchKernelGGL(pointer_bwd_kernel<4>, grid, block, 0, s, a);

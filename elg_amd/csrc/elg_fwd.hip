@@ -128,7 +128,7 @@ template <int NCH, bool TSP, bool TRAIN>
 __device__ __forceinline__ FwdOut finish_step(const elg_rollout_args& A, int N1, int lane, float* sb,
                                               const unsigned long long (&mk)[NCH], const float (&s)[NCH], int snid,
                                               float addval, int forced_sel, float uni, float* full_row, size_t b,
-                                              size_t r, size_t Rcap) {
+                                              size_t r, size_t Rcap, float* pcj_out = nullptr) {
     // ---- scatter the slot terms to node order (xi everywhere else)   models.py:405-413
     const float dflt = A.has_penalty ? A.xi : 0.f;
 #pragma unroll
@@ -236,6 +236,17 @@ __device__ __forceinline__ FwdOut finish_step(const elg_rollout_args& A, int N1,
             if (n < N1) rPC[n] = e[ch] * inv * cj;
             if (n == sel) A.trCsel[b * Rcap + r] = cj;
         }
+    }
+    if (pcj_out) {       // the caller stores the Jacobian row itself: pcj_out[0 .. NCH) = p clip (1 - tanh^2) of this lane's nodes,
+                         // pcj_out[NCH] = clip (1 - tanh^2) at the chosen node (uniform)
+        float cs_ = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const float cj = A.clip * (1.f - th[ch] * th[ch]);
+            pcj_out[ch] = e[ch] * inv * cj;
+            if ((sel >> 6) == ch) cs_ = readlane(cj, sel & 63);
+        }
+        pcj_out[NCH] = cs_;
     }
     FwdOut o;
     o.sel = sel;
@@ -1735,7 +1746,10 @@ __device__ __forceinline__ void mt_env_update(MtTraj& st, unsigned long long* vi
     }
 }
 
-template <int NCH, bool TSP, int NG>
+// TRAIN (round 3): the rows a backward over saved rows needs, time-major (r = t M + m) as the cooperative kernel writes them:
+// query q and glimpse output o, the glimpse's log2-sum-exp per head (in units of s log2(e) / 4), the row's mask words
+// (NCH 64-bit words), load, k-NN slot ids + slot features, the softmax x clip Jacobian row and its value at the chosen node.
+template <int NCH, bool TSP, int NG, bool TRAIN>
 __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_args A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NTR = 16 * NG, NOWN = 2 * NG, QP = 132, SP = 64 * NCH + 4;
@@ -1783,6 +1797,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
     const float4* gV = reinterpret_cast<const float4*>(gF + (size_t)NP * ELG_E) + (size_t)wave * NT * 64 + lane;
     const float4* gPK = reinterpret_cast<const float4*>(gF + (size_t)2 * NP * ELG_E) + lane;
     const int step_cap = TSP ? N1 : 2 * N1 + 2;
+    const size_t Rcap = (size_t)A.Tmax * A.M;
 
     // the wave's trajectories: q = wave + 8 j (row q % 16 of MFMA group q / 16); every loop over j is unrolled, so st[] stays
     // in (scalar) registers
@@ -1838,6 +1853,17 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
 #pragma unroll
                         for (int c = 0; c < NCH; ++c) sMaskW[q * NCH + c] = mk[c];
                     }
+                    const size_t rrow = (size_t)b * Rcap + (size_t)t * A.M + m_base + q;        // this trajectory's row of step t
+                    if (TRAIN) {
+                        if (lane < NCH) {
+                            unsigned long long w = mk[0];
+#pragma unroll
+                            for (int c = 1; c < NCH; ++c) w = lane == c ? mk[c] : w;
+                            A.trMask[rrow * NCH + lane] = w;
+                        }
+                        if (lane < 32) *reinterpret_cast<float4*>(A.trQ + rrow * ELG_E + cb) = q4;
+                        if (lane == 0 && A.trLoad) A.trLoad[rrow] = s1.load;
+                    }
                     if (A.has_penalty || A.has_local) {
                         wave_lds_fence();
                         const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, s1, lane, mk, sb, sMaskW + q * NCH, A.euclidean != 0);
@@ -1847,6 +1873,13 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                             float* X = sX + q * CO_XP;
                             X[CO_XF + lane] = S.f0; X[CO_XF + ELG_SLOT_STRIDE + lane] = S.f1; X[CO_XF + 2 * ELG_SLOT_STRIDE + lane] = S.f2;
                             reinterpret_cast<int*>(X)[CO_XS + lane] = S.smask ? (S.snid >= 0 ? -2 : -1) : S.snid;
+                        }
+                        if (TRAIN && A.trSlot && lane < ELG_SLOT_STRIDE) {
+                            A.trSlot[rrow * ELG_SLOT_STRIDE + lane] = (S.smask && S.snid >= 0) ? -2 : S.snid;
+                            if (A.trF) {
+                                float* fr = A.trF + rrow * (3 * ELG_SLOT_STRIDE) + lane;
+                                fr[0] = S.f0; fr[ELG_SLOT_STRIDE] = S.f1; fr[2 * ELG_SLOT_STRIDE] = S.f2;
+                            }
                         }
                     }
                 } else {
@@ -1957,8 +1990,14 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                 for (int g = 0; g < NG; ++g) {
                     const float l = quarters_sum(lrun[g]);
                     const float inv = l > 0.f ? 1.0f / l : 0.f;
-                    *reinterpret_cast<float4*>(sQ + (16 * g + lo) * QP + 16 * wave + 4 * hi) =
-                        make_float4((o[g][0] + o2[g][0]) * inv, (o[g][1] + o2[g][1]) * inv, (o[g][2] + o2[g][2]) * inv, (o[g][3] + o2[g][3]) * inv);
+                    const float4 ov = make_float4((o[g][0] + o2[g][0]) * inv, (o[g][1] + o2[g][1]) * inv, (o[g][2] + o2[g][2]) * inv,
+                                                  (o[g][3] + o2[g][3]) * inv);
+                    *reinterpret_cast<float4*>(sQ + (16 * g + lo) * QP + 16 * wave + 4 * hi) = ov;
+                    if (TRAIN && l > 0.f && m_base + 16 * g + lo < A.M) {       // a decoding trajectory: a_h[n] = exp2(s cs - lse)
+                        const size_t rrow = (size_t)b * Rcap + (size_t)t * A.M + m_base + 16 * g + lo;
+                        *reinterpret_cast<float4*>(A.trO + rrow * ELG_E + 16 * wave + 4 * hi) = ov;
+                        if (hi == 0) A.trLse[rrow * ELG_H + wave] = __log2f(l) + mrun[g] * cs;
+                    }
                 }
             }
             ELG_STAMP(sc_, 2);
@@ -2035,7 +2074,21 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                 float* frow = (A.full_probs && t < A.dump_T) ? A.full_probs + (bmq * A.dump_T + t) * N1 : nullptr;
                 if (A.has_local && lane < ELG_SLOT_STRIDE) addval += sX[q * CO_XP + CO_XU + lane] * A.inv_ens;
                 // finish_step scatters through a node-indexed scratch row: the score row itself (the scores are in registers now)
-                const FwdOut fo = finish_step<NCH, TSP, false>(A, N1, lane, srow, mk, s, sn, addval, fsel, uni, frow, (size_t)b, 0, 0);
+                // (TRAIN: the softmax x clip Jacobian row comes back in registers and is stored here -- finish_step's own row
+                // stores, inlined into this kernel, run into a code-generation error of the address-space cast of `srow`)
+                float pcj[NCH + 1];
+                const FwdOut fo = finish_step<NCH, TSP, false>(A, N1, lane, srow, mk, s, sn, addval, fsel, uni, frow, (size_t)b, 0, 0,
+                                                               TRAIN ? pcj : nullptr);
+                if (TRAIN) {
+                    const size_t rrow = (size_t)b * Rcap + (size_t)t * A.M + m_base + q;
+                    float* rPC = A.trPC + rrow * N1;
+#pragma unroll
+                    for (int ch = 0; ch < NCH; ++ch) {
+                        const int n = lane + 64 * ch;
+                        if (n < N1) rPC[n] = pcj[ch];
+                    }
+                    if (lane == 0) A.trCsel[rrow] = pcj[NCH];
+                }
                 sl = __builtin_amdgcn_readfirstlane(fo.sel);
                 pp = i2f(__builtin_amdgcn_readfirstlane(f2i(fo.p)));
             };
@@ -2071,12 +2124,12 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
     }
 }
 
-template <int NCH, bool TSP, int NG>
+template <int NCH, bool TSP, int NG, bool TRAIN>
 static int launch_fwd_mt_g(const elg_rollout_args& A, hipStream_t stream) {
     constexpr int NTR = 16 * NG;
     const size_t lds = ((size_t)NTR * 132 + (size_t)NTR * (64 * NCH + 4) + (size_t)NTR * NCH * 4 + (A.has_local ? NTR * CO_XP + CL_SIZE : 0) +
                         ((A.N1 + 3) & ~3) + (size_t)8 * ELG_SB_MIN) * 4;
-    auto kern = rollout_fwd_mt_kernel<NCH, TSP, NG>;
+    auto kern = rollout_fwd_mt_kernel<NCH, TSP, NG, TRAIN>;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         (void)hipGetLastError();
@@ -2098,8 +2151,14 @@ static int launch_fwd_mt_g(const elg_rollout_args& A, hipStream_t stream) {
 // would put more than one workgroup on a CU anyway; the score rows of 32 trajectories fit LDS up to 512 nodes
 template <int NCH, bool TSP>
 static int launch_fwd_mt(const elg_rollout_args& A, hipStream_t stream) {
-    if (NCH <= 8 && (long long)A.B * ((A.M + 15) / 16) > 256) return launch_fwd_mt_g<NCH, TSP, (NCH <= 8 ? 2 : 1)>(A, stream);
-    return launch_fwd_mt_g<NCH, TSP, 1>(A, stream);
+    const bool two = NCH <= 8 && (long long)A.B * ((A.M + 15) / 16) > 256;
+    if (A.trMask) {     // training forward: saves the backward rows
+        if (!A.trPC || !A.trCsel || !A.trQ || !A.trO || !A.trLse) return fail(ELG_EINVAL, "rollout: incomplete training rows (128 < N1 <= 1024 needs trMask, trLse, trPC, trCsel, trQ, trO)");
+        if (two) return launch_fwd_mt_g<NCH, TSP, (NCH <= 8 ? 2 : 1), true>(A, stream);
+        return launch_fwd_mt_g<NCH, TSP, 1, true>(A, stream);
+    }
+    if (two) return launch_fwd_mt_g<NCH, TSP, (NCH <= 8 ? 2 : 1), false>(A, stream);
+    return launch_fwd_mt_g<NCH, TSP, 1, false>(A, stream);
 }
 
 // =============================================================================================
@@ -2472,7 +2531,8 @@ static int dispatch_fwd(const elg_rollout_args& A, hipStream_t stream) {
         if (train && (!A.trPC || !A.trCsel || !A.trQ || !A.trO)) return fail(ELG_EINVAL, "rollout: incomplete training rows");
         return train ? launch_fwd_coop<TSP, true>(A, stream) : launch_fwd_coop<TSP, false>(A, stream);
     }
-    if (A.trMask && !A.trA) return fail(ELG_EINVAL, "rollout: this kernel needs trA (mask-only rows: cooperative kernel)");
+    const bool mt_shape = !lds && nch > 2 && nch <= 16 && !A.use_state && A.do_decode && A.do_update && A.max_steps <= 0 && A.variant == 0;
+    if (A.trMask && !A.trA && !mt_shape) return fail(ELG_EINVAL, "rollout: this kernel needs trA (mask-only rows: cooperative / streaming kernels)");
     if (A.trA) {        // training forward: saves the backward rows; built for N1 <= 128, 8 waves
         if (!A.trPC || !A.trCsel || !A.trQ || !A.trO) return fail(ELG_EINVAL, "rollout: incomplete training rows");
         if (A.use_state) return fail(ELG_EINVAL, "rollout: training rows need the fused rollout");

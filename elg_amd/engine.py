@@ -327,7 +327,9 @@ class TrainRows:
         Rcap = Tcap * M
         self.B, self.M, self.N1, self.Tcap, self.Rcap = B, M, N1, Tcap, Rcap
         self._A = None                          # glimpse weights: only for forwards that cannot save mask rows
-        self.Mask = torch.zeros(B, Rcap, 2, device=dev, dtype=torch.int64)    # feasibility mask words per row
+        # feasibility mask words per row: 128 bits, or the streaming kernel's node chunks (256 / 512 / 1024 bits)
+        self.W = 2 if N1 <= 128 else 4 if N1 <= 256 else 8 if N1 <= 512 else 16
+        self.Mask = torch.zeros(B, Rcap, self.W, device=dev, dtype=torch.int64)
         self.Lse = torch.zeros(B, Rcap, H, device=dev)                        # glimpse log2-sum-exp per (row, head)
         self.use_mask = False                   # set by the forward that filled the rows
         self.PC = torch.empty(B, Rcap, N1, device=dev)
@@ -349,8 +351,15 @@ class TrainRows:
         key = (B, M, N1, Tcap, str(dev))
         ws = cls._cache.get(key)
         if ws is None:
+            if N1 > 128:
+                cls._cache.clear()              # one large-N workspace at a time (GBs each)
             ws = cls._cache[key] = TrainRows(B, M, N1, Tcap, dev)
         return ws
+
+    @staticmethod
+    def nbytes(B, M, N1, Tcap):
+        """HBM a workspace of this shape takes (the (B,Rcap,N1) score rows dominate)."""
+        return 4 * B * Tcap * M * (N1 + 2 * E + 3 * 48 + 48 + 2 + H + 2 * 16)
 
     @property
     def A(self):
@@ -394,6 +403,20 @@ class RolloutResult:
     rows: Optional["TrainRows"] = None      # backward rows saved by a training forward
 
 
+LARGE_ROWS_BUDGET = 0.45          # fraction of the free HBM the saved rows of a 128 < N1 <= 1024 training forward may take
+
+
+def _rows_fit(B, M, N1, Tcap, dev) -> bool:
+    """Saved rows for 128 < N1 <= 1024 are (B, Tcap M, N1) floats: used when they (and one instance of the backward's
+    scratch) fit in the free HBM, else the step trains through the replay backward (which holds only the decoded rows)."""
+    key = (B, M, N1, Tcap, str(dev))
+    if key in TrainRows._cache:
+        return True
+    free, _ = torch.cuda.mem_get_info(dev)
+    one_ws = 4 * int(L.lib().elg_decoder_bwd_ws_floats(1, Tcap * M, N1))
+    return TrainRows.nbytes(B, M, N1, Tcap) + one_ws <= LARGE_ROWS_BUDGET * free
+
+
 def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mode: int, *, forced=None, seed: int = 0,
                     uniforms=None, dump_T: int = 0, geometry=None, Tcap: Optional[int] = None,
                     train: bool = False, variant: int = 0, dump: str = "probs") -> RolloutResult:
@@ -431,14 +454,17 @@ def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mo
         scratch = torch.empty(n_scratch, device=dev)           # score rows (N1 > 1024) / fragment-major tables (N1 > 128)
         a.scratch = _ptr(scratch)
     rows = None
-    if train and N1 <= 128 and pol.ens == 1:      # (an ensemble trains through the replay backward)
+    # an ensemble trains through the replay backward; so do shapes whose rows would not fit next to the backward's scratch
+    save_rows = train and pol.ens == 1 and (N1 <= 128 or (N1 <= 1024 and variant == 0 and _rows_fit(B, M, N1, Tcap, dev)))
+    if save_rows:
         rows = TrainRows.get(B, M, N1, Tcap, dev)
         rows.prepare()
         # the cooperative kernel (what dispatch_fwd picks for this launch shape) saves the rows' 128-bit mask words and the
         # glimpse log2-sum-exp per head instead of the glimpse weights: the backward recomputes the weights from q, K, the
         # mask and the saved normaliser (28 MFMAs + one exp2 per weight).  4.2 GB less workspace and 6.6 GB less HBM traffic
         # per step at the bench shape, and no slower (the forward's 3.3 GB of scattered stores cost what the recompute does)
-        rows.use_mask = bool(a.lds_stage and a.waves == 8 and 4 <= N1 <= 112 and variant == 0)
+        # The streaming kernel (128 < N1 <= 1024) saves the same rows with W = 4 / 8 / 16 mask words.
+        rows.use_mask = bool((a.lds_stage and a.waves == 8 and 4 <= N1 <= 112 and variant == 0) or N1 > 128)
         a.trA = None if rows.use_mask else _ptr(rows.A)
         a.trMask = _ptr(rows.Mask) if rows.use_mask else None
         a.trLse = _ptr(rows.Lse) if rows.use_mask else None
@@ -604,7 +630,17 @@ class _ChosenProbs(torch.autograd.Function):
         a.T_dev, a.gprob_T = _ptr(ctx.T_dev), g.shape[1]
         # `training: only_local`: the decoder tables are constants (zeros) -- the glimpse backward would compute gradients nobody reads
         a.tables_frozen = int(not any(ctx.needs_input_grad[7:14]))
+        big = None
+        if N1 > 128:
+            # row contractions as batched GEMMs over (8, R, N1) buffers: scratch for as many instances as fit, the call walks
+            # the batch in chunks of that many
+            per = int(L.lib().elg_decoder_bwd_ws_floats(1, R, N1))
+            free, _ = torch.cuda.mem_get_info(dev)
+            nb = max(1, min(B, int(0.6 * free) // (4 * per)))
+            big = torch.empty(nb * per, device=dev)
+            a.ws, a.ws_floats, a.mask_words = _ptr(big), big.numel(), rows.W
         L.check(L.lib().elg_decoder_bwd(C.byref(a), _stream()), "elg_decoder_bwd")
+        del big
         if meta.has_local:
             # rows are independent given the saved slot features: 16 rows per wavefront on the matrix cores
             n_slots = meta.K + (0 if tsp else 1)

@@ -380,7 +380,8 @@ typedef struct elg_decoder_bwd_args {
     const float* trLoad;        /* (B,Rcap) CVRP                                                                  */
     const int32_t* trSlot;      /* (B,Rcap,48) or NULL (no local policy)                                          */
     const float* trA;           /* (B,8,Rcap,N1) glimpse weights, or NULL if trMask is given                      */
-    const uint64_t* trMask;     /* (B,Rcap,2) mask words: the weights are recomputed from trQ, Kmat               */
+    const uint64_t* trMask;     /* (B,Rcap,W) mask words: the weights are recomputed from trQ, Kmat.  W = 2 for N1 <= 128;
+                                 * for the rows of the streaming kernel W = mask_words = 4 / 8 / 16 (N1 <= 256 / 512 / 1024)  */
     const float* trLse;         /* (B,Rcap,8) with trMask: the forward's log2-sum-exp per head (NULL: recompute)  */
     const float *Kmat, *Vmat, *PK;          /* (B,N1,128) decoder tables                                          */
     float *dK, *dV, *dPK;       /* (B,N1,128) out (+=)                                                            */
@@ -400,8 +401,18 @@ typedef struct elg_decoder_bwd_args {
     int32_t tables_frozen;      /* 1: the decoder tables carry no gradient (`training: only_local`, CVRPModel.py:78-131: they
                                  * are zeros): only the softmax / pointer pass runs (it produces rowDU for the local policy);
                                  * dK, dV, dQ1, dQ2, dwl are left untouched                                            */
+    /* 128 < N1 <= 1024 (rows saved by the streaming rollout kernel; T_dev must be NULL): the row contractions run as batched
+     * f32 MFMA GEMMs (elg_gemm_f32_batched) around three small row kernels; trPC is overwritten with d s (in place). */
+    int32_t mask_words;         /* W of trMask for N1 > 128 (ignored otherwise)                                        */
+    int32_t pad_large;
+    float* ws;                  /* scratch for N1 > 128 (NULL otherwise): k * elg_decoder_bwd_ws_floats(1, R, N1) floats,
+                                 * 1 <= k <= B -- the batch is walked in chunks of k instances                          */
+    int64_t ws_floats;
 } elg_decoder_bwd_args;
 int elg_decoder_bwd(const elg_decoder_bwd_args* args, void* stream);
+/* Scratch of elg_decoder_bwd for N1 > 128: two (B,8,R,N1) buffers (glimpse weights / their cotangents) + the (B,R,128) query
+ * cotangent rows; 0 for N1 <= 128. */
+int64_t elg_decoder_bwd_ws_floats(int32_t B, int64_t R, int32_t N1);
 
 #ifdef __cplusplus
 }

@@ -89,3 +89,17 @@ def pytest_sessionfinish(session, exitstatus):
         faulthandler.dump_traceback(all_threads=True)
         os._exit(status)
     threading.Thread(target=_last_resort, daemon=True).start()
+
+
+@pytest.fixture(autouse=True)
+def _fixed_host_seeds():
+    """Every test starts from the same host RNG state: the POMO starts are drawn with Python's `random` (reference
+    CVRPModel.py:46-51), the instance generators use numpy / torch -- a run of the suite is then reproducible draw for draw."""
+    import random
+
+    import numpy as np
+    import torch
+    random.seed(1234)
+    np.random.seed(1234)
+    torch.manual_seed(1234)
+    yield
