@@ -74,7 +74,7 @@ class DecoderBwdArgs(C.Structure):
                 ("PK", _vp), ("dK", _vp), ("dV", _vp), ("dPK", _vp), ("dpb", _vp), ("dQ1", _vp), ("dQ2", _vp), ("dwl", _vp),
                 ("rowDU", _vp), ("dO", _vp), ("idx_prev", _vp), ("idx_first", _vp), ("rowW", _vp),
                 ("T_dev", _vp), ("gprob_T", C.c_int32), ("tables_frozen", C.c_int32),
-                ("mask_words", C.c_int32), ("pad_large", C.c_int32), ("ws", _vp), ("ws_floats", C.c_int64)]
+                ("mask_words", C.c_int32), ("mfma_mode", C.c_int32), ("ws", _vp), ("ws_floats", C.c_int64)]
 
 
 class LocalWeights(C.Structure):

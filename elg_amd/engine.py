@@ -403,6 +403,9 @@ class RolloutResult:
     rows: Optional["TrainRows"] = None      # backward rows saved by a training forward
 
 
+# Arithmetic of the glimpse backward's products (elg_decoder_bwd_args.mfma_mode): 0 = f32 MFMAs, 1 .. 3 = split-bf16 terms
+BWD_MFMA_MODE = int(os.environ.get("ELG_BWD_MFMA_MODE", "0"))
+
 LARGE_ROWS_BUDGET = 0.45          # fraction of the free HBM the saved rows of a 128 < N1 <= 1024 training forward may take
 
 
@@ -630,6 +633,7 @@ class _ChosenProbs(torch.autograd.Function):
         a.T_dev, a.gprob_T = _ptr(ctx.T_dev), g.shape[1]
         # `training: only_local`: the decoder tables are constants (zeros) -- the glimpse backward would compute gradients nobody reads
         a.tables_frozen = int(not any(ctx.needs_input_grad[7:14]))
+        a.mfma_mode = BWD_MFMA_MODE
         big = None
         if N1 > 128:
             # row contractions as batched GEMMs over (8, R, N1) buffers: scratch for as many instances as fit, the call walks
