@@ -323,6 +323,10 @@ def main():
             "config": {"workload": "CVRP-100 batch=64/GPU pomo=100 joint (local policy on), BASELINE configs[1]",
                        "global_batch": LOCAL_BATCH * world, "pomo": POMO, "problem_size": N_NODES,
                        "parallelism": f"dp{world}", "n_ranks_seen": ranks_seen,
+                       # every product of the step is f32 (f32 MFMA / VALU) except, at mode > 0, the five products of the glimpse
+                       # backward kernel: bf16 terms of the f32 operands on v_mfma_f32_16x16x32_bf16, f32 accumulation
+                       "glimpse_bwd_mfma_mode": {0: "f32", 1: "split-bf16, 2 terms",
+                                                 2: "split-bf16, 3-term scores + 2-term linear products"}[eng.BWD_MFMA_MODE],
                        "grad_allreduce": (None if bucket is None else
                                           {"backend": torch.distributed.get_backend(), "calls": bucket.calls,
                                            "elements": bucket.numel})},

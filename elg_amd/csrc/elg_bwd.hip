@@ -1041,6 +1041,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float load_on = seg.load ? 1.f : 0.f;
     const int bh = blockIdx.y, b = bh >> 3, h = bh & 7;
     const int split = blockIdx.x;
+    const float cs = 0.25f * 1.4426950408889634f;
 
     // operand images, one chunk per wave and round.  K (dq: dup, node of (hi, v) x channel lo), K (q K^T: dup, node lo x
     // channel 4 v + hi), V (single, node lo x channel 4 v + hi); nodes past N1 - 1 are zeros
@@ -1050,8 +1051,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int n = 16 * nt + 4 * hi + v;
-            kv[v] = n < N1 ? Kmat[((size_t)b * N1 + n) * ELG_E + h * 16 + lo] : 0.f;
-            k2[v] = n2 < N1 ? Kmat[((size_t)b * N1 + n2) * ELG_E + h * 16 + 4 * v + hi] : 0.f;
+            // (the 1/4 of the softmax backward rides on K here and on q below -- exact; the scores' log2(e)/4 on K)
+            kv[v] = n < N1 ? 0.25f * Kmat[((size_t)b * N1 + n) * ELG_E + h * 16 + lo] : 0.f;
+            k2[v] = n2 < N1 ? cs * Kmat[((size_t)b * N1 + n2) * ELG_E + h * 16 + 4 * v + hi] : 0.f;
             vv[v] = n2 < N1 ? Vmat[((size_t)b * N1 + n2) * ELG_E + h * 16 + 4 * v + hi] : 0.f;
         }
         unsigned p[6];
@@ -1125,7 +1127,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     unsigned long long mw[4][2];
     const int tile0 = t_lo + wave_u;
     if (tile0 < t_hi) ELG_GBF_LOAD(tile0, doA, oA, doB, qB, qA, mw, sgp, sgf, sgl, lsv)
-    const float cs = 0.25f * 1.4426950408889634f;
     for (int tile = tile0; tile < t_hi; tile += 4) {
         const int r0 = tile << 4;                                  // wave-uniform
         const int rleft = R - 1 - r0;
@@ -1148,9 +1149,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         float doto = doA[0] * oA[0];
         doto = fmaf(doA[1], oA[1], doto); doto = fmaf(doA[2], oA[2], doto); doto = fmaf(doA[3], oA[3], doto);
         doto = quarters_sum(doto);                                // row lo, in every lane
-        float dv[4];
+        f32x4 ndv;                                                  // - <dO, O> of row 4 hi + v: the accumulator input of dA
 #pragma unroll
-        for (int v = 0; v < 4; ++v) dv[v] = __shfl(doto, 4 * hi + v);   // row 4 hi + v
+        for (int v = 0; v < 4; ++v) ndv[v] = -__shfl(doto, 4 * hi + v);
         // per-tile operands: q single (scores), dO / dO^T / q^T dup
         unsigned qt[6];
         bf_terms<TS>(qA[0], qA[1], qA[2], qA[3], qt);
@@ -1159,7 +1160,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         u32x4 do1, do2, dob1, dob2, qb1, qb2;
         bf_dup(doA[0], doA[1], doA[2], doA[3], do1, do2);
         bf_dup(doB[0], doB[1], doB[2], doB[3], dob1, dob2);
-        bf_dup(qB[0], qB[1], qB[2], qB[3], qb1, qb2);
+        bf_dup(0.25f * qB[0], 0.25f * qB[1], 0.25f * qB[2], 0.25f * qB[3], qb1, qb2);
         // dq^T[row 4 hi + v][channel lo] = sum over the nodes of dS[row][node] K[node][channel]
         f32x4 dq = {0.f, 0.f, 0.f, 0.f};
         auto dq_chunk = [&](int c) {                               // from the transposed dS tile of chunk c
@@ -1178,7 +1179,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const uint4 kb = *reinterpret_cast<const uint4*>(sK2 + ((NT + nt) * 64 + lane) * 4);
             const uint4 vw = *reinterpret_cast<const uint4*>(sV + (nt * 64 + lane) * 4);
             const u32x4 vq = {vw.x, vw.y, vw.z, vw.w};
-            f32x4 S = {0.f, 0.f, 0.f, 0.f}, dA = {0.f, 0.f, 0.f, 0.f};
+            // accumulator inputs: - lse (or - inf for a closed node: exp2 -> exactly 0) for the scores, - <dO, O> for dA
+            const int bit = (nt >> 1) + 16 * (nt & 1);                 // (compile-time after unrolling)
+            f32x4 S, dA = ndv;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const unsigned closed = (unsigned)((int)(cm[v] << (31 - bit)) >> 31);    // ~0 for a closed node, 0 for an open one
+                S[v] = __uint_as_float((closed & 0xff800000u) | (~closed & __float_as_uint(-lsv[v])));
+            }
             S = mfma_bf(q12, u32x4{ka.x, ka.y, ka.z, ka.w}, S);
             dA = mfma_bf(do1, vq, dA);
             S = mfma_bf(q12, u32x4{kb.x, kb.y, kb.z, kb.w}, S);
@@ -1187,13 +1195,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const uint4 kc = *reinterpret_cast<const uint4*>(sK2 + ((2 * NT + nt) * 64 + lane) * 4);
                 S = mfma_bf(q13, u32x4{kc.x, kc.y, kc.z, kc.w}, S);
             }
-            const int bit = (nt >> 1) + 16 * (nt & 1);                 // (compile-time after unrolling)
             float aw[4], ds1[4];
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const unsigned open = ((cm[v] >> bit) & 1u) - 1u;                        // 0 for a closed node, ~0 for an open one
-                aw[v] = __uint_as_float(__float_as_uint(__builtin_amdgcn_exp2f(fmaf(S[v], cs, -lsv[v]))) & open);
-                ds1[v] = (0.25f * aw[v]) * (dA[v] - dv[v]);                               // node 16 nt + lo, row 4 hi + v
+                aw[v] = __builtin_amdgcn_exp2f(S[v]);
+                ds1[v] = aw[v] * dA[v];                            // 4 dS: node 16 nt + lo, row 4 hi + v
             }
             const u32x4 dsq = bf_single(ds1[0], ds1[1], ds1[2], ds1[3]);
             const u32x4 aq = bf_single(aw[0], aw[1], aw[2], aw[3]);

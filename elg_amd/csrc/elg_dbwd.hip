@@ -111,7 +111,7 @@ __global__ __launch_bounds__(512, 4) void pointer_bwd_kernel(const PtrBwd a) {
     // ---- staging loads of a tile into registers (all unguarded: rows past R are clamped and get w = 0)
     float pc[NPT];
     float4 rw, o4;
-#define PB_LOAD(TILE, PCV, RWV, OV)                                                                        \
+#define PB_LOAD(TILE, PCV, RWV, OV, SLV)                                                                       \
     {                                                                                                      \
         const int rr_ = min(((TILE) << 4) + srow, R - 1);                                                  \
         const float* p_ = a.PC + (brow + rr_) * N1;                                                        \
@@ -119,8 +119,17 @@ __global__ __launch_bounds__(512, 4) void pointer_bwd_kernel(const PtrBwd a) {
         RWV = a.rowW[(size_t)b * R + rr_];                                                                 \
         if (((TILE) << 4) + srow >= R) { RWV.x = 0.f; RWV.y = 0.f; }                                       \
         OV = *reinterpret_cast<const float4*>(a.rowO + (brow + rr_) * ELG_E + 4 * sl);                     \
+        /* slot indices of the tile's 16 x 48 cotangent cells: fetched with the tile, a load issued when the dl tile is   \
+         * in LDS exposed a full memory latency per tile */                                                \
+        if (a.rowDU) {                                                                                     \
+            SLV[0] = slot_p[min((size_t)(brow + ((TILE) << 4)) * 48 + tid, slot_last)];                    \
+            SLV[1] = slot_p[min((size_t)(brow + ((TILE) << 4)) * 48 + 512 + (tid & 255), slot_last)];      \
+        }                                                                                                  \
     }
-    PB_LOAD(t_lo, pc, rw, o4)
+    int slv[2] = {-1, -1};
+    const int* slot_p = a.rowDU ? a.Slot : reinterpret_cast<const int*>(a.rowW);
+    const size_t slot_last = (brow + R) * 48 - 1;
+    PB_LOAD(t_lo, pc, rw, o4, slv)
     for (int tile = t_lo; tile < t_hi; ++tile) {
         const int r0 = tile << 4;
         // dl tile -> LDS (nodes past N1 are exact zeros), O tile -> LDS
@@ -140,22 +149,27 @@ __global__ __launch_bounds__(512, 4) void pointer_bwd_kernel(const PtrBwd a) {
             *reinterpret_cast<float4*>(sO + srow * OP + 4 * sl) = o4;
         }
         __syncthreads();
+        int slvn[2] = {-1, -1};
         {
             const int tn = min(tile + 1, t_hi - 1);                     // the last prefetch re-reads its own tile, unused
-            PB_LOAD(tn, pc, rw, o4)
+            PB_LOAD(tn, pc, rw, o4, slvn)
         }
         if (tid < N1) {
 #pragma unroll
             for (int row = 0; row < 16; ++row) dpb_acc += sDL[row * DLP + tid];
         }
-        if (a.rowDU)
-            for (int idx = tid; idx < 16 * 48; idx += 512) {
-                const int row = idx / 48, j = idx - row * 48;
-                if (r0 + row < R) {
-                    const int s = a.Slot[(brow + r0 + row) * 48 + j];
-                    a.rowDU[((size_t)b * R + r0 + row) * 48 + j] = s >= 0 ? sDL[row * DLP + s] * a.inv_ens : 0.f;
+        if (a.rowDU) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int idx = q ? 512 + (tid & 255) : tid;
+                const int row = idx / 48;
+                if ((q == 0 || tid < 256) && r0 + row < R) {
+                    const int s = slv[q];
+                    a.rowDU[((size_t)b * R + r0) * 48 + idx] = s >= 0 ? sDL[row * DLP + s] * a.inv_ens : 0.f;
                 }
             }
+        }
+        slv[0] = slvn[0]; slv[1] = slvn[1];
         // dO^T[d][row] = sum_n PK[n][d] dl[row][n]   (D: lane holds d = 4 hi + i of row lo)
         f32x4 dot = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

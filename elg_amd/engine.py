@@ -403,8 +403,10 @@ class RolloutResult:
     rows: Optional["TrainRows"] = None      # backward rows saved by a training forward
 
 
-# Arithmetic of the glimpse backward's products (elg_decoder_bwd_args.mfma_mode): 0 = f32 MFMAs, 1 .. 3 = split-bf16 terms
-BWD_MFMA_MODE = int(os.environ.get("ELG_BWD_MFMA_MODE", "0"))
+# Arithmetic of the glimpse backward's five products (elg_decoder_bwd_args.mfma_mode; include/elg_hip.h): 0 = f32 MFMAs (exact
+# f32 products), 1 = split-bf16 with 2 terms per operand, 2 = split-bf16 with a 3-term score product (the default: 7.5e-6 of the
+# largest gradient entry against float64 where the f32 MFMAs give 1.1e-6 -- tests/test_gpu_train_glue.py -- at 0.6 of the time)
+BWD_MFMA_MODE = int(os.environ.get("ELG_BWD_MFMA_MODE", "2"))
 
 LARGE_ROWS_BUDGET = 0.45          # fraction of the free HBM the saved rows of a 128 < N1 <= 1024 training forward may take
 
