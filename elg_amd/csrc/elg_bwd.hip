@@ -9,6 +9,7 @@
 //                        in LDS accumulators, one flush per workgroup
 #include "elg_rollout.h"
 #include "elg_bwd_internal.h"
+#include "elg_bf16.h"
 #include <string>
 
 namespace elg {
@@ -974,44 +975,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // closed bits are compacted to one register per row at the head of a tile; the weights of a chunk are recomputed inside
 // the chunk loop.
 // =============================================================================================
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pk_bf16(float a, float b) {       // v_cvt_pk_bf16_f32: a -> bits 0..15, b -> bits 16..31
-    f32x2_t v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-}
-__device__ __forceinline__ float bf_lo(unsigned p) { return __uint_as_float(p << 16); }
-__device__ __forceinline__ float bf_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
-// terms of 4 values: t1 = (p[0], p[1]), t2 = (p[2], p[3]), t3 = (p[4], p[5]); each word packs two values
-template <int T>
-__device__ __forceinline__ void bf_terms(float x0, float x1, float x2, float x3, unsigned (&p)[6]) {
-    p[0] = pk_bf16(x0, x1); p[1] = pk_bf16(x2, x3);
-    x0 -= bf_lo(p[0]); x1 -= bf_hi(p[0]); x2 -= bf_lo(p[1]); x3 -= bf_hi(p[1]);
-    p[2] = pk_bf16(x0, x1); p[3] = pk_bf16(x2, x3);
-    if (T >= 3) {
-        x0 -= bf_lo(p[2]); x1 -= bf_hi(p[2]); x2 -= bf_lo(p[3]); x3 -= bf_hi(p[3]);
-        p[4] = pk_bf16(x0, x1); p[5] = pk_bf16(x2, x3);
-    } else {
-        p[4] = 0u; p[5] = 0u;
-    }
-}
-__device__ __forceinline__ u32x4 bf_single(float x0, float x1, float x2, float x3) {     // [x1 | x2]
-    unsigned p[6];
-    bf_terms<2>(x0, x1, x2, x3, p);
-    return u32x4{p[0], p[1], p[2], p[3]};
-}
-__device__ __forceinline__ void bf_dup(float x0, float x1, float x2, float x3, u32x4& d1, u32x4& d2) {   // [x1 | x1], [x2 | x2]
-    unsigned p[6];
-    bf_terms<2>(x0, x1, x2, x3, p);
-    d1 = u32x4{p[0], p[1], p[0], p[1]};
-    d2 = u32x4{p[2], p[3], p[2], p[3]};
-}
-__device__ __forceinline__ f32x4 mfma_bf(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
 template <int NT, int TS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void glimpse_bwd_bf16_kernel(
     const unsigned long long* __restrict__ rowMask, const float* __restrict__ dO, const float* __restrict__ rowO,

@@ -13,6 +13,7 @@
 // (local policy + decoder); and the TSP counterparts (TSP/utils.py:7-26, TSPEnv.py, TSPModel.py,
 // TSP/models.py:48-110,244-303).
 #include "elg_rollout.h"
+#include "elg_bf16.h"
 #include <string>
 
 namespace elg {
@@ -1625,37 +1626,72 @@ __device__ __forceinline__ void glimpse_tile(const float* __restrict__ sK, const
 // Fragment-major copies of an instance's K / V / PK for rollout_fwd_mt_kernel: every MFMA operand fragment of a 16-node
 // tile is one 16-byte load per lane out of a contiguous 1 KB block, so the per-step stream out of L2 moves whole cache
 // lines (the row-major tables give 64-byte pieces of 512-byte rows).  NP = 64 NCH padded nodes, NT = NP / 16 tiles;
-// lane = 16 hi + lo.  Per instance, floats:
-//   Kf [h][tile][lane][j] = K [16 tile + lo][16 h + 4 hi + j]             at 0
-//   Vf [h][tile][lane][j] = V [16 tile + 4 hi + j][16 h + lo]             at NP * 128
-//   PKf[tile][s4][lane][j] = PK[16 tile + lo][16 s4 + 4 hi + j]           at 2 * NP * 128
+// lane = 16 hi + lo.  Per instance, in floats / 32-bit words:
+//   Kb [h][tile][form][lane][w]: bf16 terms of K[16 tile + lo][16 h + 4 hi + j], j < 4, as the A operand of the score product
+//                                S^T = K_h q^T: form 0 = [k1 | k2], form 1 = [k1 | k3] (two values per word)   at 0   (NP * 256 words)
+//     (16 trajectories per workgroup; with 32 the two operand forms of four node tiles in flight spill registers: those
+//      kernels read Kf[h][tile][lane][j] = K[16 tile + lo][16 h + 4 hi + j] (f32) in the same place and keep the f32 product)
+//   Vf [h][tile][lane][j] = V [16 tile + 4 hi + j][16 h + lo]  (f32)                                          at NP * 256
+//   PKb[tile][kb][term][lane][w] = bf16 terms 1 .. 3 of PK[16 tile + lo][32 kb + 8 hi + 2 w, + 1]            at NP * 384  (NP * 192 words)
+// Both products with a per-launch constant operand -- the glimpse scores K q^T and the pointer scores PK o -- run on
+// v_mfma_f32_16x16x32_bf16 over three bf16 terms per operand (csrc/elg_bf16.h: what is dropped is 2^-24 of a product, an f32
+// rounding): 3 instructions of 16 cycles per (node tile, head) where the f32 form took 4 of 32, 24 per (node tile, 128 channels)
+// where it took 32 of 32.  Both phases kept the matrix pipe ~70 % busy.  The weights x values product stays on f32 MFMAs (its
+// left operand is formed per step: splitting it would cost what the faster instruction saves).
 // Rows past N1 are zero (their nodes are masked).
 // =============================================================================================
+constexpr int MT_KB_WORDS = 256;                              // words of Kb per padded node
+constexpr int MT_PKB_WORDS = 192;                             // words of PKb per padded node
 __global__ __launch_bounds__(256) void mt_repack_kernel(const float* __restrict__ K, const float* __restrict__ V,
-                                                        const float* __restrict__ PK, float* __restrict__ F, int N1, int NP) {
+                                                        const float* __restrict__ PK, float* __restrict__ F, int N1, int NP,
+                                                        int k_terms) {
     const int b = blockIdx.y;
-    const int per = NP * 32;                                  // float4s per table
+    const int per = NP * 32;                                  // float4s per f32 table
     const int o = blockIdx.x * 256 + threadIdx.x;
-    if (o >= 3 * per) return;
+    const size_t NE = (size_t)N1 * ELG_E;
+    float* Fb = F + (size_t)b * NP * (MT_KB_WORDS + ELG_E + MT_PKB_WORDS);
+    if (o >= 2 * per) {
+        // PKb: one thread per (tile, kb, lane) writes the three term quads
+        const int r = o - 2 * per;
+        if (r >= NP * 16) return;
+        const int lane = r & 63, lo = lane & 15, hi = lane >> 4, kb = (r >> 6) & 3, tile = r >> 8, n = 16 * tile + lo;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = n < N1 ? PK[b * NE + (size_t)n * ELG_E + 32 * kb + 8 * hi + j] : 0.f;
+        unsigned pa[6], pb[6];
+        bf_terms<3>(x[0], x[1], x[2], x[3], pa);
+        bf_terms<3>(x[4], x[5], x[6], x[7], pb);
+        uint4* dst = reinterpret_cast<uint4*>(Fb + (size_t)NP * (MT_KB_WORDS + ELG_E)) + ((size_t)(tile * 4 + kb) * 3) * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) dst[t * 64] = make_uint4(pa[2 * t], pa[2 * t + 1], pb[2 * t], pb[2 * t + 1]);
+        return;
+    }
     const int which = o / per, r = o % per;
     const int lane = r & 63, lo = lane & 15, hi = lane >> 4;
-    const size_t NE = (size_t)N1 * ELG_E;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (which == 0) {
         const int NT = NP >> 4, h = (r >> 6) / NT, tile = (r >> 6) % NT, n = 16 * tile + lo;
         if (n < N1) v = *reinterpret_cast<const float4*>(K + b * NE + (size_t)n * ELG_E + 16 * h + 4 * hi);
-    } else if (which == 1) {
+        if (!k_terms) {                 // Kf[h][tile][lane][j] (f32): the 32-trajectory kernels keep the f32 score product
+            reinterpret_cast<float4*>(Fb)[r] = v;
+            return;
+        }
+        unsigned pt[6];
+        bf_terms<3>(v.x, v.y, v.z, v.w, pt);
+        uint4* dst = reinterpret_cast<uint4*>(Fb) + ((size_t)(h * NT + tile) * 2) * 64 + lane;
+        dst[0] = make_uint4(pt[0], pt[1], pt[2], pt[3]);
+        dst[64] = make_uint4(pt[0], pt[1], pt[4], pt[5]);
+        return;
+    }
+    {
         const int NT = NP >> 4, h = (r >> 6) / NT, tile = (r >> 6) % NT, n = 16 * tile + 4 * hi;
         const float* src = V + b * NE + 16 * h + lo;
         if (n < N1) v.x = src[(size_t)n * ELG_E];
         if (n + 1 < N1) v.y = src[(size_t)(n + 1) * ELG_E];
         if (n + 2 < N1) v.z = src[(size_t)(n + 2) * ELG_E];
         if (n + 3 < N1) v.w = src[(size_t)(n + 3) * ELG_E];
-    } else {
-        const int tile = r >> 9, s4 = (r >> 6) & 7, n = 16 * tile + lo;
-        if (n < N1) v = *reinterpret_cast<const float4*>(PK + b * NE + (size_t)n * ELG_E + 16 * s4 + 4 * hi);
     }
-    reinterpret_cast<float4*>(F + (size_t)b * 3 * NP * ELG_E)[o] = v;
+    reinterpret_cast<float4*>(Fb + (size_t)NP * MT_KB_WORDS)[r] = v;
 }
 
 // =============================================================================================
@@ -1753,6 +1789,7 @@ template <int NCH, bool TSP, int NG, bool TRAIN>
 __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_args A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NTR = 16 * NG, NOWN = 2 * NG, QP = 132, SP = 64 * NCH + 4;
+    constexpr int OBP = 68;                                 // words of a bf16 term row of o (128 channels + 8: conflict-free b128 reads)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lo = lane & 15, hi = lane >> 4;
@@ -1765,8 +1802,9 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
     const int m_base = tile * NTR;
     // LDS: query / glimpse-output rows | score rows | mask words | visited words | slot blocks | local tables | demand |
     //      per-wave slot scratch
-    float* sQ = lds;
-    float* sSc = sQ + NTR * QP;                            // score rows (pointer -> choice)
+    float* sQ = lds;                                       // query rows; after the glimpse: the three bf16 term planes of o
+    unsigned* sOb = reinterpret_cast<unsigned*>(lds);      //   [term][trajectory][OBP]
+    float* sSc = sQ + NTR * 3 * OBP;                       // score rows (pointer -> choice)
     unsigned long long* sMaskW = reinterpret_cast<unsigned long long*>(sSc + NTR * SP);
     unsigned long long* sVis = sMaskW + NTR * NCH;
     float* sX = reinterpret_cast<float*>(sVis + NTR * NCH);             // slot blocks (owners -> local policy -> owners)
@@ -1792,10 +1830,11 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
     I.ntheta = A.nbr_theta + (size_t)b * N1 * N1;
     I.loc = A.loc;
     constexpr int NP = 64 * NCH, NT = 4 * NCH;              // padded nodes / tiles of the fragment-major tables
-    const float* gF = A.scratch + (size_t)b * 3 * NP * ELG_E;
-    const float4* gK = reinterpret_cast<const float4*>(gF) + (size_t)wave * NT * 64 + lane;                  // head = wave
-    const float4* gV = reinterpret_cast<const float4*>(gF + (size_t)NP * ELG_E) + (size_t)wave * NT * 64 + lane;
-    const float4* gPK = reinterpret_cast<const float4*>(gF + (size_t)2 * NP * ELG_E) + lane;
+    const float* gF = A.scratch + (size_t)b * NP * (MT_KB_WORDS + ELG_E + MT_PKB_WORDS);
+    constexpr bool BFS = NG == 1;                          // score product on bf16 terms (see mt_repack_kernel)
+    const uint4* gK = reinterpret_cast<const uint4*>(gF) + (size_t)wave * NT * (BFS ? 2 : 1) * 64 + lane;    // head = wave: [tile][form][lane]
+    const float4* gV = reinterpret_cast<const float4*>(gF + (size_t)NP * MT_KB_WORDS) + (size_t)wave * NT * 64 + lane;
+    const uint4* gPK = reinterpret_cast<const uint4*>(gF + (size_t)NP * (MT_KB_WORDS + ELG_E)) + lane;     // [tile][kb][term][lane]
     const int step_cap = TSP ? N1 : 2 * N1 + 2;
     const size_t Rcap = (size_t)A.Tmax * A.M;
 
@@ -1905,22 +1944,40 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
             // ================= glimpse: wave = head; every K / V fragment serves the NG groups of 16 trajectories =================
             {
                 const float cs = 0.25f * 1.4426950408889634f;
-                float4 q4[NG];
+                u32x4 q11[NG], q22[NG], q31[NG];            // the query's bf16 terms as the B operand: [q1 | q1], [q2 | q2], [q3 | q1]
                 float mrun[NG], lrun[NG];
                 f32x4c o[NG], o2[NG];
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
-                    q4[g] = *reinterpret_cast<const float4*>(sQ + (16 * g + lo) * QP + 16 * wave + 4 * hi);     // trajectory 16 g + lo
+                    const float4 qv = *reinterpret_cast<const float4*>(sQ + (16 * g + lo) * QP + 16 * wave + 4 * hi);     // trajectory 16 g + lo
+                    if (BFS) {
+                        unsigned pt[6];
+                        bf_terms<3>(qv.x, qv.y, qv.z, qv.w, pt);
+                        q11[g] = u32x4{pt[0], pt[1], pt[0], pt[1]};
+                        q22[g] = u32x4{pt[2], pt[3], pt[2], pt[3]};
+                        q31[g] = u32x4{pt[4], pt[5], pt[0], pt[1]};
+                    } else {            // f32 product: the four query values ride in q11
+                        q11[g] = u32x4{__float_as_uint(qv.x), __float_as_uint(qv.y), __float_as_uint(qv.z), __float_as_uint(qv.w)};
+                        q22[g] = q11[g]; q31[g] = q11[g];
+                    }
                     mrun[g] = -1e30f; lrun[g] = 0.f;
                     o[g] = f32x4c{0.f, 0.f, 0.f, 0.f}; o2[g] = f32x4c{0.f, 0.f, 0.f, 0.f};
                 }
+                __syncthreads();        // every head has its queries: the rows are free for the term planes of o (cheap: the waves
+                                        // left the previous barrier a few instructions ago)
                 // four node tiles (64 nodes) per softmax update: independent S chains on the matrix cores, one running-max
                 // rescale per 64 nodes; the next four tiles' fragments are in flight meanwhile
-                float4 kf[4], kn[4], vf[4], vn[4];
-                auto load4 = [&](int nt0, float4 (&kk)[4], float4 (&vv)[4]) {
+                uint4 kf[8], kn[8];                          // [tile u4][form] (f32 product: [tile u4][0] = the four f32 values)
+                float4 vf[4], vn[4];
+                auto load4 = [&](int nt0, uint4 (&kk)[8], float4 (&vv)[4]) {
 #pragma unroll
                     for (int u4 = 0; u4 < 4; ++u4) {
-                        kk[u4] = gK[(nt0 + u4) * 64];
+                        if (BFS) {
+                            kk[2 * u4] = gK[(nt0 + u4) * 128];
+                            kk[2 * u4 + 1] = gK[(nt0 + u4) * 128 + 64];
+                        } else {
+                            kk[2 * u4] = gK[(nt0 + u4) * 64];
+                        }
                         vv[u4] = gV[(nt0 + u4) * 64];
                     }
                 };
@@ -1937,22 +1994,35 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                             const float4 m4 = *reinterpret_cast<const float4*>(sSc + (16 * g + lo) * SP + 16 * (nt + u4) + 4 * hi);
                             S[g][u4] = f32x4c{m4.x, m4.y, m4.z, m4.w};
                         }
+                    // S^T += K_h q^T: [k1 | k2] [q1 | q1] + [k1 | k2] [q2 | q2] + [k1 | k3] [q3 | q1]
+                    if (!BFS) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+#pragma unroll
+                            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                                for (int u4 = 0; u4 < 4; ++u4) {
+                                    const uint4 kq = kf[2 * u4];
+                                    const unsigned kc = c == 0 ? kq.x : c == 1 ? kq.y : c == 2 ? kq.z : kq.w;
+                                    S[g][u4] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(kc), __uint_as_float(q11[g][c]), S[g][u4], 0, 0, 0);
+                                }
+                    } else {
 #pragma unroll
                     for (int g = 0; g < NG; ++g)
 #pragma unroll
-                        for (int u4 = 0; u4 < 4; ++u4) S[g][u4] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u4].x, q4[g].x, S[g][u4], 0, 0, 0);
+                        for (int u4 = 0; u4 < 4; ++u4)
+                            S[g][u4] = mfma_bf(u32x4{kf[2 * u4].x, kf[2 * u4].y, kf[2 * u4].z, kf[2 * u4].w}, q11[g], S[g][u4]);
 #pragma unroll
                     for (int g = 0; g < NG; ++g)
 #pragma unroll
-                        for (int u4 = 0; u4 < 4; ++u4) S[g][u4] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u4].y, q4[g].y, S[g][u4], 0, 0, 0);
+                        for (int u4 = 0; u4 < 4; ++u4)
+                            S[g][u4] = mfma_bf(u32x4{kf[2 * u4].x, kf[2 * u4].y, kf[2 * u4].z, kf[2 * u4].w}, q22[g], S[g][u4]);
 #pragma unroll
                     for (int g = 0; g < NG; ++g)
 #pragma unroll
-                        for (int u4 = 0; u4 < 4; ++u4) S[g][u4] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u4].z, q4[g].z, S[g][u4], 0, 0, 0);
-#pragma unroll
-                    for (int g = 0; g < NG; ++g)
-#pragma unroll
-                        for (int u4 = 0; u4 < 4; ++u4) S[g][u4] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u4].w, q4[g].w, S[g][u4], 0, 0, 0);
+                        for (int u4 = 0; u4 < 4; ++u4)
+                            S[g][u4] = mfma_bf(u32x4{kf[2 * u4 + 1].x, kf[2 * u4 + 1].y, kf[2 * u4 + 1].z, kf[2 * u4 + 1].w}, q31[g], S[g][u4]);
+                    }
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
                         float tm = ELG_NEG_INF;
@@ -1984,7 +2054,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                     for (int g = 0; g < NG; ++g) { MT_PV(g, 0, o[g]) MT_PV(g, 1, o2[g]) MT_PV(g, 2, o[g]) MT_PV(g, 3, o2[g]) }
 #undef MT_PV
 #pragma unroll
-                    for (int u4 = 0; u4 < 4; ++u4) { kf[u4] = kn[u4]; vf[u4] = vn[u4]; }
+                    for (int u4 = 0; u4 < 4; ++u4) { kf[2 * u4] = kn[2 * u4]; kf[2 * u4 + 1] = kn[2 * u4 + 1]; vf[u4] = vn[u4]; }
                 }
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
@@ -1992,7 +2062,13 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                     const float inv = l > 0.f ? 1.0f / l : 0.f;
                     const float4 ov = make_float4((o[g][0] + o2[g][0]) * inv, (o[g][1] + o2[g][1]) * inv, (o[g][2] + o2[g][2]) * inv,
                                                   (o[g][3] + o2[g][3]) * inv);
-                    *reinterpret_cast<float4*>(sQ + (16 * g + lo) * QP + 16 * wave + 4 * hi) = ov;
+                    {   // o as bf16 terms: the B operand of the pointer product (channels 16 wave + 4 hi .. + 3 of trajectory 16 g + lo)
+                        unsigned pt[6];
+                        bf_terms<3>(ov.x, ov.y, ov.z, ov.w, pt);
+#pragma unroll
+                        for (int tm = 0; tm < 3; ++tm)
+                            *reinterpret_cast<uint2*>(sOb + (tm * NTR + 16 * g + lo) * OBP + 8 * wave + 2 * hi) = make_uint2(pt[2 * tm], pt[2 * tm + 1]);
+                    }
                     if (TRAIN && l > 0.f && m_base + 16 * g + lo < A.M) {       // a decoding trajectory: a_h[n] = exp2(s cs - lse)
                         const size_t rrow = (size_t)b * Rcap + (size_t)t * A.M + m_base + 16 * g + lo;
                         *reinterpret_cast<float4*>(A.trO + rrow * ELG_E + 16 * wave + 4 * hi) = ov;
@@ -2008,10 +2084,13 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
             const int nloc = A.has_local ? NG : 0, W0 = 8 - nloc, skip = nloc ? 3 * W0 : 0;
             if (wave >= W0) co_local16_call(sT, A.loc, sX + (7 - wave) * 16 * CO_XP, lo, hi);
             {
-                float4 pk[8], pkn[8];
-                auto loadpk = [&](int nt, float4 (&d)[8]) {
+                // s^T[node][trajectory] = sum over the channels of PK[node][c] o[trajectory][c] on v_mfma_f32_16x16x32_bf16:
+                // per 32 channels the six term products a1 b1, a1 b2, a2 b1, a2 b2, a1 b3, a3 b1 (24 instructions of 16 cycles per
+                // node tile and group where the f32 form took 32 of 32 cycles; this phase kept the matrix pipe ~70 % busy)
+                uint4 pk[12], pkn[12];
+                auto loadpk = [&](int nt, uint4 (&d)[12]) {
 #pragma unroll
-                    for (int s4 = 0; s4 < 8; ++s4) d[s4] = gPK[(nt * 8 + s4) * 64];
+                    for (int s4 = 0; s4 < 12; ++s4) d[s4] = gPK[(nt * 12 + s4) * 64];
                 };
                 int nt = (wave < W0 ? wave : skip + wave);
                 if (nt < NTn) loadpk(nt, pk);
@@ -2024,14 +2103,23 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
 #pragma unroll
                     for (int g = 0; g < NG; ++g) { a0[g] = f32x4c{0.f, 0.f, 0.f, 0.f}; a1[g] = f32x4c{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-                    for (int s4 = 0; s4 < 8; ++s4) {
+                    for (int kb = 0; kb < 4; ++kb) {
+                        const u32x4 A1 = {pk[3 * kb].x, pk[3 * kb].y, pk[3 * kb].z, pk[3 * kb].w};
+                        const u32x4 A2 = {pk[3 * kb + 1].x, pk[3 * kb + 1].y, pk[3 * kb + 1].z, pk[3 * kb + 1].w};
+                        const u32x4 A3 = {pk[3 * kb + 2].x, pk[3 * kb + 2].y, pk[3 * kb + 2].z, pk[3 * kb + 2].w};
 #pragma unroll
                         for (int g = 0; g < NG; ++g) {
-                            const float4 ov = *reinterpret_cast<const float4*>(sQ + (16 * g + lo) * QP + 4 * hi + 16 * s4);
-                            a0[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(pk[s4].x, ov.x, a0[g], 0, 0, 0);
-                            a1[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(pk[s4].y, ov.y, a1[g], 0, 0, 0);
-                            a0[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(pk[s4].z, ov.z, a0[g], 0, 0, 0);
-                            a1[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(pk[s4].w, ov.w, a1[g], 0, 0, 0);
+                            const unsigned* ob = sOb + (16 * g + lo) * OBP + 16 * kb + 4 * hi;      // channels 32 kb + 8 hi .. + 7
+                            const uint4 q1 = *reinterpret_cast<const uint4*>(ob);
+                            const uint4 q2 = *reinterpret_cast<const uint4*>(ob + NTR * OBP);
+                            const uint4 q3 = *reinterpret_cast<const uint4*>(ob + 2 * NTR * OBP);
+                            const u32x4 B1 = {q1.x, q1.y, q1.z, q1.w}, B2 = {q2.x, q2.y, q2.z, q2.w}, B3 = {q3.x, q3.y, q3.z, q3.w};
+                            a0[g] = mfma_bf(A1, B1, a0[g]);
+                            a1[g] = mfma_bf(A1, B2, a1[g]);
+                            a0[g] = mfma_bf(A2, B1, a0[g]);
+                            a1[g] = mfma_bf(A2, B2, a1[g]);
+                            a0[g] = mfma_bf(A1, B3, a0[g]);
+                            a1[g] = mfma_bf(A3, B1, a1[g]);
                         }
                     }
                     const int nb = 16 * nt + 4 * hi;
@@ -2041,7 +2129,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                         *reinterpret_cast<float4*>(sSc + (16 * g + lo) * SP + nb) =
                             make_float4(a0[g][0] + a1[g][0] + p0, a0[g][1] + a1[g][1] + p1, a0[g][2] + a1[g][2] + p2, a0[g][3] + a1[g][3] + p3);
 #pragma unroll
-                    for (int s4 = 0; s4 < 8; ++s4) pk[s4] = pkn[s4];
+                    for (int s4 = 0; s4 < 12; ++s4) pk[s4] = pkn[s4];
                     nt = nxt;
                 }
             }
@@ -2127,7 +2215,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
 template <int NCH, bool TSP, int NG, bool TRAIN>
 static int launch_fwd_mt_g(const elg_rollout_args& A, hipStream_t stream) {
     constexpr int NTR = 16 * NG;
-    const size_t lds = ((size_t)NTR * 132 + (size_t)NTR * (64 * NCH + 4) + (size_t)NTR * NCH * 4 + (A.has_local ? NTR * CO_XP + CL_SIZE : 0) +
+    const size_t lds = ((size_t)NTR * 3 * 68 + (size_t)NTR * (64 * NCH + 4) + (size_t)NTR * NCH * 4 + (A.has_local ? NTR * CO_XP + CL_SIZE : 0) +
                         ((A.N1 + 3) & ~3) + (size_t)8 * ELG_SB_MIN) * 4;
     auto kern = rollout_fwd_mt_kernel<NCH, TSP, NG, TRAIN>;
     static size_t attr_lds = 0;
@@ -2142,7 +2230,8 @@ static int launch_fwd_mt_g(const elg_rollout_args& A, hipStream_t stream) {
     B2.tiles = (A.M + NTR - 1) / NTR;                      // this kernel's geometry: 16 NG trajectories per workgroup
     (void)hipGetLastError();
     constexpr int NP = 64 * NCH;
-    hipLaunchKernelGGL(mt_repack_kernel, dim3((3 * NP * 32 + 255) / 256, A.B), dim3(256), 0, stream, A.Kmat, A.Vmat, A.PK, A.scratch, A.N1, NP);
+    hipLaunchKernelGGL(mt_repack_kernel, dim3((2 * NP * 32 + NP * 16 + 255) / 256, A.B), dim3(256), 0, stream, A.Kmat, A.Vmat, A.PK, A.scratch, A.N1, NP,
+                       NG == 1 ? 1 : 0);
     hipLaunchKernelGGL(kern, dim3(B2.B * B2.tiles), dim3(512), lds, stream, B2);
     return launch_status("rollout_fwd_mt");
 }
@@ -2577,7 +2666,7 @@ int64_t elg_rollout_scratch_floats(int32_t B, int32_t M, int32_t N1, int32_t var
     if (variant == 2 || N1 > 1024) return (int64_t)B * M * N1;                     // score rows of rollout_fwd_xl_kernel
     if (N1 > 128 && variant == 0) {                                                // fragment-major K / V / PK copies
         const int nch = (N1 + 63) / 64, NP = 64 * (nch <= 4 ? 4 : nch <= 8 ? 8 : 16);
-        return (int64_t)B * 3 * NP * ELG_E;
+        return (int64_t)B * NP * (MT_KB_WORDS + ELG_E + MT_PKB_WORDS);
     }
     return 0;
 }

@@ -197,8 +197,9 @@ def test_streaming_kernel_needs_its_workspace():
     gc, L, eng = _imports()
     lib = L.lib()
     assert lib.elg_rollout_scratch_floats(4, 10, 101, 0) == 0                      # cooperative kernel: none
-    assert lib.elg_rollout_scratch_floats(4, 10, 200, 0) == 4 * 3 * 256 * 128      # fragment-major K / V / PK, 64 NCH = 256 rows
-    assert lib.elg_rollout_scratch_floats(4, 10, 600, 0) == 4 * 3 * 1024 * 128
+    # fragment-major bf16 terms of K (256 words per node), V (f32), bf16 terms of PK (192 words per node); 64 NCH = 256 padded rows
+    assert lib.elg_rollout_scratch_floats(4, 10, 200, 0) == 4 * 256 * (256 + 128 + 192)
+    assert lib.elg_rollout_scratch_floats(4, 10, 600, 0) == 4 * 1024 * (256 + 128 + 192)
     assert lib.elg_rollout_scratch_floats(4, 10, 200, 1) == 0                      # one-wavefront-per-trajectory kernel: none
     assert lib.elg_rollout_scratch_floats(2, 10, 3001, 0) == 2 * 10 * 3001         # score rows of the N1 > 1024 kernel
     N, B, M = 150, 1, 4

@@ -7,13 +7,14 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from elg_amd import engine as eng  # noqa: E402
 
 
 def main():
     kind, N, B = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-    M = int(sys.argv[4]) if len(sys.argv) > 4 else N
+    only = sys.argv[4] if len(sys.argv) > 4 and not sys.argv[4].isdigit() else None       # "rows" / "replay": that path only
+    M = int(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4].isdigit() else N
     dev = "cuda:0"
     if kind == "cvrp":
         from elg_amd.CVRP.CVRPEnv import CVRPEnv as Env
@@ -34,7 +35,7 @@ def main():
         batch = lambda: torch.rand(B, N, 2)
     from elg_amd.optim import Adam
     out = {}
-    for path in ("rows", "replay"):
+    for path in ((only,) if only else ("rows", "replay")):
         eng.TrainRows._cache.clear()
         torch.cuda.empty_cache()
         eng.LARGE_ROWS_BUDGET = 0.45 if path == "rows" else 0.0
@@ -57,7 +58,8 @@ def main():
         out[path] = dict(ms=[round(t, 2) for t in ts], saved_rows=saved, loss=float(J),
                          peak_GB=round(torch.cuda.max_memory_allocated() / 2 ** 30, 2))
         torch.cuda.reset_peak_memory_stats()
-    out["speedup"] = round(min(out["replay"]["ms"][2:]) / min(out["rows"]["ms"][2:]), 3)
+    if not only:
+        out["speedup"] = round(min(out["replay"]["ms"][2:]) / min(out["rows"]["ms"][2:]), 3)
     print(json.dumps(dict(kind=kind, N=N, B=B, M=M, **out)))
 
 
