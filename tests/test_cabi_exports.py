@@ -34,7 +34,7 @@ def test_struct_layout_matches_c():
              ("elg_enc_weights", _lib.EncWeights, ["emb_depot_w", "emb_w", "layer", "dec_Wq_first", "dec_bc"]),
              ("elg_encoder_args", _lib.EncoderArgs, ["problem", "eps", "xy", "W", "enc", "Q2", "wl", "ws", "ws_floats"]),
              ("elg_encoder_bwd_args", _lib.EncoderBwdArgs, ["fwd", "g_enc", "gpb", "gwl", "G", "ws2", "ws2_floats"]),
-             ("elg_decoder_bwd_args", _lib.DecoderBwdArgs, ["problem", "inv_ens", "Rcap", "gprob", "trLse", "Kmat", "dwl", "rowDU", "rowW", "T_dev", "gprob_T", "tables_frozen", "mask_words", "ws", "ws_floats"]),
+             ("elg_decoder_bwd_args", _lib.DecoderBwdArgs, ["problem", "inv_ens", "Rcap", "gprob", "trLse", "Kmat", "dwl", "rowDU", "rowW", "T_dev", "gprob_T", "tables_frozen", "mask_words", "mfma_mode", "ws", "ws_floats"]),
              ("elg_local_weights", _lib.LocalWeights, ["init_emb_w", "cur_token_emb", "combine_b"])]
     src = '#include <stdio.h>\n#include <stddef.h>\n#include "elg_hip.h"\nint main(){\n'
     for cname, _, fields in pairs:

@@ -55,7 +55,8 @@ def test_pomo_loss_tsp_zero_normaliser_guard():
 
 @pytest.mark.parametrize("tsp,recompute,mode,N1", [(False, False, 0, 23), (True, False, 0, 23), (False, True, 0, 23),
                                                     (False, True, 0, 101), (False, True, 1, 101), (True, True, 1, 23),
-                                                    (False, True, 2, 101), (True, True, 2, 101), (False, True, 1, 37)])
+                                                    (False, True, 2, 101), (True, True, 2, 101), (False, True, 1, 37), (False, True, 2, 112),
+                                                    (True, True, 2, 65)])
 def test_decoder_bwd_matches_torch(tsp, recompute, mode, N1):
     """elg_decoder_bwd on synthetic saved rows against the dense torch algebra it stands for (include/elg_hip.h):
     dl = w (Csel [n == a] - PC), dO = dl PK, dPK = dl^T O, dpb = sum dl, dU = dl[slot] / ens, glimpse backward
