@@ -1629,8 +1629,6 @@ __device__ __forceinline__ void glimpse_tile(const float* __restrict__ sK, const
 // lane = 16 hi + lo.  Per instance, in floats / 32-bit words:
 //   Kb [h][tile][form][lane][w]: bf16 terms of K[16 tile + lo][16 h + 4 hi + j], j < 4, as the A operand of the score product
 //                                S^T = K_h q^T: form 0 = [k1 | k2], form 1 = [k1 | k3] (two values per word)   at 0   (NP * 256 words)
-//     (16 trajectories per workgroup; with 32 the two operand forms of four node tiles in flight spill registers: those
-//      kernels read Kf[h][tile][lane][j] = K[16 tile + lo][16 h + 4 hi + j] (f32) in the same place and keep the f32 product)
 //   Vf [h][tile][lane][j] = V [16 tile + 4 hi + j][16 h + lo]  (f32)                                          at NP * 256
 //   PKb[tile][kb][term][lane][w] = bf16 terms 1 .. 3 of PK[16 tile + lo][32 kb + 8 hi + 2 w, + 1]            at NP * 384  (NP * 192 words)
 // Both products with a per-launch constant operand -- the glimpse scores K q^T and the pointer scores PK o -- run on
@@ -1643,8 +1641,7 @@ __device__ __forceinline__ void glimpse_tile(const float* __restrict__ sK, const
 constexpr int MT_KB_WORDS = 256;                              // words of Kb per padded node
 constexpr int MT_PKB_WORDS = 192;                             // words of PKb per padded node
 __global__ __launch_bounds__(256) void mt_repack_kernel(const float* __restrict__ K, const float* __restrict__ V,
-                                                        const float* __restrict__ PK, float* __restrict__ F, int N1, int NP,
-                                                        int k_terms) {
+                                                        const float* __restrict__ PK, float* __restrict__ F, int N1, int NP) {
     const int b = blockIdx.y;
     const int per = NP * 32;                                  // float4s per f32 table
     const int o = blockIdx.x * 256 + threadIdx.x;
@@ -1672,10 +1669,6 @@ __global__ __launch_bounds__(256) void mt_repack_kernel(const float* __restrict_
     if (which == 0) {
         const int NT = NP >> 4, h = (r >> 6) / NT, tile = (r >> 6) % NT, n = 16 * tile + lo;
         if (n < N1) v = *reinterpret_cast<const float4*>(K + b * NE + (size_t)n * ELG_E + 16 * h + 4 * hi);
-        if (!k_terms) {                 // Kf[h][tile][lane][j] (f32): the 32-trajectory kernels keep the f32 score product
-            reinterpret_cast<float4*>(Fb)[r] = v;
-            return;
-        }
         unsigned pt[6];
         bf_terms<3>(v.x, v.y, v.z, v.w, pt);
         uint4* dst = reinterpret_cast<uint4*>(Fb) + ((size_t)(h * NT + tile) * 2) * 64 + lane;
@@ -1831,8 +1824,8 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
     I.loc = A.loc;
     constexpr int NP = 64 * NCH, NT = 4 * NCH;              // padded nodes / tiles of the fragment-major tables
     const float* gF = A.scratch + (size_t)b * NP * (MT_KB_WORDS + ELG_E + MT_PKB_WORDS);
-    constexpr bool BFS = NG == 1;                          // score product on bf16 terms (see mt_repack_kernel)
-    const uint4* gK = reinterpret_cast<const uint4*>(gF) + (size_t)wave * NT * (BFS ? 2 : 1) * 64 + lane;    // head = wave: [tile][form][lane]
+    constexpr int TU = NG == 1 ? 4 : 2;                    // node tiles per softmax update of the glimpse
+    const uint4* gK = reinterpret_cast<const uint4*>(gF) + (size_t)wave * NT * 2 * 64 + lane;                // head = wave: [tile][form][lane]
     const float4* gV = reinterpret_cast<const float4*>(gF + (size_t)NP * MT_KB_WORDS) + (size_t)wave * NT * 64 + lane;
     const uint4* gPK = reinterpret_cast<const uint4*>(gF + (size_t)NP * (MT_KB_WORDS + ELG_E)) + lane;     // [tile][kb][term][lane]
     const int step_cap = TSP ? N1 : 2 * N1 + 2;
@@ -1950,85 +1943,64 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     const float4 qv = *reinterpret_cast<const float4*>(sQ + (16 * g + lo) * QP + 16 * wave + 4 * hi);     // trajectory 16 g + lo
-                    if (BFS) {
-                        unsigned pt[6];
-                        bf_terms<3>(qv.x, qv.y, qv.z, qv.w, pt);
-                        q11[g] = u32x4{pt[0], pt[1], pt[0], pt[1]};
-                        q22[g] = u32x4{pt[2], pt[3], pt[2], pt[3]};
-                        q31[g] = u32x4{pt[4], pt[5], pt[0], pt[1]};
-                    } else {            // f32 product: the four query values ride in q11
-                        q11[g] = u32x4{__float_as_uint(qv.x), __float_as_uint(qv.y), __float_as_uint(qv.z), __float_as_uint(qv.w)};
-                        q22[g] = q11[g]; q31[g] = q11[g];
-                    }
+                    unsigned pt[6];
+                    bf_terms<3>(qv.x, qv.y, qv.z, qv.w, pt);
+                    q11[g] = u32x4{pt[0], pt[1], pt[0], pt[1]};
+                    q22[g] = u32x4{pt[2], pt[3], pt[2], pt[3]};
+                    q31[g] = u32x4{pt[4], pt[5], pt[0], pt[1]};
                     mrun[g] = -1e30f; lrun[g] = 0.f;
                     o[g] = f32x4c{0.f, 0.f, 0.f, 0.f}; o2[g] = f32x4c{0.f, 0.f, 0.f, 0.f};
                 }
                 __syncthreads();        // every head has its queries: the rows are free for the term planes of o (cheap: the waves
                                         // left the previous barrier a few instructions ago)
-                // four node tiles (64 nodes) per softmax update: independent S chains on the matrix cores, one running-max
-                // rescale per 64 nodes; the next four tiles' fragments are in flight meanwhile
-                uint4 kf[8], kn[8];                          // [tile u4][form] (f32 product: [tile u4][0] = the four f32 values)
-                float4 vf[4], vn[4];
-                auto load4 = [&](int nt0, uint4 (&kk)[8], float4 (&vv)[4]) {
+                // TU node tiles per softmax update: independent S chains on the matrix cores, one running-max rescale per 16 TU
+                // nodes; with 32 trajectories per workgroup two tiles (four spill registers)
+                uint4 kf[2 * TU], kn[2 * TU];                // [tile u4][form]
+                float4 vf[TU], vn[TU];
+                auto load4 = [&](int nt0, uint4 (&kk)[2 * TU], float4 (&vv)[TU]) {
 #pragma unroll
-                    for (int u4 = 0; u4 < 4; ++u4) {
-                        if (BFS) {
-                            kk[2 * u4] = gK[(nt0 + u4) * 128];
-                            kk[2 * u4 + 1] = gK[(nt0 + u4) * 128 + 64];
-                        } else {
-                            kk[2 * u4] = gK[(nt0 + u4) * 64];
-                        }
+                    for (int u4 = 0; u4 < TU; ++u4) {
+                        kk[2 * u4] = gK[(nt0 + u4) * 128];
+                        kk[2 * u4 + 1] = gK[(nt0 + u4) * 128 + 64];
                         vv[u4] = gV[(nt0 + u4) * 64];
                     }
                 };
                 load4(0, kf, vf);
 #pragma unroll 1
-                for (int nt = 0; nt < NTn; nt += 4) {
-                    load4(min(nt + 4, NT - 4), kn, vn);
+                for (int nt = 0; nt < NTn; nt += TU) {
+                    load4(min(nt + TU, NT - TU), kn, vn);
                     __builtin_amdgcn_sched_barrier(0);            // the loads stay here: in flight under this iteration's MFMAs
-                    f32x4c S[NG][4];
+                    f32x4c S[NG][TU];
 #pragma unroll
                     for (int g = 0; g < NG; ++g)
 #pragma unroll
-                        for (int u4 = 0; u4 < 4; ++u4) {               // accumulator input = the additive mask of the tile's nodes
+                        for (int u4 = 0; u4 < TU; ++u4) {              // accumulator input = the additive mask of the tile's nodes
                             const float4 m4 = *reinterpret_cast<const float4*>(sSc + (16 * g + lo) * SP + 16 * (nt + u4) + 4 * hi);
                             S[g][u4] = f32x4c{m4.x, m4.y, m4.z, m4.w};
                         }
                     // S^T += K_h q^T: [k1 | k2] [q1 | q1] + [k1 | k2] [q2 | q2] + [k1 | k3] [q3 | q1]
-                    if (!BFS) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-#pragma unroll
-                            for (int g = 0; g < NG; ++g)
-#pragma unroll
-                                for (int u4 = 0; u4 < 4; ++u4) {
-                                    const uint4 kq = kf[2 * u4];
-                                    const unsigned kc = c == 0 ? kq.x : c == 1 ? kq.y : c == 2 ? kq.z : kq.w;
-                                    S[g][u4] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(kc), __uint_as_float(q11[g][c]), S[g][u4], 0, 0, 0);
-                                }
-                    } else {
 #pragma unroll
                     for (int g = 0; g < NG; ++g)
 #pragma unroll
-                        for (int u4 = 0; u4 < 4; ++u4)
+                        for (int u4 = 0; u4 < TU; ++u4)
                             S[g][u4] = mfma_bf(u32x4{kf[2 * u4].x, kf[2 * u4].y, kf[2 * u4].z, kf[2 * u4].w}, q11[g], S[g][u4]);
 #pragma unroll
                     for (int g = 0; g < NG; ++g)
 #pragma unroll
-                        for (int u4 = 0; u4 < 4; ++u4)
+                        for (int u4 = 0; u4 < TU; ++u4)
                             S[g][u4] = mfma_bf(u32x4{kf[2 * u4].x, kf[2 * u4].y, kf[2 * u4].z, kf[2 * u4].w}, q22[g], S[g][u4]);
 #pragma unroll
                     for (int g = 0; g < NG; ++g)
 #pragma unroll
-                        for (int u4 = 0; u4 < 4; ++u4)
+                        for (int u4 = 0; u4 < TU; ++u4)
                             S[g][u4] = mfma_bf(u32x4{kf[2 * u4 + 1].x, kf[2 * u4 + 1].y, kf[2 * u4 + 1].z, kf[2 * u4 + 1].w}, q31[g], S[g][u4]);
-                    }
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
                         float tm = ELG_NEG_INF;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            tm = fmaxf(fmaxf(tm, fmaxf(S[g][0][i], S[g][1][i])), fmaxf(S[g][2][i], S[g][3][i]));
+                        for (int u4 = 0; u4 < TU; ++u4)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) tm = fmaxf(tm, S[g][u4][i]);
                         tm = quarters_max(tm);
                         const float mnew = fmaxf(mrun[g], tm);
                         const float sc = __builtin_amdgcn_exp2f((mrun[g] - mnew) * cs);
@@ -2038,23 +2010,25 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                         for (int i = 0; i < 4; ++i) { o[g][i] *= sc; o2[g][i] *= sc; }
                         const float cm = -mnew * cs;
 #pragma unroll
-                        for (int u4 = 0; u4 < 4; ++u4)
+                        for (int u4 = 0; u4 < TU; ++u4)
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 S[g][u4][i] = __builtin_amdgcn_exp2f(fmaf(S[g][u4][i], cs, cm));
                                 lrun[g] += S[g][u4][i];
                             }
                     }
-#define MT_PV(GG, U, ACC)                                                                             \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[U].x, S[GG][U][0], ACC, 0, 0, 0);                    \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[U].y, S[GG][U][1], ACC, 0, 0, 0);                    \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[U].z, S[GG][U][2], ACC, 0, 0, 0);                    \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[U].w, S[GG][U][3], ACC, 0, 0, 0);
 #pragma unroll
-                    for (int g = 0; g < NG; ++g) { MT_PV(g, 0, o[g]) MT_PV(g, 1, o2[g]) MT_PV(g, 2, o[g]) MT_PV(g, 3, o2[g]) }
-#undef MT_PV
+                    for (int g = 0; g < NG; ++g)
 #pragma unroll
-                    for (int u4 = 0; u4 < 4; ++u4) { kf[2 * u4] = kn[2 * u4]; kf[2 * u4 + 1] = kn[2 * u4 + 1]; vf[u4] = vn[u4]; }
+                        for (int u4 = 0; u4 < TU; ++u4) {             // O^T += V_h^T P^T, two accumulator chains
+                            f32x4c& acc = (u4 & 1) ? o2[g] : o[g];
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[u4].x, S[g][u4][0], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[u4].y, S[g][u4][1], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[u4].z, S[g][u4][2], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[u4].w, S[g][u4][3], acc, 0, 0, 0);
+                        }
+#pragma unroll
+                    for (int u4 = 0; u4 < TU; ++u4) { kf[2 * u4] = kn[2 * u4]; kf[2 * u4 + 1] = kn[2 * u4 + 1]; vf[u4] = vn[u4]; }
                 }
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
@@ -2230,8 +2204,7 @@ static int launch_fwd_mt_g(const elg_rollout_args& A, hipStream_t stream) {
     B2.tiles = (A.M + NTR - 1) / NTR;                      // this kernel's geometry: 16 NG trajectories per workgroup
     (void)hipGetLastError();
     constexpr int NP = 64 * NCH;
-    hipLaunchKernelGGL(mt_repack_kernel, dim3((2 * NP * 32 + NP * 16 + 255) / 256, A.B), dim3(256), 0, stream, A.Kmat, A.Vmat, A.PK, A.scratch, A.N1, NP,
-                       NG == 1 ? 1 : 0);
+    hipLaunchKernelGGL(mt_repack_kernel, dim3((2 * NP * 32 + NP * 16 + 255) / 256, A.B), dim3(256), 0, stream, A.Kmat, A.Vmat, A.PK, A.scratch, A.N1, NP);
     hipLaunchKernelGGL(kern, dim3(B2.B * B2.tiles), dim3(512), lds, stream, B2);
     return launch_status("rollout_fwd_mt");
 }
