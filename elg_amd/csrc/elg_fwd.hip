@@ -185,22 +185,25 @@ __device__ __forceinline__ FwdOut finish_step(const elg_rollout_args& A, int N1,
     if (A.mode == ELG_MODE_FORCED) {
         sel = forced_sel;
     } else if (A.mode == ELG_MODE_GREEDY) {
-        // argmax over probabilities, ties -> lowest node index (torch.argmax)
+        // argmax over probabilities, ties -> lowest node index (torch.argmax): the maximum by a DPP all-reduce, then the first
+        // node that attains it by one ballot per 64-node chunk (the butterfly on (value, index) pairs this replaces went
+        // through ds_bpermute: 12 LDS round trips in a row)
+        float pv[NCH];
         float bv = -1.f;
-        int bn = 0x7fffffff;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             const int n = lane + 64 * ch;
-            const float pv = e[ch] * inv;
-            if (n < N1 && pv > bv) { bv = pv; bn = n; }
+            pv[ch] = n < N1 ? e[ch] * inv : -1.f;
+            bv = fmaxf(bv, pv[ch]);
         }
+        bv = wave_max(bv);
+        int found = -1;
 #pragma unroll
-        for (int m = 1; m < 64; m <<= 1) {
-            const float ov = shfl_xor(bv, m);
-            const int on = shfl_xor(bn, m);
-            if (ov > bv || (ov == bv && on < bn)) { bv = ov; bn = on; }
+        for (int ch = 0; ch < NCH; ++ch) {
+            const unsigned long long hit = __ballot(pv[ch] == bv);
+            if (found < 0 && hit) found = 64 * ch + (int)__builtin_ctzll(hit);
         }
-        sel = bn;
+        sel = found < 0 ? 0 : found;
     } else {
         // inverse-CDF sample in node order
         float cs[NCH];
@@ -889,18 +892,23 @@ __device__ __forceinline__ void co_finish4(const elg_rollout_args& A, int N1, in
     if (A.mode == ELG_MODE_FORCED) {
         sel = (act && A.forced && t < A.Tforced) ? A.forced[bm * A.Tforced + t] : 0;
     } else if (A.mode == ELG_MODE_GREEDY) {
+        // argmax of the trajectory's row (16 lanes), ties -> lowest node index: row maximum by DPP, then the first node that
+        // attains it from one ballot per 16-node slice (the (value, index) butterfly went through ds_bpermute: 8 LDS round trips)
+        float pvk[NK];
         float bv = -1.f;
-        int bn = 0x7fffffff;
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
-            const float pv = e[k] * inv;
-            if (lo + 16 * k < N1 && pv > bv) { bv = pv; bn = lo + 16 * k; }
+            pvk[k] = lo + 16 * k < N1 ? e[k] * inv : -1.f;
+            bv = fmaxf(bv, pvk[k]);
         }
+        bv = row16_max(bv);
+        int bn = 0;
+        bool got = false;
 #pragma unroll
-        for (int mm = 1; mm < 16; mm <<= 1) {                        // stays inside the 16-lane row
-            const float ov = shfl_xor(bv, mm);
-            const int on = shfl_xor(bn, mm);
-            if (ov > bv || (ov == bv && on < bn)) { bv = ov; bn = on; }
+        for (int k = 0; k < NK; ++k) {
+            const unsigned long long hit = __ballot(pvk[k] == bv);
+            const unsigned seg = (unsigned)(hit >> (lane & 48)) & 0xffffu;       // this trajectory's 16 lanes
+            if (!got && seg) { bn = 16 * k + __builtin_ctz(seg); got = true; }
         }
         sel = bn;
     } else {
@@ -2445,11 +2453,12 @@ __global__ __launch_bounds__(512) void rollout_fwd_xl_kernel(const elg_rollout_a
                         }
                         if (x > mx) { mx = x; bn = n; }
                     }
-#pragma unroll
-                    for (int mk2 = 1; mk2 < 64; mk2 <<= 1) {
-                        const float ov = shfl_xor(mx, mk2);
-                        const int on = shfl_xor(bn, mk2);
-                        if (ov > mx || (ov == mx && on < bn)) { mx = ov; bn = on; }
+                    {   // wave argmax, ties -> lowest node: DPP all-reduce of the value, then of the (negated) index among its holders
+                        const float gmx = wave_max(mx);
+                        const float cand = (mx == gmx && bn != 0x7fffffff) ? -(float)bn : -3.0e38f;     // node indices < 2^24: exact in f32
+                        const float first = -wave_max(cand);
+                        bn = first < 1.0e9f ? (int)first : 0;
+                        mx = gmx;
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
                     // pass 2: normaliser
