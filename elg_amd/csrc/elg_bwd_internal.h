@@ -34,4 +34,9 @@ int glimpse_bwd_launch(const float* rowA, const unsigned long long* mk, const fl
                        long long rowA_rows, long long rowO_rows, long long rowQ_rows, int splits, const GlimpseSeg& seg,
                        hipStream_t s);
 
+// csrc/elg_gemm.hip: elg_gemm_f32_batched with the contraction split over `split_k` workgroups accumulating into a zeroed C
+int gemm_f32_batched_splitk(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int transA,
+                            int transB, int n_outer, int n_inner, long sA_outer, long sA_inner, long sB_outer, long sB_inner,
+                            long sC_outer, long sC_inner, float alpha, int split_k, void* stream);
+
 }  // namespace elg

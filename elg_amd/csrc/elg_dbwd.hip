@@ -256,39 +256,87 @@ __global__ __launch_bounds__(256) void rows_dl_kernel(const PtrBwd a, float* __r
     }
 }
 
-// a_h[n] = closed(n) ? 0 : exp2(s cs - lse) in place over S = q_h K_h^T        grid (rows / 4, B * 8)
+// The two element-wise passes over the (R, N1) matrices of an (instance, head) run over the FLAT index space, four consecutive
+// elements per thread as one aligned 16-byte access (rows of N1 = N + 1 floats are not aligned: one wavefront per row moved
+// 2 TB/s, half of what this does); the row's scalars (lse, mask word, <dO, O>) come through the cache.
+// a_h[r][n] = closed(r, n) ? 0 : exp2(s cs - lse[r]) in place over S = q_h K_h^T          grid (R N1 / 1024, B * 8)
 __global__ __launch_bounds__(256) void rows_attn_kernel(float* __restrict__ S, const unsigned long long* __restrict__ mask,
                                                         const float* __restrict__ lse, int R, long long Rcap, int N1, int W) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = blockIdx.x * 4 + wave;
-    if (r >= R) return;
     const int bh = blockIdx.y, b = bh >> 3, h = bh & 7;
+    const long long total = (long long)R * N1;
+    const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= total) return;
     const float cs = 0.25f * 1.4426950408889634f;
-    const size_t rrow = (size_t)b * Rcap + r;
-    const float l = lse[rrow * 8 + h];
-    float* row = S + ((size_t)bh * R + r) * N1;
-    for (int c = 0; 64 * c < N1; ++c) {
-        const int n = lane + 64 * c;
-        const unsigned long long w = mask[rrow * W + c];
-        if (n < N1) row[n] = ((w >> lane) & 1ull) ? 0.f : __builtin_amdgcn_exp2f(fmaf(row[n], cs, -l));
+    float* base = S + (size_t)bh * total;                  // 16-byte aligned for every bh when total % 4 == 0; else scalar path
+    int r = (int)(i0 / N1), n = (int)(i0 - (long long)r * N1);
+    const bool vec = !(total & 3) && i0 + 3 < total;
+    float v[4];
+    if (vec) { const float4 t = *reinterpret_cast<const float4*>(base + i0); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = i0 + e < total ? base[i0 + e] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (i0 + e < total) {
+            const size_t rrow = (size_t)b * Rcap + r;
+            const unsigned long long w = mask[rrow * W + (n >> 6)];
+            v[e] = ((w >> (n & 63)) & 1ull) ? 0.f : __builtin_amdgcn_exp2f(fmaf(v[e], cs, -lse[rrow * 8 + h]));
+        }
+        if (++n == N1) { n = 0; ++r; }
+    }
+    if (vec) *reinterpret_cast<float4*>(base + i0) = make_float4(v[0], v[1], v[2], v[3]);
+    else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (i0 + e < total) base[i0 + e] = v[e];
     }
 }
 
-// d S = a (dA - <dO_h, O_h>) / 4 in place over dA                              grid (rows / 4, B * 8)
-__global__ __launch_bounds__(256) void rows_ds_kernel(float* __restrict__ dA, const float* __restrict__ Aw,
-                                                      const float* __restrict__ dO, const float* __restrict__ O, int R,
-                                                      long long Rdo, long long Rcap, int N1) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = blockIdx.x * 4 + wave;
+// <dO_h, O_h> per (row, head)                                                              grid (R / 16, B): 16 lanes per row
+__global__ __launch_bounds__(256) void rows_doto_kernel(const float* __restrict__ dO, const float* __restrict__ O,
+                                                        float* __restrict__ doto, int R, long long Rdo, long long Rcap) {
+    const int b = blockIdx.y, r = blockIdx.x * 16 + (threadIdx.x >> 4), c8 = (threadIdx.x & 15) * 8;
     if (r >= R) return;
+    const float4 a0 = *reinterpret_cast<const float4*>(dO + ((size_t)b * Rdo + r) * ELG_E + c8);
+    const float4 a1 = *reinterpret_cast<const float4*>(dO + ((size_t)b * Rdo + r) * ELG_E + c8 + 4);
+    const float4 o0 = *reinterpret_cast<const float4*>(O + ((size_t)b * Rcap + r) * ELG_E + c8);
+    const float4 o1 = *reinterpret_cast<const float4*>(O + ((size_t)b * Rcap + r) * ELG_E + c8 + 4);
+    float d = a0.x * o0.x + a0.y * o0.y + a0.z * o0.z + a0.w * o0.w + a1.x * o1.x + a1.y * o1.y + a1.z * o1.z + a1.w * o1.w;
+    d += dpp<0xB1>(d);                                    // the head's two 8-channel halves sit in neighbouring lanes
+    if (!(threadIdx.x & 1)) doto[((size_t)b * R + r) * 8 + (threadIdx.x & 15) / 2] = d;
+}
+
+// d S = a (dA - <dO_h, O_h>) / 4 in place over dA                                          grid (R N1 / 1024, B * 8)
+__global__ __launch_bounds__(256) void rows_ds_kernel(float* __restrict__ dA, const float* __restrict__ Aw,
+                                                      const float* __restrict__ doto, int R, int N1) {
     const int bh = blockIdx.y, b = bh >> 3, h = bh & 7;
-    float d = 0.f;
-    if (lane < 16) d = dO[((size_t)b * Rdo + r) * ELG_E + h * 16 + lane] * O[((size_t)b * Rcap + r) * ELG_E + h * 16 + lane];
-    const float doto = row16_sum(d);
-    const float dt = readlane(doto, 0);
-    float* row = dA + ((size_t)bh * R + r) * N1;
-    const float* arow = Aw + ((size_t)bh * R + r) * N1;
-    for (int n = lane; n < N1; n += 64) row[n] = 0.25f * arow[n] * (row[n] - dt);
+    const long long total = (long long)R * N1;
+    const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= total) return;
+    float* base = dA + (size_t)bh * total;
+    const float* abase = Aw + (size_t)bh * total;
+    int r = (int)(i0 / N1), n = (int)(i0 - (long long)r * N1);
+    const bool vec = !(total & 3) && i0 + 3 < total;
+    float v[4], a[4];
+    if (vec) {
+        const float4 t = *reinterpret_cast<const float4*>(base + i0), u = *reinterpret_cast<const float4*>(abase + i0);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; a[0] = u.x; a[1] = u.y; a[2] = u.z; a[3] = u.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = i0 + e < total ? base[i0 + e] : 0.f; a[e] = i0 + e < total ? abase[i0 + e] : 0.f; }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (i0 + e < total) v[e] = 0.25f * a[e] * (v[e] - doto[((size_t)b * R + r) * 8 + h]);
+        if (++n == N1) { n = 0; ++r; }
+    }
+    if (vec) *reinterpret_cast<float4*>(base + i0) = make_float4(v[0], v[1], v[2], v[3]);
+    else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (i0 + e < total) base[i0 + e] = v[e];
+    }
 }
 
 // backward of the query gather: d Q1[prev[r]] += dQ[r], d Q2[first[r]] += dQ[r] (TSP), d wl += load[r] dQ[r] (CVRP)
@@ -367,28 +415,35 @@ static int decoder_bwd_large(const elg_decoder_bwd_args* p, PtrBwd& a, hipStream
         // d o = d s PK ;  d PK = d s^T o
         DB_TRY(elg_gemm_f32_batched(dl, p->PK + tb, dOl, (int)Rl, ELG_E, N1, N1, ELG_E, ELG_E, 0, 0, nb, 1, Rcap * N1, 0,
                                     (int64_t)N1 * ELG_E, 0, R * ELG_E, 0, 1.f, st))
-        DB_TRY(elg_gemm_f32_batched(dl, Ol, p->dPK + tb, N1, ELG_E, (int)Rl, N1, ELG_E, ELG_E, 1, 0, nb, 1, Rcap * N1, 0, Rcap * ELG_E, 0,
-                                    (int64_t)N1 * ELG_E, 0, 1.f, st))
+        // (the three reductions over the rows -- dPK, dK, dV -- split the rows over enough workgroups to fill the chip and
+        // accumulate into the caller-zeroed outputs)
+        const int mt_ = (N1 + 63) / 64;
+        const int sk1 = (int)max(1LL, min(16LL, min(Rl / 512, 2048LL / ((long long)mt_ * 2 * nb))));
+        const int sk8 = (int)max(1LL, min(16LL, min(Rl / 512, 2048LL / ((long long)mt_ * 8 * nb))));
+        DB_TRY(gemm_f32_batched_splitk(dl, Ol, p->dPK + tb, N1, ELG_E, (int)Rl, N1, ELG_E, ELG_E, 1, 0, nb, 1, Rcap * N1, 0, Rcap * ELG_E, 0,
+                                       (long)N1 * ELG_E, 0, 1.f, sk1, st))
         if (p->tables_frozen) continue;
         // s_h = q_h K_h^T  -> a_h (in place)
         DB_TRY(elg_gemm_f32_batched(Ql, p->Kmat + tb, Sbuf, (int)Rl, N1, 16, ELG_E, ELG_E, N1, 0, 1, nb, 8, Rcap * ELG_E, 16,
                                     (int64_t)N1 * ELG_E, 16, 8 * Rl * N1, Rl * N1, 1.f, st))
-        hipLaunchKernelGGL(rows_attn_kernel, dim3((unsigned)((Rl + 3) / 4), nb * 8), dim3(256), 0, s, Sbuf,
+        const unsigned flat_blocks = (unsigned)((Rl * N1 + 1023) / 1024);
+        hipLaunchKernelGGL(rows_attn_kernel, dim3(flat_blocks, nb * 8), dim3(256), 0, s, Sbuf,
                            reinterpret_cast<const unsigned long long*>(p->trMask) + ((size_t)b0 * Rcap + r_lo) * W,
                            p->trLse + ((size_t)b0 * Rcap + r_lo) * 8, (int)Rl, Rcap, N1, W);
         DB_TRY(launch_status("rows_attn"))
         // dA_h = dO_h V_h^T -> dS_h (in place)
         DB_TRY(elg_gemm_f32_batched(dOl, p->Vmat + tb, Dbuf, (int)Rl, N1, 16, ELG_E, ELG_E, N1, 0, 1, nb, 8, R * ELG_E, 16,
                                     (int64_t)N1 * ELG_E, 16, 8 * Rl * N1, Rl * N1, 1.f, st))
-        hipLaunchKernelGGL(rows_ds_kernel, dim3((unsigned)((Rl + 3) / 4), nb * 8), dim3(256), 0, s, Dbuf, Sbuf, dOl, Ol, (int)Rl, R, Rcap, N1);
+        hipLaunchKernelGGL(rows_doto_kernel, dim3((unsigned)((Rl + 15) / 16), nb), dim3(256), 0, s, dOl, Ol, dQr, (int)Rl, R, Rcap);
+        hipLaunchKernelGGL(rows_ds_kernel, dim3(flat_blocks, nb * 8), dim3(256), 0, s, Dbuf, Sbuf, dQr, (int)Rl, N1);
         DB_TRY(launch_status("rows_ds"))
         // d q_h = dS_h K_h ;  d K_h = dS_h^T q_h ;  d V_h = a_h^T dO_h
         DB_TRY(elg_gemm_f32_batched(Dbuf, p->Kmat + tb, dQr, (int)Rl, 16, N1, N1, ELG_E, ELG_E, 0, 0, nb, 8, 8 * Rl * N1, Rl * N1,
                                     (int64_t)N1 * ELG_E, 16, Rl * ELG_E, 16, 1.f, st))
-        DB_TRY(elg_gemm_f32_batched(Dbuf, Ql, p->dK + tb, N1, 16, (int)Rl, N1, ELG_E, ELG_E, 1, 0, nb, 8, 8 * Rl * N1, Rl * N1,
-                                    Rcap * ELG_E, 16, (int64_t)N1 * ELG_E, 16, 1.f, st))
-        DB_TRY(elg_gemm_f32_batched(Sbuf, dOl, p->dV + tb, N1, 16, (int)Rl, N1, ELG_E, ELG_E, 1, 0, nb, 8, 8 * Rl * N1, Rl * N1,
-                                    R * ELG_E, 16, (int64_t)N1 * ELG_E, 16, 1.f, st))
+        DB_TRY(gemm_f32_batched_splitk(Dbuf, Ql, p->dK + tb, N1, 16, (int)Rl, N1, ELG_E, ELG_E, 1, 0, nb, 8, 8 * Rl * N1, Rl * N1,
+                                       Rcap * ELG_E, 16, (long)N1 * ELG_E, 16, 1.f, sk8, st))
+        DB_TRY(gemm_f32_batched_splitk(Sbuf, dOl, p->dV + tb, N1, 16, (int)Rl, N1, ELG_E, ELG_E, 1, 0, nb, 8, 8 * Rl * N1, Rl * N1,
+                                       R * ELG_E, 16, (long)N1 * ELG_E, 16, 1.f, sk8, st))
         hipLaunchKernelGGL(rows_qgather_bwd_kernel, dim3((unsigned)((Rl + rpb - 1) / rpb), nb), dim3(256), 0, s, dQr,
                            p->idx_prev + (size_t)b0 * R + r_lo, tsp ? p->idx_first + (size_t)b0 * R + r_lo : nullptr,
                            tsp ? nullptr : p->trLoad + (size_t)b0 * Rcap + r_lo, p->dQ1 + tb, tsp ? p->dQ2 + tb : nullptr,

@@ -173,6 +173,17 @@ extern "C" int elg_gemm_f32_alpha(const float* A, const float* B, float* C, cons
     return gemm_launch(A, B, C, bias, M, N, K, lda, ldb, ldc, transA, transB, relu, split_k, a_rowsum, alpha, 1, 1, st, stream);
 }
 
+namespace elg {
+// internal (csrc/elg_bwd_internal.h): the batched product with the contraction split over `split_k` workgroups that ACCUMULATE into
+// a caller-zeroed C with f32 atomics -- the row reductions of the large-instance decoder backward (K = decode rows, M, N small)
+int gemm_f32_batched_splitk(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int transA,
+                            int transB, int n_outer, int n_inner, long sA_outer, long sA_inner, long sB_outer, long sB_inner,
+                            long sC_outer, long sC_inner, float alpha, int split_k, void* stream) {
+    const long st[6] = {sA_outer, sA_inner, sB_outer, sB_inner, sC_outer, sC_inner};
+    return gemm_launch(A, B, C, nullptr, M, N, K, lda, ldb, ldc, transA, transB, 0, split_k, nullptr, alpha, n_outer, n_inner, st, stream);
+}
+}  // namespace elg
+
 extern "C" int elg_gemm_f32_batched(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                                     int transA, int transB, int n_outer, int n_inner, int64_t sA_outer, int64_t sA_inner,
                                     int64_t sB_outer, int64_t sB_inner, int64_t sC_outer, int64_t sC_inner, float alpha,
