@@ -256,43 +256,6 @@ __global__ __launch_bounds__(256) void rows_dl_kernel(const PtrBwd a, float* __r
     }
 }
 
-// The two element-wise passes over the (R, N1) matrices of an (instance, head) run over the FLAT index space, four consecutive
-// elements per thread as one aligned 16-byte access (rows of N1 = N + 1 floats are not aligned: one wavefront per row moved
-// 2 TB/s, half of what this does); the row's scalars (lse, mask word, <dO, O>) come through the cache.
-// a_h[r][n] = closed(r, n) ? 0 : exp2(s cs - lse[r]) in place over S = q_h K_h^T          grid (R N1 / 1024, B * 8)
-__global__ __launch_bounds__(256) void rows_attn_kernel(float* __restrict__ S, const unsigned long long* __restrict__ mask,
-                                                        const float* __restrict__ lse, int R, long long Rcap, int N1, int W) {
-    const int bh = blockIdx.y, b = bh >> 3, h = bh & 7;
-    const long long total = (long long)R * N1;
-    const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i0 >= total) return;
-    const float cs = 0.25f * 1.4426950408889634f;
-    float* base = S + (size_t)bh * total;                  // 16-byte aligned for every bh when total % 4 == 0; else scalar path
-    int r = (int)(i0 / N1), n = (int)(i0 - (long long)r * N1);
-    const bool vec = !(total & 3) && i0 + 3 < total;
-    float v[4];
-    if (vec) { const float4 t = *reinterpret_cast<const float4*>(base + i0); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-    else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = i0 + e < total ? base[i0 + e] : 0.f;
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (i0 + e < total) {
-            const size_t rrow = (size_t)b * Rcap + r;
-            const unsigned long long w = mask[rrow * W + (n >> 6)];
-            v[e] = ((w >> (n & 63)) & 1ull) ? 0.f : __builtin_amdgcn_exp2f(fmaf(v[e], cs, -lse[rrow * 8 + h]));
-        }
-        if (++n == N1) { n = 0; ++r; }
-    }
-    if (vec) *reinterpret_cast<float4*>(base + i0) = make_float4(v[0], v[1], v[2], v[3]);
-    else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (i0 + e < total) base[i0 + e] = v[e];
-    }
-}
-
 // <dO_h, O_h> per (row, head)                                                              grid (R / 16, B): 16 lanes per row
 __global__ __launch_bounds__(256) void rows_doto_kernel(const float* __restrict__ dO, const float* __restrict__ O,
                                                         float* __restrict__ doto, int R, long long Rdo, long long Rcap) {
@@ -307,35 +270,91 @@ __global__ __launch_bounds__(256) void rows_doto_kernel(const float* __restrict_
     if (!(threadIdx.x & 1)) doto[((size_t)b * R + r) * 8 + (threadIdx.x & 15) / 2] = d;
 }
 
-// d S = a (dA - <dO_h, O_h>) / 4 in place over dA                                          grid (R N1 / 1024, B * 8)
-__global__ __launch_bounds__(256) void rows_ds_kernel(float* __restrict__ dA, const float* __restrict__ Aw,
-                                                      const float* __restrict__ doto, int R, int N1) {
+// The two (rows x nodes) products with a 16-deep contraction -- the glimpse scores S_h = q_h K_h^T and dA_h = dO_h V_h^T -- fused
+// with their element-wise consumers, one pass over the (8, R, N1) buffer each instead of a GEMM + a read-modify-write pass:
+//   SCORE:  a[r][n]  = closed(r, n) ? 0 : exp2(S[r][n] log2(e) / 4 - lse[r])                      (writes a)
+//   !SCORE: dS[r][n] = a[r][n] (dA[r][n] - <dO_h, O_h>[r]) / 4                                     (reads a, writes dS)
+// grid (rows / 64, B * 8), 4 waves x 16 rows; the table operand (K_h or V_h: N1 x 16) is staged once per workgroup in LDS in
+// MFMA-fragment order ([chunk][lane][4]: node 16 c + lo, channels 4 kk + hi); v_mfma_f32_16x16x4_f32 (exact f32 products).
+template <bool SCORE>
+__global__ __launch_bounds__(256) void rows_tile_kernel(const float* __restrict__ X, long long x_rows, const float* __restrict__ Tab,
+                                                        const unsigned long long* __restrict__ mask, const float* __restrict__ lse,
+                                                        const float* __restrict__ doto, const float* __restrict__ Ain,
+                                                        float* __restrict__ Out, int R, long long Rcap, int N1, int W) {
+    extern __shared__ __attribute__((aligned(16))) float sTab[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lo = lane & 15, hi = lane >> 4;
     const int bh = blockIdx.y, b = bh >> 3, h = bh & 7;
-    const long long total = (long long)R * N1;
-    const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i0 >= total) return;
-    float* base = dA + (size_t)bh * total;
-    const float* abase = Aw + (size_t)bh * total;
-    int r = (int)(i0 / N1), n = (int)(i0 - (long long)r * N1);
-    const bool vec = !(total & 3) && i0 + 3 < total;
-    float v[4], a[4];
-    if (vec) {
-        const float4 t = *reinterpret_cast<const float4*>(base + i0), u = *reinterpret_cast<const float4*>(abase + i0);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; a[0] = u.x; a[1] = u.y; a[2] = u.z; a[3] = u.w;
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = i0 + e < total ? base[i0 + e] : 0.f; a[e] = i0 + e < total ? abase[i0 + e] : 0.f; }
+    const int NTc = (N1 + 15) >> 4;
+    for (int i = threadIdx.x; i < NTc * 64; i += 256) {
+        const int c = i >> 6, l = i & 63, n = 16 * c + (l & 15), k = l >> 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < N1) {
+            const float* t = Tab + ((size_t)b * N1 + n) * ELG_E + h * 16 + k;
+            v = make_float4(t[0], t[4], t[8], t[12]);
+        }
+        *reinterpret_cast<float4*>(sTab + (size_t)i * 4) = v;
     }
+    __syncthreads();
+    const int r0 = blockIdx.x * 64 + 16 * wave;
+    if (r0 >= R) return;
+    const int rleft = R - 1 - r0;
+    // A operand: row r0 + lo, channels 4 kk + hi (rows past R clamped: their outputs are not stored)
+    const float* xr = X + ((size_t)b * x_rows + r0 + min(lo, rleft)) * ELG_E + h * 16 + hi;
+    const float xa[4] = {xr[0], xr[4], xr[8], xr[12]};
+    float rs[4];                                   // per D row 4 hi + v: lse (SCORE) or <dO, O> (!SCORE)
+    size_t mrow[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (i0 + e < total) v[e] = 0.25f * a[e] * (v[e] - doto[((size_t)b * R + r) * 8 + h]);
-        if (++n == N1) { n = 0; ++r; }
+    for (int v = 0; v < 4; ++v) {
+        const int rv = r0 + min(4 * hi + v, rleft);
+        mrow[v] = ((size_t)b * Rcap + rv) * W;
+        rs[v] = SCORE ? lse[((size_t)b * Rcap + rv) * 8 + h] : doto[((size_t)b * R + rv) * 8 + h];
     }
-    if (vec) *reinterpret_cast<float4*>(base + i0) = make_float4(v[0], v[1], v[2], v[3]);
-    else {
+    const float cs = 0.25f * 1.4426950408889634f;
+    // 64 nodes (four chunks) at a time through a per-wave LDS tile [16 rows][68]: the D tiles hold a row's nodes 16 apart per
+    // lane, memory wants 64 consecutive floats of a row per wavefront access (rows_tile_kernel moved 1.4 TB/s with 64-byte pieces)
+    float* sSt = sTab + (size_t)NTc * 256 + wave * (16 * 68);
+    for (int g = 0; 64 * g < N1; ++g) {
+        const int nn = 64 * g + lane;                      // this lane's node in the row-wise accesses
+        if (!SCORE) {
+#pragma unroll 4
+            for (int rr = 0; rr < 16; ++rr)
+                sSt[rr * 68 + lane] = (rr <= rleft && nn < N1) ? Ain[((size_t)bh * R + r0 + rr) * N1 + nn] : 0.f;
+            wave_lds_fence();
+        }
+        unsigned long long mw[4] = {0ull, 0ull, 0ull, 0ull};
+        if (SCORE) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (i0 + e < total) base[i0 + e] = v[e];
+            for (int v = 0; v < 4; ++v) mw[v] = mask[mrow[v] + g];
+        }
+        float res[4][4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const int c = 4 * g + cc;
+            f32x4 D = {0.f, 0.f, 0.f, 0.f};
+            if (c < NTc) {
+                const float4 tb = *reinterpret_cast<const float4*>(sTab + ((size_t)c * 64 + lane) * 4);
+                D = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0], tb.x, D, 0, 0, 0);
+                D = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[1], tb.y, D, 0, 0, 0);
+                D = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[2], tb.z, D, 0, 0, 0);
+                D = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[3], tb.w, D, 0, 0, 0);
+            }
+            const int nb_ = 16 * cc + lo;                  // node within the group
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                if (SCORE) res[cc][v] = ((mw[v] >> nb_) & 1ull) ? 0.f : __builtin_amdgcn_exp2f(fmaf(D[v], cs, -rs[v]));
+                else res[cc][v] = 0.25f * sSt[(4 * hi + v) * 68 + nb_] * (D[v] - rs[v]);
+            }
+        }
+        if (!SCORE) wave_lds_fence();                      // every lane has read its weights: the tile is reused for the results
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) sSt[(4 * hi + v) * 68 + 16 * cc + lo] = res[cc][v];
+        wave_lds_fence();
+#pragma unroll 4
+        for (int rr = 0; rr < 16; ++rr)
+            if (rr <= rleft && nn < N1) Out[((size_t)bh * R + r0 + rr) * N1 + nn] = sSt[rr * 68 + lane];
+        wave_lds_fence();
     }
 }
 
@@ -423,20 +442,26 @@ static int decoder_bwd_large(const elg_decoder_bwd_args* p, PtrBwd& a, hipStream
         DB_TRY(gemm_f32_batched_splitk(dl, Ol, p->dPK + tb, N1, ELG_E, (int)Rl, N1, ELG_E, ELG_E, 1, 0, nb, 1, Rcap * N1, 0, Rcap * ELG_E, 0,
                                        (long)N1 * ELG_E, 0, 1.f, sk1, st))
         if (p->tables_frozen) continue;
-        // s_h = q_h K_h^T  -> a_h (in place)
-        DB_TRY(elg_gemm_f32_batched(Ql, p->Kmat + tb, Sbuf, (int)Rl, N1, 16, ELG_E, ELG_E, N1, 0, 1, nb, 8, Rcap * ELG_E, 16,
-                                    (int64_t)N1 * ELG_E, 16, 8 * Rl * N1, Rl * N1, 1.f, st))
-        const unsigned flat_blocks = (unsigned)((Rl * N1 + 1023) / 1024);
-        hipLaunchKernelGGL(rows_attn_kernel, dim3(flat_blocks, nb * 8), dim3(256), 0, s, Sbuf,
+        // a_h = masked softmax weights from q_h K_h^T, the mask words and the saved normaliser (one pass)
+        const size_t tab_lds = ((size_t)((N1 + 15) / 16) * 64 * 4 + 4 * 16 * 68) * sizeof(float);
+        const dim3 tgrid((unsigned)((Rl + 63) / 64), nb * 8);
+        static bool tile_attr = false;
+        if (!tile_attr) {                                  // table (<= 64 KB at 1024 nodes) + the four staging tiles
+            (void)hipGetLastError();
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(rows_tile_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(rows_tile_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+                return fail(ELG_ELAUNCH, "decoder_bwd: hipFuncSetAttribute failed");
+            tile_attr = true;
+        }
+        hipLaunchKernelGGL((rows_tile_kernel<true>), tgrid, dim3(256), tab_lds, s, Ql, Rcap, p->Kmat + tb,
                            reinterpret_cast<const unsigned long long*>(p->trMask) + ((size_t)b0 * Rcap + r_lo) * W,
-                           p->trLse + ((size_t)b0 * Rcap + r_lo) * 8, (int)Rl, Rcap, N1, W);
-        DB_TRY(launch_status("rows_attn"))
-        // dA_h = dO_h V_h^T -> dS_h (in place)
-        DB_TRY(elg_gemm_f32_batched(dOl, p->Vmat + tb, Dbuf, (int)Rl, N1, 16, ELG_E, ELG_E, N1, 0, 1, nb, 8, R * ELG_E, 16,
-                                    (int64_t)N1 * ELG_E, 16, 8 * Rl * N1, Rl * N1, 1.f, st))
+                           p->trLse + ((size_t)b0 * Rcap + r_lo) * 8, nullptr, nullptr, Sbuf, (int)Rl, Rcap, N1, W);
+        DB_TRY(launch_status("rows_tile<score>"))
+        // dS_h = a_h (dO_h V_h^T - <dO_h, O_h>) / 4 (one pass; <dO, O> per (row, head) first, in the place of dQ)
         hipLaunchKernelGGL(rows_doto_kernel, dim3((unsigned)((Rl + 15) / 16), nb), dim3(256), 0, s, dOl, Ol, dQr, (int)Rl, R, Rcap);
-        hipLaunchKernelGGL(rows_ds_kernel, dim3(flat_blocks, nb * 8), dim3(256), 0, s, Dbuf, Sbuf, dQr, (int)Rl, N1);
-        DB_TRY(launch_status("rows_ds"))
+        hipLaunchKernelGGL((rows_tile_kernel<false>), tgrid, dim3(256), tab_lds, s, dOl, R, p->Vmat + tb, nullptr, nullptr, dQr, Sbuf,
+                           Dbuf, (int)Rl, Rcap, N1, W);
+        DB_TRY(launch_status("rows_tile<dscore>"))
         // d q_h = dS_h K_h ;  d K_h = dS_h^T q_h ;  d V_h = a_h^T dO_h
         DB_TRY(elg_gemm_f32_batched(Dbuf, p->Kmat + tb, dQr, (int)Rl, 16, N1, N1, ELG_E, ELG_E, 0, 0, nb, 8, 8 * Rl * N1, Rl * N1,
                                     (int64_t)N1 * ELG_E, 16, Rl * ELG_E, 16, 1.f, st))
