@@ -401,13 +401,15 @@ typedef struct elg_decoder_bwd_args {
     int32_t tables_frozen;      /* 1: the decoder tables carry no gradient (`training: only_local`, CVRPModel.py:78-131: they
                                  * are zeros): only the softmax / pointer pass runs (it produces rowDU for the local policy);
                                  * dK, dV, dQ1, dQ2, dwl are left untouched                                            */
-    /* 128 < N1 <= 1024 (rows saved by the streaming rollout kernel; T_dev must be NULL): the row contractions run as batched
-     * f32 MFMA GEMMs (elg_gemm_f32_batched) around three small row kernels; trPC is overwritten with d s (in place). */
+    /* 128 < N1 <= 1024 (rows saved by the streaming rollout kernel; T_dev must be NULL): the glimpse weights and their
+     * cotangents are formed by two tile kernels (f32 MFMA) into the scratch below, the remaining row contractions run as batched
+     * f32 MFMA GEMMs (the reductions over the rows accumulate with f32 atomics: dK, dV, dPK must be zeroed, as for N1 <= 128);
+     * trPC is overwritten with d s (in place). */
     int32_t mask_words;         /* W of trMask for N1 > 128 (ignored otherwise)                                        */
     int32_t mfma_mode;          /* N1 <= 128, mask-row mode: arithmetic of the glimpse backward's five products.  0: f32 MFMAs
                                  * (v_mfma_f32_16x16x4_f32, exact f32; 1.1e-6 of the largest gradient entry against float64).
                                  * Split-bf16 (v_mfma_f32_16x16x32_bf16 on bf16 terms of the f32 operands, f32 accumulation):
-                                 * 1 = 2 terms per operand (16 significand bits; 1.5e-5), 2 = 3-term score product q K^T +
+                                 * 1 = 2 terms per operand (16 significand bits; 3e-5), 2 = 3-term score product q K^T +
                                  * 2-term linear products (7.5e-6)                                                        */
     float* ws;                  /* scratch for N1 > 128 (NULL otherwise): k * elg_decoder_bwd_ws_floats(1, R, N1) floats,
                                  * 1 <= k <= B -- the batch is walked in chunks of k instances                          */
