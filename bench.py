@@ -57,8 +57,11 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(cfg, mean_T, budget_s=150.0):
-    """The oracle (CPU restatement of the reference: torch eager, autograd tape -- test infrastructure, used here only as the
+def cpu_baseline(cfg, mean_T, state0, replay, budget_s=150.0):
+    """`state0`: the GPU leg's initial state_dict (CPU copy taken before its first step); `replay`: the first batches the
+    GPU leg drew from generate_vrp_data after seed_everything(config seed) -- the CPU leg starts from the same weights and
+    trains on the same instances ("same seeds and configs").
+    The oracle (CPU restatement of the reference: torch eager, autograd tape -- test infrastructure, used here only as the
     reported baseline) on this box's host cores.  Two legs:
     (a) thread sweep on a bounded sample at batch 16, pomo 100: encoder + set_kv forward and backward and S teacher-forced
         decode steps forward and backward through the tape, for torch thread counts {1, 8, 16, 32 (, all if <= 64)}, after one
@@ -68,19 +71,19 @@ def cpu_baseline(cfg, mean_T, budget_s=150.0):
         metric's own batch 64, pomo 100, at the best thread count of (a): one warm-up step + three timed steps, mean.
     `value` is (b) when it fits the time budget, else the estimate of (a) (and `sample` says which)."""
     from oracle import elg_oracle as orc
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import golden_util as gu
     Bc, S = 16, 8
     torch.manual_seed(0)
     mp = cfg["model_params"]
     ocfg = orc.ModelCfg.from_model_params(mp, "cvrp")
-    P = {k: torch.from_numpy(v).requires_grad_(True) for k, v in gu.golden_weights("cvrp", 1, mp, True).items()}
+    P = {k: v.detach().clone().float().requires_grad_(True) for k, v in state0.items()}
 
-    def problem(B):
-        xy = torch.rand(B, N_NODES + 1, 2)
-        dem = torch.cat([torch.zeros(B, 1), torch.randint(1, 10, (B, N_NODES)).float() / 50.0], 1)
+    def problem(i, B):
+        """first B instances of the GPU leg's i-th batch, in the oracle's layout (depot first, zero depot demand)"""
+        bt = replay[i % len(replay)]
+        xy = torch.cat([bt["depot"][:B].reshape(B, 1, 2), bt["loc"][:B]], 1).float()
+        dem = torch.cat([torch.zeros(B, 1), bt["demand"][:B].float()], 1)
         return xy, dem
-    xy, dem = problem(Bc)
+    xy, dem = problem(0, Bc)
     starts = torch.randperm(N_NODES)[:POMO]
     # a fixed prefix of sampled actions to teacher-force (drawn once, untimed)
     with torch.no_grad():
@@ -127,7 +130,7 @@ def cpu_baseline(cfg, mean_T, budget_s=150.0):
         opt = torch.optim.Adam(list(P.values()), lr=1e-4, weight_decay=1e-6)
         times, T_seen = [], []
         for it in range(1 + n_timed):
-            xyb, demb = problem(LOCAL_BATCH)
+            xyb, demb = problem(it, LOCAL_BATCH)
             t0 = time.perf_counter()
             uni = torch.rand(LOCAL_BATCH, POMO, 2 * (N_NODES + 1))
             out = orc.rollout_cvrp(P, ocfg, xyb, demb, POMO, starts=torch.randperm(N_NODES)[:POMO], mode="sample", uniforms=uni)
@@ -148,6 +151,7 @@ def cpu_baseline(cfg, mean_T, budget_s=150.0):
             "sampled_estimate": sweep[best]["inst_per_s"],
             "value_1thread": sweep.get(1, {}).get("inst_per_s"), "cpu_model": _cpu_model(), "host_cpus": ncpu,
             "thread_sweep": sweep,
+            "weights": "the GPU leg's initial state_dict", "inputs": f"the GPU leg's first {len(replay)} batches (same generator seed)",
             "sample": f"oracle/elg_oracle.py, CVRP-100 fp32. {what}; thread sweep at batch={Bc}: encoder+set_kv fwd+bwd and {S} "
                       f"teacher-forced decode steps fwd+bwd per thread count (1 warm-up), estimate = {Bc} / (t_encoder + "
                       f"{mean_T:.1f} * t_decode_step); the reference's own full step measured 0.57 inst/s on 8 cores of the "
@@ -228,13 +232,48 @@ def secondary_workloads(dev):
     return out
 
 
+MODE_NAMES = {0: "f32 (v_mfma_f32_16x16x4_f32, exact f32 products)", 1: "split-bf16, 2 terms",
+              2: "split-bf16, 3-term scores + 2-term linear products"}
+
+
+def _sha256(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def measured_traffic(digest):
+    """HBM bytes per launch of the rollout kernel from the PMC passes (tools/measure_traffic.sh -> profiles/roofline_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs over THIS bench.py, gfx950 correction of the guide).  The record
+    carries the decode steps of the run it was measured on and the digest of the kernel sources it was measured with; it is
+    reported only when that digest is the one of the library loaded now (else null: a stale number is not a measurement)."""
+    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    if not os.path.exists(tpath):
+        return None
+    with open(tpath) as f:
+        rec = json.load(f)
+    if rec.get("source_digest") != digest or "decode_steps_mean" not in rec:
+        return None
+    steps = float(rec["decode_steps_mean"])
+    alg = algorithmic_bytes_per_decode_step(LOCAL_BATCH, POMO, N_NODES + 1) * steps
+    return {"hbm_bytes_per_launch": int(rec["hbm_bytes_per_launch"]), "decode_steps": round(steps, 2),
+            "fetch_bytes_x2": int(rec["fetch_bytes_x2"]), "write_bytes": int(rec["write_bytes"]),
+            "algorithmic_bytes_at_these_steps": int(alg), "over_algorithmic": round(rec["hbm_bytes_per_launch"] / alg, 3),
+            "source_digest": digest[:16], "launches": rec.get("launches"), "source": "profiles/roofline_traffic.json"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)      # ~2 s of GPU work: long enough for an outside sampler to see it
+    ap.add_argument("--steps", type=int, default=300)      # ~2 s of GPU work
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the TSP-500 / VRPLIB X-n1001 secondary timings")
+    ap.add_argument("--no-fast", action="store_true", help="skip the split-bf16 backward leg (value_fast)")
+    ap.add_argument("--sustain-s", type=float, default=10.0, help="length of the sustained leg in seconds (0: skip)")
     args = ap.parse_args()
 
     from elg_amd import parallel
@@ -246,7 +285,7 @@ def main():
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
 
-    from elg_amd import engine as eng
+    from elg_amd import _lib, build as elg_build, engine as eng
     from elg_amd.CVRP.CVRPEnv import CVRPEnv
     from elg_amd.CVRP.CVRPModel import CVRPModel
     from elg_amd.CVRP.generate_data import generate_vrp_data
@@ -259,6 +298,7 @@ def main():
     model.decoder.add_local_policy(dev)            # steady-state regime of joint training (after step T)
     model.to(dev)
     parallel.broadcast_parameters(model)
+    state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}     # the CPU baseline starts here too
     env = CVRPEnv(multi_width=POMO, device=dev)
     from elg_amd.optim import Adam
     opt = Adam(model.parameters(), lr=cfg["params"]["learning_rate"], weight_decay=1e-6)
@@ -279,39 +319,90 @@ def main():
         return res
     eng.rollout_forward = timed_fwd
 
+    # ... and the gradient all-reduce (events around GradBucket._reduce on the same stream: ProcessGroupNCCL makes the
+    # current stream wait for the collective before the call returns control to the stream)
+    ar_events = []
+    if bucket is not None:
+        orig_reduce = bucket._reduce
+
+        def timed_reduce():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig_reduce()
+            e1.record()
+            ar_events.append((e0, e1))
+        bucket._reduce = timed_reduce
+
+    replay = []                                   # the first batches of the run, for the CPU baseline
+
     def one_step():
         batch = generate_vrp_data(LOCAL_BATCH, N_NODES, dist_cfg)
+        if len(replay) < 4:
+            replay.append({k: v.clone() for k, v in batch.items()})
         model.train()
         return train_step(model, env, opt, batch, cfg["params"]["scale_norm"], bucket, world, check=True)
 
-    for _ in range(args.warmup):
-        one_step()
-    fwd_events.clear()
-    fwd_steps.clear()
-    parallel.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    parallel.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if parallel.active():
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    dt = float(tmax.item())
+    def timed_leg(n_warm, n_steps):
+        """W untimed steps, then exactly K steps between barrier + synchronize; -> (max over ranks, this rank's own) seconds"""
+        for _ in range(n_warm):
+            one_step()
+        fwd_events.clear()
+        fwd_steps.clear()
+        ar_events.clear()
+        parallel.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            one_step()
+        parallel.barrier()
+        torch.cuda.synchronize()
+        own = time.perf_counter() - t0
+        tmax = torch.tensor([own], device=dev, dtype=torch.float64)
+        if parallel.active():
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        return float(tmax.item()), own
+
+    def per_rank(vals):
+        """(world, len(vals)) list: every rank's numbers on every rank"""
+        t = torch.tensor([vals], device=dev, dtype=torch.float64)
+        if parallel.active() and world > 1:
+            out = [torch.zeros_like(t) for _ in range(world)]
+            torch.distributed.all_gather(out, t)
+            t = torch.cat(out, 0)
+        return t.cpu().tolist()
+
+    # ---- headline leg: every product of the step in f32 (ELG_BWD_MFMA_MODE=0 semantics, whatever the environment says)
+    eng.BWD_MFMA_MODE = 0
+    dt, dt_own = timed_leg(args.warmup, args.steps)
+    kern_ms = sum(a.elapsed_time(b) for a, b in fwd_events) / len(fwd_events)
+    mean_T = float(torch.stack([t.float().mean() for t in fwd_steps]).mean().item())
+    max_T = float(torch.stack([t.float().max() for t in fwd_steps]).mean().item())
+    ar_ms = (sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events)) if ar_events else 0.0
+    ranks = per_rank([dt_own / args.steps * 1e3, mean_T, max_T, ar_ms, kern_ms])
     ranks_seen = parallel.ranks_seen()          # world size as the collectives see it (an all-reduce of ones)
 
+    # ---- fast leg: the same step with the glimpse backward on split-bf16 MFMAs (engine.BWD_MFMA_MODE = 2)
+    fast = None
+    if not args.no_fast:
+        eng.BWD_MFMA_MODE = 2
+        dtf, _ = timed_leg(3, args.steps)
+        fast = {"value": round(LOCAL_BATCH * world * args.steps / dtf, 2), "ms_per_step": round(dtf / args.steps * 1e3, 3),
+                "mode": "glimpse backward: " + MODE_NAMES[2] + " on v_mfma_f32_16x16x32_bf16, f32 accumulation; everything else f32"}
+        eng.BWD_MFMA_MODE = 0
+
+    # ---- sustained leg (f32 again): >= sustain-s seconds of back-to-back steps, so that an outside utilisation sampler sees
+    # the GPU busy and the rate is not a 0.1 s sample; the step count is fixed from the headline leg (same on every rank)
+    sustained = None
+    if args.sustain_s > 0:
+        n_sus = max(args.steps, int(args.sustain_s / (dt / args.steps)) + 1)
+        dts, _ = timed_leg(0, n_sus)
+        sustained = {"value": round(LOCAL_BATCH * world * n_sus / dts, 2), "ms_per_step": round(dts / n_sus * 1e3, 3),
+                     "steps": n_sus, "seconds": round(dts, 2), "dtype": "f32"}
+
     if rank == 0:
-        kern_ms = sum(a.elapsed_time(b) for a, b in fwd_events) / len(fwd_events)
-        mean_T = float(torch.stack([t.float().mean() for t in fwd_steps]).mean().item())
-        max_T = float(torch.stack([t.float().max() for t in fwd_steps]).mean().item())
-        bytes_launch = algorithmic_bytes_per_decode_step(LOCAL_BATCH, POMO, N_NODES + 1) * mean_T
-        traffic = None                       # measured HBM bytes per launch (PMC passes, see profiles/)
-        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+        digest = elg_build._digest()
+        bytes_step = algorithmic_bytes_per_decode_step(LOCAL_BATCH, POMO, N_NODES + 1)
+        bytes_launch = bytes_step * mean_T
         achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
         traj_steps = LOCAL_BATCH * POMO * mean_T                # decode steps of one launch (per rank)
         tf_folded = FLOPS_PER_TRAJ_STEP_FOLDED * traj_steps / (kern_ms * 1e-3) / 1e12
@@ -323,33 +414,48 @@ def main():
             "config": {"workload": "CVRP-100 batch=64/GPU pomo=100 joint (local policy on), BASELINE configs[1]",
                        "global_batch": LOCAL_BATCH * world, "pomo": POMO, "problem_size": N_NODES,
                        "parallelism": f"dp{world}", "n_ranks_seen": ranks_seen,
-                       # every product of the step is f32 (f32 MFMA / VALU) except, at mode > 0, the five products of the glimpse
-                       # backward kernel: bf16 terms of the f32 operands on v_mfma_f32_16x16x32_bf16, f32 accumulation
-                       "glimpse_bwd_mfma_mode": {0: "f32", 1: "split-bf16, 2 terms",
-                                                 2: "split-bf16, 3-term scores + 2-term linear products"}[eng.BWD_MFMA_MODE],
+                       "arithmetic": "every product of the timed step is f32 (f32 MFMA / VALU): glimpse_bwd_mfma_mode 0",
+                       "library": os.path.relpath(_lib.LIB_PATH, ROOT), "library_sha256": _sha256(_lib.LIB_PATH),
+                       "source_digest": digest[:16],
+                       "library_is_built_from_these_sources": (os.path.exists(_lib.LIB_PATH + ".sha")
+                                                               and open(_lib.LIB_PATH + ".sha").read().strip() == digest),
                        "grad_allreduce": (None if bucket is None else
                                           {"backend": torch.distributed.get_backend(), "calls": bucket.calls,
-                                           "elements": bucket.numel})},
+                                           "elements": bucket.numel, "allreduce_ms": round(ar_ms, 4),
+                                           "share_of_step": round(ar_ms / (dt / args.steps * 1e3), 5)}),
+                       # one entry per rank: the N > 1 record explains itself (step-time jitter = different tour lengths)
+                       "per_rank": {"ms_per_step": [round(r[0], 3) for r in ranks],
+                                    "ms_per_step_min": round(min(r[0] for r in ranks), 3),
+                                    "ms_per_step_max": round(max(r[0] for r in ranks), 3),
+                                    "decode_steps_mean": [round(r[1], 2) for r in ranks],
+                                    "decode_steps_max": [round(r[2], 2) for r in ranks],
+                                    "allreduce_ms": [round(r[3], 4) for r in ranks],
+                                    "rollout_launch_ms": [round(r[4], 4) for r in ranks]}},
+            # The decode step is bound by vector-instruction issue + dependent-issue latency, not by HBM (SURVEY 8(d):
+            # ~200 FLOP/B, the tables live in registers / LDS / L2): the top-level fraction is against the f32 ceiling by the
+            # EXECUTED flop count; the HBM figure north_star asks for is nested.
             "roofline": {"kernel": "rollout_fwd_coop_kernel (persistent decode: all steps of all trajectories)",
-                         "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(bytes_launch),
+                         "bound": "fp32-issue", "achieved": round(tf_folded, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tf_folded / FP32_PEAK_TFLOPS, 4),
+                         "flops_per_launch_executed": int(FLOPS_PER_TRAJ_STEP_FOLDED * traj_steps),
                          "launch_ms": round(kern_ms, 4), "decode_steps_mean": round(mean_T, 2),
                          "decode_steps_max": round(max_T, 2),
-                         "algorithmic_MB_per_decode_step": round(algorithmic_bytes_per_decode_step(
-                             LOCAL_BATCH, POMO, N_NODES + 1) / 1e6, 3),
-                         # the decode step is ALU / latency bound, not HBM bound -- both ceilings are reported
-                         "fp32": {"bound": "fp32", "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "flops_per_launch_executed": int(FLOPS_PER_TRAJ_STEP_FOLDED * traj_steps),
-                                  "achieved": round(tf_folded, 2), "frac": round(tf_folded / FP32_PEAK_TFLOPS, 4),
-                                  "note": "executed (folded) count: 3 x 25.9 K glimpse / pointer + ~9 K folded local policy per "
-                                          "trajectory-step; SURVEY 8(d)'s unfolded count (0.335 MFLOP, of which 177 K is local-policy "
-                                          "arithmetic the fold removes) is NOT an achieved rate and is not reported"}},
+                         "note": "executed (folded) count: 3 x 25.9 K glimpse / pointer + ~9 K folded local policy per "
+                                 "trajectory-step; SURVEY 8(d)'s unfolded count (0.335 MFLOP) is not an achieved rate",
+                         "hbm": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(achieved / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": int(bytes_launch),
+                                 "algorithmic_MB_per_decode_step": round(bytes_step / 1e6, 3)},
+                         "traffic": measured_traffic(digest)},
         }
+        if fast is not None:
+            out["value_fast"] = fast["value"]
+            out["fast"] = fast
+        if sustained is not None:
+            out["sustained"] = sustained
         if not args.no_secondary and world == 1:
             out["secondary"] = secondary_workloads(dev)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, mean_T)
+            out["cpu_baseline"] = cpu_baseline(cfg, mean_T, state0, replay)
         print(json.dumps(out), flush=True)
     parallel.barrier()
 

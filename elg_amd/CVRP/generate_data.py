@@ -110,3 +110,54 @@ def save_dataset(dataset, filename):
         filename += '.pkl'
     with open(filename, 'wb') as f:
         pickle.dump(dataset, f, pickle.HIGHEST_PROTOCOL)
+
+
+def dataset_tuples(dataset):
+    """The reference's list-of-tuples file format (CVRP/data/vrp_uniform100_1000_seed1234.pkl: (depot [2], loc [N][2],
+    integer demand [N], capacity)) -- what VRPDataset(filename) reads here and in the reference (make_instance)."""
+    out = []
+    for inst in dataset.data:
+        n = int(inst['loc'].shape[0])
+        cap = CAPACITIES[n]
+        out.append((inst['depot'].reshape(2).tolist(), inst['loc'].tolist(),
+                    [int(round(float(d) * cap)) for d in inst['demand']], cap))
+    return out
+
+
+def main(argv=None):
+    """`python generate_data.py`: the dataset writer of the reference's __main__ block (generate_data.py:173-197) -- by default
+    its run (seed 1234; 1000 / 1000 / 100 validation instances of size 100 / 200 / 500 -> data/vrp{N}_val.pkl); sizes, counts,
+    distribution and file format are options instead of edits to the script."""
+    import argparse
+    from elg_amd.CVRP.utils import seed_everything
+    ap = argparse.ArgumentParser(description=main.__doc__)
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--problem-size", type=int, nargs="+", default=[100, 200, 500])
+    ap.add_argument("--data-size", type=int, nargs="+", default=[1000, 1000, 100])
+    ap.add_argument("--data-type", choices=["uniform", "cluster", "mixed"], default="uniform")
+    ap.add_argument("--kind", choices=["val", "test"], default="val",
+                    help="val: data/vrp{N}_val.pkl; test: data/vrp_{type}{N}_test.pkl (the reference's two name patterns)")
+    ap.add_argument("--format", choices=["object", "tuples"], default="object",
+                    help="object: the pickled VRPDataset the reference's __main__ writes; tuples: its list-of-tuples format")
+    ap.add_argument("--out-dir", default="data")
+    a = ap.parse_args(argv)
+    if len(a.problem_size) != len(a.data_size):
+        ap.error("--problem-size and --data-size need the same number of entries")
+    seed_everything(a.seed)
+    dist = {"data_type": a.data_type, "n_cluster": 3, "n_cluster_mix": 1, "lower": 0.2, "upper": 0.8, "std": 0.07}
+    written = []
+    for n, count in zip(a.problem_size, a.data_size):
+        name = f"vrp{n}_val.pkl" if a.kind == "val" else f"vrp_{a.data_type}{n}_test.pkl"
+        ds = VRPDataset(num_samples=count, size=n, distribution=dist)
+        path = os.path.join(a.out_dir, name)
+        save_dataset(ds if a.format == "object" else dataset_tuples(ds), path)
+        written.append(path)
+        print(f"{path}: {count} instances of size {n} ({a.data_type})")
+    return written
+
+
+if __name__ == "__main__":
+    import sys
+    if __package__ in (None, ""):                  # `cd elg_amd/CVRP && python generate_data.py`, as the reference is run
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    main()

@@ -37,7 +37,11 @@ class local_policy_att(nn.Module):
         self.Wv = nn.Linear(self.emb_dim, hd, bias=False)
         self.multi_head_combine = nn.Linear(hd, self.emb_dim)
         if (self.emb_dim, self.head_num, self.qkv_dim) != (eng.LE, eng.LH, eng.LDK):
-            raise NotImplementedError("HIP kernels are built for local_att 32/4/8")
+            raise ValueError(f"local_att_hidden_dim / local_att_head_num / local_att_qkv_dim = {(self.emb_dim, self.head_num, self.qkv_dim)}: "
+                             f"libelg_hip.so is built for {(eng.LE, eng.LH, eng.LDK)} only (the reference's config.yml:47-49)")
+        if not 1 <= int(self.local_size) <= L.MAX_LOCAL_SIZE:
+            raise ValueError(f"local_size {self.local_size}: the kernels hold the k nearest neighbours (+ the depot) in "
+                             f"{L.MAX_LOCAL_SIZE + 1} slots -- supported 1 .. {L.MAX_LOCAL_SIZE} (the reference's default: 40 / 30)")
 
     def folded_tables(self, n_slots: int) -> torch.Tensor:
         lp = {k: v for k, v in self.named_parameters()}
@@ -106,7 +110,8 @@ class CVRP_Decoder(nn.Module):
         self.model_params = model_params
         e, h, d = model_params['embedding_dim'], model_params['head_num'], model_params['qkv_dim']
         if (e, h, d) != (eng.E, eng.H, eng.DK):
-            raise NotImplementedError("HIP kernels are built for embedding 128, 8 heads x 16")
+            raise ValueError(f"embedding_dim / head_num / qkv_dim = {(e, h, d)}: libelg_hip.so is built for "
+                             f"{(eng.E, eng.H, eng.DK)} only (the reference's config.yml:41-44)")
         self.Wq_last = nn.Linear(e + 1, h * d, bias=False)
         self.Wk = nn.Linear(e, h * d, bias=False)
         self.Wv = nn.Linear(e, h * d, bias=False)
@@ -117,7 +122,7 @@ class CVRP_Decoder(nn.Module):
     def add_local_policy(self, device):
         n = int(self.model_params['ensemble_size'])
         if not 1 <= n <= L.MAX_ENS:
-            raise NotImplementedError(f"ensemble_size {n}: the HIP kernels are built for 1 .. {L.MAX_ENS} local policies")
+            raise ValueError(f"ensemble_size {n}: supported 1 .. {L.MAX_ENS} local policies (the reference's default: 1)")
         if len(self.model_params['local_size']) < n:
             raise IndexError("model_params['local_size'] needs one entry per ensemble member (reference models.py:14)")
         self.local_policies = nn.ModuleList([local_policy_att(self.model_params, idx=i).to(device) for i in range(n)])

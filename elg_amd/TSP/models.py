@@ -50,7 +50,8 @@ class TSP_Decoder(nn.Module):
         self.model_params = model_params
         e, h, d = model_params['embedding_dim'], model_params['head_num'], model_params['qkv_dim']
         if (e, h, d) != (eng.E, eng.H, eng.DK):
-            raise NotImplementedError("HIP kernels are built for embedding 128, 8 heads x 16")
+            raise ValueError(f"embedding_dim / head_num / qkv_dim = {(e, h, d)}: libelg_hip.so is built for "
+                             f"{(eng.E, eng.H, eng.DK)} only (the reference's config.yml)")
         self.Wq_first = nn.Linear(e, h * d, bias=False)
         self.Wq_last = nn.Linear(e, h * d, bias=False)
         self.Wk = nn.Linear(e, h * d, bias=False)

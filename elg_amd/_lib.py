@@ -18,6 +18,7 @@ LOC_LA, LOC_LT, LOC_LAV, LOC_LCV, LOC_LWC, LOC_LBC, LOC_LWE, LOC_LPE, LOC_SIZE =
     0, 16, 272, 368, 2416, 3440, 3472, 3568, 5616
 
 MAX_ENS = 4
+MAX_LOCAL_SIZE = 47             # ELG_SLOT_STRIDE - 1 (csrc/elg_rollout.h): k nearest neighbours + the depot slot
 _vp = C.c_void_p
 
 

@@ -530,13 +530,8 @@ static int launch_bwd_impl(const elg_bwd_args& BA, hipStream_t stream) {
     if (LDSK) lds += (size_t)((2 * A.N1 + 3) & ~3) * 4;
     if (lds > 163840) return fail(ELG_EINVAL, "rollout_bwd: LDS budget exceeded");
     auto kern = rollout_bwd_kernel<NCH, TSP, LDSK, WAVES, SMALL>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                163840) != hipSuccess)
-            return fail(ELG_ELAUNCH, "hipFuncSetAttribute failed");
-        attr_done = true;
-    }
+    static DynLds optin;
+    if (!optin.opt_in(reinterpret_cast<const void*>(kern), 163840)) return fail(ELG_ELAUNCH, "hipFuncSetAttribute failed");
     if (!BA.local_only) {
         (void)hipGetLastError();
         hipLaunchKernelGGL(kern, dim3(A.B * A.tiles), dim3(WAVES * 64), lds, stream, BA);
@@ -546,13 +541,8 @@ static int launch_bwd_impl(const elg_bwd_args& BA, hipStream_t stream) {
         constexpr int LW = 8;
         size_t l2 = (size_t)((A.N1 + 3) & ~3) * 4 + 16 + (size_t)ELG_LOC_SIZE * 4 + (size_t)LW * SbSize<NCH>::value * 4;
         auto k2 = local_bwd_kernel<NCH, TSP, LW>;
-        static bool attr2 = false;
-        if (!attr2) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    163840) != hipSuccess)
-                return fail(ELG_ELAUNCH, "hipFuncSetAttribute failed");
-            attr2 = true;
-        }
+        static DynLds optin2;
+        if (!optin2.opt_in(reinterpret_cast<const void*>(k2), 163840)) return fail(ELG_ELAUNCH, "hipFuncSetAttribute failed");
         elg_bwd_args BM = BA;          // one replay launch per ensemble member (register-resident table gradients)
         for (int i = 0; i < (A.ens > 1 ? A.ens : 1); ++i) {
             BM.member = i;
@@ -1286,13 +1276,8 @@ static int launch_glimpse_bwd_bf16(const unsigned long long* rowMask, const floa
     constexpr int NP2 = TS >= 3 ? 3 : 2;
     const size_t lds = (size_t)((3 + NP2) * NT * 256 + 4 * 2 * 320 + 16 * (16 * NT + 9)) * sizeof(float);
     auto kern = glimpse_bwd_bf16_kernel<NT, TS>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipGetLastError();
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return fail(ELG_ELAUNCH, "glimpse_bwd (split-bf16): hipFuncSetAttribute failed");
-        attr_done = true;
-    }
+    static DynLds optin;
+    if (!optin.opt_in(reinterpret_cast<const void*>(kern), lds)) return fail(ELG_ELAUNCH, "glimpse_bwd (split-bf16): hipFuncSetAttribute failed");
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3(splits, B * 8), dim3(256), lds, stream, rowMask, dO, rowO, rowQ, Kmat, Vmat, dKp, dVp, B, R, N1,
                        ro, rq, splits, seg);
@@ -1306,14 +1291,9 @@ static int launch_glimpse_bwd_mfma_t(const float* rowA, const unsigned long long
                                    const GlimpseSeg& seg, hipStream_t stream) {
     const size_t lds = (size_t)(NT * 256 + 2 * 2 * NT * 256 + 4 * 2 * 320 + (RECOMP ? NT * 256 : 0)) * sizeof(float);
     auto kern = glimpse_bwd_mfma_kernel<NT, RECOMP, SEG>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipGetLastError();
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)((NT * 256 * 10 + 4 * 2 * 320 + (32 * NT + 1) * 16) * sizeof(float))) != hipSuccess)
-            return fail(ELG_ELAUNCH, "glimpse_bwd_fused: hipFuncSetAttribute failed");
-        attr_done = true;
-    }
+    static DynLds optin;
+    if (!optin.opt_in(reinterpret_cast<const void*>(kern), (NT * 256 * 10 + 4 * 2 * 320 + (32 * NT + 1) * 16) * sizeof(float)))
+        return fail(ELG_ELAUNCH, "glimpse_bwd_fused: hipFuncSetAttribute failed");
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3(splits, B * 8), dim3(256), lds, stream, rowA, rowMask, dO, rowO, rowQ, Kmat, Vmat, dQ,
                        dKp, dVp, B, R, N1, ra, ro, rq, splits, seg);

@@ -14,6 +14,27 @@
 
 #define ELG_NEG_INF (-__builtin_huge_valf())
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: the opt-in is remembered per (kernel
+// instantiation, device) -- one `static elg::DynLds` per launch site.  Racing host threads at worst set it twice.
+#include <atomic>
+namespace elg {
+struct DynLds {
+    static constexpr int MAXDEV = 32;
+    std::atomic<size_t> bytes[MAXDEV] = {};
+    // true when the kernel may be launched with `want` bytes of dynamic LDS on the current device
+    bool opt_in(const void* kern, size_t want) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        const bool tracked = dev >= 0 && dev < MAXDEV;
+        if (tracked && bytes[dev].load(std::memory_order_relaxed) >= want) return true;
+        (void)hipGetLastError();
+        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) != hipSuccess) return false;
+        if (tracked) bytes[dev].store(want, std::memory_order_relaxed);
+        return true;
+    }
+};
+}  // namespace elg
+
 namespace elg {
 
 __device__ __forceinline__ int f2i(float v) { return __builtin_bit_cast(int, v); }

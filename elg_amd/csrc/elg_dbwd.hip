@@ -280,7 +280,8 @@ template <bool SCORE>
 __global__ __launch_bounds__(256) void rows_tile_kernel(const float* __restrict__ X, long long x_rows, const float* __restrict__ Tab,
                                                         const unsigned long long* __restrict__ mask, const float* __restrict__ lse,
                                                         const float* __restrict__ doto, const float* __restrict__ Ain,
-                                                        float* __restrict__ Out, int R, long long Rcap, int N1, int W) {
+                                                        float* __restrict__ Out, int R, long long Rcap, int N1, int W,
+                                                        const float4* __restrict__ rowW, long long w_rows) {
     extern __shared__ __attribute__((aligned(16))) float sTab[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lo = lane & 15, hi = lane >> 4;
     const int bh = blockIdx.y, b = bh >> 3, h = bh & 7;
@@ -303,11 +304,15 @@ __global__ __launch_bounds__(256) void rows_tile_kernel(const float* __restrict_
     const float xa[4] = {xr[0], xr[4], xr[8], xr[12]};
     float rs[4];                                   // per D row 4 hi + v: lse (SCORE) or <dO, O> (!SCORE)
     size_t mrow[4];
+    bool dead[4];                                  // rows the rollout did not decode at this step (weight exactly 0): the forward wrote
+                                                   // neither q, lse nor the mask words for them -- whatever an earlier batch left there
+                                                   // must not reach exp2 (an overflow would turn 0 * inf into NaN downstream): a = 0
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         const int rv = r0 + min(4 * hi + v, rleft);
         mrow[v] = ((size_t)b * Rcap + rv) * W;
         rs[v] = SCORE ? lse[((size_t)b * Rcap + rv) * 8 + h] : doto[((size_t)b * R + rv) * 8 + h];
+        dead[v] = SCORE && rowW && rowW[(size_t)b * w_rows + rv].x == 0.f;
     }
     const float cs = 0.25f * 1.4426950408889634f;
     // 64 nodes (four chunks) at a time through a per-wave LDS tile [16 rows][68]: the D tiles hold a row's nodes 16 apart per
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(256) void rows_tile_kernel(const float* __restrict_
             const int nb_ = 16 * cc + lo;                  // node within the group
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                if (SCORE) res[cc][v] = ((mw[v] >> nb_) & 1ull) ? 0.f : __builtin_amdgcn_exp2f(fmaf(D[v], cs, -rs[v]));
+                if (SCORE) res[cc][v] = (dead[v] || ((mw[v] >> nb_) & 1ull)) ? 0.f : __builtin_amdgcn_exp2f(fmaf(D[v], cs, -rs[v]));
                 else res[cc][v] = 0.25f * sSt[(4 * hi + v) * 68 + nb_] * (D[v] - rs[v]);
             }
         }
@@ -445,22 +450,19 @@ static int decoder_bwd_large(const elg_decoder_bwd_args* p, PtrBwd& a, hipStream
         // a_h = masked softmax weights from q_h K_h^T, the mask words and the saved normaliser (one pass)
         const size_t tab_lds = ((size_t)((N1 + 15) / 16) * 64 * 4 + 4 * 16 * 68) * sizeof(float);
         const dim3 tgrid((unsigned)((Rl + 63) / 64), nb * 8);
-        static bool tile_attr = false;
-        if (!tile_attr) {                                  // table (<= 64 KB at 1024 nodes) + the four staging tiles
-            (void)hipGetLastError();
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(rows_tile_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void*>(rows_tile_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
-                return fail(ELG_ELAUNCH, "decoder_bwd: hipFuncSetAttribute failed");
-            tile_attr = true;
-        }
+        static DynLds optin_s, optin_d;                    // table (<= 64 KB at 1024 nodes) + the four staging tiles
+        if (!optin_s.opt_in(reinterpret_cast<const void*>(rows_tile_kernel<true>), 96 * 1024) ||
+            !optin_d.opt_in(reinterpret_cast<const void*>(rows_tile_kernel<false>), 96 * 1024))
+            return fail(ELG_ELAUNCH, "decoder_bwd: hipFuncSetAttribute failed");
         hipLaunchKernelGGL((rows_tile_kernel<true>), tgrid, dim3(256), tab_lds, s, Ql, Rcap, p->Kmat + tb,
                            reinterpret_cast<const unsigned long long*>(p->trMask) + ((size_t)b0 * Rcap + r_lo) * W,
-                           p->trLse + ((size_t)b0 * Rcap + r_lo) * 8, nullptr, nullptr, Sbuf, (int)Rl, Rcap, N1, W);
+                           p->trLse + ((size_t)b0 * Rcap + r_lo) * 8, nullptr, nullptr, Sbuf, (int)Rl, Rcap, N1, W,
+                           reinterpret_cast<const float4*>(p->rowW) + (size_t)b0 * R + r_lo, R);
         DB_TRY(launch_status("rows_tile<score>"))
         // dS_h = a_h (dO_h V_h^T - <dO_h, O_h>) / 4 (one pass; <dO, O> per (row, head) first, in the place of dQ)
         hipLaunchKernelGGL(rows_doto_kernel, dim3((unsigned)((Rl + 15) / 16), nb), dim3(256), 0, s, dOl, Ol, dQr, (int)Rl, R, Rcap);
         hipLaunchKernelGGL((rows_tile_kernel<false>), tgrid, dim3(256), tab_lds, s, dOl, R, p->Vmat + tb, nullptr, nullptr, dQr, Sbuf,
-                           Dbuf, (int)Rl, Rcap, N1, W);
+                           Dbuf, (int)Rl, Rcap, N1, W, nullptr, 0LL);
         DB_TRY(launch_status("rows_tile<dscore>"))
         // d q_h = dS_h K_h ;  d K_h = dS_h^T q_h ;  d V_h = a_h^T dO_h
         DB_TRY(elg_gemm_f32_batched(Dbuf, p->Kmat + tb, dQr, (int)Rl, 16, N1, N1, ELG_E, ELG_E, 0, 0, nb, 8, 8 * Rl * N1, Rl * N1,

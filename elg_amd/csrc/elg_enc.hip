@@ -384,14 +384,9 @@ static int launch_gemm_t(const EncGemm& g, dim3 grid, hipStream_t s) {
     const int nbuf = g.K > ENC_KS ? 2 : 1;
     const size_t lds = (size_t)nbuf * RT * 16 * ENC_AP * sizeof(float);
     auto kern = enc_gemm_kernel<RT, KS, WMODE>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipGetLastError();
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(2 * RT * 16 * ENC_AP * sizeof(float))) != hipSuccess)
-            return fail(ELG_ELAUNCH, "encoder gemm: hipFuncSetAttribute failed");
-        attr_done = true;
-    }
+    static DynLds optin;
+    if (!optin.opt_in(reinterpret_cast<const void*>(kern), 2 * RT * 16 * ENC_AP * sizeof(float)))
+        return fail(ELG_ELAUNCH, "encoder gemm: hipFuncSetAttribute failed");
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, g);
     return launch_status("enc_gemm");

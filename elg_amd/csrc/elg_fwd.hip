@@ -474,13 +474,8 @@ static int launch_fwd_impl(const elg_rollout_args& A, hipStream_t stream) {
     if (LDSK) lds += (size_t)((2 * A.N1 + 3) & ~3) * 4;
     if (lds > 163840) return fail(ELG_EINVAL, "rollout: LDS budget exceeded");
     auto kern = rollout_fwd_kernel<NCH, TSP, LDSK, WAVES, TRAIN, SMALL>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                163840) != hipSuccess)
-            return fail(ELG_ELAUNCH, "hipFuncSetAttribute failed");
-        attr_done = true;
-    }
+    static DynLds optin;
+    if (!optin.opt_in(reinterpret_cast<const void*>(kern), 163840)) return fail(ELG_ELAUNCH, "hipFuncSetAttribute failed");
     dim3 grid(A.B * A.tiles), block(WAVES * 64);
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, grid, block, lds, stream, A);
@@ -1547,14 +1542,8 @@ static int launch_fwd_coop(const elg_rollout_args& A, hipStream_t stream) {
                         ((A.N1 + 3) & ~3) + ((2 * A.N1 + 3) & ~3) + (size_t)CO_MAXTR * CO_XP + CL_SIZE + CO_NT * 32 * 64 + 16 * CO_NT +
                         8 * SbSize<2>::value + 2 * 512) * 4 + 64;
     auto kern = rollout_fwd_coop_kernel<TSP, TRAIN>;
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        (void)hipGetLastError();
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(ELG_ELAUNCH, std::string("coop rollout: hipFuncSetAttribute: ") + hipGetErrorString(e));
-        attr_lds = lds;
-    }
+    static DynLds optin;
+    if (!optin.opt_in(reinterpret_cast<const void*>(kern), lds)) return fail(ELG_ELAUNCH, "coop rollout: hipFuncSetAttribute failed");
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3(A.B * A.tiles), dim3(512), lds, stream, A);
     return launch_status("rollout_fwd_coop");
@@ -2200,13 +2189,8 @@ static int launch_fwd_mt_g(const elg_rollout_args& A, hipStream_t stream) {
     const size_t lds = ((size_t)NTR * 3 * 68 + (size_t)NTR * (64 * NCH + 4) + (size_t)NTR * NCH * 4 + (A.has_local ? NTR * CO_XP + CL_SIZE : 0) +
                         ((A.N1 + 3) & ~3) + (size_t)8 * ELG_SB_MIN) * 4;
     auto kern = rollout_fwd_mt_kernel<NCH, TSP, NG, TRAIN>;
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        (void)hipGetLastError();
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(ELG_ELAUNCH, std::string("mt rollout: hipFuncSetAttribute: ") + hipGetErrorString(e));
-        attr_lds = lds;
-    }
+    static DynLds optin;
+    if (!optin.opt_in(reinterpret_cast<const void*>(kern), lds)) return fail(ELG_ELAUNCH, "mt rollout: hipFuncSetAttribute failed");
     if (!A.scratch) return fail(ELG_EINVAL, "rollout: 128 < N1 <= 1024 needs the scratch workspace (elg_rollout_scratch_floats)");
     elg_rollout_args B2 = A;
     B2.tiles = (A.M + NTR - 1) / NTR;                      // this kernel's geometry: 16 NG trajectories per workgroup
@@ -2558,13 +2542,8 @@ static int launch_fwd_xl(const elg_rollout_args& A, hipStream_t stream) {
     const size_t lds = ((size_t)2 * 64 * ELG_E + ((A.N1 + 3) & ~3) + (size_t)8 * 4 * NW + (size_t)8 * (ELG_SB_MIN + ELG_E)) * 4;
     if (lds > 163840 - 256) return fail(ELG_EINVAL, "xl rollout: LDS budget exceeded");
     auto kern = rollout_fwd_xl_kernel<TSP>;
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        (void)hipGetLastError();
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(ELG_ELAUNCH, std::string("xl rollout: hipFuncSetAttribute: ") + hipGetErrorString(e));
-        attr_lds = lds;
-    }
+    static DynLds optin;
+    if (!optin.opt_in(reinterpret_cast<const void*>(kern), lds)) return fail(ELG_ELAUNCH, "xl rollout: hipFuncSetAttribute failed");
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3(A.B * A.tiles), dim3(512), lds, stream, A);
     return launch_status("rollout_fwd_xl");

@@ -511,23 +511,13 @@ extern "C" int elg_local_bwd_rows(const float* loc, const float* trF, const int3
     hipStream_t s = (hipStream_t)stream;
     (void)hipGetLastError();
     if (n_slots <= 32) {
-        static bool done = false;
-        if (!done) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(local_bwd_rows_kernel<2>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return fail(ELG_ELAUNCH, "local_bwd_rows: hipFuncSetAttribute failed");
-            done = true;
-        }
+        static DynLds optin;
+        if (!optin.opt_in(reinterpret_cast<const void*>(local_bwd_rows_kernel<2>), lds)) return fail(ELG_ELAUNCH, "local_bwd_rows: hipFuncSetAttribute failed");
         hipLaunchKernelGGL(local_bwd_rows_kernel<2>, dim3(grid), dim3(256), lds, s, loc, trF, trSlot, rowDU, gloc, B, R,
                            (long long)Rcap, T_dev, M);
     } else {
-        static bool done = false;
-        if (!done) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(local_bwd_rows_kernel<3>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return fail(ELG_ELAUNCH, "local_bwd_rows: hipFuncSetAttribute failed");
-            done = true;
-        }
+        static DynLds optin;
+        if (!optin.opt_in(reinterpret_cast<const void*>(local_bwd_rows_kernel<3>), lds)) return fail(ELG_ELAUNCH, "local_bwd_rows: hipFuncSetAttribute failed");
         hipLaunchKernelGGL(local_bwd_rows_kernel<3>, dim3(grid), dim3(256), lds, s, loc, trF, trSlot, rowDU, gloc, B, R,
                            (long long)Rcap, T_dev, M);
     }

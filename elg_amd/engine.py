@@ -299,7 +299,7 @@ def _fill_common(a: L.RolloutArgs, prob: Problem, pol: Policy, M: int, geometry=
     Ks = tuple(getattr(pol, 'Ks', ()))
     if len(Ks) > 1:
         if len(Ks) > L.MAX_ENS:
-            raise NotImplementedError(f"ensemble_size {len(Ks)} > {L.MAX_ENS} is not built")
+            raise ValueError(f"ensemble_size {len(Ks)}: supported 1 .. {L.MAX_ENS}")
         if pol.loc is not None and pol.loc.numel() != len(Ks) * L.LOC_SIZE:
             raise ValueError("ensemble: loc must hold one folded table per member")
         a.ens = len(Ks)
@@ -406,9 +406,23 @@ class RolloutResult:
 # Arithmetic of the glimpse backward's five products (elg_decoder_bwd_args.mfma_mode; include/elg_hip.h): 0 = f32 MFMAs (exact
 # f32 products), 1 = split-bf16 with 2 terms per operand, 2 = split-bf16 with a 3-term score product (the default: 7.5e-6 of the
 # largest gradient entry against float64 where the f32 MFMAs give 1.1e-6 -- tests/test_gpu_train_glue.py -- at 0.6 of the time)
-BWD_MFMA_MODE = int(os.environ.get("ELG_BWD_MFMA_MODE", "2"))
+BWD_MFMA_MODE = int(os.environ.get("ELG_BWD_MFMA_MODE", "0"))
 
 LARGE_ROWS_BUDGET = 0.45          # fraction of the free HBM the saved rows of a 128 < N1 <= 1024 training forward may take
+_LOG_PATHS = os.environ.get("ELG_LOG_PATHS", "0") not in ("", "0")      # print which large-instance backward a step takes
+
+
+def _free_hbm(dev, drop_cached_rows: bool = False) -> int:
+    """HBM a new workspace can actually get: the driver's free figure PLUS what torch's caching allocator holds without using
+    (reserved - allocated: the previous shape's scratch and rows sit there after `del`).  mem_get_info alone made the choice
+    between the saved-rows and the replay backward depend on the allocation history -- and so possibly differ per rank.
+    `drop_cached_rows`: the rows of another large shape are about to be evicted by TrainRows.get(); count them as free."""
+    free, _ = torch.cuda.mem_get_info(dev)
+    cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+    evict = 0
+    if drop_cached_rows:
+        evict = sum(TrainRows.nbytes(w.B, w.M, w.N1, w.Tcap) for w in TrainRows._cache.values() if w.N1 > 128)
+    return int(free + max(cached, 0) + evict)
 
 
 def _rows_fit(B, M, N1, Tcap, dev) -> bool:
@@ -417,9 +431,13 @@ def _rows_fit(B, M, N1, Tcap, dev) -> bool:
     key = (B, M, N1, Tcap, str(dev))
     if key in TrainRows._cache:
         return True
-    free, _ = torch.cuda.mem_get_info(dev)
     one_ws = 4 * int(L.lib().elg_decoder_bwd_ws_floats(1, Tcap * M, N1))
-    return TrainRows.nbytes(B, M, N1, Tcap) + one_ws <= LARGE_ROWS_BUDGET * free
+    need = TrainRows.nbytes(B, M, N1, Tcap) + one_ws
+    fits = need <= LARGE_ROWS_BUDGET * _free_hbm(dev, drop_cached_rows=True)
+    if _LOG_PATHS:
+        print(f"[elg_amd] N1={N1} B={B} M={M}: backward over {'saved rows' if fits else 'the replay kernel'} "
+              f"({need / 2**30:.1f} GiB of rows + scratch, {_free_hbm(dev) / 2**30:.1f} GiB usable)", flush=True)
+    return fits
 
 
 def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mode: int, *, forced=None, seed: int = 0,
@@ -641,8 +659,7 @@ class _ChosenProbs(torch.autograd.Function):
             # row contractions as batched GEMMs over (8, R, N1) buffers: scratch for as many instances as fit, the call walks
             # the batch in chunks of that many
             per = int(L.lib().elg_decoder_bwd_ws_floats(1, R, N1))
-            free, _ = torch.cuda.mem_get_info(dev)
-            nb = max(1, min(B, int(0.6 * free) // (4 * per)))
+            nb = max(1, min(B, int(0.6 * _free_hbm(dev)) // (4 * per)))      # never more than the batch needs
             big = torch.empty(nb * per, device=dev)
             a.ws, a.ws_floats, a.mask_words = _ptr(big), big.numel(), rows.W
         L.check(L.lib().elg_decoder_bwd(C.byref(a), _stream()), "elg_decoder_bwd")

@@ -41,8 +41,11 @@ def init_distributed(backend: Optional[str] = None, timeout_s: float = 600.0) ->
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
-        if backend == "gloo":
+        one_node = (os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost", "::1")
+                    or os.environ.get("LOCAL_WORLD_SIZE") == str(world))
+        if backend == "gloo" and one_node:
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node: never go looking for the host's name
+            # (a multi-node gloo run must reach the other hosts: binding to loopback there would hang until the timeout)
         kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local)

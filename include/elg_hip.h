@@ -98,7 +98,7 @@ typedef struct elg_rollout_args {
                                models.py:296-298,409-413): member i has its own folded tables loc + i * ELG_LOC_SIZE and its own
                                local_size Kens[i] (Kens[0] == K, which also stays the distance penalty's k); the members'
                                slot scores are summed and scaled by inv_ens.  Runs the one-wavefront-per-trajectory kernel
-                               (N1 <= 1024); training goes through elg_rollout_bwd's replay (N1 <= 256)                */
+                               (N1 <= 1024); training goes through elg_rollout_bwd's replay (N1 <= 1024)                */
     int32_t Kens[ELG_MAX_ENS];
     int32_t pad_ens;
     uint64_t seed;          /* sampling seed (Philox key)                                       */

@@ -17,26 +17,42 @@ pytestmark = pytest.mark.gpu
 DEV = gc.DEV
 
 
-def _grad_check(got, ref, rtol=2e-3):
-    """Every parameter gradient within rtol of the oracle's.  One allowance: a hidden unit of a feed-forward block whose
-    pre-activation at some node lies within fp32 rounding of 0 has its ReLU on one side here and on the other in the oracle
-    (different summation order), which moves ONE row of that block's W1 gradient (and one element of its bias gradient) by
-    that node's whole contribution -- found with tools/poison_train_large.py: cvrp-150, `random` seed 7, layer 4, unit 283
-    is off by 450 x any other row.  The worst unit of a W1 gradient is therefore left out of the comparison."""
+def _kink_units(P, cfg, xy, dem, tol=1e-5):
+    """{W1 parameter name: hidden units whose pre-activation lies within `tol` (fp32 rounding of a 128-term sum of O(1)
+    products) of 0 at some node, by the ORACLE's own forward}.  Such a unit's ReLU may fall on different sides here and in the
+    oracle (different summation order), which moves that ONE row of the block's W1 gradient (and one element of its bias
+    gradient) by the node's whole contribution -- found with tools/poison_train_large.py: cvrp-150, `random` seed 7, layer 4,
+    unit 283 was off by 450 x any other row.  Only these units are left out of the comparison; every other row is checked."""
+    taps = {}
+    with torch.no_grad():
+        orc.encoder_forward({k: v.detach() for k, v in P.items()}, cfg, xy, dem, taps=taps)
+    ff = "feed_forward" if cfg.problem == "cvrp" else "feedForward"
+    out = {}
+    for k, pre in taps.items():
+        near = (pre.abs() < tol * max(1.0, float(pre.abs().max()))).flatten(0, 1).any(dim=0)
+        out[k.replace("pre_relu", ff + ".W1")] = set(torch.nonzero(near).flatten().tolist())
+    return out
+
+
+def _grad_check(got, ref, kinks, rtol=2e-3):
+    """Every parameter gradient within rtol of the oracle's; the only rows left out are the W1 / b1 rows of the units
+    _kink_units() names.  Returns (worst error / limit, number of exempted units)."""
     rms = max(float(v.norm()) / np.sqrt(v.numel()) for v in ref.values())
-    worst = 0.0
+    worst, n_ex = 0.0, 0
     for k, r in ref.items():
         g = got[k].detach().cpu()
         d = (g - r).abs()
-        if "feed_forward.W1" in k:
-            unit = d.reshape(d.shape[0], -1).max(dim=1)[0]
-            d = d.clone()
-            d[int(unit.argmax())] = 0
+        for pre, units in kinks.items():
+            if k.startswith(pre + ".") and units:            # <prefix>.W1.weight (rows = units) and <prefix>.W1.bias
+                d = d.clone()
+                d[sorted(units)] = 0
+                n_ex += len(units) if k.endswith("weight") else 0
         err = float(d.max())
         lim = rtol * float(r.abs().max()) + 2e-3 * rms
         worst = max(worst, err / lim)
         assert err <= lim, f"{k}: max abs err {err:.3e} > {lim:.3e} (ref max {float(r.abs().max()):.3e})"
-    return worst
+    assert n_ex <= 24, f"{n_ex} hidden units exempted: the kink tolerance is not doing what it says"
+    return worst, n_ex
 
 
 @pytest.mark.parametrize("problem,N,M,B,path", [
@@ -95,8 +111,9 @@ def test_large_instance_training_step_end_to_end(problem, N, M, B, path, monkeyp
     tolJ = 2e-4 * max(1.0, abs(float(Jo.detach()))) * max(1.0, To / 100.0)
     assert abs(float(J.detach()) - float(Jo.detach())) <= tolJ, (float(J.detach()), float(Jo.detach()), tolJ)
     Jo.backward()
-    worst = _grad_check(got, {k: v.grad for k, v in P.items()})
+    worst, n_ex = _grad_check(got, {k: v.grad for k, v in P.items()}, _kink_units(P, cfg, xy, dem))
     gc.record_parity(f"train_large_{problem}{N}_{path}_grad_over_limit", worst)
+    gc.record_parity(f"train_large_{problem}{N}_{path}_relu_kink_units_exempted", n_ex)
     eng.TrainRows._cache.clear()
 
 
@@ -119,3 +136,58 @@ def test_train_step_function_at_n150():
     moved = {k: float((v.detach() - before[k]).abs().max()) for k, v in model.named_parameters()}
     assert moved["encoder.layers.0.Wq.weight"] > 0 and moved["decoder.Wq_last.weight"] > 0
     assert all(np.isfinite(m) for m in moved.values())
+
+
+@pytest.mark.parametrize("poison", [False, True])
+def test_saved_rows_workspace_is_reused_across_batches(poison):
+    """The production case the single-step tests above do not see: step k + 1 runs on a different batch in the SAME TrainRows
+    workspace.  The streaming forward writes q / lse / mask words only for the trajectories that decode at a step, so the rows of
+    finished trajectories keep what an earlier batch left there; the backward has to treat them as dead (weight 0) without
+    ever evaluating exp2 on them.  Two CVRP-150 batches with different tour lengths; with `poison` the workspace is filled
+    with values that overflow exp2 between the two steps (every live row is rewritten by the second forward)."""
+    from elg_amd import engine as eng
+    from elg_amd.CVRP.CVRPEnv import CVRPEnv
+    from elg_amd.CVRP.train import pomo_loss
+    from elg_amd.CVRP.utils import rollout
+    eng.TrainRows._cache.clear()
+    N, M, B = 150, 8, 2
+    mp = dict(gu.CVRP_MODEL_PARAMS)
+    cfg = orc.ModelCfg.from_model_params(mp, "cvrp")
+    model = gc.load_model("cvrp", 17, mp, gain=1.0).train()
+    env = CVRPEnv(multi_width=M, device=DEV)
+    torch.manual_seed(11)
+    random.seed(11)
+    for step, (seed, cap) in enumerate([(401, 40.0), (402, 110.0)]):      # small capacity: many depot returns, long tours
+        depot, loc_xy, demand = gu.golden_cvrp_problem(seed, B, N, cap)
+        batch = dict(depot=torch.from_numpy(depot), loc=torch.from_numpy(loc_xy), demand=torch.from_numpy(demand))
+        env.load_random_problems(batch)
+        rs, _, _ = env.reset()
+        for p in model.parameters():
+            p.grad = None
+        model.pre_forward(rs)
+        acts, probs, rew = rollout(model, env, 'sample')
+        rew_n = rew + 0.3 * torch.randn(B, M, device=rew.device)
+        J = pomo_loss(probs, rew_n, True)
+        J.backward()
+        ws = [w for k, w in eng.TrainRows._cache.items() if k[2] > 128]
+        assert len(ws) == 1, "both steps must share one saved-rows workspace"
+        if step == 0:
+            T0 = acts.shape[2]
+            if poison:
+                ws[0].Q.fill_(3.0e18)                 # q . K of a stale row: far beyond exp2's range
+                ws[0].Lse.fill_(-3.0e38)
+                ws[0].Mask.zero_()
+                ws[0].O.fill_(1.0e18)
+    assert acts.shape[2] != T0 or poison, "the two batches were meant to differ in length"
+    got = {k: v.grad for k, v in model.named_parameters()}
+    assert all(torch.isfinite(g).all().item() for g in got.values()), "a dead row reached the gradients"
+    xy = torch.from_numpy(np.concatenate([depot, loc_xy], 1))
+    dem = torch.from_numpy(np.concatenate([np.zeros((B, 1), np.float32), demand], 1))
+    P = {k: v.clone().requires_grad_(True) for k, v in gc.weights("cvrp", 17, mp, 1.0).items()}
+    a = acts.cpu()
+    out = orc.rollout_cvrp(P, cfg, xy, dem, M, starts=a[0, :, 1], forced=a)
+    Jo = orc.pomo_loss(out["probs"], rew_n.cpu(), True)
+    Jo.backward()
+    worst, n_ex = _grad_check(got, {k: v.grad for k, v in P.items()}, _kink_units(P, cfg, xy, dem))
+    gc.record_parity(f"train_large_rows_reused_poison{int(poison)}_grad_over_limit", worst)
+    eng.TrainRows._cache.clear()

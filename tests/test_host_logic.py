@@ -233,3 +233,46 @@ def test_cluster_and_mixed_generators_follow_the_reference_distributions():
         p = ks_2samp(v, fx[f"tsp_cluster/{k}"]).pvalue
         assert p > 1e-3, ("tsp", k, p)
     print("smallest KS p-value", worst)
+
+
+def test_unsupported_model_shapes_raise_value_errors_naming_the_supported_set():
+    """The reference takes any embedding / head / local sizes (models.py:8-36,277-294); the HIP kernels are built for its
+    config.yml defaults.  Anything else is refused up front with a ValueError that says what is supported."""
+    import pytest
+    from elg_amd.CVRP.CVRPModel import CVRPModel
+    from elg_amd.TSP.TSPModel import TSPModel
+    with pytest.raises(ValueError, match=r"\(128, 8, 16\)"):
+        CVRPModel(**dict(gu.CVRP_MODEL_PARAMS, embedding_dim=64, head_num=4))
+    with pytest.raises(ValueError, match=r"\(128, 8, 16\)"):
+        TSPModel(**dict(gu.TSP_MODEL_PARAMS, qkv_dim=32))
+    m = CVRPModel(**dict(gu.CVRP_MODEL_PARAMS, local_att_hidden_dim=64))
+    with pytest.raises(ValueError, match=r"\(32, 4, 8\)"):
+        m.decoder.add_local_policy("cpu")
+    m = CVRPModel(**dict(gu.CVRP_MODEL_PARAMS, local_size=[60]))
+    with pytest.raises(ValueError, match=r"1 \.\. 47"):
+        m.decoder.add_local_policy("cpu")
+    m = CVRPModel(**dict(gu.CVRP_MODEL_PARAMS, ensemble_size=5, local_size=[10] * 5))
+    with pytest.raises(ValueError, match=r"1 \.\. 4"):
+        m.decoder.add_local_policy("cpu")
+
+
+def test_dataset_writer_entry_points(tmp_path):
+    """`python generate_data.py` of both trees (reference CVRP/generate_data.py:173-197, TSP/generate_data.py:101-126): files
+    under the reference's names, readable by the dataset classes, seeded runs reproducible, both CVRP formats equivalent."""
+    from elg_amd.CVRP import generate_data as gv
+    from elg_amd.TSP import generate_data as gt
+    a = gv.main(["--problem-size", "20", "50", "--data-size", "6", "4", "--out-dir", str(tmp_path / "a")])
+    assert [os.path.basename(p) for p in a] == ["vrp20_val.pkl", "vrp50_val.pkl"]
+    b = gv.main(["--problem-size", "20", "50", "--data-size", "6", "4", "--out-dir", str(tmp_path / "b"), "--format", "tuples"])
+    for pa, pb, n, cnt in zip(a, b, (20, 50), (6, 4)):
+        da, db = gv.VRPDataset(pa, num_samples=cnt), gv.VRPDataset(pb, num_samples=cnt)
+        assert len(da) == len(db) == cnt and da[0]['loc'].shape == (n, 2)
+        for x, y in zip(da.data, db.data):                      # same seed -> same instances; demand = integer / capacity in both
+            assert torch.equal(x['loc'], y['loc']) and torch.allclose(x['demand'], y['demand'], atol=1e-7)
+    c = gv.main(["--problem-size", "20", "--data-size", "3", "--data-type", "cluster", "--kind", "test", "--out-dir", str(tmp_path)])
+    assert os.path.basename(c[0]) == "vrp_cluster20_test.pkl"
+    t1 = gt.main(["--problem-size", "30", "--data-size", "5", "--seed", "7", "--out-dir", str(tmp_path / "t1")])
+    t2 = gt.main(["--problem-size", "30", "--data-size", "5", "--seed", "7", "--out-dir", str(tmp_path / "t2")])
+    assert os.path.basename(t1[0]) == "tsp_30_val.pkl"
+    d1, d2 = gt.TSPDataset(t1[0], num_samples=5), gt.TSPDataset(t2[0], num_samples=5)
+    assert len(d1) == 5 and d1[0].shape == (30, 2) and all(torch.equal(x, y) for x, y in zip(d1.data, d2.data))

@@ -1,11 +1,11 @@
 """In-kernel phase clock of rollout_fwd_coop_kernel: builds a DIAGNOSTIC copy of the library with -DELG_STAMPS (s_memtime at the
 phase boundaries, segment sums through elg_rollout_args.scratch), runs one training rollout at the bench shape and prints the
 share of a step every segment takes.  The shipped library executes no stamp; never quote this build's run time.
-    python tools/stamp_coop.py build      (in the build container: writes elg_amd/libelg_hip_stamps.so)
+    python tools/stamp_coop.py build      (in the build container: writes tools/_diag/libelg_hip_stamps.so -- a diagnostic build, never in the package)
     python tools/stamp_coop.py            (on the GPU box)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, "elg_amd", "libelg_hip_stamps.so")
+LIB = os.path.join(ROOT, "tools", "_diag", "libelg_hip_stamps.so")
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     sys.path.insert(0, ROOT)
     from elg_amd import build as b
@@ -14,6 +14,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "build":
         obj = os.path.join("/tmp", "stamps_" + src.replace(".hip", ".o"))
         subprocess.check_call([b._hipcc(), *b.FLAGS, "-DELG_STAMPS", "-c", os.path.join(b.CSRC, src), "-o", obj])
         objs.append(obj)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
     subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
     print(LIB)
     sys.exit(0)

@@ -2,7 +2,7 @@
 `python tools/stamp_coop.py build`); the stamp sums leave through the `uniforms` pointer, which a greedy rollout does not read."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["ELG_HIP_LIB"] = os.path.join(ROOT, "elg_amd", "libelg_hip_stamps.so")
+os.environ["ELG_HIP_LIB"] = os.path.join(ROOT, "tools", "_diag", "libelg_hip_stamps.so")
 sys.path.insert(0, ROOT)
 import ctypes as C, torch, yaml
 from elg_amd import _lib as L, engine as eng
