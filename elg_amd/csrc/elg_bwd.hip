@@ -10,6 +10,7 @@
 #include "elg_rollout.h"
 #include "elg_bwd_internal.h"
 #include "elg_bf16.h"
+#include <cstdlib>
 #include <string>
 
 namespace elg {
@@ -1269,6 +1270,319 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// =============================================================================================
+// The f32 kernel of the training path (mfma_mode 0; mask rows + saved log2-sum-exp + gather epilogue), restructured like the
+// split-bf16 kernel above -- nodes in natural order, the rows' closed bits compacted to one register per row, the weights of a
+// chunk recomputed inside the chunk loop, - lse (or - inf for a closed node) and - <dO, o> as accumulator inputs, the V operand
+// in LDS, dq produced row-major so that the query-gather backward is a one-hot product instead of LDS float atomics -- but with
+// every arithmetic product on v_mfma_f32_16x16x4_f32 (exact f32 products, f32 accumulation).
+// =============================================================================================
+template <int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void glimpse_bwd_f32n_kernel(
+    const unsigned long long* __restrict__ rowMask, const float* __restrict__ dO, const float* __restrict__ rowO,
+    const float* __restrict__ rowQ, const float* __restrict__ Kmat, const float* __restrict__ Vmat,
+    float* __restrict__ dKp, float* __restrict__ dVp, int B, int R, int N1, size_t rowO_rows, size_t rowQ_rows, int splits,
+    const GlimpseSeg seg) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (seg.T_dev) R = min(R, seg.T_dev[0] * seg.M);                  // the host has not read the rollout's length yet
+    constexpr int SNP = 16 * NT + 9;
+    // LDS (floats): K image of dq [NT][64][4] | K image of q K^T [NT][64][4] | V image [NT][64][4] | (pad to 4 NT 256: the
+    // cross-wave reduction buffer of the epilogue aliases the images) | transpose tiles | d Q2 accumulator of the TSP decoder
+    float* sKd = lds;
+    float* sK2 = sKd + NT * 256;
+    float* sV = sK2 + NT * 256;
+    float* sRed = lds;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lo = lane & 15, hi = lane >> 4;
+    float* sTr = lds + 4 * NT * 256 + wave * (2 * 320);       // two 16 x 16 transpose tiles (pitch 20)
+    float* sSeg2 = lds + 4 * NT * 256 + 4 * 2 * 320;           // [16][SNP] d Q2, channel-major (odd pitch: see above)
+    const bool tsp = seg.idx_first != nullptr;
+    if (tsp)
+        for (int i = threadIdx.x; i < 16 * SNP; i += 256) sSeg2[i] = 0.f;
+    const int* seg_first = tsp ? seg.idx_first : seg.idx_prev;
+    const float* seg_load = seg.load ? seg.load : reinterpret_cast<const float*>(seg.idx_prev);
+    const size_t seg_lrows = seg.load ? (size_t)seg.load_rows : (size_t)R;
+    const float load_on = seg.load ? 1.f : 0.f;
+    const int bh = blockIdx.y, b = bh >> 3, h = bh & 7;
+    const int split = blockIdx.x;
+    const float cs = 0.25f * 1.4426950408889634f;
+
+    // operand images, one chunk per wave and round.  K (dq: node of (hi, v) x channel lo), K (q K^T: node lo x channel 4 v + hi),
+    // V (node lo x channel 4 v + hi); nodes past N1 - 1 are zeros
+    for (int nt = wave; nt < NT; nt += 4) {
+        float kv[4], k2[4], vv[4];
+        const int n2 = 16 * nt + lo;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int n = 16 * nt + 4 * hi + v;
+            // (the 1/4 of the softmax backward rides on K here and on q below -- exact; the scores' log2(e)/4 on K)
+            kv[v] = n < N1 ? 0.25f * Kmat[((size_t)b * N1 + n) * ELG_E + h * 16 + lo] : 0.f;
+            k2[v] = n2 < N1 ? cs * Kmat[((size_t)b * N1 + n2) * ELG_E + h * 16 + 4 * v + hi] : 0.f;
+            vv[v] = n2 < N1 ? Vmat[((size_t)b * N1 + n2) * ELG_E + h * 16 + 4 * v + hi] : 0.f;
+        }
+        *reinterpret_cast<float4*>(sKd + (nt * 64 + lane) * 4) = make_float4(kv[0], kv[1], kv[2], kv[3]);
+        *reinterpret_cast<float4*>(sK2 + (nt * 64 + lane) * 4) = make_float4(k2[0], k2[1], k2[2], k2[3]);
+        *reinterpret_cast<float4*>(sV + (nt * 64 + lane) * 4) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    }
+    // accumulators over the wave's tiles: dK_h, dV_h and d Q1_h (rows = nodes 16 nt + 4 hi + v, column = channel lo); d wl
+    f32x4 dKacc[NT], dVacc[NT], dGacc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        dKacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dVacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dGacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float dwl_acc = 0.f;
+
+    int tile_first = 0, ntile = (R + 15) >> 4;
+    __shared__ int sTb;
+    if (threadIdx.x == 0) sTb = 0;
+    __syncthreads();
+    if (seg.tlen) {
+        // same live range as pointer_bwd_kernel: decode steps t0 .. max_m tlen[b,m] - 1 of this instance
+        int mx = 0;
+        for (int m = threadIdx.x; m < seg.M; m += 256) mx = max(mx, seg.tlen[(size_t)b * seg.M + m]);
+        mx = (int)wave_max((float)mx);
+        if (lane == 0) atomicMax(&sTb, mx);
+        __syncthreads();
+        tile_first = live_tile_first(seg.t0, seg.M);
+        ntile = (min(R, sTb * seg.M) + 15) >> 4;
+    }
+    const int per = (max(ntile - tile_first, 0) + splits - 1) / splits;
+    const int t_lo = tile_first + split * per, t_hi = min(ntile, t_lo + per);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // ---- tile loads (unguarded, rows past R clamped to the last valid row; see the f32 kernel), one tile ahead.  The gather
+    // indices / loads are fetched for the rows 4 hi + v of the lane's k-slots.
+#define ELG_GBF_LOAD(TILE, DOA, OA, DOB, QB, QA, MW, SP, SF, SL, LS)                                              \
+    {                                                                                                             \
+        const int r0_ = (TILE) << 4;                                                                              \
+        const int rleft_ = R - 1 - r0_;                                                                           \
+        const unsigned long long* __restrict__ Mt = rowMask + ((size_t)b * rowQ_rows + r0_) * 2;                  \
+        _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                                           \
+            const int rv_ = min(4 * hi + v, rleft_);                                                              \
+            MW[v][0] = Mt[rv_ * 2]; MW[v][1] = Mt[rv_ * 2 + 1];                                                   \
+            LS[v] = seg.lse[((size_t)b * rowQ_rows + r0_ + rv_) * 8 + h];                                         \
+            SP[v] = seg.idx_prev[(size_t)b * R + r0_ + rv_];                                                      \
+            SF[v] = seg_first[(size_t)b * R + r0_ + rv_];                                                         \
+            SL[v] = seg_load[(size_t)b * seg_lrows + r0_ + rv_];                                                  \
+        }                                                                                                         \
+        const float* __restrict__ dOt = dO + ((size_t)b * R + r0_) * ELG_E + h * 16;                              \
+        const float* __restrict__ Ot = rowO + ((size_t)b * rowO_rows + r0_) * ELG_E + h * 16;                     \
+        const float* __restrict__ Qt = rowQ + ((size_t)b * rowQ_rows + r0_) * ELG_E + h * 16;                     \
+        const unsigned offA = (unsigned)(min(lo, rleft_) * ELG_E + hi);                                           \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                        \
+            DOA[kk] = dOt[offA + 4 * kk]; OA[kk] = Ot[offA + 4 * kk]; QA[kk] = Qt[offA + 4 * kk];                 \
+        }                                                                                                         \
+        _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                                           \
+            const int rr = 4 * hi + v;                                                                            \
+            const unsigned offB = (unsigned)(min(rr, rleft_) * ELG_E + lo);                                       \
+            const float mk = (rr <= rleft_) ? 1.f : 0.f;                                                          \
+            DOB[v] = dOt[offB] * mk;                                                                              \
+            QB[v] = Qt[offB] * mk;                                                                                \
+        }                                                                                                         \
+    }
+    float doA[4], oA[4], doB[4], qB[4], qA[4], lsv[4], sgl[4];
+    int sgp[4], sgf[4];
+    unsigned long long mw[4][2];
+    const int tile0 = t_lo + wave_u;
+    if (tile0 < t_hi) ELG_GBF_LOAD(tile0, doA, oA, doB, qB, qA, mw, sgp, sgf, sgl, lsv)
+    for (int tile = tile0; tile < t_hi; tile += 4) {
+        const int r0 = tile << 4;                                  // wave-uniform
+        const int rleft = R - 1 - r0;
+        float doAn[4], oAn[4], doBn[4], qBn[4], qAn[4], lsvn[4], sgln[4];
+        int sgpn[4], sgfn[4];
+        unsigned long long mwn[4][2];
+        {
+            const int tn = min(tile + 4, t_hi - 1);                // the last prefetch re-reads a valid tile, unused
+            ELG_GBF_LOAD(tn, doAn, oAn, doBn, qBn, qAn, mwn, sgpn, sgfn, sgln, lsvn)
+        }
+        // closed bits of this lane's nodes 16 nt + lo, one register per row 4 hi + v: chunk nt at bit (nt >> 1) + 16 (nt & 1)
+        unsigned cm[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const unsigned long long x0 = mw[v][0] >> lo, x1 = mw[v][1] >> lo;
+            cm[v] = ((unsigned)x0 & 0x10001u) | (((unsigned)(x0 >> 32) & 0x10001u) << 1) | (((unsigned)x1 & 0x10001u) << 2) |
+                    (((unsigned)(x1 >> 32) & 0x10001u) << 3);
+        }
+        // <dO_h, O_h> per row: partial over this lane's 4 channels, summed over the 4 lane groups
+        float doto = doA[0] * oA[0];
+        doto = fmaf(doA[1], oA[1], doto); doto = fmaf(doA[2], oA[2], doto); doto = fmaf(doA[3], oA[3], doto);
+        doto = quarters_sum(doto);                                // row lo, in every lane
+        f32x4 ndv;                                                  // - <dO, O> of row 4 hi + v: the accumulator input of dA
+#pragma unroll
+        for (int v = 0; v < 4; ++v) ndv[v] = -__shfl(doto, 4 * hi + v);
+        // (the 1/4 of the softmax backward rides on q^T here and on the K image of dq -- exact)
+        const float qb[4] = {0.25f * qB[0], 0.25f * qB[1], 0.25f * qB[2], 0.25f * qB[3]};
+        // dq^T[row 4 hi + v][channel lo] = sum over the nodes of dS[row][node] K[node][channel]
+        f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+        auto dq_chunk = [&](int c) {                               // from the transposed dS tile of chunk c
+            const float* pb = sTr + (c & 1) * 320;
+            const float4 k1 = *reinterpret_cast<const float4*>(sKd + (c * 64 + lane) * 4);
+            dq = __builtin_amdgcn_mfma_f32_16x16x4f32(pb[(4 * hi + 0) * 20 + lo], k1.x, dq, 0, 0, 0);
+            dq = __builtin_amdgcn_mfma_f32_16x16x4f32(pb[(4 * hi + 1) * 20 + lo], k1.y, dq, 0, 0, 0);
+            dq = __builtin_amdgcn_mfma_f32_16x16x4f32(pb[(4 * hi + 2) * 20 + lo], k1.z, dq, 0, 0, 0);
+            dq = __builtin_amdgcn_mfma_f32_16x16x4f32(pb[(4 * hi + 3) * 20 + lo], k1.w, dq, 0, 0, 0);
+        };
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            // a_h[row 4 hi + v][node 16 nt + lo] = closed ? 0 : exp2(q_h . K_h[node] log2(e) / 4 - lse)
+            const float4 ka = *reinterpret_cast<const float4*>(sK2 + (nt * 64 + lane) * 4);
+            const float4 vw = *reinterpret_cast<const float4*>(sV + (nt * 64 + lane) * 4);
+            // accumulator inputs: - lse (or - inf for a closed node: exp2 -> exactly 0) for the scores, - <dO, O> for dA
+            const int bit = (nt >> 1) + 16 * (nt & 1);                 // (compile-time after unrolling)
+            f32x4 S, dA = ndv;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const unsigned closed = (unsigned)((int)(cm[v] << (31 - bit)) >> 31);    // ~0 for a closed node, 0 for an open one
+                S[v] = __uint_as_float((closed & 0xff800000u) | (~closed & __float_as_uint(-lsv[v])));
+            }
+            S = __builtin_amdgcn_mfma_f32_16x16x4f32(qA[0], ka.x, S, 0, 0, 0);
+            dA = __builtin_amdgcn_mfma_f32_16x16x4f32(doA[0], vw.x, dA, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_16x16x4f32(qA[1], ka.y, S, 0, 0, 0);
+            dA = __builtin_amdgcn_mfma_f32_16x16x4f32(doA[1], vw.y, dA, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_16x16x4f32(qA[2], ka.z, S, 0, 0, 0);
+            dA = __builtin_amdgcn_mfma_f32_16x16x4f32(doA[2], vw.z, dA, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_16x16x4f32(qA[3], ka.w, S, 0, 0, 0);
+            dA = __builtin_amdgcn_mfma_f32_16x16x4f32(doA[3], vw.w, dA, 0, 0, 0);
+            float aw[4], ds1[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                aw[v] = __builtin_amdgcn_exp2f(S[v]);
+                ds1[v] = aw[v] * dA[v];                            // 4 dS: node 16 nt + lo, row 4 hi + v
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                dKacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds1[v], qb[v], dKacc[nt], 0, 0, 0);
+                dVacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[v], doB[v], dVacc[nt], 0, 0, 0);
+            }
+            // dS with the row on the lane: transposed through per-wave LDS, consumed one chunk later so the round trip is off
+            // the dependency chain
+            *reinterpret_cast<float4*>(sTr + (nt & 1) * 320 + lo * 20 + 4 * hi) = make_float4(ds1[0], ds1[1], ds1[2], ds1[3]);
+            wave_lds_fence();
+            if (nt > 0) dq_chunk(nt - 1);
+        }
+        dq_chunk(NT - 1);
+        wave_lds_fence();
+        // ---- the query-gather backward of the tile: d Q1[node] += sum over the rows gathered at that node of dq[row], as a
+        // product with the one-hot matrix P[node][row] = [prev(row) = node] on v_mfma_f32_16x16x32_bf16.  This is a SCATTER, not
+        // reduced-precision arithmetic: P is 0 / 1 (exact in bf16), dq enters as its three bf16 terms dq1 + dq2 + dq3, which
+        // reproduce the f32 value to 2^-27 (elg_bf16.h), every product is exact and the accumulation is f32 -- the same result,
+        // to f32 rounding, as the LDS float atomics on a (node, channel) accumulator that took 31 % of the kernel before.
+        // [P | P] [dq1 | dq2] + [P | 0] [dq3 | 0]: two instructions (32 cycles) per chunk.  Rows past R: -1.
+        {
+            unsigned dt[6];
+            bf_terms<3>(dq[0], dq[1], dq[2], dq[3], dt);
+            const u32x4 dqs = {dt[0], dt[1], dt[2], dt[3]};
+            const u32x4 dq3 = {dt[4], dt[5], 0u, 0u};
+            int pv[4];
+            float lw = 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const bool live = 4 * hi + v <= rleft;
+                pv[v] = live ? sgp[v] - lo : -1;                                   // == 16 nt  <=>  prev(row) == 16 nt + lo
+                lw = fmaf(live ? sgl[v] : 0.f, dq[v], lw);
+            }
+            dwl_acc = fmaf(load_on, lw, dwl_acc);                                   // d wl[channel lo], this lane group's rows
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const unsigned e0 = pv[0] == 16 * nt ? 0x3f80u : 0u, e1 = pv[1] == 16 * nt ? 0x3f800000u : 0u;
+                const unsigned e2 = pv[2] == 16 * nt ? 0x3f80u : 0u, e3 = pv[3] == 16 * nt ? 0x3f800000u : 0u;
+                const unsigned w0 = e0 | e1, w1 = e2 | e3;
+                dGacc[nt] = mfma_bf(u32x4{w0, w1, w0, w1}, dqs, dGacc[nt]);
+                dGacc[nt] = mfma_bf(u32x4{w0, w1, 0u, 0u}, dq3, dGacc[nt]);
+            }
+            if (tsp) {                                                              // d Q2: the tour's first node (LDS atomics)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    if (4 * hi + v <= rleft) atomicAdd(sSeg2 + lo * SNP + sgf[v], dq[v]);
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            doA[v] = doAn[v]; oA[v] = oAn[v]; doB[v] = doBn[v]; qB[v] = qBn[v]; qA[v] = qAn[v]; lsv[v] = lsvn[v];
+            mw[v][0] = mwn[v][0]; mw[v][1] = mwn[v][1];
+            sgp[v] = sgpn[v]; sgf[v] = sgfn[v]; sgl[v] = sgln[v];
+        }
+    }
+#undef ELG_GBF_LOAD
+    // d wl[h 16 + lo]: the four lane groups hold disjoint rows
+    if (seg.dwl) {
+        const float t = quarters_sum(dwl_acc);
+        if (hi == 0 && t != 0.f) atomicAdd(seg.dwl + h * 16 + lo, t);
+    }
+    __syncthreads();                                                // every wave's LDS atomics are done, the images are dead
+    if (tsp)
+        for (int i = threadIdx.x; i < N1 * 16; i += 256) {
+            const int n = i >> 4, d = i & 15;
+            const float v2 = sSeg2[d * SNP + n];
+            if (v2 != 0.f) atomicAdd(seg.dQ2 + ((size_t)b * N1 + n) * ELG_E + h * 16 + d, v2);
+        }
+    // ---- sum the four waves' accumulators pairwise through LDS (over the dead images): first (dK_h, dV_h), then d Q1_h.
+    // D rows are nodes 16 nt + 4 hi + v.
+    auto reduce_pair = [&](f32x4 (&X)[NT], f32x4 (&Y)[NT]) {
+        auto dump = [&](float* dst) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int idx = (16 * nt + 4 * hi + v) * 16 + lo;
+                    dst[idx] = X[nt][v];
+                    dst[NT * 256 + idx] = Y[nt][v];
+                }
+        };
+        auto addin = [&](const float* src) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int idx = (16 * nt + 4 * hi + v) * 16 + lo;
+                    X[nt][v] += src[idx];
+                    Y[nt][v] += src[NT * 256 + idx];
+                }
+        };
+        if (wave >= 2) dump(sRed + (size_t)(wave - 2) * (2 * NT * 256));
+        __syncthreads();
+        if (wave < 2) addin(sRed + (size_t)wave * (2 * NT * 256));
+        __syncthreads();
+        if (wave == 1) dump(sRed);
+        __syncthreads();
+        if (wave == 0) addin(sRed);
+        __syncthreads();
+        if (wave == 0) dump(sRed);
+        __syncthreads();
+    };
+    reduce_pair(dKacc, dVacc);
+    for (int i = threadIdx.x; i < 2 * NT * 256; i += 256) {
+        const float sum = sRed[i];
+        const int which = i / (NT * 256), idx = i % (NT * 256);
+        const int n = idx >> 4, d = idx & 15;
+        if (n < N1) {
+            float* out = which ? dVp : dKp;
+            if (seg.accumulate) atomicAdd(out + ((size_t)b * N1 + n) * ELG_E + h * 16 + d, sum);
+            else out[(((size_t)split * B + b) * N1 + n) * ELG_E + h * 16 + d] = sum;
+        }
+    }
+    __syncthreads();
+    reduce_pair(dGacc, dVacc);                                      // (the second array rides along, unused)
+    for (int i = threadIdx.x; i < NT * 256; i += 256) {
+        const float sum = sRed[i];
+        const int n = i >> 4, d = i & 15;
+        if (n < N1 && sum != 0.f) atomicAdd(seg.dQ1 + ((size_t)b * N1 + n) * ELG_E + h * 16 + d, sum);
+    }
+}
+
+template <int NT>
+static int launch_glimpse_bwd_f32n(const unsigned long long* rowMask, const float* dO, const float* rowO, const float* rowQ,
+                                   const float* Kmat, const float* Vmat, float* dKp, float* dVp, int B, int R, int N1, size_t ro,
+                                   size_t rq, int splits, const GlimpseSeg& seg, hipStream_t stream) {
+    const size_t lds = (size_t)(4 * NT * 256 + 4 * 2 * 320 + 16 * (16 * NT + 9)) * sizeof(float);
+    auto kern = glimpse_bwd_f32n_kernel<NT>;
+    static DynLds optin;
+    if (!optin.opt_in(reinterpret_cast<const void*>(kern), lds)) return fail(ELG_ELAUNCH, "glimpse_bwd (f32): hipFuncSetAttribute failed");
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3(splits, B * 8), dim3(256), lds, stream, rowMask, dO, rowO, rowQ, Kmat, Vmat, dKp, dVp, B, R, N1,
+                       ro, rq, splits, seg);
+    return launch_status("glimpse_bwd_f32n");
+}
+
 template <int NT, int TS>
 static int launch_glimpse_bwd_bf16(const unsigned long long* rowMask, const float* dO, const float* rowO, const float* rowQ,
                                    const float* Kmat, const float* Vmat, float* dKp, float* dVp, int B, int R, int N1, size_t ro,
@@ -1328,6 +1642,16 @@ int glimpse_bwd_launch(const float* rowA, const unsigned long long* mk, const fl
     if (N1 > 128) return fail(ELG_ENOTIMPL, "glimpse_bwd_fused: N1 > 128 not built (use elg_glimpse_rows_bwd)");
     if (!dQ && !seg.idx_prev) return fail(ELG_EINVAL, "glimpse_bwd_fused: neither dQ nor the gather epilogue requested");
     const int nt = (N1 + 15) / 16;
+    static const bool old_f32 = getenv("ELG_GLIMPSE_F32_OLD") != nullptr;      // A/B timing against the previous f32 kernel
+    if (seg.mfma_mode == 0 && mk && seg.lse && seg.idx_prev && !dQ && !old_f32) {
+#define ELG_GBN(NT) return launch_glimpse_bwd_f32n<NT>(mk, dO, rowO, rowQ, Kmat, Vmat, dK_part, dV_part, B, R, N1, (size_t)rowO_rows, \
+                                                        (size_t)rowQ_rows, splits, seg, s);
+        if (nt <= 2) ELG_GBN(2)
+        if (nt <= 4) ELG_GBN(4)
+        if (nt <= 7) ELG_GBN(7)
+        ELG_GBN(8)
+#undef ELG_GBN
+    }
     if (seg.mfma_mode > 0 && mk && seg.lse && seg.idx_prev && !dQ) {
         // split-bf16 products (mask rows + saved normaliser + gather epilogue: the training path)
 #define ELG_GBF(NT)                                                                                                         \

@@ -17,9 +17,10 @@ pytestmark = pytest.mark.gpu
 DEV = gc.DEV
 
 
-def _kink_units(P, cfg, xy, dem, tol=1e-5):
-    """{W1 parameter name: hidden units whose pre-activation lies within `tol` (fp32 rounding of a 128-term sum of O(1)
-    products) of 0 at some node, by the ORACLE's own forward}.  Such a unit's ReLU may fall on different sides here and in the
+def _kink_units(P, cfg, xy, dem, tol=8e-6):
+    """{W1 parameter name: hidden units whose pre-activation lies within `tol` of 0 at some node, by the ORACLE's own forward}.
+    tol = 8e-6 absolute: the oracle's fp32 pre-activations differ from its own fp64 evaluation by up to 3.6e-6 (mean 2.5e-7;
+    measured at cvrp-150, all six layers, |pre| up to 8), so two correct fp32 evaluations can disagree by about twice that.  Such a unit's ReLU may fall on different sides here and in the
     oracle (different summation order), which moves that ONE row of the block's W1 gradient (and one element of its bias
     gradient) by the node's whole contribution -- found with tools/poison_train_large.py: cvrp-150, `random` seed 7, layer 4,
     unit 283 was off by 450 x any other row.  Only these units are left out of the comparison; every other row is checked."""
@@ -29,12 +30,12 @@ def _kink_units(P, cfg, xy, dem, tol=1e-5):
     ff = "feed_forward" if cfg.problem == "cvrp" else "feedForward"
     out = {}
     for k, pre in taps.items():
-        near = (pre.abs() < tol * max(1.0, float(pre.abs().max()))).flatten(0, 1).any(dim=0)
+        near = (pre.abs() < tol).flatten(0, 1).any(dim=0)
         out[k.replace("pre_relu", ff + ".W1")] = set(torch.nonzero(near).flatten().tolist())
     return out
 
 
-def _grad_check(got, ref, kinks, rtol=2e-3):
+def _grad_check(got, ref, kinks, rtol=2e-3, cap=32):
     """Every parameter gradient within rtol of the oracle's; the only rows left out are the W1 / b1 rows of the units
     _kink_units() names.  Returns (worst error / limit, number of exempted units)."""
     rms = max(float(v.norm()) / np.sqrt(v.numel()) for v in ref.values())
@@ -51,7 +52,8 @@ def _grad_check(got, ref, kinks, rtol=2e-3):
         lim = rtol * float(r.abs().max()) + 2e-3 * rms
         worst = max(worst, err / lim)
         assert err <= lim, f"{k}: max abs err {err:.3e} > {lim:.3e} (ref max {float(r.abs().max()):.3e})"
-    assert n_ex <= 24, f"{n_ex} hidden units exempted: the kink tolerance is not doing what it says"
+    # (the number of pre-activations within 8e-6 of 0 grows with the number of nodes: ~3e-5 of them, e.g. 35 units at tsp-1000)
+    assert n_ex <= cap, f"{n_ex} hidden units exempted (cap {cap}): the kink tolerance is not doing what it says"
     return worst, n_ex
 
 
@@ -111,7 +113,7 @@ def test_large_instance_training_step_end_to_end(problem, N, M, B, path, monkeyp
     tolJ = 2e-4 * max(1.0, abs(float(Jo.detach()))) * max(1.0, To / 100.0)
     assert abs(float(J.detach()) - float(Jo.detach())) <= tolJ, (float(J.detach()), float(Jo.detach()), tolJ)
     Jo.backward()
-    worst, n_ex = _grad_check(got, {k: v.grad for k, v in P.items()}, _kink_units(P, cfg, xy, dem))
+    worst, n_ex = _grad_check(got, {k: v.grad for k, v in P.items()}, _kink_units(P, cfg, xy, dem), cap=16 + B * N // 10)
     gc.record_parity(f"train_large_{problem}{N}_{path}_grad_over_limit", worst)
     gc.record_parity(f"train_large_{problem}{N}_{path}_relu_kink_units_exempted", n_ex)
     eng.TrainRows._cache.clear()
