@@ -272,7 +272,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the TSP-500 / VRPLIB X-n1001 secondary timings")
-    ap.add_argument("--no-fast", action="store_true", help="skip the split-bf16 backward leg (value_fast)")
+    ap.add_argument("--no-fast", action="store_true", help="skip the split-bf16 backward leg (value_fast) and the bf16 leg (value_bf16)")
     ap.add_argument("--sustain-s", type=float, default=10.0, help="length of the sustained leg in seconds (0: skip)")
     args = ap.parse_args()
 
@@ -390,6 +390,22 @@ def main():
                 "mode": "glimpse backward: " + MODE_NAMES[2] + " on v_mfma_f32_16x16x32_bf16, f32 accumulation; everything else f32"}
         eng.BWD_MFMA_MODE = 0
 
+    # ---- bf16 leg (BASELINE configs[1] "bf16"): the rollout's three table products on bf16 operands (engine.FWD_PRECISION = 1;
+    # its backward recomputes the scores the same way: elg_decoder_bwd mode 3), everything else as in the headline
+    bf16 = None
+    if not args.no_fast:
+        eng.FWD_PRECISION = 1
+        dtb, _ = timed_leg(3, args.steps)
+        kb_ms = sum(a.elapsed_time(b) for a, b in fwd_events) / len(fwd_events)
+        bf16 = {"value": round(LOCAL_BATCH * world * args.steps / dtb, 2), "ms_per_step": round(dtb / args.steps * 1e3, 3),
+                "rollout_launch_ms": round(kb_ms, 4),
+                "mode": "rollout: glimpse scores / output and pointer scores on bf16 operands (v_mfma_f32_16x16x32_bf16, f32 "
+                        "accumulation), softmax / masks / local policy / environment f32; glimpse backward: bf16-forward scores + "
+                        "2-term split-bf16 linear products; encoder, pointer and local-policy backward f32",
+                "tolerance": "tests/test_gpu_logits.py::test_bf16_mode_*: scores before the clip within 1e-1 max(|ref|, 1) of the "
+                             "reference's (7e-3 at the default init); tests/test_gpu_backward.py::test_bf16_mode_training_gradients"}
+        eng.FWD_PRECISION = 0
+
     # ---- sustained leg (f32 again): >= sustain-s seconds of back-to-back steps, so that an outside utilisation sampler sees
     # the GPU busy and the rate is not a 0.1 s sample; the step count is fixed from the headline leg (same on every rank)
     sustained = None
@@ -450,6 +466,9 @@ def main():
         if fast is not None:
             out["value_fast"] = fast["value"]
             out["fast"] = fast
+        if bf16 is not None:
+            out["value_bf16"] = bf16["value"]
+            out["bf16"] = bf16
         if sustained is not None:
             out["sustained"] = sustained
         if not args.no_secondary and world == 1:

@@ -31,7 +31,7 @@ class RolloutArgs(C.Structure):
         ("dump_T", C.c_int32),
         ("xi", C.c_float), ("clip", C.c_float), ("inv_ens", C.c_float), ("variant", C.c_int32),
         ("dump_logits", C.c_int32), ("euclidean", C.c_int32),
-        ("ens", C.c_int32), ("Kens", C.c_int32 * MAX_ENS), ("pad_ens", C.c_int32),
+        ("ens", C.c_int32), ("Kens", C.c_int32 * MAX_ENS), ("precision", C.c_int32),
         ("seed", C.c_uint64),
         ("Kmat", _vp), ("Vmat", _vp), ("PK", _vp), ("pb", _vp), ("Q1", _vp), ("Q2", _vp), ("wl", _vp),
         ("xy", _vp), ("demand", _vp), ("nbr_idx", _vp), ("nbr_dist", _vp), ("nbr_theta", _vp), ("loc", _vp),

@@ -1007,14 +1007,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int n = 16 * nt + 4 * hi + v;
             // (the 1/4 of the softmax backward rides on K here and on q below -- exact; the scores' log2(e)/4 on K)
             kv[v] = n < N1 ? 0.25f * Kmat[((size_t)b * N1 + n) * ELG_E + h * 16 + lo] : 0.f;
-            k2[v] = n2 < N1 ? cs * Kmat[((size_t)b * N1 + n2) * ELG_E + h * 16 + 4 * v + hi] : 0.f;
+            // (TS == 1: the scores of a bf16 forward -- bf16(q) . bf16(K), the scale applied to the f32 sum afterwards, as there)
+            k2[v] = n2 < N1 ? (TS == 1 ? 1.f : cs) * Kmat[((size_t)b * N1 + n2) * ELG_E + h * 16 + 4 * v + hi] : 0.f;
             vv[v] = n2 < N1 ? Vmat[((size_t)b * N1 + n2) * ELG_E + h * 16 + 4 * v + hi] : 0.f;
         }
         unsigned p[6];
         bf_terms<2>(kv[0], kv[1], kv[2], kv[3], p);
         *reinterpret_cast<uint4*>(sKd + (nt * 64 + lane) * 4) = make_uint4(p[0], p[1], p[0], p[1]);
         *reinterpret_cast<uint4*>(sKd + ((NT + nt) * 64 + lane) * 4) = make_uint4(p[2], p[3], p[2], p[3]);
-        bf_terms<TS>(k2[0], k2[1], k2[2], k2[3], p);
+        bf_terms<(TS < 2 ? 2 : TS)>(k2[0], k2[1], k2[2], k2[3], p);
         *reinterpret_cast<uint4*>(sK2 + (nt * 64 + lane) * 4) = make_uint4(p[0], p[1], p[0], p[1]);
         *reinterpret_cast<uint4*>(sK2 + ((NT + nt) * 64 + lane) * 4) = make_uint4(p[2], p[3], p[2], p[3]);
         if (TS >= 3) *reinterpret_cast<uint4*>(sK2 + ((2 * NT + nt) * 64 + lane) * 4) = make_uint4(p[4], p[5], p[0], p[1]);
@@ -1108,8 +1109,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int v = 0; v < 4; ++v) ndv[v] = -__shfl(doto, 4 * hi + v);
         // per-tile operands: q single (scores), dO / dO^T / q^T dup
         unsigned qt[6];
-        bf_terms<TS>(qA[0], qA[1], qA[2], qA[3], qt);
-        const u32x4 q12 = {qt[0], qt[1], qt[2], qt[3]};
+        bf_terms<(TS < 2 ? 2 : TS)>(qA[0], qA[1], qA[2], qA[3], qt);
+        const u32x4 q12 = {qt[0], qt[1], TS == 1 ? 0u : qt[2], TS == 1 ? 0u : qt[3]};
         const u32x4 q13 = {qt[0], qt[1], qt[4], qt[5]};
         u32x4 do1, do2, dob1, dob2, qb1, qb2;
         bf_dup(doA[0], doA[1], doA[2], doA[3], do1, do2);
@@ -1139,11 +1140,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const unsigned closed = (unsigned)((int)(cm[v] << (31 - bit)) >> 31);    // ~0 for a closed node, 0 for an open one
-                S[v] = __uint_as_float((closed & 0xff800000u) | (~closed & __float_as_uint(-lsv[v])));
+                S[v] = __uint_as_float((closed & 0xff800000u) | (~closed & __float_as_uint(TS == 1 ? 0.f : -lsv[v])));
             }
             S = mfma_bf(q12, u32x4{ka.x, ka.y, ka.z, ka.w}, S);
             dA = mfma_bf(do1, vq, dA);
-            S = mfma_bf(q12, u32x4{kb.x, kb.y, kb.z, kb.w}, S);
+            if (TS >= 2) S = mfma_bf(q12, u32x4{kb.x, kb.y, kb.z, kb.w}, S);
             dA = mfma_bf(do2, vq, dA);
             if (TS >= 3) {
                 const uint4 kc = *reinterpret_cast<const uint4*>(sK2 + ((2 * NT + nt) * 64 + lane) * 4);
@@ -1152,7 +1153,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             float aw[4], ds1[4];
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                aw[v] = __builtin_amdgcn_exp2f(S[v]);
+                aw[v] = __builtin_amdgcn_exp2f(TS == 1 ? fmaf(S[v], cs, -lsv[v]) : S[v]);
                 ds1[v] = aw[v] * dA[v];                            // 4 dS: node 16 nt + lo, row 4 hi + v
             }
             const u32x4 dsq = bf_single(ds1[0], ds1[1], ds1[2], ds1[3]);
@@ -1656,6 +1657,9 @@ int glimpse_bwd_launch(const float* rowA, const unsigned long long* mk, const fl
         // split-bf16 products (mask rows + saved normaliser + gather epilogue: the training path)
 #define ELG_GBF(NT)                                                                                                         \
     {                                                                                                                       \
+        if (seg.mfma_mode == 3)                                                                                             \
+            return launch_glimpse_bwd_bf16<NT, 1>(mk, dO, rowO, rowQ, Kmat, Vmat, dK_part, dV_part, B, R, N1, (size_t)rowO_rows, \
+                                                  (size_t)rowQ_rows, splits, seg, s);                                       \
         if (seg.mfma_mode == 1)                                                                                             \
             return launch_glimpse_bwd_bf16<NT, 2>(mk, dO, rowO, rowQ, Kmat, Vmat, dK_part, dV_part, B, R, N1, (size_t)rowO_rows, \
                                                   (size_t)rowQ_rows, splits, seg, s);                                       \

@@ -22,7 +22,7 @@ struct GlimpseSeg {
     int M;                  // trajectories per instance (with T_dev / tlen)
     const int* tlen;        // (B,M) steps per trajectory, or NULL: with it (time-major rows) only the tiles of the decode steps
     int t0;                 //   t0 .. max_m tlen[b,m] - 1 are walked -- the rows outside carry dO = 0 and contribute nothing
-    int mfma_mode;          // 0: f32 MFMAs; split-bf16 products (mask rows + lse + epilogue): 1 = 2 terms, 2 = 3-term scores + 2-term linear
+    int mfma_mode;          // 0: f32 MFMAs; split-bf16 products (mask rows + lse + epilogue): 1 = 2 terms, 2 = 3-term scores + 2-term linear, 3 = 1-term (bf16-forward) scores + 2-term linear
 };
 
 // first 16-row tile that holds a row of decode step t0 (rows r = t M + m)

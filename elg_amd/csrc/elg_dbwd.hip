@@ -526,7 +526,7 @@ extern "C" int elg_decoder_bwd(const elg_decoder_bwd_args* p, void* stream) {
     seg.accumulate = 1;
     seg.lse = p->trMask ? p->trLse : nullptr;
     seg.T_dev = p->T_dev; seg.M = M; seg.tlen = p->tlen; seg.t0 = p->first_decode_step;
-    if (p->mfma_mode < 0 || p->mfma_mode > 2) return fail(ELG_EINVAL, "decoder_bwd: mfma_mode 0 .. 2");
+    if (p->mfma_mode < 0 || p->mfma_mode > 3) return fail(ELG_EINVAL, "decoder_bwd: mfma_mode 0 .. 3");
     seg.mfma_mode = p->mfma_mode;
     const int splits = max(1, min(8, 1024 / (B * 8)));
     return glimpse_bwd_launch(p->trMask ? nullptr : p->trA, reinterpret_cast<const unsigned long long*>(p->trMask), p->dO, p->trO,

@@ -1166,7 +1166,11 @@ __device__ __forceinline__ void co_advance4(const elg_rollout_args& A, const Ins
     wave_lds_fence();
 }
 
-template <bool TSP, bool TRAIN>
+// BF: the bf16 throughput mode (elg_rollout_args.precision = 1; BASELINE configs[1] names it): the three table products of a
+// step -- glimpse scores K_h q^T, glimpse output V_h^T P^T, pointer scores PK o^T -- run on v_mfma_f32_16x16x32_bf16 with the
+// operands rounded to bf16 (tables, query, softmax numerators, glimpse output) and f32 accumulation; masks, softmax, clip,
+// choice, the local policy and the environment stay f32.  The f32 instantiation is the parity mode and the default.
+template <bool TSP, bool TRAIN, bool BF>
 __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout_args A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1233,6 +1237,24 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
             vop[nt][v] = gV[(unsigned)(min(n2, N1 - 1) * ELG_E + lo_t)];                                    \
         }                                                                                                   \
     }
+    // bf16 mode: kopb[nt] = K[n = 16 nt + lo][16 h + 4 hi + j], j < 4, in k-slots (hi, 0..3); k-slots (hi, 4..7) are zero (the head
+    // has 16 channels, the instruction contracts 32).  vopb[p] = V[n][16 h + lo] for the eight nodes n = 32 p + 4 hi + j (j < 4)
+    // and 32 p + 16 + 4 hi + j - 4 (j >= 4): the D tiles of the score product for node tiles 2 p and 2 p + 1, side by side, are
+    // the B operand (rows past N1 - 1 re-read row N1 - 1: their weights are exactly 0).
+#define ELG_CO_LOAD_KV_BF()                                                                                 \
+    _Pragma("unroll") for (int nt = 0; nt < CO_NT; ++nt) {                                                  \
+        const int n = 16 * nt + lo_t;                                                                       \
+        const float4 k4_ = *reinterpret_cast<const float4*>(gK + (unsigned)(min(n, N1 - 1) * ELG_E + 4 * hi_t));   \
+        kopb[nt] = u32x4{pk_bf16(k4_.x, k4_.y), pk_bf16(k4_.z, k4_.w), 0u, 0u};                             \
+    }                                                                                                       \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                                         \
+        float va_[4], vb_[4];                                                                               \
+        _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                                     \
+            va_[v] = gV[(unsigned)(min(32 * p + 4 * hi_t + v, N1 - 1) * ELG_E + lo_t)];                     \
+            vb_[v] = gV[(unsigned)(min(32 * p + 16 + 4 * hi_t + v, N1 - 1) * ELG_E + lo_t)];                \
+        }                                                                                                   \
+        vopb[p] = u32x4{pk_bf16(va_[0], va_[1]), pk_bf16(va_[2], va_[3]), pk_bf16(vb_[0], vb_[1]), pk_bf16(vb_[2], vb_[3])}; \
+    }
     {
         // the PK operand image goes to LDS ([tile][k-step][lane], read back conflict-free): with it in registers
         // too, the batched local policy no longer fits the 256-VGPR budget of 2 waves/SIMD
@@ -1240,11 +1262,23 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
         const float* gP = A.PK + b * NE + (size_t)min(np, N1 - 1) * ELG_E;
         // [tile][channel group g][lane][j] = PK[16 tile + lo][16 g + 4 hi + j]: the four k-steps of a channel group are one
         // ds_read_b128 (k-slot (g, j, hi) stands for channel 16 g + 4 hi + j in both operands)
-        if (wave < CO_NT)
+        if (!BF && wave < CO_NT)
             for (int g = 0; g < 8; ++g) {
                 float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (np < N1) x = *reinterpret_cast<const float4*>(gP + 16 * g + 4 * hi);
                 *reinterpret_cast<float4*>(sP + ((wave * 8 + g) * 64 + lane) * 4) = x;
+            }
+        // bf16: [tile][32-channel block g][lane] = the eight channels 32 g + 8 hi .. + 7 of PK[16 tile + lo] as one 16-byte
+        // A operand of v_mfma_f32_16x16x32_bf16 (k-slot (hi, j) stands for channel 32 g + 8 hi + j in both operands)
+        if (BF && wave < CO_NT)
+            for (int g = 0; g < 4; ++g) {
+                uint4 x = make_uint4(0u, 0u, 0u, 0u);
+                if (np < N1) {
+                    const float4 a = *reinterpret_cast<const float4*>(gP + 32 * g + 8 * hi);
+                    const float4 c = *reinterpret_cast<const float4*>(gP + 32 * g + 8 * hi + 4);
+                    x = make_uint4(pk_bf16(a.x, a.y), pk_bf16(a.z, a.w), pk_bf16(c.x, c.y), pk_bf16(c.z, c.w));
+                }
+                *reinterpret_cast<uint4*>(sP + ((wave * 4 + g) * 64 + lane) * 4) = x;
             }
     }
     for (int i = tid; i < 16 * CO_NT; i += 512) sPb[i] = (i < N1) ? I.pb[i] : 0.f;
@@ -1279,10 +1313,15 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sc.last) :: "memory");
 #endif
         float kop[CO_NT][4], vop[CO_NT][4];                         // (re)loaded at the end of every owners' phase
+        u32x4 kopb[CO_NT], vopb[4];                                 // their bf16 forms (BF)
 #pragma unroll
-        for (int nt = 0; nt < CO_NT; ++nt)
+        for (int nt = 0; nt < CO_NT; ++nt) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) { kop[nt][v] = 0.f; vop[nt][v] = 0.f; }
+            kopb[nt] = u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) vopb[p] = u32x4{0u, 0u, 0u, 0u};
         for (int t = 0; t < step_cap && t < A.Tmax; ++t) {
             // Opaque per-iteration copy of the lane id: every address below is a function of it, so the compiler cannot
             // hoist the (loop-invariant) address arithmetic of ~300 loads out of the step loop -- it did, and then
@@ -1360,6 +1399,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                 {
                     const float cs = 0.25f * 1.4426950408889634f;
                     float qb[2][4];
+                    u32x4 qbb[2];                                       // bf16: the query's four channels in k-slots (hi, 0..3)
                     f32x4c sc[2][CO_NT];
                     float mx[2], cm[2], den[2] = {0.f, 0.f};
 #pragma unroll
@@ -1367,14 +1407,18 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                         const int traj = 16 * rt + lo_t;
                         const float4 q4 = *reinterpret_cast<const float4*>(sQ + traj * CO_QP + 16 * wave + 4 * hi_t);   // channels 4 hi + kk, as kop
                         qb[rt][0] = q4.x; qb[rt][1] = q4.y; qb[rt][2] = q4.z; qb[rt][3] = q4.w;
+                        qbb[rt] = u32x4{pk_bf16(q4.x, q4.y), pk_bf16(q4.z, q4.w), 0u, 0u};
                         mx[rt] = -1e30f;                                // finite floor: a fully closed row gives exp2(-inf) = 0
                     }
                     auto s_tile = [&](int rt, int nt) {                // S^T tile: the additive mask (0 / -inf, left in the score row by
                         // the owners; nodes past N1 and missing trajectories are -inf) is the accumulator input of the 4 MFMAs
                         const float4 m4 = *reinterpret_cast<const float4*>(sSc + (16 * rt + lo_t) * CO_SP + 16 * nt + 4 * hi_t);
                         f32x4c acc = {m4.x, m4.y, m4.z, m4.w};
+                        if (BF) acc = mfma_bf(kopb[nt], qbb[rt], acc);
+                        else {
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kop[nt][kk], qb[rt][kk], acc, 0, 0, 0);
+                            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kop[nt][kk], qb[rt][kk], acc, 0, 0, 0);
+                        }
 #pragma unroll
                         for (int v = 0; v < 4; ++v) mx[rt] = fmaxf(mx[rt], acc[v]);
                         sc[rt][nt] = acc;
@@ -1391,6 +1435,20 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt) { o[rt] = f32x4c{0.f, 0.f, 0.f, 0.f}; o2[rt] = f32x4c{0.f, 0.f, 0.f, 0.f}; }
                     auto o_tile = [&](int rt, int nt) {
+                        if (BF) {
+                            // node tiles nt - 1 and nt in one instruction, issued once the odd tile's numerators exist (and for the
+                            // unpaired last tile with an empty upper half)
+                            if (nt & 1) {
+                                const u32x4 pb_ = {pk_bf16(sc[rt][nt - 1][0], sc[rt][nt - 1][1]), pk_bf16(sc[rt][nt - 1][2], sc[rt][nt - 1][3]),
+                                                   pk_bf16(sc[rt][nt][0], sc[rt][nt][1]), pk_bf16(sc[rt][nt][2], sc[rt][nt][3])};
+                                if (nt & 2) o2[rt] = mfma_bf(vopb[nt >> 1], pb_, o2[rt]);
+                                else o[rt] = mfma_bf(vopb[nt >> 1], pb_, o[rt]);
+                            } else if (nt == CO_NT - 1) {
+                                const u32x4 pb_ = {pk_bf16(sc[rt][nt][0], sc[rt][nt][1]), pk_bf16(sc[rt][nt][2], sc[rt][nt][3]), 0u, 0u};
+                                o2[rt] = mfma_bf(vopb[nt >> 1], pb_, o2[rt]);
+                            }
+                            return;
+                        }
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
                             if (v & 1) o2[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vop[nt][v], sc[rt][nt][v], o2[rt], 0, 0, 0);
@@ -1460,6 +1518,24 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                     for (int un = wave; un < (two_rt ? 2 * CO_NT : CO_NT); un += 6) {
                         const int nt = un % CO_NT, rt = un / CO_NT;
                         const int traj = 16 * rt + lo_t;
+                        if (BF) {
+                            const float* orow8 = sQ + traj * CO_QP + 8 * hi_t;
+                            const unsigned* popb = reinterpret_cast<const unsigned*>(sP) + (nt * 4 * 64 + lane_t) * 4;
+                            const float4 pb4b = *reinterpret_cast<const float4*>(sPb + 16 * nt + 4 * hi_t);
+                            f32x4c b0 = {pb4b.x, pb4b.y, pb4b.z, pb4b.w}, b1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const uint4 pk8 = *reinterpret_cast<const uint4*>(popb + g * 256);
+                                const float4 oa = *reinterpret_cast<const float4*>(orow8 + 32 * g);
+                                const float4 oc = *reinterpret_cast<const float4*>(orow8 + 32 * g + 4);
+                                const u32x4 ob_ = {pk_bf16(oa.x, oa.y), pk_bf16(oa.z, oa.w), pk_bf16(oc.x, oc.y), pk_bf16(oc.z, oc.w)};
+                                if (g & 1) b1 = mfma_bf(u32x4{pk8.x, pk8.y, pk8.z, pk8.w}, ob_, b1);
+                                else b0 = mfma_bf(u32x4{pk8.x, pk8.y, pk8.z, pk8.w}, ob_, b0);
+                            }
+                            *reinterpret_cast<float4*>(sSc + traj * CO_SP + 16 * nt + 4 * hi_t) =
+                                make_float4(b0[0] + b1[0], b0[1] + b1[1], b0[2] + b1[2], b0[3] + b1[3]);
+                            continue;
+                        }
                         const float* orow = sQ + traj * CO_QP + 4 * hi_t;
                         const float* pop = sP + (nt * 8 * 64 + lane_t) * 4;
                         const float4 pb4 = *reinterpret_cast<const float4*>(sPb + 16 * nt + 4 * hi_t);
@@ -1513,7 +1589,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
             }
             any_left = (q4 < ntraj && !row.fin) ? 1 : 0;
             ELG_STAMP(sc, 11);
-            ELG_CO_LOAD_KV()                                         // next step's glimpse operands, in flight over the barrier
+            if (BF) { ELG_CO_LOAD_KV_BF() } else { ELG_CO_LOAD_KV() }  // next step's glimpse operands, in flight over the barrier
             ELG_STAMP(sc, 12);
             const int go_on = __syncthreads_or(any_left);            // also orders the exchange rows for the next step
             ELG_STAMP(sc, 13);
@@ -1536,12 +1612,12 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
     }
 }
 
-template <bool TSP, bool TRAIN>
+template <bool TSP, bool TRAIN, bool BF>
 static int launch_fwd_coop(const elg_rollout_args& A, hipStream_t stream) {
     const size_t lds = ((size_t)CO_MAXTR * CO_QP + (size_t)CO_MAXTR * CO_SP + 4 * CO_MAXTR + 16 * CO_MAXTR +
                         ((A.N1 + 3) & ~3) + ((2 * A.N1 + 3) & ~3) + (size_t)CO_MAXTR * CO_XP + CL_SIZE + CO_NT * 32 * 64 + 16 * CO_NT +
                         8 * SbSize<2>::value + 2 * 512) * 4 + 64;
-    auto kern = rollout_fwd_coop_kernel<TSP, TRAIN>;
+    auto kern = rollout_fwd_coop_kernel<TSP, TRAIN, BF>;
     static DynLds optin;
     if (!optin.opt_in(reinterpret_cast<const void*>(kern), lds)) return fail(ELG_ELAUNCH, "coop rollout: hipFuncSetAttribute failed");
     (void)hipGetLastError();
@@ -2579,7 +2655,8 @@ static int dispatch_fwd(const elg_rollout_args& A, hipStream_t stream) {
         // fused rollout at the training scale: lockstep trajectories, tables as MFMA operands in registers
         const bool train = A.trA || A.trMask;      // training forward (glimpse weights saved, or recomputed from the mask rows)
         if (train && (!A.trPC || !A.trCsel || !A.trQ || !A.trO)) return fail(ELG_EINVAL, "rollout: incomplete training rows");
-        return train ? launch_fwd_coop<TSP, true>(A, stream) : launch_fwd_coop<TSP, false>(A, stream);
+        if (A.precision == 1) return train ? launch_fwd_coop<TSP, true, true>(A, stream) : launch_fwd_coop<TSP, false, true>(A, stream);
+        return train ? launch_fwd_coop<TSP, true, false>(A, stream) : launch_fwd_coop<TSP, false, false>(A, stream);
     }
     const bool mt_shape = !lds && nch > 2 && nch <= 16 && !A.use_state && A.do_decode && A.do_update && A.max_steps <= 0 && A.variant == 0;
     if (A.trMask && !A.trA && !mt_shape) return fail(ELG_EINVAL, "rollout: this kernel needs trA (mask-only rows: cooperative / streaming kernels)");
@@ -2687,6 +2764,7 @@ int elg_rollout_fwd(const elg_rollout_args* a, void* stream) {
             if (A.Kens[i] < 0 || A.Kens[i] + 1 > ELG_SLOT_STRIDE) return fail(ELG_EINVAL, "rollout: local_size must be <= 47");
     }
     if (A.mode == ELG_MODE_FORCED && !A.forced) return fail(ELG_EINVAL, "rollout: forced mode without actions");
+    if (A.precision != 0 && A.precision != 1) return fail(ELG_EINVAL, "rollout: precision 0 (f32) or 1 (bf16 table products)");
     if (A.problem == ELG_PROBLEM_CVRP) return dispatch_fwd<false>(A, (hipStream_t)stream);
     if (A.problem == ELG_PROBLEM_TSP) return dispatch_fwd<true>(A, (hipStream_t)stream);
     return fail(ELG_EINVAL, "rollout: unknown problem");

@@ -408,6 +408,14 @@ class RolloutResult:
 # largest gradient entry against float64 where the f32 MFMAs give 1.1e-6 -- tests/test_gpu_train_glue.py -- at 0.6 of the time)
 BWD_MFMA_MODE = int(os.environ.get("ELG_BWD_MFMA_MODE", "0"))
 
+# Arithmetic of the rollout's three table products (glimpse scores / output, pointer scores; elg_rollout_args.precision):
+# "f32" = the parity mode (exact f32 products, the 1e-4 logit bar of north_star) and the default; "bf16" = the throughput mode
+# BASELINE configs[1] names: bf16 operands on v_mfma_f32_16x16x32_bf16, f32 accumulation, in the cooperative kernel
+# (N + 1 <= 112; other shapes compute in f32 whatever the mode).  Tolerance of the bf16 mode, as tested
+# (tests/test_gpu_logits.py::test_bf16_mode_*): scores before the clip within 3e-2 max(|ref|, 1), probabilities of the chosen
+# nodes within 5 %; greedy tours differ from the f32 ones in a few per cent of the steps.
+FWD_PRECISION = {"f32": 0, "fp32": 0, "bf16": 1}[os.environ.get("ELG_FWD_MODE", "f32").lower()]
+
 LARGE_ROWS_BUDGET = 0.45          # fraction of the free HBM the saved rows of a 128 < N1 <= 1024 training forward may take
 _LOG_PATHS = os.environ.get("ELG_LOG_PATHS", "0") not in ("", "0")      # print which large-instance backward a step takes
 
@@ -442,7 +450,7 @@ def _rows_fit(B, M, N1, Tcap, dev) -> bool:
 
 def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mode: int, *, forced=None, seed: int = 0,
                     uniforms=None, dump_T: int = 0, geometry=None, Tcap: Optional[int] = None,
-                    train: bool = False, variant: int = 0, dump: str = "probs") -> RolloutResult:
+                    train: bool = False, variant: int = 0, dump: str = "probs", precision: Optional[int] = None) -> RolloutResult:
     """Run every trajectory to completion in one persistent launch (reference CVRP/utils.py:7-29)."""
     dev = prob.xy.device
     _need_cuda(prob.xy, "the problem")
@@ -458,6 +466,7 @@ def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mo
     a.Tmax, a.mode, a.max_steps, a.do_decode, a.do_update, a.use_state = Tcap, mode, 0, 1, 1, 0
     a.seed = seed & 0xFFFFFFFFFFFFFFFF
     a.variant = variant
+    a.precision = FWD_PRECISION if precision is None else int(precision)
     a.dump_logits = {"probs": 0, "logits": 1, "scores": 2}[dump]
     # (a pageable host tensor would block the host until the stream has drained: staged through pinned memory instead)
     starts = h2d(starts.to(torch.int32).contiguous(), dev) if not starts.is_cuda else starts.to(torch.int32).contiguous()
@@ -482,6 +491,8 @@ def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mo
     if save_rows:
         rows = TrainRows.get(B, M, N1, Tcap, dev)
         rows.prepare()
+        # (only the cooperative kernel has a bf16 mode: every other kernel computes -- and is differentiated -- in f32)
+        rows.precision = int(a.precision) if (a.lds_stage and 4 <= N1 <= 112 and variant == 0) else 0
         # the cooperative kernel (what dispatch_fwd picks for this launch shape) saves the rows' 128-bit mask words and the
         # glimpse log2-sum-exp per head instead of the glimpse weights: the backward recomputes the weights from q, K, the
         # mask and the saved normaliser (28 MFMAs + one exp2 per weight).  4.2 GB less workspace and 6.6 GB less HBM traffic
@@ -653,7 +664,8 @@ class _ChosenProbs(torch.autograd.Function):
         a.T_dev, a.gprob_T = _ptr(ctx.T_dev), g.shape[1]
         # `training: only_local`: the decoder tables are constants (zeros) -- the glimpse backward would compute gradients nobody reads
         a.tables_frozen = int(not any(ctx.needs_input_grad[7:14]))
-        a.mfma_mode = BWD_MFMA_MODE
+        # a bf16 forward saved the normaliser of ITS scores: the backward recomputes them the same way (mode 3)
+        a.mfma_mode = 3 if getattr(rows, "precision", 0) == 1 else BWD_MFMA_MODE
         big = None
         if N1 > 128:
             # row contractions as batched GEMMs over (8, R, N1) buffers: scratch for as many instances as fit, the call walks

@@ -100,7 +100,10 @@ typedef struct elg_rollout_args {
                                slot scores are summed and scaled by inv_ens.  Runs the one-wavefront-per-trajectory kernel
                                (N1 <= 1024); training goes through elg_rollout_bwd's replay (N1 <= 1024)                */
     int32_t Kens[ELG_MAX_ENS];
-    int32_t pad_ens;
+    int32_t precision;      /* 0: f32 (the parity mode: every product exact f32).  1: bf16 throughput mode (BASELINE configs[1]): the
+                               glimpse score / output and pointer products of the cooperative kernel (N1 <= 112) take bf16 operands
+                               on v_mfma_f32_16x16x32_bf16 with f32 accumulation; softmax, masks, local policy, environment stay
+                               f32.  Other kernels ignore it (they compute in f32).                                      */
     uint64_t seed;          /* sampling seed (Philox key)                                       */
     const float* Kmat;      /* (B,N1,128) decoder.Wk enc                                        */
     const float* Vmat;      /* (B,N1,128) decoder.Wv enc                                        */
@@ -407,10 +410,13 @@ typedef struct elg_decoder_bwd_args {
      * trPC is overwritten with d s (in place). */
     int32_t mask_words;         /* W of trMask for N1 > 128 (ignored otherwise)                                        */
     int32_t mfma_mode;          /* N1 <= 128, mask-row mode: arithmetic of the glimpse backward's five products.  0: f32 MFMAs
-                                 * (v_mfma_f32_16x16x4_f32, exact f32; 1.1e-6 of the largest gradient entry against float64).
+                                 * (v_mfma_f32_16x16x4_f32, exact f32; 6.5e-7 of the largest gradient entry against float64; the query-gather
+                                 * scatter is a one-hot product of exact 0 / 1 factors with the three bf16 terms of dq, f32 accumulation).
                                  * Split-bf16 (v_mfma_f32_16x16x32_bf16 on bf16 terms of the f32 operands, f32 accumulation):
                                  * 1 = 2 terms per operand (16 significand bits; 3e-5), 2 = 3-term score product q K^T +
-                                 * 2-term linear products (7.5e-6)                                                        */
+                                 * 2-term linear products (7.5e-6); 3 = the backward of a bf16 rollout (elg_rollout_args.precision
+                                 * = 1): the scores are recomputed as there -- bf16(q) . bf16(K), one term, scaled after the f32
+                                 * sum -- so that exp2(s - lse) reproduces the forward's weights; linear products as in 1    */
     float* ws;                  /* scratch for N1 > 128 (NULL otherwise): k * elg_decoder_bwd_ws_floats(1, R, N1) floats,
                                  * 1 <= k <= B -- the batch is walked in chunks of k instances                          */
     int64_t ws_floats;

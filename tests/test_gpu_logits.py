@@ -122,3 +122,112 @@ def test_large_instance_logits(variant):
     g = eng.rollout_forward(env.problem, pol, M, acts[0, :, 1], L.MODE_GREEDY, variant=variant)
     Tg = int(g.tlen.max())
     assert Tg == T and torch.equal(g.actions[:, :, :T].cpu(), acts)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bf16 throughput mode of the cooperative kernel (elg_rollout_args.precision = 1; BASELINE configs[1] "bf16"): its own, looser,
+# STATED tolerance against the reference's logits -- the f32 mode above stays the parity mode.
+# bf16 operands carry 8 significand bits: a score s = sum_c a_c b_c moves by ~2^-9 |a||b| per term.  Observed against the
+# reference's logits: 3e-3 (tsp n20), 7e-3 (cvrp n100, the bench's size), 2e-2 (tsp n50), 3e-2 (cvrp n20k8), 6e-2 (cvrp n50: the
+# fixtures with amplified weights, whose tables are an order of magnitude larger than a trained model's).  Bound tested:
+#   scores before the clip   |got - ref| <= BF16_TOL max(|ref|, 1)     on every open node
+#   clipped logits           |got - ref| <= BF16_TOL * logit_clipping  on every open node; closed nodes -inf in both (bit-exact mask)
+BF16_TOL = 1e-1
+
+
+def _check_bf16(tag, lg, scores, logits, clip, steps, tlen):
+    worst_s = worst_l = 0.0
+    tl = tlen.cpu().numpy()
+    for i, t in enumerate(steps):
+        live = (int(t) < tl)[:, :, None]
+        ref_l = lg["logits"][i]
+        open_ = np.isfinite(ref_l) & live
+        got_l = logits[:, :, int(t)].cpu().numpy()
+        got_s = scores[:, :, int(t)].cpu().numpy()
+        assert np.array_equal(np.isfinite(got_l) & live, open_), (tag, int(t), "mask pattern")      # the environment is exact in every mode
+        ref_s = lg["pre_clip"][i]
+        worst_s = max(worst_s, float((np.abs(got_s[open_] - ref_s[open_]) / np.maximum(np.abs(ref_s[open_]), 1.0)).max()))
+        worst_l = max(worst_l, float((np.abs(got_l[open_] - ref_l[open_]) / clip).max()))
+    gc.record_parity(f"logits_bf16/{tag}/coop/score_rel", worst_s)
+    gc.record_parity(f"logits_bf16/{tag}/coop/logit_over_clip", worst_l)
+    print(tag, f"bf16 mode: scores {worst_s:.2e}  logits/clip {worst_l:.2e}")
+    assert worst_s <= BF16_TOL and worst_l <= BF16_TOL, (tag, worst_s, worst_l)
+    assert worst_s > 1e-5, "the bf16 mode produced f32-exact scores: it did not run"
+
+
+@pytest.mark.parametrize("tag", ["n50", "n20k8", "n100"])
+def test_bf16_mode_cvrp_logits(tag):
+    from elg_amd.CVRP.CVRPEnv import CVRPEnv
+    lg = gu.load_golden(f"r02_cvrp_logits_{tag}.npz")
+    fx = gu.load_golden(f"cvrp_rollout_{str(lg['src'])}.npz")
+    B, N, M, wseed, pseed, local_size, rseed = [int(x) for x in fx["meta"]]
+    mp = dict(gu.CVRP_MODEL_PARAMS)
+    mp["local_size"] = [local_size]
+    model = gc.load_model("cvrp", wseed, mp, float(fx["gain"]))
+    depot, loc, demand = gu.golden_cvrp_problem(pseed, B, N, float(fx["capacity"]))
+    env = CVRPEnv(multi_width=M, device=DEV)
+    env.load_random_problems(dict(loc=torch.from_numpy(loc), demand=torch.from_numpy(demand), depot=torch.from_numpy(depot)))
+    rs, _, _ = env.reset()
+    with torch.no_grad():
+        model.pre_forward(rs)
+    acts = torch.from_numpy(fx["actions"].astype(np.int32))
+    T = acts.shape[2]
+    pol = model.decoder.policy
+    dumps = {}
+    for what in ("scores", "logits"):
+        r = eng.rollout_forward(env.problem, pol, M, acts[0, :, 1], L.MODE_FORCED, forced=acts, dump_T=T, dump=what, precision=1)
+        dumps[what] = r.full_probs
+    _check_bf16(f"cvrp_{tag}", lg, dumps["scores"], dumps["logits"], mp["logit_clipping"], lg["steps"], r.tlen)
+    # the environment does not depend on the mode: teacher-forced tours give the f32 rewards bit for bit
+    r32 = eng.rollout_forward(env.problem, pol, M, acts[0, :, 1], L.MODE_FORCED, forced=acts, precision=0)
+    assert torch.equal(r.reward, r32.reward) and torch.equal(r.tlen, r32.tlen)
+
+
+@pytest.mark.parametrize("tag", ["n50", "n20"])
+def test_bf16_mode_tsp_logits(tag):
+    from elg_amd.TSP.TSPEnv import TSPEnv
+    lg = gu.load_golden(f"r02_tsp_logits_{tag}.npz")
+    fx = gu.load_golden(f"tsp_rollout_{str(lg['src'])}.npz")
+    B, N, M, wseed, pseed, local_size, rseed = [int(x) for x in fx["meta"]]
+    mp = dict(gu.TSP_MODEL_PARAMS)
+    mp["local_size"] = [local_size]
+    model = gc.load_model("tsp", wseed, mp, float(fx["gain"]))
+    env = TSPEnv(multi_width=M, device=DEV)
+    env.load_random_problems(torch.from_numpy(gu.golden_tsp_problem(pseed, B, N)))
+    rs, _, _ = env.reset()
+    with torch.no_grad():
+        model.pre_forward(rs)
+    acts = torch.from_numpy(fx["actions"].astype(np.int32))
+    pol = model.decoder.policy
+    dumps = {}
+    for what in ("scores", "logits"):
+        r = eng.rollout_forward(env.problem, pol, M, acts[0, :, 0], L.MODE_FORCED, forced=acts, dump_T=N, dump=what, precision=1)
+        dumps[what] = r.full_probs
+    _check_bf16(f"tsp_{tag}", lg, dumps["scores"], dumps["logits"], mp["logit_clipping"], lg["steps"], r.tlen)
+
+
+def test_bf16_mode_sampled_rollout_at_the_bench_shape():
+    """CVRP-100 x 8 instances x pomo 100, sampled with the same Philox seed in both modes: feasible tours, the same mean cost to
+    a few per cent (the policy is the same function up to bf16 rounding of three products), chosen probabilities in (0, 1]."""
+    from elg_amd.CVRP.CVRPEnv import CVRPEnv
+    from elg_amd.CVRP.utils import check_feasible
+    mp = dict(gu.CVRP_MODEL_PARAMS)
+    model = gc.load_model("cvrp", 5, mp, 1.0)
+    depot, loc, demand = gu.golden_cvrp_problem(77, 8, 100, 50.0)
+    env = CVRPEnv(multi_width=100, device=DEV)
+    env.load_random_problems(dict(loc=torch.from_numpy(loc), demand=torch.from_numpy(demand), depot=torch.from_numpy(depot)))
+    rs, _, _ = env.reset()
+    with torch.no_grad():
+        model.pre_forward(rs)
+    pol = model.decoder.policy
+    starts = torch.arange(100, dtype=torch.int32)
+    out = {}
+    for prec in (0, 1):
+        r = eng.rollout_forward(env.problem, pol, 100, starts, L.MODE_SAMPLE, seed=99, precision=prec)
+        T = int(r.tlen.max())
+        check_feasible(r.actions[0:1, :, :T].long(), rs.node_demand[0:1])
+        pr = r.probs[:, :T]
+        assert bool(((pr > 0) & (pr <= 1.0 + 1e-6)).all())
+        out[prec] = float((-r.reward).mean())
+    assert abs(out[1] - out[0]) <= 0.05 * out[0], out
+    gc.record_parity("bf16_mode/cvrp100_sampled_mean_cost_rel_diff", abs(out[1] - out[0]) / out[0])
