@@ -110,14 +110,24 @@ def test_rccl_allreduce_in_the_training_step(tmp_path):
 
 
 def test_bench_under_the_launcher(tmp_path):
+    """bench.py as the driver starts it for N > 1 (`python -m torch.distributed.run`), with the RCCL all-reduce forced at world
+    size 1: 50 timed steps.  The record must explain itself -- per-rank step times and decode steps, the all-reduce's own time
+    (HIP events around GradBucket._reduce) -- and the 5 MB all-reduce must stay below 3 % of the step."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2",
-           "--no-cpu-baseline", "--no-secondary"]
+           "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "50", "--warmup", "3",
+           "--no-cpu-baseline", "--no-secondary", "--no-fast", "--sustain-s", "0"]
     (rc, log), = _run_children([(cmd, _env({"ELG_FORCE_DIST": "1"}))], tmp_path, "bench_launcher_", limit_s=240, cwd=ROOT)
     assert rc == 0, log[-4000:]
     line = [ln for ln in log.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["n_gpus"] == 1 and out["steps"] == 50 and out["value"] > 0 and out["scaling"] == "weak" and out["dtype"] == "f32"
     cfg = out["config"]
     assert cfg["parallelism"] == "dp1" and cfg["n_ranks_seen"] == 1
-    assert cfg["grad_allreduce"]["backend"] == "nccl" and cfg["grad_allreduce"]["calls"] == 5     # 2 warm-up + 3 timed
+    ar = cfg["grad_allreduce"]
+    assert ar["backend"] == "nccl" and ar["calls"] == 53                                          # 3 warm-up + 50 timed
+    assert 0.0 < ar["allreduce_ms"] and ar["share_of_step"] < 0.03, ar
+    pr = cfg["per_rank"]
+    assert len(pr["ms_per_step"]) == 1 and pr["ms_per_step_min"] <= pr["ms_per_step_max"]
+    assert 80 < pr["decode_steps_mean"][0] <= pr["decode_steps_max"][0] < 202
+    assert out["roofline"]["bound"] != "hbm" and "hbm" in out["roofline"]
+    assert cfg["library_is_built_from_these_sources"] and len(cfg["library_sha256"]) == 64
