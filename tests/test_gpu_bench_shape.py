@@ -65,9 +65,13 @@ def test_train_step_gradients_at_the_bench_row_count_vs_float64(mode, bound, mon
     Jo = orc.pomo_loss(out["probs"], rew_n.cpu().double(), True)
     Jo.backward()
     worst_dec, worst_enc = 0.0, 0.0
+    # (the biases in front of an instance norm have an exactly-zero true gradient -- the norm removes the per-channel mean --:
+    # encoder tensors are measured against max(their own maximum, 1e-3 of the largest encoder gradient))
+    enc_floor = 1e-3 * max(float(p.grad.abs().max()) for k, p in P.items() if k.startswith("encoder."))
     for k, p in P.items():
         r = p.grad
-        err = float((got[k] - r).abs().max() / r.abs().max().clamp_min(1e-300))
+        scale = float(r.abs().max()) if k.startswith("decoder.") else max(float(r.abs().max()), enc_floor)
+        err = float((got[k] - r).abs().max()) / scale
         if k.startswith("decoder."):
             worst_dec = max(worst_dec, err)
             assert err <= bound, f"{k}: {err:.3e} of the tensor maximum (bound {bound:g}, mode {mode})"
@@ -78,7 +82,7 @@ def test_train_step_gradients_at_the_bench_row_count_vs_float64(mode, bound, mon
     gc.record_parity("bench_rows/chosen_prob_rel_vs_float64", pe)
     print(f"mode {mode}: T = {T}, decoder/local {worst_dec:.2e}, encoder {worst_enc:.2e}, chosen probabilities {pe:.2e}")
     # the encoder's gradients pass through six ReLU layers: a unit at its kink may move single rows (see test_gpu_train_large)
-    assert worst_enc <= 2e-2, worst_enc
+    assert worst_enc <= 2e-3, worst_enc
 
 
 def test_bench_launch_geometry_against_the_oracle():
