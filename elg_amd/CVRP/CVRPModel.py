@@ -36,9 +36,12 @@ class CVRPModel(nn.Module):
             xy = torch.cat((reset_state.depot_xy, reset_state.node_xy), dim=1)
             demand = torch.cat((torch.zeros_like(reset_state.depot_xy[:, :, 0]), reset_state.node_demand), dim=1)
         mp = self.model_params
+        # (the local fold FIRST: autograd runs the younger node first, so the encoder's backward is queued before the fold's
+        # backward has to wait for the side-stream row kernel -- engine.SIDE_LOCAL_BWD)
+        loc = self.decoder.fold_local()
         self.encoded_nodes, tables = enc_host.encode_and_fold(L.PROBLEM_CVRP, xy, demand, self._encoder_params(),
                                                               int(mp['encoder_layer_num']), int(mp['ff_hidden_dim']))
-        self.decoder.set_tables(self.encoded_nodes, tables, self.decoder.fold_local())
+        self.decoder.set_tables(self.encoded_nodes, tables, loc)
 
     @staticmethod
     def draw_starts(problem_size, multi_width):

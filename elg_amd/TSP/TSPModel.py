@@ -28,10 +28,11 @@ class TSPModel(nn.Module):
     def pre_forward(self, reset_state):
         """reference TSPModel.py:17-24: encoder + decoder.set_kv as one call into libelg_hip.so (elg_encoder_fwd)."""
         mp = self.model_params
+        loc = self.decoder.fold_local()             # first: see CVRPModel.pre_forward (backward order of the two nodes)
         self.encoded_nodes, tables = enc_host.encode_and_fold(L.PROBLEM_TSP, reset_state.problems, None,
                                                               self._encoder_params(), int(mp['encoder_layer_num']),
                                                               int(mp['ff_hidden_dim']))
-        self.decoder.set_tables(self.encoded_nodes, tables, self.decoder.fold_local())
+        self.decoder.set_tables(self.encoded_nodes, tables, loc)
 
     @staticmethod
     def draw_starts(problem_size, pomo_size):

@@ -139,7 +139,7 @@ def lib() -> C.CDLL:
         L.elg_pomo_loss.argtypes = [f, f, i, i, i, i64, i64, f, f, f, f, f, f]
         L.elg_add_instnorm_fwd.argtypes = [f, f, f, f, f, f, f, i, i, i, fl, f]
         L.elg_add_instnorm_bwd.argtypes = [f, f, f, f, f, f, f, i, i, i, f]
-        L.elg_local_bwd_rows.argtypes = [f, f, f, f, f, i, i, i64, i, f, i, f]
+        L.elg_local_bwd_rows.argtypes = [f, f, f, f, f, i, i, i64, i, f, i, i, f]
         L.elg_adam_step.argtypes = [f, f, f, i, f, f, f, i64, fl, fl, fl, fl, fl, i64, fl, f]
         L.elg_encoder_ws_floats.argtypes = [i, i, i, i, i]
         L.elg_encoder_ws_floats.restype = i64

@@ -24,6 +24,7 @@
 #include "elg_common.h"
 #include "elg_rollout.h"
 #include "../../include/elg_hip.h"
+#include <cstdlib>
 #include <string>
 
 namespace elg {
@@ -500,14 +501,15 @@ using namespace elg;
 
 extern "C" int elg_local_bwd_rows(const float* loc, const float* trF, const int32_t* trSlot, const float* rowDU,
                                   float* gloc, int B, int R, int64_t Rcap, int n_slots, const int32_t* T_dev, int M,
-                                  void* stream) {
+                                  int max_workgroups, void* stream) {
     if (!loc || !trF || !trSlot || !rowDU || !gloc) return fail(ELG_EINVAL, "local_bwd_rows: null buffer");
     if (B <= 0 || R <= 0 || Rcap < R) return fail(ELG_EINVAL, "local_bwd_rows: bad sizes");
     if (T_dev && M <= 0) return fail(ELG_EINVAL, "local_bwd_rows: T_dev needs M");
     if (n_slots <= 0 || n_slots > ELG_SLOT_STRIDE) return fail(ELG_EINVAL, "local_bwd_rows: local_size must be <= 47");
     const size_t lds = (size_t)(S_TABLES + 4 * NTRB * S_TR + ELG_LOC_SIZE) * sizeof(float);
     const long long ntiles = (long long)B * ((R + 15) / 16);
-    const int grid = (int)std::min<long long>((ntiles + 3) / 4, 256);   // 464 registers: one workgroup per CU
+    int grid = (int)std::min<long long>((ntiles + 3) / 4, 256);         // 464 registers: one workgroup per CU
+    if (max_workgroups > 0) grid = std::min(grid, max_workgroups);
     hipStream_t s = (hipStream_t)stream;
     (void)hipGetLastError();
     if (n_slots <= 32) {

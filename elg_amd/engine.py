@@ -186,6 +186,28 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, bias
 # ----------------------------------------------------------------------------------------------
 # weight folding (differentiable torch: autograd carries the kernel's table gradients back)
 # ----------------------------------------------------------------------------------------------
+# The local-policy row backward (elg_local_bwd_rows, 0.57 ms at the bench shape, one 464-register wave per SIMD) depends on the
+# pointer backward only and feeds nothing but the fold backward below; the encoder's backward chain that follows the decoder
+# backward is ~75 latency-bound launches that leave most of the chip idle.  With ELG_SIDE_LOCAL_BWD (default on) the row kernel
+# runs on a side stream over a PART of the CUs (it cannot share a CU with anything: registers) next to that chain, and
+# _FoldLocal.backward -- which autograd runs after the encoder's node, see CVRPModel.pre_forward -- waits for it.
+SIDE_LOCAL_BWD = os.environ.get("ELG_SIDE_LOCAL_BWD", "1") not in ("", "0")
+SIDE_LOCAL_BWD_GRID = int(os.environ.get("ELG_LOCAL_BWD_GRID", "0"))       # workgroups of the side-stream launch (0: half the CUs)
+SIDE_LOCAL_MIN_TILES_PER_CU = 64         # below this many 16-row tiles per CU the row kernel is too short to be worth a second stream
+_N_CUS: Dict[int, int] = {}
+
+
+def n_cus(dev=None) -> int:
+    """Compute units of the device (256 on an MI355X), cached."""
+    idx = torch.cuda.current_device() if dev is None else torch.device(dev).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    if idx not in _N_CUS:
+        _N_CUS[idx] = int(torch.cuda.get_device_properties(idx).multi_processor_count)
+    return _N_CUS[idx]
+_PENDING_SIDE: list = []        # events of side-stream launches whose result the next _FoldLocal.backward consumes
+
+
 class _FoldLocal(torch.autograd.Function):
     @staticmethod
     def forward(ctx, nfeat, n_slots, positional, We, be, c, Wq, Wk, Wv, Wc, bc):
@@ -204,6 +226,8 @@ class _FoldLocal(torch.autograd.Function):
         params = ctx.saved_tensors
         nfeat, n_slots, positional = ctx.meta
         dev = params[0].device
+        while _PENDING_SIDE:                        # gloc was produced on the side stream
+            torch.cuda.current_stream(dev).wait_event(_PENDING_SIDE.pop())
         w = L.LocalWeights(*[C.c_void_p(p.data_ptr()) for p in params])
         sizes = [p.numel() for p in params]
         flat = torch.empty(sum(sizes), device=dev)
@@ -273,12 +297,13 @@ class Policy:
         return len(self.Ks) if len(self.Ks) > 1 else 1
 
 
-def launch_geometry(B: int, M: int, N1: int):
-    """(waves, tiles, lds_stage).  256 CUs, one workgroup per CU when K/V/PK are staged in LDS:
-    aim for ~256 workgroups of 8 waves (2 per SIMD, 256-VGPR budget: no spills)."""
+def launch_geometry(B: int, M: int, N1: int, n_cu: Optional[int] = None):
+    """(waves, tiles, lds_stage).  One workgroup per CU (256 on an MI355X) when K/V/PK are staged in LDS:
+    aim for ~n_cu workgroups of 8 waves (2 per SIMD, 256-VGPR budget: no spills)."""
     lds = 1 if N1 <= 112 else 0          # tables on chip: cooperative MFMA kernel (fused rollouts), LDS copies otherwise
     waves = 8
-    n_cu = 256
+    if n_cu is None:
+        n_cu = n_cus() if torch.cuda.is_available() else 256
     tiles = max(1, min(M, (n_cu + B - 1) // B))
     if not lds and N1 <= 128:
         tiles = max(tiles, min(M, (4 * n_cu + B - 1) // B))
@@ -520,7 +545,7 @@ class _ChosenProbs(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, prob: Problem, pol_meta: Policy, M, actions, probs_val, T, geometry,
-                Kt, Vt, PKt, pbt, Q1t, Q2t, wlt, loct, rows=None, rows_gen=-1, tlen=None, T_dev=None):
+                Kt, Vt, PKt, pbt, Q1t, Q2t, wlt, loct, rows=None, rows_gen=-1, tlen=None, T_dev=None, loc_from_fold=False):
         ctx.prob, ctx.pol_meta, ctx.M, ctx.T, ctx.geometry = prob, pol_meta, M, T, geometry
         ctx.rows, ctx.rows_gen = rows, rows_gen
         ctx.T_dev = T_dev                       # device-resident step count (the host only knows the bound T)
@@ -529,6 +554,8 @@ class _ChosenProbs(torch.autograd.Function):
         ctx.save_for_backward(actions, Kt, Vt, PKt, pbt, Q1t, Q2t if Q2t is not None else Kt.new_empty(0),
                               wlt if wlt is not None else Kt.new_empty(0), loct if loct is not None else Kt.new_empty(0))
         ctx.has = (Q2t is not None, wlt is not None, loct is not None)
+        # the consumer of d loc is known to wait for a side-stream launch only when loc came out of _FoldLocal
+        ctx.loc_from_fold = bool(loc_from_fold)
         out = probs_val.contiguous().clone()
         ctx.probs_out = out.detach()
         return out
@@ -622,7 +649,7 @@ class _ChosenProbs(torch.autograd.Function):
         if haswl:
             dwl = (rowLoad[:, :, None] * dQ).sum(dim=(0, 1))
         return (None, None, None, None, None, None, None,
-                dK, dV, dPK, dpb, dQ1, dQ2, dwl, gloc if hasloc else None, None, None, None, None)
+                dK, dV, dPK, dpb, dQ1, dQ2, dwl, gloc if hasloc else None, None, None, None, None, None)
 
     @staticmethod
     def _backward_saved_rows(ctx, g, rows):
@@ -679,11 +706,24 @@ class _ChosenProbs(torch.autograd.Function):
         if meta.has_local:
             # rows are independent given the saved slot features: 16 rows per wavefront on the matrix cores
             n_slots = meta.K + (0 if tsp else 1)
-            L.check(L.lib().elg_local_bwd_rows(_ptr(loct), _ptr(rows.F), _ptr(rows.Slot), _ptr(ws.rowDU), _ptr(gloc),
-                                               B, R, rows.Rcap, n_slots, _ptr(ctx.T_dev), M, _stream()),
-                    "elg_local_bwd_rows")
+
+            def launch(max_wg=0):
+                L.check(L.lib().elg_local_bwd_rows(_ptr(loct), _ptr(rows.F), _ptr(rows.Slot), _ptr(ws.rowDU), _ptr(gloc),
+                                                   B, R, rows.Rcap, n_slots, _ptr(ctx.T_dev), M, max_wg, _stream()),
+                        "elg_local_bwd_rows")
+            # (worth it when the row kernel is long enough to matter: >= 64 16-row tiles per CU it would leave idle)
+            if SIDE_LOCAL_BWD and ctx.loc_from_fold and N1 <= 128 and B * R >= 16 * SIDE_LOCAL_MIN_TILES_PER_CU * n_cus(dev):
+                main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+                side.wait_stream(main)               # rowDU (pointer backward) and the zero fill of gloc are on the main stream
+                with torch.cuda.stream(side):
+                    launch(SIDE_LOCAL_BWD_GRID or n_cus(dev) // 2)     # half the chip (measured: 5.61 -> 5.43 ms per step)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                _PENDING_SIDE.append(ev)
+            else:
+                launch()
         return (None, None, None, None, None, None, None,
-                dK, dV, dPK, dpb, dQ1, dQ2, dwl if haswl else None, gloc if hasloc else None, None, None, None, None)
+                dK, dV, dPK, dpb, dQ1, dQ2, dwl if haswl else None, gloc if hasloc else None, None, None, None, None, None)
 
 
 class _BwdScratch:
@@ -718,7 +758,8 @@ def chosen_probs(prob: Problem, pol: Policy, M: int, res: RolloutResult, T: int,
         raise ValueError("chosen_probs: T_dev needs a training forward (saved rows)")
     return _ChosenProbs.apply(prob, pol, M, res.actions, res.probs[:, :T, :], T, geometry,
                               t["K"], t["V"], t["PK"], t["pb"], t["Q1"], t.get("Q2"), t.get("wl"), pol.loc,
-                              rows, getattr(res, "rows_gen", -1), res.tlen, T_dev)
+                              rows, getattr(res, "rows_gen", -1), res.tlen, T_dev,
+                              pol.loc is not None and type(pol.loc.grad_fn).__name__ == "_FoldLocalBackward")
 
 
 # ----------------------------------------------------------------------------------------------
@@ -804,7 +845,7 @@ def add_instance_norm(a: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, bet
 def _teardown():
     # no device synchronisation here: freeing a buffer orders itself behind the work that uses it, and an exit path must
     # never be able to block on the GPU (another process may hold it)
-    for cache in (_PINNED, TrainRows._cache, _BwdScratch._cache, _SIDE):
+    for cache in (_PINNED, TrainRows._cache, _BwdScratch._cache, _SIDE, _PENDING_SIDE):
         cache.clear()
 
 

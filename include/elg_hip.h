@@ -194,9 +194,12 @@ int elg_rollout_bwd(const elg_bwd_args* args, void* stream);
  * the folded tables): 16 rows per wavefront tile, every contraction with a shared table as v_mfma_f32_16x16x4_f32.
  * loc (ELG_LOC_SIZE); trF (B,Rcap,3,48) / trSlot (B,Rcap,48) as saved by a training forward; rowDU (B,R,48) from
  * elg_rows_prep; gloc (ELG_LOC_SIZE) accumulated (caller zeroes).  n_slots = local_size (+1 for the CVRP depot).
- * T_dev (or NULL) / M: as elg_decoder_bwd_args.T_dev -- R = min(R, T_dev[0] * M) is taken on the device. */
+ * T_dev (or NULL) / M: as elg_decoder_bwd_args.T_dev -- R = min(R, T_dev[0] * M) is taken on the device.
+ * max_workgroups: 0 = one workgroup per CU (the kernel holds 464 registers per lane: it shares a CU with nothing); > 0 caps the
+ * persistent grid, so that a caller that runs the kernel on a side stream leaves the other CUs to the work it overlaps with
+ * (the training step: next to the encoder's latency-bound backward chain, on half the chip). */
 int elg_local_bwd_rows(const float* loc, const float* trF, const int32_t* trSlot, const float* rowDU, float* gloc,
-                       int B, int R, int64_t Rcap, int n_slots, const int32_t* T_dev, int M, void* stream);
+                       int B, int R, int64_t Rcap, int n_slots, const int32_t* T_dev, int M, int max_workgroups, void* stream);
 
 /* Row-wise part of the glimpse backward (softmax backward of models.py:478-500 on the saved weights):
  * per decode row r and head h:  dS = a (dO_h V_h^T - <dO_h, O_h>) / 4,  dQ_h = dS K_h.
