@@ -202,10 +202,20 @@ def secondary_workloads(dev):
     tenv = TSPEnv(multi_width=500, device=dev)
     tenv.load_random_problems(torch.rand(16, 500, 2))
     rs, _, _ = tenv.reset()
+    from elg_amd import engine as eng_
+
+    def with_bf16(fn):
+        eng_.FWD_PRECISION = 1
+        try:
+            return fn()
+        finally:
+            eng_.FWD_PRECISION = 0
     with torch.no_grad():
         tm.pre_forward(rs)
         ms = timed(lambda: tsp_rollout(tm, tenv, "greedy"))
+        ms_bf = with_bf16(lambda: timed(lambda: tsp_rollout(tm, tenv, "greedy")))
     out["tsp500_b16_pomo500_greedy_rollout_ms"] = round(ms, 2)
+    out["tsp500_b16_pomo500_greedy_rollout_ms_bf16"] = round(ms_bf, 2)
     out["tsp500_trajectory_steps_per_s"] = round(16 * 500 * 499 / (ms * 1e-3), 0)
     out["tsp500_roofline"] = secondary_roofline(16, 500, 500, 499, ms, tsp=True)
     inst_path = os.path.join(ROOT, "tests", "golden", "vrplib", "X", "X-n1001-k43.vrp")
@@ -225,7 +235,9 @@ def secondary_workloads(dev):
             return cvrp_rollout(cm, cenv, "greedy")
         with torch.no_grad():
             ms = timed(one, reps=2)
+            ms_bf = with_bf16(lambda: timed(one, reps=2))
         out["vrplib_X-n1001-k43_aug8_pomo1000_greedy_instance_ms"] = round(ms, 1)
+        out["vrplib_X-n1001-k43_aug8_pomo1000_greedy_instance_ms_bf16"] = round(ms_bf, 1)
         # (whole instance: encoder + tables + rollout; decode steps = the longest tour of the run is not read back here:
         # lower bound N + 1 steps per trajectory -- every customer once -- so both fractions are lower bounds too)
         out["vrplib_X-n1001_roofline"] = secondary_roofline(8, 1000, 1001, 1001, ms, tsp=False)

@@ -1760,6 +1760,49 @@ __global__ __launch_bounds__(256) void mt_repack_kernel(const float* __restrict_
     reinterpret_cast<float4*>(Fb + (size_t)NP * MT_KB_WORDS)[r] = v;
 }
 
+// bf16 throughput mode (elg_rollout_args.precision = 1) of the streaming kernel: one bf16 term per table entry, per instance
+// (32-bit words; NT = NP / 16 node tiles):
+//   Kb1[h][tile][lane][2]  = K[16 tile + lo][16 h + 4 hi + j], j < 4 (two values per word): k-slots (hi, 0..3) of the A operand
+//                            of S^T = K_h q^T, k-slots (hi, 4..7) are zero (16 channels per head, the instruction contracts 32)
+//   Vb [h][pair][lane][4]  = V[32 pair + 4 hi + j][16 h + lo] (j < 4) | V[32 pair + 16 + 4 hi + j][16 h + lo]: the A operand of
+//                            O^T += V_h^T P^T over TWO node tiles, whose score D tiles side by side are the B operand
+//   PKb1[tile][kb][lane][4] = PK[16 tile + lo][32 kb + 8 hi + j], j < 8
+// 12 KB per node tile and step out of L2 instead of 36 KB; 1 + 1/2 + 4 instructions of 16 cycles per (node tile, head / 128
+// channels) instead of 3 x 16 + 4 x 32 + 24 x 16 cycles.  Inference only (a training forward at these sizes computes in f32).
+constexpr int MT_BF_WORDS = 192;                              // words per padded node: 64 (K) + 64 (V) + 64 (PK)
+__global__ __launch_bounds__(256) void mt_repack_bf16_kernel(const float* __restrict__ K, const float* __restrict__ V,
+                                                             const float* __restrict__ PK, unsigned* __restrict__ F, int N1, int NP) {
+    const int b = blockIdx.y;
+    const int NT = NP >> 4;
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    const size_t NE = (size_t)N1 * ELG_E;
+    unsigned* Fb = F + (size_t)b * NP * MT_BF_WORDS;
+    const int lane = o & 63, lo = lane & 15, hi = lane >> 4;
+    const int nK = 8 * NT * 64, nV = 8 * (NT / 2) * 64, nP = NT * 4 * 64;
+    if (o < nK) {
+        const int h = (o >> 6) / NT, tile = (o >> 6) % NT, n = 16 * tile + lo;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < N1) v = *reinterpret_cast<const float4*>(K + b * NE + (size_t)n * ELG_E + 16 * h + 4 * hi);
+        reinterpret_cast<uint2*>(Fb)[o] = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
+    } else if (o < nK + nV) {
+        const int r = o - nK, h = (r >> 6) / (NT / 2), pair = (r >> 6) % (NT / 2);
+        const float* src = V + b * NE + 16 * h + lo;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = 32 * pair + 16 * (j >> 2) + 4 * hi + (j & 3);
+            x[j] = n < N1 ? src[(size_t)n * ELG_E] : 0.f;
+        }
+        reinterpret_cast<uint4*>(Fb + (size_t)NP * 64)[r] = make_uint4(pk_bf16(x[0], x[1]), pk_bf16(x[2], x[3]), pk_bf16(x[4], x[5]), pk_bf16(x[6], x[7]));
+    } else if (o < nK + nV + nP) {
+        const int r = o - nK - nV, kb = (r >> 6) & 3, tile = r >> 8, n = 16 * tile + lo;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = n < N1 ? PK[b * NE + (size_t)n * ELG_E + 32 * kb + 8 * hi + j] : 0.f;
+        reinterpret_cast<uint4*>(Fb + (size_t)NP * 128)[r] = make_uint4(pk_bf16(x[0], x[1]), pk_bf16(x[2], x[3]), pk_bf16(x[4], x[5]), pk_bf16(x[6], x[7]));
+    }
+}
+
 // =============================================================================================
 // rollout_fwd_mt_kernel: 128 < N1 <= 1024 (TSP-200/500, VRPLIB X).  16 lockstep trajectories per workgroup.
 //   owners   (wave w owns trajectories w and w + 8; one wavefront per trajectory, the code of rollout_fwd_kernel):
@@ -1851,8 +1894,9 @@ __device__ __forceinline__ void mt_env_update(MtTraj& st, unsigned long long* vi
 // TRAIN (round 3): the rows a backward over saved rows needs, time-major (r = t M + m) as the cooperative kernel writes them:
 // query q and glimpse output o, the glimpse's log2-sum-exp per head (in units of s log2(e) / 4), the row's mask words
 // (NCH 64-bit words), load, k-NN slot ids + slot features, the softmax x clip Jacobian row and its value at the chosen node.
-template <int NCH, bool TSP, int NG, bool TRAIN>
+template <int NCH, bool TSP, int NG, bool TRAIN, bool BF = false>
 __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_args A) {
+    static_assert(!(BF && TRAIN), "the bf16 mode of the streaming kernel is inference only");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NTR = 16 * NG, NOWN = 2 * NG, QP = 132, SP = 64 * NCH + 4;
     constexpr int OBP = 68;                                 // words of a bf16 term row of o (128 channels + 8: conflict-free b128 reads)
@@ -1896,7 +1940,11 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
     I.ntheta = A.nbr_theta + (size_t)b * N1 * N1;
     I.loc = A.loc;
     constexpr int NP = 64 * NCH, NT = 4 * NCH;              // padded nodes / tiles of the fragment-major tables
-    const float* gF = A.scratch + (size_t)b * NP * (MT_KB_WORDS + ELG_E + MT_PKB_WORDS);
+    const float* gF = A.scratch + (size_t)b * NP * (BF ? MT_BF_WORDS : MT_KB_WORDS + ELG_E + MT_PKB_WORDS);
+    // bf16 mode: [h][tile][lane] uint2 | [h][pair][lane] uint4 | [tile][kb][lane] uint4
+    const uint2* gKb = reinterpret_cast<const uint2*>(gF) + (size_t)wave * NT * 64 + lane;
+    const uint4* gVb = reinterpret_cast<const uint4*>(gF + (size_t)NP * 64) + (size_t)wave * (NT / 2) * 64 + lane;
+    const uint4* gPb = reinterpret_cast<const uint4*>(gF + (size_t)NP * 128) + lane;
     constexpr int TU = NG == 1 ? 4 : 2;                    // node tiles per softmax update of the glimpse
     const uint4* gK = reinterpret_cast<const uint4*>(gF) + (size_t)wave * NT * 2 * 64 + lane;                // head = wave: [tile][form][lane]
     const float4* gV = reinterpret_cast<const float4*>(gF + (size_t)NP * MT_KB_WORDS) + (size_t)wave * NT * 64 + lane;
@@ -2026,6 +2074,70 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                 }
                 __syncthreads();        // every head has its queries: the rows are free for the term planes of o (cheap: the waves
                                         // left the previous barrier a few instructions ago)
+                if constexpr (BF) {
+                    // ---- bf16 mode: one instruction per score tile, one per PAIR of node tiles for the output
+                    u32x4 qb1[NG];
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) qb1[g] = u32x4{q11[g][0], q11[g][1], 0u, 0u};
+                    uint2 kf[TU], kn[TU];
+                    uint4 vf[TU / 2], vn[TU / 2];
+                    auto loadb = [&](int nt0, uint2 (&kk)[TU], uint4 (&vv)[TU / 2]) {
+#pragma unroll
+                        for (int u4 = 0; u4 < TU; ++u4) kk[u4] = gKb[(nt0 + u4) * 64];
+#pragma unroll
+                        for (int u2 = 0; u2 < TU / 2; ++u2) vv[u2] = gVb[(nt0 / 2 + u2) * 64];
+                    };
+                    loadb(0, kf, vf);
+#pragma unroll 1
+                    for (int nt = 0; nt < NTn; nt += TU) {
+                        loadb(min(nt + TU, NT - TU), kn, vn);
+                        __builtin_amdgcn_sched_barrier(0);
+                        f32x4c S[NG][TU];
+#pragma unroll
+                        for (int g = 0; g < NG; ++g)
+#pragma unroll
+                            for (int u4 = 0; u4 < TU; ++u4) {
+                                const float4 m4 = *reinterpret_cast<const float4*>(sSc + (16 * g + lo) * SP + 16 * (nt + u4) + 4 * hi);
+                                S[g][u4] = mfma_bf(u32x4{kf[u4].x, kf[u4].y, 0u, 0u}, qb1[g], f32x4c{m4.x, m4.y, m4.z, m4.w});
+                            }
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) {
+                            float tm = ELG_NEG_INF;
+#pragma unroll
+                            for (int u4 = 0; u4 < TU; ++u4)
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) tm = fmaxf(tm, S[g][u4][i]);
+                            tm = quarters_max(tm);
+                            const float mnew = fmaxf(mrun[g], tm);
+                            const float sc = __builtin_amdgcn_exp2f((mrun[g] - mnew) * cs);
+                            mrun[g] = mnew;
+                            lrun[g] *= sc;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { o[g][i] *= sc; o2[g][i] *= sc; }
+                            const float cm = -mnew * cs;
+#pragma unroll
+                            for (int u4 = 0; u4 < TU; ++u4)
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    S[g][u4][i] = __builtin_amdgcn_exp2f(fmaf(S[g][u4][i], cs, cm));
+                                    lrun[g] += S[g][u4][i];
+                                }
+                        }
+#pragma unroll
+                        for (int g = 0; g < NG; ++g)
+#pragma unroll
+                            for (int u2 = 0; u2 < TU / 2; ++u2) {
+                                const u32x4 pb_ = {pk_bf16(S[g][2 * u2][0], S[g][2 * u2][1]), pk_bf16(S[g][2 * u2][2], S[g][2 * u2][3]),
+                                                   pk_bf16(S[g][2 * u2 + 1][0], S[g][2 * u2 + 1][1]), pk_bf16(S[g][2 * u2 + 1][2], S[g][2 * u2 + 1][3])};
+                                f32x4c& acc = (u2 & 1) ? o2[g] : o[g];
+                                acc = mfma_bf(u32x4{vf[u2].x, vf[u2].y, vf[u2].z, vf[u2].w}, pb_, acc);
+                            }
+#pragma unroll
+                        for (int u4 = 0; u4 < TU; ++u4) kf[u4] = kn[u4];
+#pragma unroll
+                        for (int u2 = 0; u2 < TU / 2; ++u2) vf[u2] = vn[u2];
+                    }
+                } else {
                 // TU node tiles per softmax update: independent S chains on the matrix cores, one running-max rescale per 16 TU
                 // nodes; with 32 trajectories per workgroup two tiles (four spill registers)
                 uint4 kf[2 * TU], kn[2 * TU];                // [tile u4][form]
@@ -2103,6 +2215,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
 #pragma unroll
                     for (int u4 = 0; u4 < TU; ++u4) { kf[2 * u4] = kn[2 * u4]; kf[2 * u4 + 1] = kn[2 * u4 + 1]; vf[u4] = vn[u4]; }
                 }
+                }                                                   // !BF
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     const float l = quarters_sum(lrun[g]);
@@ -2134,12 +2247,50 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                 // s^T[node][trajectory] = sum over the channels of PK[node][c] o[trajectory][c] on v_mfma_f32_16x16x32_bf16:
                 // per 32 channels the six term products a1 b1, a1 b2, a2 b1, a2 b2, a1 b3, a3 b1 (24 instructions of 16 cycles per
                 // node tile and group where the f32 form took 32 of 32 cycles; this phase kept the matrix pipe ~70 % busy)
+                int nt = (wave < W0 ? wave : skip + wave);
+                if constexpr (BF) {
+                    // ---- bf16 mode: one term per operand: four instructions per node tile and group
+                    uint4 pk[4], pkn[4];
+                    auto loadpb = [&](int nt_, uint4 (&d)[4]) {
+#pragma unroll
+                        for (int kb = 0; kb < 4; ++kb) d[kb] = gPb[(nt_ * 4 + kb) * 64];
+                    };
+                    if (nt < NTn) loadpb(nt, pk);
+#pragma unroll 1
+                    while (nt < NTn) {
+                        const int nxt = nt + (nt < skip ? W0 : 8);
+                        loadpb(min(nxt, NTn - 1), pkn);
+                        __builtin_amdgcn_sched_barrier(0);
+                        f32x4c a0[NG], a1[NG];
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) { a0[g] = f32x4c{0.f, 0.f, 0.f, 0.f}; a1[g] = f32x4c{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                        for (int kb = 0; kb < 4; ++kb) {
+                            const u32x4 A1 = {pk[kb].x, pk[kb].y, pk[kb].z, pk[kb].w};
+#pragma unroll
+                            for (int g = 0; g < NG; ++g) {
+                                const uint4 q1 = *reinterpret_cast<const uint4*>(sOb + (16 * g + lo) * OBP + 16 * kb + 4 * hi);
+                                const u32x4 B1 = {q1.x, q1.y, q1.z, q1.w};
+                                if (kb & 1) a1[g] = mfma_bf(A1, B1, a1[g]);
+                                else a0[g] = mfma_bf(A1, B1, a0[g]);
+                            }
+                        }
+                        const int nb = 16 * nt + 4 * hi;
+                        const float p0 = I.pb[min(nb, N1 - 1)], p1 = I.pb[min(nb + 1, N1 - 1)], p2 = I.pb[min(nb + 2, N1 - 1)], p3 = I.pb[min(nb + 3, N1 - 1)];
+#pragma unroll
+                        for (int g = 0; g < NG; ++g)
+                            *reinterpret_cast<float4*>(sSc + (16 * g + lo) * SP + nb) =
+                                make_float4(a0[g][0] + a1[g][0] + p0, a0[g][1] + a1[g][1] + p1, a0[g][2] + a1[g][2] + p2, a0[g][3] + a1[g][3] + p3);
+#pragma unroll
+                        for (int kb = 0; kb < 4; ++kb) pk[kb] = pkn[kb];
+                        nt = nxt;
+                    }
+                } else {
                 uint4 pk[12], pkn[12];
                 auto loadpk = [&](int nt, uint4 (&d)[12]) {
 #pragma unroll
                     for (int s4 = 0; s4 < 12; ++s4) d[s4] = gPK[(nt * 12 + s4) * 64];
                 };
-                int nt = (wave < W0 ? wave : skip + wave);
                 if (nt < NTn) loadpk(nt, pk);
 #pragma unroll 1
                 while (nt < NTn) {
@@ -2179,6 +2330,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                     for (int s4 = 0; s4 < 12; ++s4) pk[s4] = pkn[s4];
                     nt = nxt;
                 }
+                }                                                   // !BF
             }
             ELG_STAMP(sc_, 4);
             __syncthreads();
@@ -2259,12 +2411,12 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
     }
 }
 
-template <int NCH, bool TSP, int NG, bool TRAIN>
+template <int NCH, bool TSP, int NG, bool TRAIN, bool BF = false>
 static int launch_fwd_mt_g(const elg_rollout_args& A, hipStream_t stream) {
     constexpr int NTR = 16 * NG;
     const size_t lds = ((size_t)NTR * 3 * 68 + (size_t)NTR * (64 * NCH + 4) + (size_t)NTR * NCH * 4 + (A.has_local ? NTR * CO_XP + CL_SIZE : 0) +
                         ((A.N1 + 3) & ~3) + (size_t)8 * ELG_SB_MIN) * 4;
-    auto kern = rollout_fwd_mt_kernel<NCH, TSP, NG, TRAIN>;
+    auto kern = rollout_fwd_mt_kernel<NCH, TSP, NG, TRAIN, BF>;
     static DynLds optin;
     if (!optin.opt_in(reinterpret_cast<const void*>(kern), lds)) return fail(ELG_ELAUNCH, "mt rollout: hipFuncSetAttribute failed");
     if (!A.scratch) return fail(ELG_EINVAL, "rollout: 128 < N1 <= 1024 needs the scratch workspace (elg_rollout_scratch_floats)");
@@ -2272,7 +2424,12 @@ static int launch_fwd_mt_g(const elg_rollout_args& A, hipStream_t stream) {
     B2.tiles = (A.M + NTR - 1) / NTR;                      // this kernel's geometry: 16 NG trajectories per workgroup
     (void)hipGetLastError();
     constexpr int NP = 64 * NCH;
-    hipLaunchKernelGGL(mt_repack_kernel, dim3((2 * NP * 32 + NP * 16 + 255) / 256, A.B), dim3(256), 0, stream, A.Kmat, A.Vmat, A.PK, A.scratch, A.N1, NP);
+    if (BF) {
+        constexpr int NTt = NP / 16;
+        hipLaunchKernelGGL(mt_repack_bf16_kernel, dim3(((8 * NTt + 4 * NTt + 4 * NTt) * 64 + 255) / 256, A.B), dim3(256), 0, stream, A.Kmat, A.Vmat,
+                           A.PK, reinterpret_cast<unsigned*>(A.scratch), A.N1, NP);
+    } else
+        hipLaunchKernelGGL(mt_repack_kernel, dim3((2 * NP * 32 + NP * 16 + 255) / 256, A.B), dim3(256), 0, stream, A.Kmat, A.Vmat, A.PK, A.scratch, A.N1, NP);
     hipLaunchKernelGGL(kern, dim3(B2.B * B2.tiles), dim3(512), lds, stream, B2);
     return launch_status("rollout_fwd_mt");
 }
@@ -2286,6 +2443,10 @@ static int launch_fwd_mt(const elg_rollout_args& A, hipStream_t stream) {
         if (!A.trPC || !A.trCsel || !A.trQ || !A.trO || !A.trLse) return fail(ELG_EINVAL, "rollout: incomplete training rows (128 < N1 <= 1024 needs trMask, trLse, trPC, trCsel, trQ, trO)");
         if (two) return launch_fwd_mt_g<NCH, TSP, (NCH <= 8 ? 2 : 1), true>(A, stream);
         return launch_fwd_mt_g<NCH, TSP, 1, true>(A, stream);
+    }
+    if (A.precision == 1) {
+        if (two) return launch_fwd_mt_g<NCH, TSP, (NCH <= 8 ? 2 : 1), false, true>(A, stream);
+        return launch_fwd_mt_g<NCH, TSP, 1, false, true>(A, stream);
     }
     if (two) return launch_fwd_mt_g<NCH, TSP, (NCH <= 8 ? 2 : 1), false>(A, stream);
     return launch_fwd_mt_g<NCH, TSP, 1, false>(A, stream);

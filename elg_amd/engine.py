@@ -492,6 +492,8 @@ def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mo
     a.seed = seed & 0xFFFFFFFFFFFFFFFF
     a.variant = variant
     a.precision = FWD_PRECISION if precision is None else int(precision)
+    if train and N1 > 128:
+        a.precision = 0                  # the saved-rows backward of the streaming kernel differentiates the f32 forward
     a.dump_logits = {"probs": 0, "logits": 1, "scores": 2}[dump]
     # (a pageable host tensor would block the host until the stream has drained: staged through pinned memory instead)
     starts = h2d(starts.to(torch.int32).contiguous(), dev) if not starts.is_cuda else starts.to(torch.int32).contiguous()

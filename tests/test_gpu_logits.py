@@ -231,3 +231,36 @@ def test_bf16_mode_sampled_rollout_at_the_bench_shape():
         out[prec] = float((-r.reward).mean())
     assert abs(out[1] - out[0]) <= 0.05 * out[0], out
     gc.record_parity("bf16_mode/cvrp100_sampled_mean_cost_rel_diff", abs(out[1] - out[0]) / out[0])
+
+
+def test_bf16_mode_streaming_kernel_logits_and_tours():
+    """The bf16 mode of the node-streaming kernel (128 < N1 <= 1024; one bf16 term per table entry): N1 = 151 against the
+    reference's logits with the mode's stated tolerance; feasible greedy tours whose cost is within 2 % of the f32 kernel's."""
+    from elg_amd.CVRP.CVRPEnv import CVRPEnv
+    from elg_amd.CVRP.utils import check_feasible
+    lg = gu.load_golden("r02_cvrp_logits_n150.npz")
+    B, N, M, wseed, pseed = [int(x) for x in lg["meta"]]
+    mp = dict(gu.CVRP_MODEL_PARAMS)
+    model = gc.load_model("cvrp", wseed, mp, 1.0)
+    depot, loc, demand = gu.golden_cvrp_problem(pseed, B, N, float(lg["capacity"]))
+    env = CVRPEnv(multi_width=M, device=DEV)
+    env.load_random_problems(dict(loc=torch.from_numpy(loc), demand=torch.from_numpy(demand), depot=torch.from_numpy(depot)))
+    rs, _, _ = env.reset()
+    with torch.no_grad():
+        model.pre_forward(rs)
+    acts = torch.from_numpy(lg["actions"].astype(np.int32))
+    T = acts.shape[2]
+    pol = model.decoder.policy
+    dumps = {}
+    for what in ("scores", "logits"):
+        r = eng.rollout_forward(env.problem, pol, M, acts[0, :, 1], L.MODE_FORCED, forced=acts, dump_T=T, dump=what, precision=1)
+        dumps[what] = r.full_probs
+    np.testing.assert_allclose(r.reward.cpu().numpy(), lg["reward"], rtol=2e-6)          # the environment is exact in every mode
+    _check_bf16("cvrp_n150_streaming", lg, dumps["scores"], dumps["logits"], mp["logit_clipping"], lg["steps"], r.tlen)
+    cost = {}
+    for prec in (0, 1):
+        g = eng.rollout_forward(env.problem, pol, M, acts[0, :, 1], L.MODE_GREEDY, precision=prec)
+        Tg = int(g.tlen.max())
+        check_feasible(g.actions[0:1, :, :Tg].long(), rs.node_demand[0:1])
+        cost[prec] = float((-g.reward).mean())
+    assert abs(cost[1] - cost[0]) <= 0.02 * cost[0], cost
