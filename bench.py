@@ -140,10 +140,10 @@ def cpu_baseline(cfg, mean_T, state0, replay, budget_s=150.0):
             opt.step()
             if it > 0:
                 times.append(time.perf_counter() - t0)
-                T_seen.append(int(out["actions"].shape[2]))
+                T_seen.append(int(out["actions"].shape[2]))      # the longest trajectory of the batch (the loop's length)
         dt = sum(times) / len(times)
         full = {"inst_per_s": round(LOCAL_BATCH / dt, 4), "seconds_per_step": [round(t, 2) for t in times], "batch": LOCAL_BATCH,
-                "warmup_steps": 1, "timed_steps": n_timed, "decode_steps": T_seen, "threads": best}
+                "warmup_steps": 1, "timed_steps": n_timed, "decode_steps_longest_trajectory": T_seen, "threads": best}
     value = full["inst_per_s"] if full else sweep[best]["inst_per_s"]
     what = (f"value = mean of {n_timed} whole training steps (after 1 warm-up) at batch={LOCAL_BATCH} pomo={POMO}, {best} threads"
             if full else "value = the sampled estimate (whole steps did not fit the time budget)")
