@@ -161,9 +161,11 @@ def test_side_stream_local_backward_equals_the_inline_launch(monkeypatch):
         assert not eng._PENDING_SIDE, "the fold backward must have consumed the side-stream event"
         grads[side] = {k: v.grad.detach().clone() for k, v in model.named_parameters()}
     worst = 0.0
+    # (the biases in front of an instance norm have an exactly-zero true gradient: measured against a floor, as above)
+    floor = 1e-2 * max(float(v.abs().max()) for v in grads[False].values())
     for k, g in grads[True].items():
         ref = grads[False][k]
-        err = float((g - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+        err = float((g - ref).abs().max()) / max(float(ref.abs().max()), floor)
         worst = max(worst, err)
         assert err <= 2e-4, (k, err)            # (two runs of the SAME path differ by ~3e-5: float atomics)
     gc.record_parity("side_stream_local_bwd/grad_rel_diff", worst)
