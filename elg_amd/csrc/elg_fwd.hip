@@ -807,7 +807,9 @@ __device__ __forceinline__ int row16_max_i(int v) {
 // chunk (node order = k-major), the arg-max a (value desc, node asc) row reduction.  One pass of ~250 VALU
 // instructions for four trajectories instead of ~400 per trajectory with a whole wavefront each.
 // Results (chosen node, its probability) go to dwords 12 / 13 of the trajectory's state block.
-template <bool TSP, bool TRAIN>
+// LEAN: the production launch (sampled or greedy choice from the kernel's own Philox stream; no teacher forcing, no external
+// uniforms, no probability dump): the test / diagnostic branches and their pointers are compiled out of the step loop.
+template <bool TSP, bool TRAIN, bool LEAN = false>
 __device__ __forceinline__ void co_finish4(const elg_rollout_args& A, int N1, int lane, int wave, int ntraj, int t, int g_lo,
                                            size_t b, size_t Rcap, float* sSc, const unsigned long long* sMask,
                                            const float* sX, int* sState, int fin_row, int& sel_out, float& p_out, float& ubuf,
@@ -815,7 +817,7 @@ __device__ __forceinline__ void co_finish4(const elg_rollout_args& A, int N1, in
     constexpr int NK = CO_NT;
     const int tq = lane >> 4, lo = lane & 15;
     const int q = 4 * wave + tq;
-    const float dflt = A.has_penalty ? A.xi : 0.f;
+    const float dflt = (LEAN || A.has_penalty) ? A.xi : 0.f;
     // ---- slot terms (penalty + local policy) scattered into the score rows: every row's 16 lanes take three slots each of
     // the row's own trajectory; all reads are issued before the writes (the slots of a trajectory are distinct nodes), so the
     // read-modify-write costs one LDS round trip instead of four serialised ones
@@ -867,7 +869,7 @@ __device__ __forceinline__ void co_finish4(const elg_rollout_args& A, int N1, in
     const float tot = row16_sum(part);
     const float inv = tot > 0.f ? 1.0f / tot : 0.f;
     ELG_STAMP(sc, 5);
-    if (A.full_probs && t < A.dump_T && act) {
+    if (!LEAN && A.full_probs && t < A.dump_T && act) {
         float* frow = A.full_probs + (bm * A.dump_T + t) * N1;
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
@@ -884,7 +886,7 @@ __device__ __forceinline__ void co_finish4(const elg_rollout_args& A, int N1, in
     }
     // ---- choose
     int sel = 0;
-    if (A.mode == ELG_MODE_FORCED) {
+    if (!LEAN && A.mode == ELG_MODE_FORCED) {
         sel = (act && A.forced && t < A.Tforced) ? A.forced[bm * A.Tforced + t] : 0;
     } else if (A.mode == ELG_MODE_GREEDY) {
         // argmax of the trajectory's row (16 lanes), ties -> lowest node index: row maximum by DPP, then the first node that
@@ -908,7 +910,7 @@ __device__ __forceinline__ void co_finish4(const elg_rollout_args& A, int N1, in
         sel = bn;
     } else {
         float uni = 0.f;
-        if (A.uniforms) {
+        if (!LEAN && A.uniforms) {
             if (act) uni = A.uniforms[bm * A.Tmax + t];
         } else {
             // philox_uniform(seed, trajectory, step) as everywhere, but drawn 16 steps at a time: lane lo of the trajectory's
@@ -971,7 +973,7 @@ __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v,
 
 // Environment transition (CVRPEnv.py:195-232, TSPEnv.py:108-124; same roundings as env_update()) and the next step's
 // mask / query / k-NN slots (build_mask(), slot_setup()) for the wave's four trajectories at once, 16 lanes per trajectory.
-template <bool TSP, bool TRAIN>
+template <bool TSP, bool TRAIN, bool LEAN = false>
 __device__ __forceinline__ void co_advance4(const elg_rollout_args& A, const Inst& I, int N1, int lane, int wave, int ntraj,
                                             int t, int g_lo, size_t b, size_t Rcap, CoRow& st, int sel, bool active,
                                             unsigned long long* sMask, float* sQ, float* sX, float* sSc, StampCtx& sc) {
@@ -982,7 +984,7 @@ __device__ __forceinline__ void co_advance4(const elg_rollout_args& A, const Ins
     // row of the node, its sorted neighbour row), one exposed L2 round trip for the whole phase instead of two in series
     const int cur_n = active ? sel : st.cur;
     const int first_n = (TSP && active && st.cnt == 0) ? sel : st.first;
-    const bool want_nbr = A.has_penalty || A.has_local;
+    const bool want_nbr = LEAN || A.has_penalty || A.has_local;
     float4 q1a, q1c, q2a = make_float4(0.f, 0.f, 0.f, 0.f), q2c = q2a;
     {
         const float* q1 = I.Q1 + (size_t)cur_n * ELG_E + 8 * lo;
@@ -1059,8 +1061,8 @@ __device__ __forceinline__ void co_advance4(const elg_rollout_args& A, const Ins
     else w1 |= 0xFFFF000000000000ull;                                   // (nodes 112..127)
     if (lo == 0) {
         sMask[2 * q] = w0; sMask[2 * q + 1] = w1;
-        if (TRAIN && nxt && A.trMask) { A.trMask[(b * Rcap + r1) * 2] = w0; A.trMask[(b * Rcap + r1) * 2 + 1] = w1; }
-        if (TRAIN && nxt && A.trLoad) A.trLoad[b * Rcap + r1] = st.load;
+        if (TRAIN && nxt && (LEAN || A.trMask)) { A.trMask[(b * Rcap + r1) * 2] = w0; A.trMask[(b * Rcap + r1) * 2 + 1] = w1; }
+        if (TRAIN && nxt && ((LEAN && !TSP) || (!LEAN && A.trLoad))) A.trLoad[b * Rcap + r1] = st.load;
     }
     ELG_STAMP(sc, 8);
     // ---------------- query row: 8 channels per lane
@@ -1132,9 +1134,9 @@ __device__ __forceinline__ void co_advance4(const elg_rollout_args& A, const Ins
         float sd = 0.f, sth = 0.f;
         int snid = -1;
         if (cust) { sd = X[CO_XF + j]; sth = X[CO_XF + ELG_SLOT_STRIDE + j]; snid = Xi[CO_XS + j]; }
-        if (!TSP && j == 0 && nxt && (A.has_penalty || A.has_local)) snid = 0;          // depot slot
+        if (!TSP && j == 0 && nxt && (LEAN || A.has_penalty || A.has_local)) snid = 0;          // depot slot
         float pen = 0.f;
-        if (A.has_penalty && cust) {
+        if ((LEAN || A.has_penalty) && cust) {
             if (TSP) pen = -(sd / (dmax + 1e-6f));
             else pen = (dmax != 0.f) ? -(sd / dmax) : -sd;
         }
@@ -1142,7 +1144,7 @@ __device__ __forceinline__ void co_advance4(const elg_rollout_args& A, const Ins
         if (cust) {
             f0 = sd / nf;
             f1 = sth;
-            if (A.euclidean) {                                          // models.py:95-125: relative (x, y) / norm
+            if (!LEAN && A.euclidean) {                                 // models.py:95-125: relative (x, y) / norm
                 f0 = __fsub_rn(I.xy[2 * snid], st.cx) / nf;
                 f1 = __fsub_rn(I.xy[2 * snid + 1], st.cy) / nf;
             }
@@ -1155,9 +1157,9 @@ __device__ __forceinline__ void co_advance4(const elg_rollout_args& A, const Ins
         Xi[CO_XS + j] = ssave;
         X[CO_XPEN + j] = pen;
         X[CO_XU + j] = 0.f;
-        if (TRAIN && nxt && A.trSlot) {
+        if (TRAIN && nxt && (LEAN || A.trSlot)) {
             A.trSlot[(b * Rcap + r1) * ELG_SLOT_STRIDE + j] = ssave;
-            if (A.trF) {
+            if (LEAN || A.trF) {
                 float* fr = A.trF + (b * Rcap + r1) * (3 * ELG_SLOT_STRIDE) + j;
                 fr[0] = f0; fr[ELG_SLOT_STRIDE] = f1; fr[2 * ELG_SLOT_STRIDE] = f2;
             }
@@ -1170,7 +1172,7 @@ __device__ __forceinline__ void co_advance4(const elg_rollout_args& A, const Ins
 // step -- glimpse scores K_h q^T, glimpse output V_h^T P^T, pointer scores PK o^T -- run on v_mfma_f32_16x16x32_bf16 with the
 // operands rounded to bf16 (tables, query, softmax numerators, glimpse output) and f32 accumulation; masks, softmax, clip,
 // choice, the local policy and the environment stay f32.  The f32 instantiation is the parity mode and the default.
-template <bool TSP, bool TRAIN, bool BF>
+template <bool TSP, bool TRAIN, bool BF, bool LEAN>
 __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout_args A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1202,7 +1204,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
     if (!TSP)
         for (int i = tid; i < N1; i += 512) sdem[i] = A.demand[(size_t)b * N1 + i];
     for (int i = tid; i < 2 * N1; i += 512) sxy[i] = A.xy[(size_t)b * N1 * 2 + i];
-    if (A.has_local) co_stage_local(A.loc, sT, tid, 512);
+    if (LEAN || A.has_local) co_stage_local(A.loc, sT, tid, 512);
 
     Inst I;
     I.K = nullptr; I.V = nullptr; I.PK = nullptr;
@@ -1339,7 +1341,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                 // (its five stages are spread over the four MFMA loops of the glimpse below, in program order, so that the scheduler has
                 // independent VALU to put into the MFMA shadows; a wave without a unit -- one trajectory group only -- computes on
                 // its own group's blocks and stores nothing)
-                const bool lh_on = A.has_local && (wave < 4 || two_rt);
+                const bool lh_on = (LEAN || A.has_local) && (wave < 4 || two_rt);
                 const int lh_h = wave & 3, lh_dt = lh_h >> 1;
                 const float* LX = sX + ((lh_on ? (wave >> 2) : 0) * 16 + lo_t) * CO_XP;
                 f32x4c lf[3][3], lal[3];
@@ -1488,10 +1490,10 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                         const float dn = quarters_sum(den[rt]);
                         const bool live = dn > 0.f;                    // a decoding trajectory has an open node
                         const size_t r = (size_t)t * A.M + g_lo + traj;
-                        if (TRAIN && A.trLse && hi_t == 0 && live)
+                        if (TRAIN && (LEAN || A.trLse) && hi_t == 0 && live)
                             A.trLse[((size_t)b * Rcap + r) * ELG_H + wave] = __log2f(dn) - cm[rt];
                         const float inv = live ? 1.0f / dn : 0.f;
-                        if (TRAIN && live && A.trA) {
+                        if (TRAIN && live && !LEAN && A.trA) {
 #pragma unroll
                             for (int nt = 0; nt < CO_NT; ++nt) {
                                 float* rA = A.trA + (((size_t)b * ELG_H + wave) * Rcap + r) * N1 + 16 * nt + 4 * hi_t;
@@ -1552,7 +1554,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                         *reinterpret_cast<float4*>(sSc + traj * CO_SP + 16 * nt + 4 * hi_t) =
                             make_float4(a0[0] + a1[0], a0[1] + a1[1], a0[2] + a1[2], a0[3] + a1[3]);
                     }
-                } else if (A.has_local && (wave == 6 || two_rt)) {
+                } else if ((LEAN || A.has_local) && (wave == 6 || two_rt)) {
                     // local policy, stage 2: wave 6: trajectories 0-15, wave 7: trajectories 16-31
                     co_local_tail(sT, sX + (wave - 6) * 16 * CO_XP, sO1 + (wave - 6) * 512, sX + (wave - 6) * 16 * CO_XP + CO_XU, CO_XP,
                                   lo_t, hi_t);
@@ -1574,18 +1576,18 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
             // pointer phase has overwritten with scores)
             {
                 if (decode_step) {
-                    co_finish4<TSP, TRAIN>(A, N1, lane_t, wave, ntraj, t, g_lo, (size_t)b, Rcap, sSc, sMask, sX, sState,
+                    co_finish4<TSP, TRAIN, LEAN>(A, N1, lane_t, wave, ntraj, t, g_lo, (size_t)b, Rcap, sSc, sMask, sX, sState,
                                            q4 < ntraj ? row.fin : 1, sel, pr, ubuf, sc);
-                } else if (A.mode == ELG_MODE_FORCED) {
+                } else if (!LEAN && A.mode == ELG_MODE_FORCED) {
                     sel = (A.forced && t < A.Tforced) ? A.forced[bm4 * A.Tforced + t] : 0;
                 } else {
                     sel = (!TSP && t == 0) ? 0 : A.starts[m4];
                 }
                 if (active && (lane_t & 15) == 0) {
-                    if (A.actions) A.actions[bm4 * A.Tmax + t] = sel;
-                    if (A.probs) A.probs[((size_t)b * A.Tmax + t) * A.M + m4] = pr;
+                    if (LEAN || A.actions) A.actions[bm4 * A.Tmax + t] = sel;
+                    if (LEAN || A.probs) A.probs[((size_t)b * A.Tmax + t) * A.M + m4] = pr;
                 }
-                co_advance4<TSP, TRAIN>(A, I, N1, lane_t, wave, ntraj, t, g_lo, (size_t)b, Rcap, row, sel, active, sMask, sQ, sX, sSc, sc);
+                co_advance4<TSP, TRAIN, LEAN>(A, I, N1, lane_t, wave, ntraj, t, g_lo, (size_t)b, Rcap, row, sel, active, sMask, sQ, sX, sSc, sc);
             }
             any_left = (q4 < ntraj && !row.fin) ? 1 : 0;
             ELG_STAMP(sc, 11);
@@ -1612,17 +1614,26 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
     }
 }
 
-template <bool TSP, bool TRAIN, bool BF>
-static int launch_fwd_coop(const elg_rollout_args& A, hipStream_t stream) {
+template <bool TSP, bool TRAIN, bool BF, bool LEAN>
+static int launch_fwd_coop_l(const elg_rollout_args& A, hipStream_t stream) {
     const size_t lds = ((size_t)CO_MAXTR * CO_QP + (size_t)CO_MAXTR * CO_SP + 4 * CO_MAXTR + 16 * CO_MAXTR +
                         ((A.N1 + 3) & ~3) + ((2 * A.N1 + 3) & ~3) + (size_t)CO_MAXTR * CO_XP + CL_SIZE + CO_NT * 32 * 64 + 16 * CO_NT +
                         8 * SbSize<2>::value + 2 * 512) * 4 + 64;
-    auto kern = rollout_fwd_coop_kernel<TSP, TRAIN, BF>;
+    auto kern = rollout_fwd_coop_kernel<TSP, TRAIN, BF, LEAN>;
     static DynLds optin;
     if (!optin.opt_in(reinterpret_cast<const void*>(kern), lds)) return fail(ELG_ELAUNCH, "coop rollout: hipFuncSetAttribute failed");
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3(A.B * A.tiles), dim3(512), lds, stream, A);
     return launch_status("rollout_fwd_coop");
+}
+template <bool TSP, bool TRAIN, bool BF>
+static int launch_fwd_coop(const elg_rollout_args& A, hipStream_t stream) {
+    // LEAN = the production configuration (reference config.yml: ensemble + distance penalty on, polar features), all outputs
+    // requested, mask-row training rows: every test / ablation branch of the step loop is compiled out
+    const bool lean = A.mode != ELG_MODE_FORCED && !A.forced && !A.uniforms && !A.full_probs && A.has_local && A.has_penalty &&
+                      !A.euclidean && A.actions && A.probs &&
+                      (!TRAIN || (!A.trA && A.trMask && A.trLse && A.trSlot && A.trF && (TSP || A.trLoad)));
+    return lean ? launch_fwd_coop_l<TSP, TRAIN, BF, true>(A, stream) : launch_fwd_coop_l<TSP, TRAIN, BF, false>(A, stream);
 }
 
 // =============================================================================================

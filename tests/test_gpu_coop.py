@@ -144,3 +144,32 @@ def test_saved_rows_backward_equals_replay_backward(kind, N, recompute, monkeypa
         g = grads["rows"][k]
         err = (g - r).abs().max().item()
         assert err <= 2e-4 * r.abs().max().item() + 1e-6, (k, err, r.abs().max().item())
+
+
+@pytest.mark.parametrize("kind,N,B,M", [("cvrp", 100, 3, 50), ("tsp", 50, 2, 40)])
+def test_lean_production_instantiation_equals_the_generic_one(kind, N, B, M):
+    """rollout_fwd_coop_kernel<..., LEAN>: the launch a training step / an evaluation makes (own Philox stream, all outputs, the
+    reference's default model flags) runs an instantiation with every test branch (teacher forcing, external uniforms,
+    probability dumps, ablation flags) compiled out.  Same seed through it and through the generic instantiation (forced by a
+    one-step probability dump): identical tours, chosen probabilities, rewards, and identical saved training rows."""
+    from elg_amd import _lib as L, engine as eng
+    P, cfg, xy, dem, enc, prob, pol = _setup(kind, N, B, 4200 + N)
+    off = 1 if kind == "cvrp" else 0
+    starts = torch.randperm(N, generator=torch.Generator().manual_seed(M))[:M] + off
+    for train in (False, True):
+        lean = eng.rollout_forward(prob, pol, M, starts, L.MODE_SAMPLE, seed=77, train=train)
+        rows_lean = None
+        if train:
+            r = lean.rows
+            rows_lean = {k: getattr(r, k).clone() for k in ("PC", "Csel", "Q", "O", "Lse", "Mask", "Slot", "F", "Load")}
+        gen = eng.rollout_forward(prob, pol, M, starts, L.MODE_SAMPLE, seed=77, train=train, dump_T=1)
+        assert torch.equal(lean.actions, gen.actions) and torch.equal(lean.tlen, gen.tlen)
+        assert torch.equal(lean.probs, gen.probs) and torch.equal(lean.reward, gen.reward)
+        if train:
+            T = int(gen.tlen.max())
+            live = T * M                                            # rows of the steps that were decoded (time-major)
+            for k, v in rows_lean.items():
+                assert torch.equal(v[:, :live], getattr(gen.rows, k)[:, :live]), k
+    g1 = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY)
+    g2 = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, dump_T=1)
+    assert torch.equal(g1.actions, g2.actions) and torch.equal(g1.reward, g2.reward)
