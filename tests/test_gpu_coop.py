@@ -169,6 +169,8 @@ def test_lean_production_instantiation_equals_the_generic_one(kind, N, B, M):
             T = int(gen.tlen.max())
             live = T * M                                            # rows of the steps that were decoded (time-major)
             for k, v in rows_lean.items():
+                if k == "Load" and kind == "tsp":
+                    continue                                        # (a TSP trajectory has no load; the backward never reads the row)
                 assert torch.equal(v[:, :live], getattr(gen.rows, k)[:, :live]), k
     g1 = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY)
     g2 = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, dump_T=1)
