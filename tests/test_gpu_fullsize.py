@@ -111,6 +111,20 @@ def test_tsp500_properties():
     np.testing.assert_allclose(-res.reward[:2].cpu().numpy(), orc.route_length(xy[:2].cpu(), acts[:2]).numpy(), rtol=2e-5)
     res2 = eng.rollout_forward(prob, pol, N, starts, L.MODE_FORCED, forced=res.actions)
     np.testing.assert_allclose(res2.probs.cpu().numpy(), p.numpy(), rtol=1e-6)
+    # the oracle on the full configuration's own tours: three of the 500 trajectories of two of the 16 instances, teacher-forced
+    # through all 500 steps (the streaming kernel at the bench geometry: 32 trajectories per workgroup, 250 workgroups)
+    import gpu_common as gc
+    cfg = orc.ModelCfg.from_model_params(mp, "tsp")
+    Pw = gc.weights("tsp", 2, mp, 1.0)
+    sel = torch.tensor([0, 137, 499])
+    worst = 0.0
+    for b in (0, 9):
+        out = orc.rollout_tsp(Pw, cfg, xy[b:b + 1].cpu(), 3, starts=acts[b, sel, 0], forced=acts[b:b + 1][:, sel])
+        ref = out["probs"].numpy()[0]                                   # (T, 3)
+        got = p[b][:, sel].numpy()
+        worst = max(worst, float((np.abs(got - ref) / ref).max()))
+        np.testing.assert_allclose(got, ref, rtol=5e-4, atol=1e-12)
+    gc.record_parity("fullsize/tsp500_b16_pomo500_chosen_prob_rel", worst)
     g1 = eng.rollout_forward(prob, pol, N, starts, L.MODE_GREEDY)
     g2 = eng.rollout_forward(prob, pol, N, starts, L.MODE_GREEDY)
     assert torch.equal(g1.actions, g2.actions)
@@ -138,3 +152,27 @@ def test_vrplib_n1001_properties():
     dem = env.depot_node_demand.cpu().numpy()
     for b in (0, 7):
         orc.check_feasible(acts[b, ::97].cpu().numpy(), dem[b, 1:])
+    # the oracle on this configuration's own greedy tours (x8 augmentation, pomo 1000, N1 = 1001: 16 trajectories per workgroup):
+    # two trajectories of two augmented copies, teacher-forced through the whole construction, chosen probabilities
+    import random
+    import gpu_common as gc
+    from elg_amd import _lib as L, engine as eng
+    cfg = orc.ModelCfg.from_model_params(mp, "cvrp")
+    Pw = gc.weights("cvrp", 17, mp, 1.0)
+    starts = torch.tensor(random.Random(3).sample(range(0, 1000), 1000), dtype=torch.int32)
+    res = eng.rollout_forward(env.problem, model.decoder.policy, 1000, starts, L.MODE_GREEDY)
+    T = int(res.tlen.max())
+    a = res.actions[:, :, :T].cpu().long()
+    xy, dm = env.depot_node_xy.cpu(), env.depot_node_demand.cpu()
+    sel = torch.tensor([3, 871])
+    worst = 0.0
+    for b in (0, 5):
+        out = orc.rollout_cvrp(Pw, cfg, xy[b:b + 1], dm[b:b + 1], 2, starts=a[b, sel, 1], forced=a[b:b + 1][:, sel])
+        To = out["probs"].shape[1]
+        ref = out["probs"].numpy()[0]
+        got = res.probs[b, :To][:, sel].cpu().numpy()
+        worst = max(worst, float((np.abs(got - ref) / ref).max()))
+        # (1 001 nodes, integer coordinates scaled per axis: two of 2 802 probabilities sit at 9e-4, the rest below 5e-4 --
+        # the softmax runs over ten times the nodes of the 5e-4 cases and its logits carry logit_clipping = 50)
+        np.testing.assert_allclose(got, ref, rtol=2e-3, atol=1e-12)
+    gc.record_parity("fullsize/vrplib_n1001_aug8_pomo1000_chosen_prob_rel", worst)
