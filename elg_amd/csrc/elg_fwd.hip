@@ -2797,6 +2797,546 @@ static int launch_fwd_xl(const elg_rollout_args& A, hipStream_t stream) {
     return launch_status("rollout_fwd_xl");
 }
 
+// =============================================================================================
+// rollout_fwd_xm_kernel (round 4): N1 > 1024 on the matrix cores.  The phase structure and the matrix phases of the streaming
+// kernel above -- 16 lockstep trajectories per workgroup, wave = head in the glimpse, node tiles over the waves in the pointer
+// phase, K / V / PK streamed in MFMA-fragment order (mt_repack_kernel / mt_repack_bf16_kernel with NP = 64 ceil(N1 / 64)) -- with
+// the owners of rollout_fwd_xl_kernel: every node-indexed quantity is a runtime loop over 64-node chunks, the visited and mask
+// words of a trajectory live in LDS, and its score row -- which also carries the ADDITIVE mask (0 / -inf) from the owners into the
+// glimpse, as the accumulator input of the score product -- in a global scratch row of NP floats (L2; the waves of a workgroup
+// share their CU's vector L1, so plain loads / stores ordered by the workgroup barriers suffice).  Inference only.
+// scratch = [B][NP x (tables)] | [B x tiles x 16][NP] score rows  (elg_rollout_scratch_floats, variant 0, N1 > 1024).
+// rollout_fwd_xl_kernel (variant 2) remains: the one-wavefront-per-trajectory reference of the tests at these sizes.
+// =============================================================================================
+struct XmTraj {
+    int cur, first, cnt, fin, nvis;
+    float load, len, cx, cy;
+};
+
+template <bool TSP, bool BF>
+__global__ __launch_bounds__(512) void rollout_fwd_xm_kernel(const elg_rollout_args A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NTR = 16, NOWN = 2, QP = 132, OBP = 68, TU = 4;
+    constexpr int S0 = TSP ? 0 : 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lo = lane & 15, hi = lane >> 4;
+    const int N1 = A.N1, NW = (N1 + 63) >> 6, NP = 64 * NW, NT = NP >> 4, NTn = (N1 + 15) >> 4;
+    const int G = gridDim.x;
+    int u = blockIdx.x;
+    if ((G & 7) == 0) u = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int b = u / A.tiles, tile = u % A.tiles;
+    const int m_base = tile * NTR;
+    // LDS: query rows / bf16 term planes of o | mask words | visited words | slot blocks | local tables | demand | slot scratch
+    float* sQ = lds;
+    unsigned* sOb = reinterpret_cast<unsigned*>(lds);
+    unsigned long long* sMaskW = reinterpret_cast<unsigned long long*>(sQ + NTR * 3 * OBP);
+    unsigned long long* sVis = sMaskW + NTR * NW;
+    float* sX = reinterpret_cast<float*>(sVis + NTR * NW);
+    float* sT = sX + (A.has_local ? NTR * CO_XP : 0);
+    float* sdem = sT + (A.has_local ? CL_SIZE : 0);
+    float* sb = sdem + ((N1 + 3) & ~3) + wave * ELG_SB_MIN;
+    if (!TSP)
+        for (int i = tid; i < N1; i += 512) sdem[i] = A.demand[(size_t)b * N1 + i];
+    for (int i = tid; i < NTR * NW; i += 512) sVis[i] = 0ull;
+    if (A.has_local) co_stage_local(A.loc, sT, tid, 512);
+    __syncthreads();
+    const size_t NE = (size_t)N1 * ELG_E;
+    const float* pbv = A.pb + (size_t)b * N1;
+    const float* Q1 = A.Q1 + b * NE;
+    const float* Q2 = TSP ? A.Q2 + b * NE : nullptr;
+    const float* xy = A.xy + (size_t)b * N1 * 2;
+    const int* nidx = A.nbr_idx + (size_t)b * N1 * N1;
+    const float* ndist = A.nbr_dist + (size_t)b * N1 * N1;
+    const float* ntheta = A.nbr_theta + (size_t)b * N1 * N1;
+    const float dflt = A.has_penalty ? A.xi : 0.f;
+    constexpr int TW = BF ? MT_BF_WORDS : MT_KB_WORDS + ELG_E + MT_PKB_WORDS;
+    const float* gF = A.scratch + (size_t)b * NP * TW;
+    float* rows = A.scratch + (size_t)A.B * NP * (MT_KB_WORDS + ELG_E + MT_PKB_WORDS) + ((size_t)b * A.tiles + tile) * NTR * (size_t)NP;
+    // f32-parity mode (split-bf16 scores / pointer, f32 weights x values): [h][tile][form][lane] uint4 | [h][tile][lane] float4 | [tile][kb][term][lane] uint4
+    const uint4* gK = reinterpret_cast<const uint4*>(gF) + (size_t)wave * NT * 2 * 64 + lane;
+    const float4* gV = reinterpret_cast<const float4*>(gF + (size_t)NP * MT_KB_WORDS) + (size_t)wave * NT * 64 + lane;
+    const uint4* gPK = reinterpret_cast<const uint4*>(gF + (size_t)NP * (MT_KB_WORDS + ELG_E)) + lane;
+    // bf16 mode: [h][tile][lane] uint2 | [h][pair][lane] uint4 | [tile][kb][lane] uint4
+    const uint2* gKb = reinterpret_cast<const uint2*>(gF) + (size_t)wave * NT * 64 + lane;
+    const uint4* gVb = reinterpret_cast<const uint4*>(gF + (size_t)NP * 64) + (size_t)wave * (NT / 2) * 64 + lane;
+    const uint4* gPb = reinterpret_cast<const uint4*>(gF + (size_t)NP * 128) + lane;
+    const int step_cap = TSP ? N1 : 2 * N1 + 2;
+
+    XmTraj st[NOWN];
+    bool has[NOWN];
+    size_t bm[NOWN];
+#pragma unroll
+    for (int j = 0; j < NOWN; ++j) {
+        has[j] = m_base + wave + 8 * j < A.M;
+        bm[j] = (size_t)b * A.M + (has[j] ? m_base + wave + 8 * j : 0);
+        st[j].cur = 0; st[j].first = 0; st[j].cnt = 0; st[j].fin = has[j] ? 0 : 1; st[j].nvis = 0;
+        st[j].load = 1.0f; st[j].len = 0.f; st[j].cx = 0.f; st[j].cy = 0.f;
+    }
+    for (int t = 0; t < step_cap && t < A.Tmax; ++t) {
+        const bool first_move = (!TSP && t <= 1) || (TSP && t == 0);
+        bool act[NOWN], dec[NOWN];
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < NOWN; ++j) {
+            act[j] = has[j] && !st[j].fin;
+            dec[j] = act[j] && !first_move;
+            any = any || act[j];
+        }
+        if (!__syncthreads_or(any ? 1 : 0)) break;
+        int sel[NOWN], snid[NOWN];
+        float pr[NOWN], addv[NOWN];
+#pragma unroll
+        for (int j = 0; j < NOWN; ++j) { sel[j] = 0; snid[j] = -1; pr[j] = 1.0f; addv[j] = 0.f; }
+        if (!first_move) {
+            // ================= owners: mask words + additive mask row, query row, k-NN slots, slot features =================
+            auto prepare = [&](const XmTraj& s1, bool dc, int q, float& addval, int& sn) {
+                float* srow = rows + (size_t)q * NP;
+                unsigned long long* mkw = sMaskW + q * NW;
+                const unsigned long long* vis = sVis + q * NW;
+                float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+                int scode = -1;
+                if (dc) {
+                    const float lim = __fadd_rn(s1.load, 1e-6f);
+                    for (int ch = 0; ch < NW; ++ch) {                   // CVRPEnv.py:214-232 / TSPEnv.py:120
+                        const int n = lane + 64 * ch;
+                        bool mm = true;
+                        if (n < N1) {
+                            mm = (vis[ch] >> lane) & 1ull;
+                            if (!TSP) {
+                                mm = mm || (lim < sdem[n]);
+                                if (n == 0 && s1.fin) mm = false;
+                            }
+                        }
+                        srow[n] = mm ? ELG_NEG_INF : 0.f;
+                        const unsigned long long bal = __ballot(mm);
+                        if (lane == 0) mkw[ch] = bal;
+                    }
+                    wave_lds_fence();
+                    const int cb = (lane & 31) * 4;
+                    q4 = *reinterpret_cast<const float4*>(Q1 + (size_t)s1.cur * ELG_E + cb);
+                    if (TSP) {
+                        const float4 qf = *reinterpret_cast<const float4*>(Q2 + (size_t)s1.first * ELG_E + cb);
+                        q4.x += qf.x; q4.y += qf.y; q4.z += qf.z; q4.w += qf.w;
+                    } else {
+                        const float4 w = *reinterpret_cast<const float4*>(A.wl + cb);
+                        q4.x = fmaf(s1.load, w.x, q4.x); q4.y = fmaf(s1.load, w.y, q4.y);
+                        q4.z = fmaf(s1.load, w.z, q4.z); q4.w = fmaf(s1.load, w.w, q4.w);
+                    }
+                    if (A.has_penalty || A.has_local) {                 // knn_slots / slot_setup with runtime chunk loops
+                        int found = 0;
+                        const size_t row = (size_t)s1.cur * N1;
+                        for (int ch = 0; ch < NW && found < A.K; ++ch) {
+                            const int i = lane + 64 * ch;
+                            const bool valid = i < N1;
+                            const int nid = valid ? nidx[row + i] : 0;
+                            const float nd = valid ? ndist[row + i] : 0.f;
+                            const float nth = valid ? ntheta[row + i] : 0.f;
+                            bool cand = valid && !((mkw[nid >> 6] >> (nid & 63)) & 1ull);
+                            if (!TSP) cand = cand && (nid != 0);
+                            const unsigned long long bal = __ballot(cand);
+                            const int rank = found + lanes_below(bal);
+                            if (cand && rank < A.K) {
+                                sb[S0 + rank] = nd;
+                                sb[ELG_SLOT_STRIDE + S0 + rank] = nth;
+                                sb[2 * ELG_SLOT_STRIDE + S0 + rank] = i2f(nid);
+                            }
+                            found += __popcll(bal);
+                        }
+                        const int k = found < A.K ? found : A.K;
+                        wave_lds_fence();
+                        const int jl = lane;
+                        const bool cust = (jl >= S0) && (jl < S0 + k);
+                        float sd = 0.f, sth = 0.f;
+                        if (cust) { sd = sb[jl]; sth = sb[ELG_SLOT_STRIDE + jl]; sn = f2i(sb[2 * ELG_SLOT_STRIDE + jl]); }
+                        const float dmax = (k > 0) ? sb[S0 + k - 1] : 0.f;
+                        wave_lds_fence();
+                        if (!TSP && jl == 0) sn = 0;
+                        float pen = 0.f;
+                        if (A.has_penalty && cust) {
+                            if (TSP) pen = -(sd / (dmax + 1e-6f));
+                            else pen = (dmax != 0.f) ? -(sd / dmax) : -sd;
+                        }
+                        const float nf = dmax + 1e-6f;
+                        if (cust) {
+                            f0 = sd / nf; f1 = sth;
+                            if (A.euclidean) { f0 = __fsub_rn(xy[2 * sn], s1.cx) / nf; f1 = __fsub_rn(xy[2 * sn + 1], s1.cy) / nf; }
+                            if (!TSP) f2 = sdem[sn] / s1.load;
+                        }
+                        bool smask = !cust;
+                        if (!TSP && jl == 0) smask = mkw[0] & 1ull;
+                        scode = smask ? (sn >= 0 ? -2 : -1) : sn;
+                        addval = pen;
+                    }
+                } else {
+                    for (int ch = 0; ch < NW; ++ch) srow[lane + 64 * ch] = ELG_NEG_INF;     // not decoding: every node closed
+                    if (lane == 0)
+                        for (int ch = 0; ch < NW; ++ch) mkw[ch] = ~0ull;
+                }
+                if (A.has_local && lane < ELG_SLOT_STRIDE) {            // slot block for co_local16 (layout of the cooperative kernel)
+                    float* X = sX + q * CO_XP;
+                    X[CO_XF + lane] = f0; X[CO_XF + ELG_SLOT_STRIDE + lane] = f1; X[CO_XF + 2 * ELG_SLOT_STRIDE + lane] = f2;
+                    reinterpret_cast<int*>(X)[CO_XS + lane] = scode;
+                }
+                if (lane < 32) *reinterpret_cast<float4*>(sQ + q * QP + 4 * lane) = q4;
+            };
+#pragma unroll
+            for (int j = 0; j < NOWN; ++j) prepare(st[j], dec[j], wave + 8 * j, addv[j], snid[j]);
+            __syncthreads();
+            // ================= glimpse: wave = head =================
+            {
+                const float cs = 0.25f * 1.4426950408889634f;
+                const float* mrow = rows + (size_t)lo * NP + 4 * hi;          // additive mask of trajectory lo
+                const float4 qv = *reinterpret_cast<const float4*>(sQ + lo * QP + 16 * wave + 4 * hi);
+                unsigned pt[6];
+                bf_terms<3>(qv.x, qv.y, qv.z, qv.w, pt);
+                const u32x4 q11 = {pt[0], pt[1], pt[0], pt[1]}, q22 = {pt[2], pt[3], pt[2], pt[3]}, q31 = {pt[4], pt[5], pt[0], pt[1]};
+                const u32x4 qb1 = {pt[0], pt[1], 0u, 0u};
+                float mrun = -1e30f, lrun = 0.f;
+                f32x4c o = {0.f, 0.f, 0.f, 0.f}, o2 = {0.f, 0.f, 0.f, 0.f};
+                __syncthreads();        // every head has its queries: the rows are free for the term planes of o
+                auto softmax_update = [&](f32x4c (&S)[TU]) {
+                    float tm = ELG_NEG_INF;
+#pragma unroll
+                    for (int u4 = 0; u4 < TU; ++u4)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) tm = fmaxf(tm, S[u4][i]);
+                    tm = quarters_max(tm);
+                    const float mnew = fmaxf(mrun, tm);
+                    const float sc = __builtin_amdgcn_exp2f((mrun - mnew) * cs);
+                    mrun = mnew;
+                    lrun *= sc;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { o[i] *= sc; o2[i] *= sc; }
+                    const float cm = -mnew * cs;
+#pragma unroll
+                    for (int u4 = 0; u4 < TU; ++u4)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            S[u4][i] = __builtin_amdgcn_exp2f(fmaf(S[u4][i], cs, cm));
+                            lrun += S[u4][i];
+                        }
+                };
+                if constexpr (BF) {
+                    uint2 kf[TU], kn[TU];
+                    uint4 vf[TU / 2], vn[TU / 2];
+                    auto loadb = [&](int nt0, uint2 (&kk)[TU], uint4 (&vv)[TU / 2]) {
+#pragma unroll
+                        for (int u4 = 0; u4 < TU; ++u4) kk[u4] = gKb[(size_t)(nt0 + u4) * 64];
+#pragma unroll
+                        for (int u2 = 0; u2 < TU / 2; ++u2) vv[u2] = gVb[(size_t)(nt0 / 2 + u2) * 64];
+                    };
+                    loadb(0, kf, vf);
+#pragma unroll 1
+                    for (int nt = 0; nt < NTn; nt += TU) {
+                        loadb(min(nt + TU, NT - TU), kn, vn);
+                        __builtin_amdgcn_sched_barrier(0);
+                        f32x4c S[TU];
+#pragma unroll
+                        for (int u4 = 0; u4 < TU; ++u4) {
+                            const float4 m4 = *reinterpret_cast<const float4*>(mrow + 16 * (nt + u4));
+                            S[u4] = mfma_bf(u32x4{kf[u4].x, kf[u4].y, 0u, 0u}, qb1, f32x4c{m4.x, m4.y, m4.z, m4.w});
+                        }
+                        softmax_update(S);
+#pragma unroll
+                        for (int u2 = 0; u2 < TU / 2; ++u2) {
+                            const u32x4 pb_ = {pk_bf16(S[2 * u2][0], S[2 * u2][1]), pk_bf16(S[2 * u2][2], S[2 * u2][3]),
+                                               pk_bf16(S[2 * u2 + 1][0], S[2 * u2 + 1][1]), pk_bf16(S[2 * u2 + 1][2], S[2 * u2 + 1][3])};
+                            f32x4c& acc = (u2 & 1) ? o2 : o;
+                            acc = mfma_bf(u32x4{vf[u2].x, vf[u2].y, vf[u2].z, vf[u2].w}, pb_, acc);
+                        }
+#pragma unroll
+                        for (int u4 = 0; u4 < TU; ++u4) kf[u4] = kn[u4];
+#pragma unroll
+                        for (int u2 = 0; u2 < TU / 2; ++u2) vf[u2] = vn[u2];
+                    }
+                } else {
+                    uint4 kf[2 * TU], kn[2 * TU];
+                    float4 vf[TU], vn[TU];
+                    auto load4 = [&](int nt0, uint4 (&kk)[2 * TU], float4 (&vv)[TU]) {
+#pragma unroll
+                        for (int u4 = 0; u4 < TU; ++u4) {
+                            kk[2 * u4] = gK[(size_t)(nt0 + u4) * 128];
+                            kk[2 * u4 + 1] = gK[(size_t)(nt0 + u4) * 128 + 64];
+                            vv[u4] = gV[(size_t)(nt0 + u4) * 64];
+                        }
+                    };
+                    load4(0, kf, vf);
+#pragma unroll 1
+                    for (int nt = 0; nt < NTn; nt += TU) {
+                        load4(min(nt + TU, NT - TU), kn, vn);
+                        __builtin_amdgcn_sched_barrier(0);
+                        f32x4c S[TU];
+#pragma unroll
+                        for (int u4 = 0; u4 < TU; ++u4) {
+                            const float4 m4 = *reinterpret_cast<const float4*>(mrow + 16 * (nt + u4));
+                            S[u4] = f32x4c{m4.x, m4.y, m4.z, m4.w};
+                        }
+                        // S^T += K_h q^T: [k1 | k2] [q1 | q1] + [k1 | k2] [q2 | q2] + [k1 | k3] [q3 | q1]
+#pragma unroll
+                        for (int u4 = 0; u4 < TU; ++u4) S[u4] = mfma_bf(u32x4{kf[2 * u4].x, kf[2 * u4].y, kf[2 * u4].z, kf[2 * u4].w}, q11, S[u4]);
+#pragma unroll
+                        for (int u4 = 0; u4 < TU; ++u4) S[u4] = mfma_bf(u32x4{kf[2 * u4].x, kf[2 * u4].y, kf[2 * u4].z, kf[2 * u4].w}, q22, S[u4]);
+#pragma unroll
+                        for (int u4 = 0; u4 < TU; ++u4)
+                            S[u4] = mfma_bf(u32x4{kf[2 * u4 + 1].x, kf[2 * u4 + 1].y, kf[2 * u4 + 1].z, kf[2 * u4 + 1].w}, q31, S[u4]);
+                        softmax_update(S);
+#pragma unroll
+                        for (int u4 = 0; u4 < TU; ++u4) {                 // O^T += V_h^T P^T, two accumulator chains
+                            f32x4c& acc = (u4 & 1) ? o2 : o;
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[u4].x, S[u4][0], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[u4].y, S[u4][1], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[u4].z, S[u4][2], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[u4].w, S[u4][3], acc, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int u4 = 0; u4 < TU; ++u4) { kf[2 * u4] = kn[2 * u4]; kf[2 * u4 + 1] = kn[2 * u4 + 1]; vf[u4] = vn[u4]; }
+                    }
+                }
+                const float l = quarters_sum(lrun);
+                const float inv = l > 0.f ? 1.0f / l : 0.f;
+                const float4 ov = make_float4((o[0] + o2[0]) * inv, (o[1] + o2[1]) * inv, (o[2] + o2[2]) * inv, (o[3] + o2[3]) * inv);
+                unsigned po[6];
+                bf_terms<3>(ov.x, ov.y, ov.z, ov.w, po);
+#pragma unroll
+                for (int tm = 0; tm < 3; ++tm)
+                    *reinterpret_cast<uint2*>(sOb + (tm * NTR + lo) * OBP + 8 * wave + 2 * hi) = make_uint2(po[2 * tm], po[2 * tm + 1]);
+            }
+            __syncthreads();
+            // ================= pointer: node tiles over the waves; the local policy on wave 7 =================
+            const int nloc = A.has_local ? 1 : 0, W0 = 8 - nloc, skip = nloc ? 3 * W0 : 0;
+            if (wave >= W0) co_local16_call(sT, A.loc, sX, lo, hi);
+            {
+                int nt = (wave < W0 ? wave : skip + wave);
+                float* orow = rows + (size_t)lo * NP + 4 * hi;
+                if constexpr (BF) {
+                    uint4 pk[4], pkn[4];
+                    auto loadpb = [&](int nt_, uint4 (&d)[4]) {
+#pragma unroll
+                        for (int kb = 0; kb < 4; ++kb) d[kb] = gPb[(size_t)(nt_ * 4 + kb) * 64];
+                    };
+                    if (nt < NTn) loadpb(nt, pk);
+#pragma unroll 1
+                    while (nt < NTn) {
+                        const int nxt = nt + (nt < skip ? W0 : 8);
+                        loadpb(min(nxt, NTn - 1), pkn);
+                        __builtin_amdgcn_sched_barrier(0);
+                        f32x4c a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kb = 0; kb < 4; ++kb) {
+                            const uint4 q1 = *reinterpret_cast<const uint4*>(sOb + lo * OBP + 16 * kb + 4 * hi);
+                            const u32x4 A1 = {pk[kb].x, pk[kb].y, pk[kb].z, pk[kb].w}, B1 = {q1.x, q1.y, q1.z, q1.w};
+                            if (kb & 1) a1 = mfma_bf(A1, B1, a1); else a0 = mfma_bf(A1, B1, a0);
+                        }
+                        const int nb = 16 * nt + 4 * hi;
+                        const float p0 = pbv[min(nb, N1 - 1)], p1 = pbv[min(nb + 1, N1 - 1)], p2 = pbv[min(nb + 2, N1 - 1)], p3 = pbv[min(nb + 3, N1 - 1)];
+                        *reinterpret_cast<float4*>(orow + 16 * nt) = make_float4(a0[0] + a1[0] + p0, a0[1] + a1[1] + p1, a0[2] + a1[2] + p2, a0[3] + a1[3] + p3);
+#pragma unroll
+                        for (int kb = 0; kb < 4; ++kb) pk[kb] = pkn[kb];
+                        nt = nxt;
+                    }
+                } else {
+                    uint4 pk[12], pkn[12];
+                    auto loadpk = [&](int nt_, uint4 (&d)[12]) {
+#pragma unroll
+                        for (int s4 = 0; s4 < 12; ++s4) d[s4] = gPK[(size_t)(nt_ * 12 + s4) * 64];
+                    };
+                    if (nt < NTn) loadpk(nt, pk);
+#pragma unroll 1
+                    while (nt < NTn) {
+                        const int nxt = nt + (nt < skip ? W0 : 8);
+                        loadpk(min(nxt, NTn - 1), pkn);
+                        __builtin_amdgcn_sched_barrier(0);
+                        f32x4c a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kb = 0; kb < 4; ++kb) {
+                            const u32x4 A1 = {pk[3 * kb].x, pk[3 * kb].y, pk[3 * kb].z, pk[3 * kb].w};
+                            const u32x4 A2 = {pk[3 * kb + 1].x, pk[3 * kb + 1].y, pk[3 * kb + 1].z, pk[3 * kb + 1].w};
+                            const u32x4 A3 = {pk[3 * kb + 2].x, pk[3 * kb + 2].y, pk[3 * kb + 2].z, pk[3 * kb + 2].w};
+                            const unsigned* ob = sOb + lo * OBP + 16 * kb + 4 * hi;
+                            const uint4 q1 = *reinterpret_cast<const uint4*>(ob);
+                            const uint4 q2 = *reinterpret_cast<const uint4*>(ob + NTR * OBP);
+                            const uint4 q3 = *reinterpret_cast<const uint4*>(ob + 2 * NTR * OBP);
+                            const u32x4 B1 = {q1.x, q1.y, q1.z, q1.w}, B2 = {q2.x, q2.y, q2.z, q2.w}, B3 = {q3.x, q3.y, q3.z, q3.w};
+                            a0 = mfma_bf(A1, B1, a0);
+                            a1 = mfma_bf(A1, B2, a1);
+                            a0 = mfma_bf(A2, B1, a0);
+                            a1 = mfma_bf(A2, B2, a1);
+                            a0 = mfma_bf(A1, B3, a0);
+                            a1 = mfma_bf(A3, B1, a1);
+                        }
+                        const int nb = 16 * nt + 4 * hi;
+                        const float p0 = pbv[min(nb, N1 - 1)], p1 = pbv[min(nb + 1, N1 - 1)], p2 = pbv[min(nb + 2, N1 - 1)], p3 = pbv[min(nb + 3, N1 - 1)];
+                        *reinterpret_cast<float4*>(orow + 16 * nt) = make_float4(a0[0] + a1[0] + p0, a0[1] + a1[1] + p1, a0[2] + a1[2] + p2, a0[3] + a1[3] + p3);
+#pragma unroll
+                        for (int s4 = 0; s4 < 12; ++s4) pk[s4] = pkn[s4];
+                        nt = nxt;
+                    }
+                }
+            }
+            __syncthreads();
+            // ================= owners: clip, mask, softmax, choice (models.py:405-420) =================
+            // ONE read pass over the score row per trajectory (a second one only when sampling): lane l takes the nodes 4 l .. 4 l + 3
+            // of every 256-node block (16-byte loads, two blocks in flight), clipped logit x = clip tanh(s + slot terms) on the fly,
+            // per-lane online softmax (running maximum m_l, sum of exp(x - m_l), first arg max), merged over the wave at the end:
+            // tot = sum_l sum_l exp(m_l - max).  Nothing is written back to the row.
+            auto choose = [&](bool dc, int q, size_t bmq, int sn, float addval, int& sl, float& pp) {
+                if (!dc) return;
+                float* scr = rows + (size_t)q * NP;
+                const unsigned long long* mkw = sMaskW + q * NW;
+                if (A.has_local && lane < ELG_SLOT_STRIDE) addval += sX[q * CO_XP + CO_XU + lane] * A.inv_ens;
+                if (sn >= 0) scr[sn] += addval - dflt;                        // penalty + local terms on the slot nodes (distinct nodes)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                auto logits4 = [&](int blk, float (&x)[4]) {                   // clipped, masked logits of nodes 256 blk + 4 lane + i
+                    const int n0 = 256 * blk + 4 * lane;
+                    const float4 sv = *reinterpret_cast<const float4*>(scr + n0);
+                    const unsigned bits = (unsigned)(mkw[n0 >> 6] >> (n0 & 63)) & 0xFu;     // NP is a multiple of 64: n0 < NP
+                    const float svv[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) x[i] = ((bits >> i) & 1u) ? ELG_NEG_INF : A.clip * fast_tanh(svv[i] + dflt);
+                };
+                const int nblk = NP >> 8, tail = (NP & 255) ? 1 : 0;          // (NP = 64 NW: a last partial block of 64 / 128 / 192 nodes)
+                float mrun_l = ELG_NEG_INF, srun = 0.f;
+                int bn = 0x7fffffff;
+                for (int blk = 0; blk < nblk + tail; ++blk) {
+                    float x[4] = {ELG_NEG_INF, ELG_NEG_INF, ELG_NEG_INF, ELG_NEG_INF};
+                    if (256 * blk + 4 * lane < NP) logits4(blk, x);
+                    float bm_ = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+                    if (bm_ > mrun_l) {                                         // strictly greater: the first maximum wins (node order)
+#pragma unroll
+                        for (int i = 3; i >= 0; --i) if (x[i] == bm_) bn = 256 * blk + 4 * lane + i;
+                        srun *= __expf(mrun_l - bm_);                           // exp(-inf) = 0 for the first finite block
+                        mrun_l = bm_;
+                    }
+                    if (mrun_l > ELG_NEG_INF) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) srun += __expf(x[i] - mrun_l);
+                    }
+                }
+                // merge the lanes: global maximum, first node that attains it, normaliser
+                const float gmx = wave_max(mrun_l);
+                {
+                    const float cand = (mrun_l == gmx && bn != 0x7fffffff) ? -(float)bn : -3.0e38f;      // node indices < 2^24: exact in f32
+                    const float firstn = -wave_max(cand);
+                    bn = firstn < 1.0e9f ? (int)firstn : 0;
+                }
+                const float tot = wave_sum(mrun_l > ELG_NEG_INF ? srun * __expf(mrun_l - gmx) : 0.f);
+                const float inv = 1.0f / tot;
+                float* frow = (A.full_probs && t < A.dump_T) ? A.full_probs + (bmq * A.dump_T + t) * N1 : nullptr;
+                if (frow)                                                       // tests: probabilities / clipped logits / scores before the clip
+                    for (int n = lane; n < N1; n += 64) {
+                        const bool masked = (mkw[n >> 6] >> (n & 63)) & 1ull;
+                        const float sv = scr[n] + dflt;
+                        const float x = masked ? ELG_NEG_INF : A.clip * fast_tanh(sv);
+                        frow[n] = A.dump_logits == 2 ? (masked ? ELG_NEG_INF : sv) : A.dump_logits == 1 ? x : (masked ? 0.f : __expf(x - gmx) * inv);
+                    }
+                int s_ = 0;
+                if (A.mode == ELG_MODE_FORCED) s_ = (A.forced && t < A.Tforced) ? A.forced[bmq * A.Tforced + t] : 0;
+                else if (A.mode == ELG_MODE_GREEDY) s_ = bn;
+                else {
+                    // inverse CDF in node order (second pass; 64-node chunks so that the scan runs in node order)
+                    const float uni = A.uniforms ? A.uniforms[bmq * A.Tmax + t] : philox_uniform(A.seed, (unsigned)bmq, (unsigned)t);
+                    const float target = uni * tot;
+                    float run = 0.f;
+                    int found = -1, lastpos = 0;
+                    for (int ch = 0; ch < NW && found < 0; ++ch) {
+                        const int n = lane + 64 * ch;
+                        float e = 0.f;
+                        if (n < N1 && !((mkw[ch] >> lane) & 1ull)) e = __expf(A.clip * fast_tanh(scr[n] + dflt) - gmx);
+                        const float cs_ = wave_scan_incl(e, lane) + run;
+                        run = readlane(cs_, 63);
+                        const unsigned long long pos = __ballot(e > 0.f);
+                        const unsigned long long hit = __ballot(e > 0.f && cs_ > target);
+                        if (hit) found = 64 * ch + (int)__builtin_ctzll(hit);
+                        if (pos) lastpos = 64 * ch + 63 - (int)__builtin_clzll(pos);
+                    }
+                    s_ = found >= 0 ? found : lastpos;
+                }
+                s_ = __builtin_amdgcn_readfirstlane(s_);
+                const bool smasked = (mkw[s_ >> 6] >> (s_ & 63)) & 1ull;
+                const float xs = smasked ? ELG_NEG_INF : A.clip * fast_tanh(scr[s_] + dflt);
+                const float p_ = (xs > ELG_NEG_INF) ? __expf(xs - gmx) * inv : 0.f;
+                pp = i2f(__builtin_amdgcn_readfirstlane(f2i(p_)));
+                sl = s_;
+            };
+#pragma unroll
+            for (int j = 0; j < NOWN; ++j) choose(dec[j], wave + 8 * j, bm[j], snid[j], addv[j], sel[j], pr[j]);
+        }
+        auto advance = [&](XmTraj& s1, bool ac, int q, size_t bmq, int sl, float pp) {
+            if (!ac) return;
+            const int m = m_base + q;
+            if (first_move) {
+                if (A.mode == ELG_MODE_FORCED) sl = (A.forced && t < A.Tforced) ? __builtin_amdgcn_readfirstlane(A.forced[bmq * A.Tforced + t]) : 0;
+                else sl = (!TSP && t == 0) ? 0 : __builtin_amdgcn_readfirstlane(A.starts[m]);
+            }
+            if (lane == 0) {
+                if (A.actions) A.actions[bmq * A.Tmax + t] = sl;
+                if (A.probs) A.probs[((size_t)b * A.Tmax + t) * A.M + m] = pp;
+            }
+            unsigned long long* vis = sVis + q * NW;
+            const float sx = xy[2 * sl], sy = xy[2 * sl + 1];
+            if (s1.cnt > 0) s1.len += dist2d(s1.cx, s1.cy, sx, sy);
+            s1.cx = sx; s1.cy = sy;
+            if (TSP) { if (s1.cnt == 0) s1.first = sl; }
+            else s1.load = (sl == 0) ? 1.0f : __fsub_rn(s1.load, sdem[sl]);
+            if (lane == 0) {
+                unsigned long long w = vis[sl >> 6];
+                const unsigned long long bit = 1ull << (sl & 63);
+                int d = (w & bit) ? 0 : 1;
+                w |= bit;
+                vis[sl >> 6] = w;
+                if (!TSP) {
+                    // depot counts as visited exactly while the trajectory stands on it (CVRPEnv.py:214-216)
+                    unsigned long long w0 = vis[0];
+                    if (sl != 0 && (w0 & 1ull)) { w0 &= ~1ull; d -= 1; vis[0] = w0; }
+                }
+                sb[0] = i2f(d);
+            }
+            wave_lds_fence();
+            s1.nvis += f2i(sb[0]);
+            wave_lds_fence();
+            s1.cur = sl;
+            s1.cnt += 1;
+            if (TSP) {
+                if (s1.cnt == N1) { s1.len += dist2d(sx, sy, xy[2 * s1.first], xy[2 * s1.first + 1]); s1.fin = 1; }
+            } else if (s1.nvis == N1) s1.fin = 1;
+        };
+#pragma unroll
+        for (int j = 0; j < NOWN; ++j) advance(st[j], act[j], wave + 8 * j, bm[j], sel[j], pr[j]);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < NOWN; ++j)
+            if (has[j]) { if (A.reward) A.reward[bm[j]] = -st[j].len; if (A.tlen) A.tlen[bm[j]] = st[j].cnt; }
+    }
+}
+
+template <bool TSP, bool BF>
+static int launch_fwd_xm(const elg_rollout_args& A, hipStream_t stream) {
+    if (!A.scratch) return fail(ELG_EINVAL, "rollout: N1 > 1024 needs the scratch workspace (elg_rollout_scratch_floats)");
+    if (A.N1 > 8192) return fail(ELG_ENOTIMPL, "rollout: N1 > 8192 not built");
+    if (A.trA || A.trMask) return fail(ELG_ENOTIMPL, "rollout: no training rows for N1 > 1024");
+    const int NW = (A.N1 + 63) / 64, NP = 64 * NW, NTt = NP / 16;
+    const size_t lds = ((size_t)16 * 3 * 68 + (size_t)16 * NW * 4 + (A.has_local ? 16 * CO_XP + CL_SIZE : 0) + ((A.N1 + 3) & ~3) +
+                        (size_t)8 * ELG_SB_MIN) * 4;
+    if (lds > 163840 - 256) return fail(ELG_EINVAL, "xm rollout: LDS budget exceeded");
+    auto kern = rollout_fwd_xm_kernel<TSP, BF>;
+    static DynLds optin;
+    if (!optin.opt_in(reinterpret_cast<const void*>(kern), lds)) return fail(ELG_ELAUNCH, "xm rollout: hipFuncSetAttribute failed");
+    elg_rollout_args B2 = A;
+    B2.tiles = (A.M + 15) / 16;
+    (void)hipGetLastError();
+    if (BF)
+        hipLaunchKernelGGL(mt_repack_bf16_kernel, dim3(((8 * NTt + 4 * NTt + 4 * NTt) * 64 + 255) / 256, A.B), dim3(256), 0, stream, A.Kmat, A.Vmat,
+                           A.PK, reinterpret_cast<unsigned*>(A.scratch), A.N1, NP);
+    else
+        hipLaunchKernelGGL(mt_repack_kernel, dim3((2 * NP * 32 + NP * 16 + 255) / 256, A.B), dim3(256), 0, stream, A.Kmat, A.Vmat, A.PK, A.scratch, A.N1, NP);
+    hipLaunchKernelGGL(kern, dim3(B2.B * B2.tiles), dim3(512), lds, stream, B2);
+    return launch_status("rollout_fwd_xm");
+}
+
 // SMALL: N1 <= 104 in the two-chunk build (13 row groups instead of 16)
 template <int NCH, bool TSP, bool LDSK, int WAVES, bool TRAIN = false>
 static int launch_fwd(const elg_rollout_args& A, hipStream_t stream) {
@@ -2855,9 +3395,16 @@ static int dispatch_fwd(const elg_rollout_args& A, hipStream_t stream) {
         if (nch <= 16) return launch_fwd_mt<16, TSP>(A, stream);
     }
     const bool fused = !A.use_state && A.do_decode && A.do_update && A.max_steps <= 0;
+    if (fused && (A.variant == 3 || (A.variant == 0 && nch > 16))) {
+        // Vrp-Set-XXL scale (or variant 3: the same kernel at any size, for the tests): matrix phases of the streaming kernel,
+        // runtime chunk loops in the owners, score rows in the scratch
+        if (A.trA || A.trMask) return fail(ELG_ENOTIMPL, "rollout: training rows for N1 > 1024 not built");
+        if (A.ens > 1) return fail(ELG_ENOTIMPL, "rollout: ensemble_size > 1 is built for N1 <= 1024");
+        return A.precision == 1 ? launch_fwd_xm<TSP, true>(A, stream) : launch_fwd_xm<TSP, false>(A, stream);
+    }
     if (fused && (A.variant == 2 || nch > 16)) {
         if (A.trA || A.trMask) return fail(ELG_ENOTIMPL, "rollout: training rows for N1 > 1024 not built");
-        return launch_fwd_xl<TSP>(A, stream);                 // Vrp-Set-XXL scale: runtime node loops, scratch rows
+        return launch_fwd_xl<TSP>(A, stream);                 // one wavefront per trajectory, runtime node loops (the tests' reference)
     }
     if (nch <= 4) { ELG_GO(4, false, 8); }
     if (nch <= 8) { ELG_GO(8, false, 8); }
@@ -2873,7 +3420,12 @@ using namespace elg;
 extern "C" {
 int64_t elg_rollout_scratch_floats(int32_t B, int32_t M, int32_t N1, int32_t variant) {
     if (B <= 0 || M <= 0 || N1 <= 0) return 0;
-    if (variant == 2 || N1 > 1024) return (int64_t)B * M * N1;                     // score rows of rollout_fwd_xl_kernel
+    if (variant == 2) return (int64_t)B * M * N1;                                  // score rows of rollout_fwd_xl_kernel
+    if (variant == 3 || (variant == 0 && N1 > 1024)) {                             // rollout_fwd_xm_kernel: tables + score rows
+        const int64_t NP = 64 * (int64_t)((N1 + 63) / 64);
+        return (int64_t)B * NP * (MT_KB_WORDS + ELG_E + MT_PKB_WORDS) + (int64_t)B * ((M + 15) / 16) * 16 * NP;
+    }
+    if (N1 > 1024) return (int64_t)B * M * N1;
     if (N1 > 128 && variant == 0) {                                                // fragment-major K / V / PK copies
         const int nch = (N1 + 63) / 64, NP = 64 * (nch <= 4 ? 4 : nch <= 8 ? 8 : 16);
         return (int64_t)B * NP * (MT_KB_WORDS + ELG_E + MT_PKB_WORDS);

@@ -89,7 +89,10 @@ typedef struct elg_rollout_args {
     int32_t variant;        /* 0: pick the kernel by shape (cooperative MFMA kernel for N1 <= 112, node-streaming MFMA kernel
                                for 128 < N1 <= 1024); 1: the one-wavefront-per-trajectory kernel for any N1 (what the step-wise
                                protocol and 112 < N1 <= 128 always use; the A/B reference of the parity tests);
-                               2: the N1 > 1024 kernel (Vrp-Set-XXL; runtime node loops, needs `scratch`) for any N1 */
+                               2: the one-wavefront-per-trajectory N1 > 1024 kernel (runtime node loops, needs `scratch`) for any
+                               N1: the tests' reference at Vrp-Set-XXL sizes; 3: the matrix-core N1 > 1024 kernel (what variant 0
+                               picks for 1024 < N1 <= 8192: 16 lockstep trajectories per workgroup, K / V / PK streamed in
+                               MFMA-fragment order, score rows in `scratch`) for any N1                                      */
     int32_t dump_logits;    /* what full_probs receives: 0 probabilities, 1 the clipped + masked logits
                                clip * tanh(s) (-inf at closed nodes), 2 the scores s before the clip            */
     int32_t euclidean;      /* model_params.euclidean: local-policy slot features (x, y) / norm relative to the current node
@@ -154,8 +157,9 @@ typedef struct elg_rollout_args {
 /* POMO construction: CVRPEnv.reset/step + CVRPModel.one_step_rollout + utils.rollout fused into one
  * persistent launch (CVRP/utils.py:7-29), or single steps of it (use_state / max_steps). */
 int elg_rollout_fwd(const elg_rollout_args* args, void* stream);
-/* Floats of elg_rollout_args.scratch a fused rollout of this shape needs (0: none): the score rows of the N1 > 1024 kernel,
-   or the fragment-major K / V / PK copies the 128 < N1 <= 1024 kernel streams its matrix-core operands from. */
+/* Floats of elg_rollout_args.scratch a fused rollout of this shape needs (0: none): the fragment-major K / V / PK copies the
+   128 < N1 <= 1024 kernel streams its matrix-core operands from; for N1 > 1024 (or variant 3) the same copies over
+   64 ceil(N1 / 64) padded rows plus one score row per trajectory slot (16 per workgroup); variant 2: B M N1 score rows. */
 int64_t elg_rollout_scratch_floats(int32_t B, int32_t M, int32_t N1, int32_t variant);
 
 /* Backward of the chosen-node probabilities w.r.t. the per-instance tables and the folded local

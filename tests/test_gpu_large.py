@@ -201,7 +201,10 @@ def test_streaming_kernel_needs_its_workspace():
     assert lib.elg_rollout_scratch_floats(4, 10, 200, 0) == 4 * 256 * (256 + 128 + 192)
     assert lib.elg_rollout_scratch_floats(4, 10, 600, 0) == 4 * 1024 * (256 + 128 + 192)
     assert lib.elg_rollout_scratch_floats(4, 10, 200, 1) == 0                      # one-wavefront-per-trajectory kernel: none
-    assert lib.elg_rollout_scratch_floats(2, 10, 3001, 0) == 2 * 10 * 3001         # score rows of the N1 > 1024 kernel
+    assert lib.elg_rollout_scratch_floats(2, 10, 3001, 2) == 2 * 10 * 3001         # score rows of the one-wavefront N1 > 1024 kernel
+    # the matrix-core N1 > 1024 kernel: the same tables over 64 ceil(N1 / 64) padded rows + one score row per trajectory slot
+    assert lib.elg_rollout_scratch_floats(2, 10, 3001, 0) == 2 * 3008 * (256 + 128 + 192) + 2 * 16 * 3008
+    assert lib.elg_rollout_scratch_floats(2, 10, 151, 3) == 2 * 192 * (256 + 128 + 192) + 2 * 16 * 192
     N, B, M = 150, 1, 4
     mp, cfg, xy, dem = _cvrp_case(N, B, 5)
     P = gc.weights("cvrp", 5, mp, 1.0)

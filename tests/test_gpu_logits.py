@@ -42,7 +42,7 @@ def _check(tag, kernel, lg, scores, logits, clip, steps, t_index, tlen):
     print(tag, kernel, f"scores {worst_s:.2e}  logits/clip {worst_l:.2e}")
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2], ids=["cooperative", "wave_per_trajectory", "xl"])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3], ids=["cooperative", "wave_per_trajectory", "xl", "xm"])
 @pytest.mark.parametrize("tag", ["n50", "n20k8", "n100"])
 def test_cvrp_logits_through_the_product_path(tag, variant):
     from elg_amd.CVRP.CVRPEnv import CVRPEnv
@@ -65,11 +65,11 @@ def test_cvrp_logits_through_the_product_path(tag, variant):
     for what in ("scores", "logits"):
         r = eng.rollout_forward(env.problem, pol, M, acts[0, :, 1], L.MODE_FORCED, forced=acts, dump_T=T, variant=variant, dump=what)
         dumps[what] = r.full_probs
-    _check(f"cvrp_{tag}", ("coop", "wave", "xl")[variant], lg, dumps["scores"], dumps["logits"], mp["logit_clipping"],
+    _check(f"cvrp_{tag}", ("coop", "wave", "xl", "xm")[variant], lg, dumps["scores"], dumps["logits"], mp["logit_clipping"],
            lg["steps"], lambda t: int(t), r.tlen)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2], ids=["cooperative", "wave_per_trajectory", "xl"])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3], ids=["cooperative", "wave_per_trajectory", "xl", "xm"])
 @pytest.mark.parametrize("tag", ["n50", "n20"])
 def test_tsp_logits_through_the_product_path(tag, variant):
     from elg_amd.TSP.TSPEnv import TSPEnv
@@ -90,11 +90,11 @@ def test_tsp_logits_through_the_product_path(tag, variant):
     for what in ("scores", "logits"):
         r = eng.rollout_forward(env.problem, pol, M, acts[0, :, 0], L.MODE_FORCED, forced=acts, dump_T=N, variant=variant, dump=what)
         dumps[what] = r.full_probs
-    _check(f"tsp_{tag}", ("coop", "wave", "xl")[variant], lg, dumps["scores"], dumps["logits"], mp["logit_clipping"],
+    _check(f"tsp_{tag}", ("coop", "wave", "xl", "xm")[variant], lg, dumps["scores"], dumps["logits"], mp["logit_clipping"],
            lg["steps"], lambda t: int(t), r.tlen)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2], ids=["node_tiled", "wave_per_trajectory", "xl"])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3], ids=["node_tiled", "wave_per_trajectory", "xl", "xm"])
 def test_large_instance_logits(variant):
     """N1 = 151: the node-tiled kernel (and the untiled one) against the reference's own greedy construction."""
     from elg_amd.CVRP.CVRPEnv import CVRPEnv
@@ -116,7 +116,7 @@ def test_large_instance_logits(variant):
         r = eng.rollout_forward(env.problem, pol, M, acts[0, :, 1], L.MODE_FORCED, forced=acts, dump_T=T, variant=variant, dump=what)
         dumps[what] = r.full_probs
     np.testing.assert_allclose(r.reward.cpu().numpy(), lg["reward"], rtol=2e-6)
-    _check("cvrp_n150", ("tiled", "wave", "xl")[variant], lg, dumps["scores"], dumps["logits"], mp["logit_clipping"],
+    _check("cvrp_n150", ("tiled", "wave", "xl", "xm")[variant], lg, dumps["scores"], dumps["logits"], mp["logit_clipping"],
            lg["steps"], lambda t: int(t), r.tlen)
     # and free-running greedy reproduces the reference's tours
     g = eng.rollout_forward(env.problem, pol, M, acts[0, :, 1], L.MODE_GREEDY, variant=variant)
@@ -263,4 +263,31 @@ def test_bf16_mode_streaming_kernel_logits_and_tours():
         Tg = int(g.tlen.max())
         check_feasible(g.actions[0:1, :, :Tg].long(), rs.node_demand[0:1])
         cost[prec] = float((-g.reward).mean())
+    assert abs(cost[1] - cost[0]) <= 0.02 * cost[0], cost
+
+
+def test_bf16_mode_xm_kernel_logits():
+    """The N1 > 1024 kernel (rollout_fwd_xm_kernel, forced at N1 = 151 by variant 3) in its bf16 mode against the reference's
+    logits: the mode's stated tolerance; greedy tours equal to the f32-parity mode's cost within 2 %."""
+    from elg_amd.CVRP.CVRPEnv import CVRPEnv
+    lg = gu.load_golden("r02_cvrp_logits_n150.npz")
+    B, N, M, wseed, pseed = [int(x) for x in lg["meta"]]
+    mp = dict(gu.CVRP_MODEL_PARAMS)
+    model = gc.load_model("cvrp", wseed, mp, 1.0)
+    depot, loc, demand = gu.golden_cvrp_problem(pseed, B, N, float(lg["capacity"]))
+    env = CVRPEnv(multi_width=M, device=DEV)
+    env.load_random_problems(dict(loc=torch.from_numpy(loc), demand=torch.from_numpy(demand), depot=torch.from_numpy(depot)))
+    rs, _, _ = env.reset()
+    with torch.no_grad():
+        model.pre_forward(rs)
+    acts = torch.from_numpy(lg["actions"].astype(np.int32))
+    T = acts.shape[2]
+    pol = model.decoder.policy
+    dumps = {}
+    for what in ("scores", "logits"):
+        r = eng.rollout_forward(env.problem, pol, M, acts[0, :, 1], L.MODE_FORCED, forced=acts, dump_T=T, dump=what, precision=1, variant=3)
+        dumps[what] = r.full_probs
+    np.testing.assert_allclose(r.reward.cpu().numpy(), lg["reward"], rtol=2e-6)
+    _check_bf16("cvrp_n150_xm", lg, dumps["scores"], dumps["logits"], mp["logit_clipping"], lg["steps"], r.tlen)
+    cost = {p: float((-eng.rollout_forward(env.problem, pol, M, acts[0, :, 1], L.MODE_GREEDY, precision=p, variant=3).reward).mean()) for p in (0, 1)}
     assert abs(cost[1] - cost[0]) <= 0.02 * cost[0], cost
