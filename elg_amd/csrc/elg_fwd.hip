@@ -1856,6 +1856,40 @@ __device__ __forceinline__ void mt_build_mask(const MtTraj& st, const unsigned l
     }
 }
 
+// The mask of a step as words (round 4; mt_build_mask above is the lane-per-node form the first version of the kernel used):
+// lane c < NCH returns word c -- visited | (CVRP) demand above the load | nodes past N1 -- with the depot open on a finished
+// trajectory (CVRPEnv.py:214-232).  One ballot + two selects per 64 nodes for CVRP, nothing per node for TSP.
+template <int NCH, bool TSP>
+__device__ __forceinline__ unsigned long long mt_mask_words(const MtTraj& st, const unsigned long long* vis, const float* sdem,
+                                                            int N1, int lane) {
+    unsigned long long w = lane < NCH ? vis[lane] : 0ull;
+    if (!TSP) {
+        const float lim = __fadd_rn(st.load, 1e-6f);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int n = lane + 64 * ch;
+            const bool ex = (n < N1) && (lim < sdem[n]);
+            const unsigned long long bal = __ballot(ex);
+            w |= (lane == ch) ? bal : 0ull;
+        }
+    }
+    const int rem = N1 - 64 * lane;                                   // nodes of word `lane` that exist
+    w |= rem >= 64 ? 0ull : (rem <= 0 ? ~0ull : ~((1ull << rem) - 1ull));
+    if (!TSP && lane == 0 && st.fin) w &= ~1ull;
+    return w;
+}
+// additive mask row (0 open / -inf closed) from the words: lane l writes the nodes 256 c + 4 l .. + 3 with one 16-byte store
+template <int NCH>
+__device__ __forceinline__ void mt_fill_additive(const unsigned long long* mkw, float* srow, int lane) {
+#pragma unroll
+    for (int c = 0; c < NCH / 4; ++c) {
+        const int n0 = 256 * c + 4 * lane;
+        const unsigned bits = (unsigned)(mkw[n0 >> 6] >> (n0 & 63));
+        *reinterpret_cast<float4*>(srow + n0) = make_float4((bits & 1u) ? ELG_NEG_INF : 0.f, (bits & 2u) ? ELG_NEG_INF : 0.f,
+                                                            (bits & 4u) ? ELG_NEG_INF : 0.f, (bits & 8u) ? ELG_NEG_INF : 0.f);
+    }
+}
+
 // env_update() with the visited words in LDS (same roundings: one fp32 subtraction for the load, dist2d for the length)
 template <int NCH, bool TSP>
 __device__ __forceinline__ void mt_env_update(MtTraj& st, unsigned long long* vis, const Inst& I, int N1, int sel, int lane) {
@@ -1928,13 +1962,14 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
     float* sSc = sQ + NTR * 3 * OBP;                       // score rows (pointer -> choice)
     unsigned long long* sMaskW = reinterpret_cast<unsigned long long*>(sSc + NTR * SP);
     unsigned long long* sVis = sMaskW + NTR * NCH;
-    float* sX = reinterpret_cast<float*>(sVis + NTR * NCH);             // slot blocks (owners -> local policy -> owners)
+    unsigned long long* sSlotW = sVis + NTR * NCH;                      // bit n: node n carries a k-NN slot of this step (choice phase)
+    float* sX = reinterpret_cast<float*>(sSlotW + NTR * NCH);           // slot blocks (owners -> local policy -> owners)
     float* sT = sX + (A.has_local ? NTR * CO_XP : 0);                   // folded local-policy tables
     float* sdem = sT + (A.has_local ? CL_SIZE : 0);
     float* sb = sdem + ((N1 + 3) & ~3) + wave * ELG_SB_MIN;
     if (!TSP)
         for (int i = tid; i < N1; i += 512) sdem[i] = A.demand[(size_t)b * N1 + i];
-    for (int i = tid; i < NTR * NCH; i += 512) sVis[i] = 0ull;
+    for (int i = tid; i < 2 * NTR * NCH; i += 512) sVis[i] = 0ull;      // visited words | slot words
     if (A.has_local) co_stage_local(A.loc, sT, tid, 512);
     __syncthreads();
     const size_t NE = (size_t)N1 * ELG_E;
@@ -2001,8 +2036,20 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
             auto prepare = [&](const MtTraj& s1, bool dc, int q, float& addval, int& sn) {
                 float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (dc) {
+                    // mask words (CVRPEnv.py:214-232 / TSPEnv.py:120): lane c < NCH assembles word c = visited | demand > load | nodes
+                    // past N1; the additive form (0 open / -inf closed) goes to the score row 16 bytes per lane
                     unsigned long long mk[NCH];
-                    mt_build_mask<NCH, TSP>(s1, sVis + q * NCH, I, N1, lane, mk, sSc + q * SP);
+                    int ln = lane;                              // (opaque per step: addresses derived from it are re-formed here instead of
+                    asm volatile("" : "+v"(ln));                //  living in registers across the matrix phases, where there are none to spare)
+                    const unsigned long long mword = mt_mask_words<NCH, TSP>(s1, sVis + q * NCH, sdem, N1, ln);
+                    if (ln < NCH) sMaskW[q * NCH + ln] = mword;
+                    wave_lds_fence();
+                    mt_fill_additive<NCH>(sMaskW + q * NCH, sSc + q * SP, ln);
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) mk[c] = 0ull;                       // (only word 0 is read below: the depot's bit)
+                    mk[0] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(mword >> 32)) << 32) |
+                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mword);
+                    ELG_STAMP(sc_, 9);
                     const int cb = (lane & 31) * 4;
                     q4 = *reinterpret_cast<const float4*>(I.Q1 + (size_t)s1.cur * ELG_E + cb);
                     if (TSP) {
@@ -2013,24 +2060,17 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                         q4.x = fmaf(s1.load, w.x, q4.x); q4.y = fmaf(s1.load, w.y, q4.y);
                         q4.z = fmaf(s1.load, w.z, q4.z); q4.w = fmaf(s1.load, w.w, q4.w);
                     }
-                    if (lane == 0) {
-#pragma unroll
-                        for (int c = 0; c < NCH; ++c) sMaskW[q * NCH + c] = mk[c];
-                    }
                     const size_t rrow = (size_t)b * Rcap + (size_t)t * A.M + m_base + q;        // this trajectory's row of step t
                     if (TRAIN) {
-                        if (lane < NCH) {
-                            unsigned long long w = mk[0];
-#pragma unroll
-                            for (int c = 1; c < NCH; ++c) w = lane == c ? mk[c] : w;
-                            A.trMask[rrow * NCH + lane] = w;
-                        }
+                        if (lane < NCH) A.trMask[rrow * NCH + lane] = mword;
                         if (lane < 32) *reinterpret_cast<float4*>(A.trQ + rrow * ELG_E + cb) = q4;
                         if (lane == 0 && A.trLoad) A.trLoad[rrow] = s1.load;
                     }
                     if (A.has_penalty || A.has_local) {
                         wave_lds_fence();
+                        ELG_STAMP(sc_, 0);
                         const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, s1, lane, mk, sb, sMaskW + q * NCH, A.euclidean != 0);
+                        ELG_STAMP(sc_, 10);
                         sn = S.snid;
                         addval = S.pen;
                         if (A.has_local && lane < ELG_SLOT_STRIDE) {        // slot block for co_local16 (layout of the coop kernel)
@@ -2047,12 +2087,10 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                         }
                     }
                 } else {
-                    if (lane == 0) {
+                    if (lane < NCH) sMaskW[q * NCH + lane] = ~0ull;
 #pragma unroll
-                        for (int c = 0; c < NCH; ++c) sMaskW[q * NCH + c] = ~0ull;
-                    }
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) sSc[q * SP + lane + 64 * c] = ELG_NEG_INF;       // not decoding: every node closed
+                    for (int c = 0; c < NCH / 4; ++c)                                               // not decoding: every node closed
+                        *reinterpret_cast<float4*>(sSc + q * SP + 256 * c + 4 * lane) = make_float4(ELG_NEG_INF, ELG_NEG_INF, ELG_NEG_INF, ELG_NEG_INF);
                     if (A.has_local && lane < ELG_SLOT_STRIDE) {
                         float* X = sX + q * CO_XP;
                         X[CO_XF + lane] = 0.f; X[CO_XF + ELG_SLOT_STRIDE + lane] = 0.f; X[CO_XF + 2 * ELG_SLOT_STRIDE + lane] = 0.f;
@@ -2349,6 +2387,101 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
             // ================= owners: clip, mask, softmax, choice =================
             auto choose = [&](bool dc, int q, size_t bmq, int sn, float addval, int& sl, float& pp) {
                 if (!dc) return;
+                if constexpr (!TRAIN) {
+                    // Inference (round 4): ONE pass over the score row, 16 bytes per lane (lane l: nodes 256 c + 4 l .. + 3), the
+                    // clipped logit x = clip tanh(s + xi | s + slot term) formed on the fly, per-lane online softmax (running
+                    // maximum, sum of exp(x - max), first arg max), merged over the wave at the end.  The slot lanes put
+                    // s + (penalty + local score) into the row themselves and flag the node in the slot words, so every value is
+                    // the sum finish_step forms; the first maximum in node order wins (models.py:405-420).
+                    int ln = lane;
+                    asm volatile("" : "+v"(ln));
+                    float* scr = sSc + q * SP;
+                    const unsigned long long* mkw = sMaskW + q * NCH;
+                    unsigned long long* slw = sSlotW + q * NCH;
+                    const float dflt = A.has_penalty ? A.xi : 0.f;
+                    if (A.has_local && ln < ELG_SLOT_STRIDE) addval += sX[q * CO_XP + CO_XU + ln] * A.inv_ens;
+                    if (sn >= 0) {
+                        scr[sn] += addval;
+                        atomicOr(slw + (sn >> 6), 1ull << (sn & 63));
+                    }
+                    wave_lds_fence();
+                    auto logits4 = [&](int n0, float (&x)[4]) {
+                        const float4 sv = *reinterpret_cast<const float4*>(scr + n0);
+                        const unsigned mb = (unsigned)(mkw[n0 >> 6] >> (n0 & 63)), sbt = (unsigned)(slw[n0 >> 6] >> (n0 & 63));
+                        const float svv[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float v = svv[i] + (((sbt >> i) & 1u) ? 0.f : dflt);
+                            x[i] = ((mb >> i) & 1u) ? ELG_NEG_INF : A.clip * fast_tanh(v);
+                        }
+                    };
+                    float mrun_l = ELG_NEG_INF, srun = 0.f;
+                    int bn = 0x7fffffff;
+#pragma unroll
+                    for (int c = 0; c < NCH / 4; ++c) {
+                        float x[4];
+                        logits4(256 * c + 4 * ln, x);
+                        const float bm_ = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+                        if (bm_ > mrun_l) {                                     // strictly greater: the first maximum wins
+#pragma unroll
+                            for (int i = 3; i >= 0; --i) if (x[i] == bm_) bn = 256 * c + 4 * ln + i;
+                            srun *= __expf(mrun_l - bm_);                       // exp(-inf) = 0 at the first open block
+                            mrun_l = bm_;
+                        }
+                        if (mrun_l > ELG_NEG_INF) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) srun += __expf(x[i] - mrun_l);
+                        }
+                    }
+                    const float gmx = wave_max(mrun_l);
+                    {
+                        const float cand = (mrun_l == gmx && bn != 0x7fffffff) ? -(float)bn : -3.0e38f;      // node indices: exact in f32
+                        const float firstn = -wave_max(cand);
+                        bn = firstn < 1.0e9f ? (int)firstn : 0;
+                    }
+                    const float tot = wave_sum(mrun_l > ELG_NEG_INF ? srun * __expf(mrun_l - gmx) : 0.f);
+                    const float inv = 1.0f / tot;
+                    float* frow = (A.full_probs && t < A.dump_T) ? A.full_probs + (bmq * A.dump_T + t) * N1 : nullptr;
+                    if (frow)                                                   // tests: probabilities / clipped logits / scores before the clip
+                        for (int n = ln; n < N1; n += 64) {
+                            const bool masked = (mkw[n >> 6] >> (n & 63)) & 1ull, slot = (slw[n >> 6] >> (n & 63)) & 1ull;
+                            const float sv = scr[n] + (slot ? 0.f : dflt);
+                            const float x = masked ? ELG_NEG_INF : A.clip * fast_tanh(sv);
+                            frow[n] = A.dump_logits == 2 ? (masked ? ELG_NEG_INF : sv) : A.dump_logits == 1 ? x : (masked ? 0.f : __expf(x - gmx) * inv);
+                        }
+                    int s_ = 0;
+                    if (A.mode == ELG_MODE_FORCED) s_ = (A.forced && t < A.Tforced) ? A.forced[bmq * A.Tforced + t] : 0;
+                    else if (A.mode == ELG_MODE_GREEDY) s_ = bn;
+                    else {
+                        // inverse CDF in node order (second pass, lane = node of a 64-node chunk so that the scan runs in node order)
+                        const float uni = A.uniforms ? A.uniforms[bmq * A.Tmax + t] : philox_uniform(A.seed, (unsigned)bmq, (unsigned)t);
+                        const float target = uni * tot;
+                        float run = 0.f;
+                        int found = -1, lastpos = 0;
+#pragma unroll 1
+                        for (int ch = 0; ch < NCH && found < 0; ++ch) {
+                            const int n = ln + 64 * ch;
+                            float e = 0.f;
+                            if (!((mkw[ch] >> ln) & 1ull)) e = __expf(A.clip * fast_tanh(scr[n] + (((slw[ch] >> ln) & 1ull) ? 0.f : dflt)) - gmx);
+                            const float cs_ = wave_scan_incl(e, ln) + run;
+                            run = readlane(cs_, 63);
+                            const unsigned long long pos = __ballot(e > 0.f);
+                            const unsigned long long hit = __ballot(e > 0.f && cs_ > target);
+                            if (hit) found = 64 * ch + (int)__builtin_ctzll(hit);
+                            if (pos) lastpos = 64 * ch + 63 - (int)__builtin_clzll(pos);
+                        }
+                        s_ = found >= 0 ? found : lastpos;
+                    }
+                    s_ = __builtin_amdgcn_readfirstlane(s_);
+                    const bool smasked = (mkw[s_ >> 6] >> (s_ & 63)) & 1ull, sslot = (slw[s_ >> 6] >> (s_ & 63)) & 1ull;
+                    const float xs = smasked ? ELG_NEG_INF : A.clip * fast_tanh(scr[s_] + (sslot ? 0.f : dflt));
+                    const float p_ = (xs > ELG_NEG_INF) ? __expf(xs - gmx) * inv : 0.f;
+                    pp = i2f(__builtin_amdgcn_readfirstlane(f2i(p_)));
+                    sl = s_;
+                    wave_lds_fence();
+                    if (sn >= 0) atomicAnd(slw + (sn >> 6), ~(1ull << (sn & 63)));          // the slot words are all-zero between steps
+                    return;
+                }
                 unsigned long long mk[NCH];
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
@@ -2364,6 +2497,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                     s[ch] = (n < N1) ? srow[n] : 0.f;
                 }
                 wave_lds_fence();
+                ELG_STAMP(sc_, 11);
                 int fsel = 0;
                 if (A.forced && t < A.Tforced) fsel = __builtin_amdgcn_readfirstlane(A.forced[bmq * A.Tforced + t]);
                 float uni = 0.f;
@@ -2377,6 +2511,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                 float pcj[NCH + 1];
                 const FwdOut fo = finish_step<NCH, TSP, false>(A, N1, lane, srow, mk, s, sn, addval, fsel, uni, frow, (size_t)b, 0, 0,
                                                                TRAIN ? pcj : nullptr);
+                ELG_STAMP(sc_, 12);
                 if (TRAIN) {
                     const size_t rrow = (size_t)b * Rcap + (size_t)t * A.M + m_base + q;
                     float* rPC = A.trPC + rrow * N1;
@@ -2425,7 +2560,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
 template <int NCH, bool TSP, int NG, bool TRAIN, bool BF = false>
 static int launch_fwd_mt_g(const elg_rollout_args& A, hipStream_t stream) {
     constexpr int NTR = 16 * NG;
-    const size_t lds = ((size_t)NTR * 3 * 68 + (size_t)NTR * (64 * NCH + 4) + (size_t)NTR * NCH * 4 + (A.has_local ? NTR * CO_XP + CL_SIZE : 0) +
+    const size_t lds = ((size_t)NTR * 3 * 68 + (size_t)NTR * (64 * NCH + 4) + (size_t)NTR * NCH * 6 + (A.has_local ? NTR * CO_XP + CL_SIZE : 0) +
                         ((A.N1 + 3) & ~3) + (size_t)8 * ELG_SB_MIN) * 4;
     auto kern = rollout_fwd_mt_kernel<NCH, TSP, NG, TRAIN, BF>;
     static DynLds optin;
