@@ -27,7 +27,7 @@ def rollout(model, env, eval_type='greedy'):
     seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if mode == L.MODE_SAMPLE else 0
     needs_grad = (eval_type != 'greedy' and torch.is_grad_enabled()
                   and any(p.requires_grad for p in model.parameters()))
-    res = eng.rollout_forward(env.problem, pol, M, starts, mode, seed=seed, train=needs_grad)
+    res = eng.rollout_forward(env.problem, pol, M, starts, mode, seed=seed, train=needs_grad, need_probs=eval_type != 'greedy')
     T, zero_prob = eng.rollout_stats(res)           # the one host sync of the rollout
     actions = res.actions[:, :, :T].long()
     env.selected_count = T

@@ -22,7 +22,7 @@ def rollout(model, env, eval_type='greedy'):
     seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if mode == L.MODE_SAMPLE else 0
     needs_grad = (eval_type != 'greedy' and torch.is_grad_enabled()
                   and any(p.requires_grad for p in model.parameters()))
-    res = eng.rollout_forward(env.problem, pol, M, starts, mode, seed=seed, train=needs_grad)
+    res = eng.rollout_forward(env.problem, pol, M, starts, mode, seed=seed, train=needs_grad, need_probs=eval_type != 'greedy')
     actions = res.actions[:, :, :N].long()
     env.selected_count = N
     env.selected_node_list = actions

@@ -516,6 +516,9 @@ __device__ __forceinline__ void stamp_at(StampCtx& c, float& slot) {
     c.last = t;
 }
 #define ELG_STAMP(c, i) stamp_at(c, (c).acc[i])
+#elif defined(ELG_MARKS)                 // ISA listing with the phase boundaries as comments (tools/isa_phase_mix.py); never shipped
+struct StampCtx {};
+#define ELG_STAMP(c, i) asm volatile("; ELG_PHASE_MARK " #i)
 #else
 struct StampCtx {};
 #define ELG_STAMP(c, i)
@@ -1864,14 +1867,21 @@ __device__ __forceinline__ unsigned long long mt_mask_words(const MtTraj& st, co
                                                             int N1, int lane) {
     unsigned long long w = lane < NCH ? vis[lane] : 0ull;
     if (!TSP) {
+        // the ballot of chunk ch is selected into lane ch.  `lane` is made opaque per call: shared between the wave's trajectories,
+        // the NCH lane tests become NCH scalar-register pairs that live across the calls and spill.  Nodes past N1 read LDS behind
+        // the demand row (the per-wave scratch: inside the allocation) -- their bits are closed below whatever the compare says.
         const float lim = __fadd_rn(st.load, 1e-6f);
+        int lc = lane;
+        asm volatile("" : "+v"(lc));
+        unsigned lo = 0u, hi = 0u;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
-            const int n = lane + 64 * ch;
-            const bool ex = (n < N1) && (lim < sdem[n]);
-            const unsigned long long bal = __ballot(ex);
-            w |= (lane == ch) ? bal : 0ull;
+            const unsigned long long bal = __ballot(lim < sdem[lc + 64 * ch]);
+            const bool mine = lc == ch;
+            lo = mine ? (unsigned)bal : lo;
+            hi = mine ? (unsigned)(bal >> 32) : hi;
         }
+        w |= ((unsigned long long)hi << 32) | lo;
     }
     const int rem = N1 - 64 * lane;                                   // nodes of word `lane` that exist
     w |= rem >= 64 ? 0ull : (rem <= 0 ? ~0ull : ~((1ull << rem) - 1ull));
@@ -2033,74 +2043,185 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
         for (int j = 0; j < NOWN; ++j) { sel[j] = 0; snid[j] = -1; pr[j] = 1.0f; addv[j] = 0.f; }
         if (!first_move) {
             // ================= owners: masks, query rows, k-NN slots =================
-            auto prepare = [&](const MtTraj& s1, bool dc, int q, float& addval, int& sn) {
-                float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (dc) {
-                    // mask words (CVRPEnv.py:214-232 / TSPEnv.py:120): lane c < NCH assembles word c = visited | demand > load | nodes
-                    // past N1; the additive form (0 open / -inf closed) goes to the score row 16 bytes per lane
-                    unsigned long long mk[NCH];
-                    int ln = lane;                              // (opaque per step: addresses derived from it are re-formed here instead of
-                    asm volatile("" : "+v"(ln));                //  living in registers across the matrix phases, where there are none to spare)
-                    const unsigned long long mword = mt_mask_words<NCH, TSP>(s1, sVis + q * NCH, sdem, N1, ln);
-                    if (ln < NCH) sMaskW[q * NCH + ln] = mword;
-                    wave_lds_fence();
-                    mt_fill_additive<NCH>(sMaskW + q * NCH, sSc + q * SP, ln);
+            // Written in STAGES over the wave's trajectories (round 4): every stage is an LDS or L2 round trip, and the trajectories'
+            // chains are independent -- one after the other they exposed every latency NOWN times.
+            {
+                int ln = lane;                                  // (opaque per step: addresses derived from it are re-formed here instead of
+                asm volatile("" : "+v"(ln));                    //  living in registers across the matrix phases, where there are none to spare)
+                constexpr int S0 = TSP ? 0 : 1;
+                const int cb = (ln & 31) * 4;
+                // ---- stage 0: everything that comes from L2 / HBM and depends on the current node only is requested first -- the
+                // query rows (q = Wq_last [enc[cur]; load], models.py:330-333; combined at the end of the phase: a use here would wait
+                // for the loads before the mask work) and the first 64 entries of cur's sorted neighbour list
+                float4 qa[NOWN], qb[NOWN];
+                int nid0[NOWN];
+                float nd0[NOWN], nth0[NOWN];
+                const bool walk = A.has_local || A.has_penalty;
 #pragma unroll
-                    for (int c = 0; c < NCH; ++c) mk[c] = 0ull;                       // (only word 0 is read below: the depot's bit)
-                    mk[0] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(mword >> 32)) << 32) |
-                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mword);
-                    ELG_STAMP(sc_, 9);
-                    const int cb = (lane & 31) * 4;
-                    q4 = *reinterpret_cast<const float4*>(I.Q1 + (size_t)s1.cur * ELG_E + cb);
-                    if (TSP) {
-                        const float4 qf = *reinterpret_cast<const float4*>(I.Q2 + (size_t)s1.first * ELG_E + cb);
-                        q4.x += qf.x; q4.y += qf.y; q4.z += qf.z; q4.w += qf.w;
-                    } else {
-                        const float4 w = *reinterpret_cast<const float4*>(I.wl + cb);
-                        q4.x = fmaf(s1.load, w.x, q4.x); q4.y = fmaf(s1.load, w.y, q4.y);
-                        q4.z = fmaf(s1.load, w.z, q4.z); q4.w = fmaf(s1.load, w.w, q4.w);
+                for (int j = 0; j < NOWN; ++j) {
+                    qa[j] = make_float4(0.f, 0.f, 0.f, 0.f); qb[j] = qa[j];
+                    nid0[j] = 0; nd0[j] = 0.f; nth0[j] = 0.f;
+                    if (!dec[j]) continue;
+                    qa[j] = *reinterpret_cast<const float4*>(I.Q1 + (size_t)st[j].cur * ELG_E + cb);
+                    qb[j] = TSP ? *reinterpret_cast<const float4*>(I.Q2 + (size_t)st[j].first * ELG_E + cb) : *reinterpret_cast<const float4*>(I.wl + cb);
+                    if (walk && ln < N1) {
+                        const size_t e = (size_t)st[j].cur * N1 + ln;
+                        nid0[j] = I.nidx[e]; nd0[j] = I.ndist[e]; nth0[j] = I.ntheta[e];
                     }
-                    const size_t rrow = (size_t)b * Rcap + (size_t)t * A.M + m_base + q;        // this trajectory's row of step t
-                    if (TRAIN) {
-                        if (lane < NCH) A.trMask[rrow * NCH + lane] = mword;
-                        if (lane < 32) *reinterpret_cast<float4*>(A.trQ + rrow * ELG_E + cb) = q4;
-                        if (lane == 0 && A.trLoad) A.trLoad[rrow] = s1.load;
+                }
+                // ---- stage 1: mask words (CVRPEnv.py:214-232 / TSPEnv.py:120): lane c < NCH assembles word c = visited | demand >
+                // load | nodes past N1
+                unsigned mk0[NOWN];                             // low half of word 0 (the depot's bit)
+#pragma unroll
+                for (int j = 0; j < NOWN; ++j) {
+                    const int q = wave + 8 * j;
+                    unsigned long long mword = ~0ull;           // not decoding: every node closed
+                    if (dec[j]) mword = mt_mask_words<NCH, TSP>(st[j], sVis + q * NCH, sdem, N1, ln);
+                    if (ln < NCH) sMaskW[q * NCH + ln] = mword;
+                    mk0[j] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mword);
+                    if (TRAIN && dec[j] && ln < NCH) A.trMask[((size_t)b * Rcap + (size_t)t * A.M + m_base + q) * NCH + ln] = mword;
+                }
+                wave_lds_fence();
+                // ---- stage 2: the additive form (0 open / -inf closed) goes to the score rows 16 bytes per lane
+#pragma unroll
+                for (int j = 0; j < NOWN; ++j) mt_fill_additive<NCH>(sMaskW + (wave + 8 * j) * NCH, sSc + (wave + 8 * j) * SP, ln);
+                ELG_STAMP(sc_, 9);
+                // ---- stages 3 + 4: k-NN slots (knn_slots / slot_setup of elg_rollout.h for the trajectories jlo .. jhi - 1 side by
+                // side): the first K open customers of cur's sorted neighbour list, compacted to slot order through the
+                // trajectory's slot block (with the local policy: the regions its features do not use yet) or the wave's scratch
+                auto slots_for = [&](int jlo, int jhi) {
+                    int found[NOWN];
+                    bool go[NOWN];
+                    int W[NOWN];                                // float offset of the scratch in the workgroup's LDS (not a pointer: a select of
+                                                                // LDS pointers turns generic and trips the compiler's address-space cast)
+                    int oD, oT, oN;                             // where distance | theta | node id of slot i wait for the slot lanes
+                    if (A.has_local) { oD = CO_XPEN; oT = CO_XU; oN = CO_XS; } else { oD = 0; oT = ELG_SLOT_STRIDE; oN = 2 * ELG_SLOT_STRIDE; }
+#pragma unroll
+                    for (int j = 0; j < NOWN; ++j) {
+                        found[j] = 0;
+                        go[j] = dec[j] && j >= jlo && j < jhi;
+                        W[j] = A.has_local ? (int)(sX - lds) + (wave + 8 * j) * CO_XP : (int)(sb - lds);
                     }
-                    if (A.has_penalty || A.has_local) {
-                        wave_lds_fence();
-                        ELG_STAMP(sc_, 0);
-                        const Slots S = slot_setup<NCH, TSP>(I, N1, A.K, A.has_penalty != 0, s1, lane, mk, sb, sMaskW + q * NCH, A.euclidean != 0);
-                        ELG_STAMP(sc_, 10);
-                        sn = S.snid;
-                        addval = S.pen;
-                        if (A.has_local && lane < ELG_SLOT_STRIDE) {        // slot block for co_local16 (layout of the coop kernel)
-                            float* X = sX + q * CO_XP;
-                            X[CO_XF + lane] = S.f0; X[CO_XF + ELG_SLOT_STRIDE + lane] = S.f1; X[CO_XF + 2 * ELG_SLOT_STRIDE + lane] = S.f2;
-                            reinterpret_cast<int*>(X)[CO_XS + lane] = S.smask ? (S.snid >= 0 ? -2 : -1) : S.snid;
+#pragma unroll 1
+                    for (int ch = 0; 64 * ch < N1; ++ch) {
+                        bool need[NOWN], any = false;
+#pragma unroll
+                        for (int j = 0; j < NOWN; ++j) { need[j] = go[j] && found[j] < A.K; any = any || need[j]; }
+                        if (!any) break;
+                        const int i = ln + 64 * ch;
+                        const bool valid = i < N1;
+                        int nid[NOWN];
+                        float nd[NOWN], nth[NOWN];
+#pragma unroll
+                        for (int j = 0; j < NOWN; ++j) {
+                            nid[j] = nid0[j]; nd[j] = nd0[j]; nth[j] = nth0[j];            // chunk 0: requested at the top of the phase
+                            if (ch > 0 && need[j] && valid) {
+                                const size_t e = (size_t)st[j].cur * N1 + i;
+                                nid[j] = I.nidx[e]; nd[j] = I.ndist[e]; nth[j] = I.ntheta[e];
+                            }
                         }
-                        if (TRAIN && A.trSlot && lane < ELG_SLOT_STRIDE) {
-                            A.trSlot[rrow * ELG_SLOT_STRIDE + lane] = (S.smask && S.snid >= 0) ? -2 : S.snid;
+#pragma unroll
+                        for (int j = 0; j < NOWN; ++j) {
+                            if (!need[j]) continue;
+                            bool cand = valid && !((sMaskW[(wave + 8 * j) * NCH + (nid[j] >> 6)] >> (nid[j] & 63)) & 1ull);
+                            if (!TSP) cand = cand && (nid[j] != 0);
+                            const unsigned long long bal = __ballot(cand);
+                            const int rank = found[j] + lanes_below(bal);
+                            if (cand && rank < A.K) {
+                                lds[W[j] + oD + S0 + rank] = nd[j];
+                                lds[W[j] + oT + S0 + rank] = nth[j];
+                                reinterpret_cast<int*>(lds)[W[j] + oN + S0 + rank] = nid[j];
+                            }
+                            found[j] += __popcll(bal);
+                        }
+                    }
+                    wave_lds_fence();
+                    float sd[NOWN], sth[NOWN], dmax[NOWN];
+                    bool cust[NOWN];
+#pragma unroll
+                    for (int j = 0; j < NOWN; ++j) {
+                        sd[j] = 0.f; sth[j] = 0.f; dmax[j] = 0.f; cust[j] = false;
+                        if (!go[j]) continue;
+                        const int k = found[j] < A.K ? found[j] : A.K;
+                        cust[j] = (ln >= S0) && (ln < S0 + k);
+                        if (cust[j]) { sd[j] = lds[W[j] + oD + ln]; sth[j] = lds[W[j] + oT + ln]; snid[j] = reinterpret_cast<const int*>(lds)[W[j] + oN + ln]; }
+                        if (k > 0) dmax[j] = lds[W[j] + oD + S0 + k - 1];
+                    }
+                    wave_lds_fence();
+#pragma unroll
+                    for (int j = 0; j < NOWN; ++j) {
+                        if (!go[j]) continue;
+                        const int q = wave + 8 * j;
+                        if (!TSP && ln == 0) snid[j] = 0;                                 // depot slot
+                        float pen = 0.f;
+                        if (A.has_penalty && cust[j]) {
+                            if (TSP) pen = -(sd[j] / (dmax[j] + 1e-6f));                  // TSP/models.py:290
+                            else pen = (dmax[j] != 0.f) ? -(sd[j] / dmax[j]) : -sd[j];    // models.py:379-405 (no epsilon)
+                        }
+                        addv[j] = pen;
+                        const float nf = dmax[j] + 1e-6f;                                 // models.py:79 / TSP :72
+                        float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+                        if (cust[j]) {
+                            if (A.euclidean) {                                            // models.py:95-125: relative (x, y) / norm
+                                const float cx = I.xy[2 * st[j].cur], cy = I.xy[2 * st[j].cur + 1];
+                                f0 = __fsub_rn(I.xy[2 * snid[j]], cx) / nf;
+                                f1 = __fsub_rn(I.xy[2 * snid[j] + 1], cy) / nf;
+                            } else { f0 = sd[j] / nf; f1 = sth[j]; }
+                            if (!TSP) f2 = sdem[snid[j]] / st[j].load;                    // CVRPEnv.py:315-316
+                        }
+                        bool smask = !cust[j];
+                        if (!TSP && ln == 0) smask = mk0[j] & 1u;                         // depot slot carries the depot's mask
+                        const int code = smask ? (snid[j] >= 0 ? -2 : -1) : snid[j];
+                        if (A.has_local && ln < ELG_SLOT_STRIDE) {        // slot block for co_local16 (layout of the coop kernel)
+                            float* X = sX + q * CO_XP;
+                            X[CO_XF + ln] = f0; X[CO_XF + ELG_SLOT_STRIDE + ln] = f1; X[CO_XF + 2 * ELG_SLOT_STRIDE + ln] = f2;
+                            reinterpret_cast<int*>(X)[CO_XS + ln] = code;
+                        }
+                        if (TRAIN && A.trSlot && ln < ELG_SLOT_STRIDE) {
+                            const size_t rrow = (size_t)b * Rcap + (size_t)t * A.M + m_base + q;
+                            A.trSlot[rrow * ELG_SLOT_STRIDE + ln] = (smask && snid[j] >= 0) ? -2 : snid[j];
                             if (A.trF) {
-                                float* fr = A.trF + rrow * (3 * ELG_SLOT_STRIDE) + lane;
-                                fr[0] = S.f0; fr[ELG_SLOT_STRIDE] = S.f1; fr[2 * ELG_SLOT_STRIDE] = S.f2;
+                                float* fr = A.trF + rrow * (3 * ELG_SLOT_STRIDE) + ln;
+                                fr[0] = f0; fr[ELG_SLOT_STRIDE] = f1; fr[2 * ELG_SLOT_STRIDE] = f2;
                             }
                         }
                     }
-                } else {
-                    if (lane < NCH) sMaskW[q * NCH + lane] = ~0ull;
-#pragma unroll
-                    for (int c = 0; c < NCH / 4; ++c)                                               // not decoding: every node closed
-                        *reinterpret_cast<float4*>(sSc + q * SP + 256 * c + 4 * lane) = make_float4(ELG_NEG_INF, ELG_NEG_INF, ELG_NEG_INF, ELG_NEG_INF);
-                    if (A.has_local && lane < ELG_SLOT_STRIDE) {
-                        float* X = sX + q * CO_XP;
-                        X[CO_XF + lane] = 0.f; X[CO_XF + ELG_SLOT_STRIDE + lane] = 0.f; X[CO_XF + 2 * ELG_SLOT_STRIDE + lane] = 0.f;
-                        reinterpret_cast<int*>(X)[CO_XS + lane] = -1;
+                };
+                ELG_STAMP(sc_, 0);
+                if (A.has_local || A.has_penalty) {
+                    // (without the local policy there are no slot blocks: one scratch per wave, one trajectory at a time.  ONE call
+                    // site: a lambda that is not inlined receives its captured LDS pointers as generic ones)
+                    const int npass = A.has_local ? 1 : NOWN;
+#pragma unroll 1
+                    for (int ps = 0; ps < npass; ++ps) {
+                        slots_for(A.has_local ? 0 : ps, A.has_local ? NOWN : ps + 1);
+                        wave_lds_fence();
                     }
                 }
-                if (lane < 32) *reinterpret_cast<float4*>(sQ + q * QP + 4 * lane) = q4;
-            };
+                ELG_STAMP(sc_, 10);
 #pragma unroll
-            for (int j = 0; j < NOWN; ++j) prepare(st[j], dec[j], wave + 8 * j, addv[j], snid[j]);
+                for (int j = 0; j < NOWN; ++j) {
+                    const int q = wave + 8 * j;
+                    if (!dec[j] && A.has_local && ln < ELG_SLOT_STRIDE) {
+                        float* X = sX + q * CO_XP;
+                        X[CO_XF + ln] = 0.f; X[CO_XF + ELG_SLOT_STRIDE + ln] = 0.f; X[CO_XF + 2 * ELG_SLOT_STRIDE + ln] = 0.f;
+                        reinterpret_cast<int*>(X)[CO_XS + ln] = -1;
+                    }
+                    float4 q4 = qa[j];
+                    if (TSP) { q4.x += qb[j].x; q4.y += qb[j].y; q4.z += qb[j].z; q4.w += qb[j].w; }       // TSP/models.py:252-255
+                    else {
+                        q4.x = fmaf(st[j].load, qb[j].x, q4.x); q4.y = fmaf(st[j].load, qb[j].y, q4.y);
+                        q4.z = fmaf(st[j].load, qb[j].z, q4.z); q4.w = fmaf(st[j].load, qb[j].w, q4.w);
+                    }
+                    if (!dec[j]) q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ln < 32) *reinterpret_cast<float4*>(sQ + q * QP + 4 * ln) = q4;
+                    if (TRAIN && dec[j]) {
+                        const size_t rrow = (size_t)b * Rcap + (size_t)t * A.M + m_base + q;                 // this trajectory's row of step t
+                        if (ln < 32) *reinterpret_cast<float4*>(A.trQ + rrow * ELG_E + cb) = q4;
+                        if (ln == 0 && A.trLoad) A.trLoad[rrow] = st[j].load;
+                    }
+                }
+            }
             ELG_STAMP(sc_, 0);
             __syncthreads();
             ELG_STAMP(sc_, 1);
@@ -2387,101 +2508,6 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
             // ================= owners: clip, mask, softmax, choice =================
             auto choose = [&](bool dc, int q, size_t bmq, int sn, float addval, int& sl, float& pp) {
                 if (!dc) return;
-                if constexpr (!TRAIN) {
-                    // Inference (round 4): ONE pass over the score row, 16 bytes per lane (lane l: nodes 256 c + 4 l .. + 3), the
-                    // clipped logit x = clip tanh(s + xi | s + slot term) formed on the fly, per-lane online softmax (running
-                    // maximum, sum of exp(x - max), first arg max), merged over the wave at the end.  The slot lanes put
-                    // s + (penalty + local score) into the row themselves and flag the node in the slot words, so every value is
-                    // the sum finish_step forms; the first maximum in node order wins (models.py:405-420).
-                    int ln = lane;
-                    asm volatile("" : "+v"(ln));
-                    float* scr = sSc + q * SP;
-                    const unsigned long long* mkw = sMaskW + q * NCH;
-                    unsigned long long* slw = sSlotW + q * NCH;
-                    const float dflt = A.has_penalty ? A.xi : 0.f;
-                    if (A.has_local && ln < ELG_SLOT_STRIDE) addval += sX[q * CO_XP + CO_XU + ln] * A.inv_ens;
-                    if (sn >= 0) {
-                        scr[sn] += addval;
-                        atomicOr(slw + (sn >> 6), 1ull << (sn & 63));
-                    }
-                    wave_lds_fence();
-                    auto logits4 = [&](int n0, float (&x)[4]) {
-                        const float4 sv = *reinterpret_cast<const float4*>(scr + n0);
-                        const unsigned mb = (unsigned)(mkw[n0 >> 6] >> (n0 & 63)), sbt = (unsigned)(slw[n0 >> 6] >> (n0 & 63));
-                        const float svv[4] = {sv.x, sv.y, sv.z, sv.w};
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float v = svv[i] + (((sbt >> i) & 1u) ? 0.f : dflt);
-                            x[i] = ((mb >> i) & 1u) ? ELG_NEG_INF : A.clip * fast_tanh(v);
-                        }
-                    };
-                    float mrun_l = ELG_NEG_INF, srun = 0.f;
-                    int bn = 0x7fffffff;
-#pragma unroll
-                    for (int c = 0; c < NCH / 4; ++c) {
-                        float x[4];
-                        logits4(256 * c + 4 * ln, x);
-                        const float bm_ = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
-                        if (bm_ > mrun_l) {                                     // strictly greater: the first maximum wins
-#pragma unroll
-                            for (int i = 3; i >= 0; --i) if (x[i] == bm_) bn = 256 * c + 4 * ln + i;
-                            srun *= __expf(mrun_l - bm_);                       // exp(-inf) = 0 at the first open block
-                            mrun_l = bm_;
-                        }
-                        if (mrun_l > ELG_NEG_INF) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) srun += __expf(x[i] - mrun_l);
-                        }
-                    }
-                    const float gmx = wave_max(mrun_l);
-                    {
-                        const float cand = (mrun_l == gmx && bn != 0x7fffffff) ? -(float)bn : -3.0e38f;      // node indices: exact in f32
-                        const float firstn = -wave_max(cand);
-                        bn = firstn < 1.0e9f ? (int)firstn : 0;
-                    }
-                    const float tot = wave_sum(mrun_l > ELG_NEG_INF ? srun * __expf(mrun_l - gmx) : 0.f);
-                    const float inv = 1.0f / tot;
-                    float* frow = (A.full_probs && t < A.dump_T) ? A.full_probs + (bmq * A.dump_T + t) * N1 : nullptr;
-                    if (frow)                                                   // tests: probabilities / clipped logits / scores before the clip
-                        for (int n = ln; n < N1; n += 64) {
-                            const bool masked = (mkw[n >> 6] >> (n & 63)) & 1ull, slot = (slw[n >> 6] >> (n & 63)) & 1ull;
-                            const float sv = scr[n] + (slot ? 0.f : dflt);
-                            const float x = masked ? ELG_NEG_INF : A.clip * fast_tanh(sv);
-                            frow[n] = A.dump_logits == 2 ? (masked ? ELG_NEG_INF : sv) : A.dump_logits == 1 ? x : (masked ? 0.f : __expf(x - gmx) * inv);
-                        }
-                    int s_ = 0;
-                    if (A.mode == ELG_MODE_FORCED) s_ = (A.forced && t < A.Tforced) ? A.forced[bmq * A.Tforced + t] : 0;
-                    else if (A.mode == ELG_MODE_GREEDY) s_ = bn;
-                    else {
-                        // inverse CDF in node order (second pass, lane = node of a 64-node chunk so that the scan runs in node order)
-                        const float uni = A.uniforms ? A.uniforms[bmq * A.Tmax + t] : philox_uniform(A.seed, (unsigned)bmq, (unsigned)t);
-                        const float target = uni * tot;
-                        float run = 0.f;
-                        int found = -1, lastpos = 0;
-#pragma unroll 1
-                        for (int ch = 0; ch < NCH && found < 0; ++ch) {
-                            const int n = ln + 64 * ch;
-                            float e = 0.f;
-                            if (!((mkw[ch] >> ln) & 1ull)) e = __expf(A.clip * fast_tanh(scr[n] + (((slw[ch] >> ln) & 1ull) ? 0.f : dflt)) - gmx);
-                            const float cs_ = wave_scan_incl(e, ln) + run;
-                            run = readlane(cs_, 63);
-                            const unsigned long long pos = __ballot(e > 0.f);
-                            const unsigned long long hit = __ballot(e > 0.f && cs_ > target);
-                            if (hit) found = 64 * ch + (int)__builtin_ctzll(hit);
-                            if (pos) lastpos = 64 * ch + 63 - (int)__builtin_clzll(pos);
-                        }
-                        s_ = found >= 0 ? found : lastpos;
-                    }
-                    s_ = __builtin_amdgcn_readfirstlane(s_);
-                    const bool smasked = (mkw[s_ >> 6] >> (s_ & 63)) & 1ull, sslot = (slw[s_ >> 6] >> (s_ & 63)) & 1ull;
-                    const float xs = smasked ? ELG_NEG_INF : A.clip * fast_tanh(scr[s_] + (sslot ? 0.f : dflt));
-                    const float p_ = (xs > ELG_NEG_INF) ? __expf(xs - gmx) * inv : 0.f;
-                    pp = i2f(__builtin_amdgcn_readfirstlane(f2i(p_)));
-                    sl = s_;
-                    wave_lds_fence();
-                    if (sn >= 0) atomicAnd(slw + (sn >> 6), ~(1ull << (sn & 63)));          // the slot words are all-zero between steps
-                    return;
-                }
                 unsigned long long mk[NCH];
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
@@ -2525,8 +2551,147 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                 sl = __builtin_amdgcn_readfirstlane(fo.sel);
                 pp = i2f(__builtin_amdgcn_readfirstlane(f2i(fo.p)));
             };
+            if constexpr (TRAIN) {
 #pragma unroll
-            for (int j = 0; j < NOWN; ++j) choose(dec[j], wave + 8 * j, bm[j], snid[j], addv[j], sel[j], pr[j]);
+                for (int j = 0; j < NOWN; ++j) choose(dec[j], wave + 8 * j, bm[j], snid[j], addv[j], sel[j], pr[j]);
+            } else {
+                // Inference (round 4): ONE pass over the score row, 16 bytes per lane (lane l: nodes 256 c + 4 l .. + 3), the clipped
+                // logit x = clip tanh(s + xi | s + slot term) formed on the fly, per-lane online softmax (running maximum, sum of
+                // exp(x - max), first arg max), merged over the wave at the end.  The slot lanes put s + (penalty + local score)
+                // into the row themselves and flag the node in the slot words, so every value is the sum finish_step forms; the
+                // first maximum in node order wins (models.py:405-420).  Written in STAGES over the wave's trajectories: the phase
+                // is a chain of LDS round trips and wave reductions, and the trajectories' chains are independent.
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                const float dflt = A.has_penalty ? A.xi : 0.f;
+                // a greedy construction whose caller does not ask for the chosen probabilities (elg_rollout_args.probs == NULL: the
+                // reference's greedy rollout returns none, CVRPModel.py:70-73 / utils.py:24-25) needs the arg max only: no normaliser
+                const bool want_p = A.probs != nullptr || A.full_probs != nullptr || A.mode != ELG_MODE_GREEDY;
+                // ---- stage 1: slot terms into the rows
+#pragma unroll
+                for (int j = 0; j < NOWN; ++j) {
+                    if (!dec[j]) continue;
+                    const int q = wave + 8 * j;
+                    float* scr = sSc + q * SP;
+                    if (A.has_local && ln < ELG_SLOT_STRIDE) addv[j] += sX[q * CO_XP + CO_XU + ln] * A.inv_ens;
+                    if (snid[j] >= 0) {
+                        scr[snid[j]] += addv[j];
+                        atomicOr(sSlotW + q * NCH + (snid[j] >> 6), 1ull << (snid[j] & 63));
+                    }
+                }
+                wave_lds_fence();
+                ELG_STAMP(sc_, 11);
+                // ---- stage 2: the pass.  x stays in registers (NCH values per lane and trajectory); masks and the slot flag enter
+                // as bit fields turned into 0 / -1 words (v_bfe_i32) -- no compare, no branch: a select on the closed bit invites the
+                // compiler to branch around the tanh per element
+                float xv[NOWN][NCH], mrun_l[NOWN];
+                float clipv = A.clip;
+                asm volatile("" : "+v"(clipv));                                 // (a vector register: the scalar one is spilled)
+#pragma unroll
+                for (int j = 0; j < NOWN; ++j) {
+                    mrun_l[j] = ELG_NEG_INF;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) xv[j][c] = ELG_NEG_INF;
+                    if (!dec[j]) continue;
+                    const int q = wave + 8 * j;
+                    const float* scr = sSc + q * SP;
+                    const unsigned long long* mkw = sMaskW + q * NCH;
+                    const unsigned long long* slw = sSlotW + q * NCH;
+#pragma unroll
+                    for (int c = 0; c < NCH / 4; ++c) {
+                        const int n0 = 256 * c + 4 * ln;
+                        const float4 sv = *reinterpret_cast<const float4*>(scr + n0);
+                        const unsigned mb = (unsigned)(mkw[n0 >> 6] >> (n0 & 63)), sbt = (unsigned)(slw[n0 >> 6] >> (n0 & 63));
+                        const float svv[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int closed = __builtin_amdgcn_sbfe((int)mb, i, 1), slot = __builtin_amdgcn_sbfe((int)sbt, i, 1);     // 0 / -1
+                            const float v = svv[i] + i2f(~slot & f2i(dflt));                  // s + xi, or the slot lanes' s + slot term
+                            const float x = fmaf(clipv, fast_tanh(v), i2f(closed & (int)0xff800000u));   // + (-inf) on a closed node
+                            xv[j][4 * c + i] = x;
+                            mrun_l[j] = fmaxf(mrun_l[j], x);
+                        }
+                    }
+                }
+                ELG_STAMP(sc_, 12);
+                // ---- stage 3: merge the lanes: the maximum, the first node that attains it, the normaliser
+                float gmx[NOWN], tot[NOWN];
+                int bn[NOWN];
+#pragma unroll
+                for (int j = 0; j < NOWN; ++j) gmx[j] = wave_max(mrun_l[j]);
+#pragma unroll
+                for (int j = 0; j < NOWN; ++j) {
+                    float part = 0.f;
+                    int first = 0x7fffffff;
+#pragma unroll
+                    for (int c = NCH / 4 - 1; c >= 0; --c)
+#pragma unroll
+                        for (int i = 3; i >= 0; --i) {
+                            first = (xv[j][4 * c + i] == gmx[j]) ? 256 * c + 4 * ln + i : first;
+                            if (want_p) part += __expf(xv[j][4 * c + i] - gmx[j]);
+                        }
+                    // (node indices are exact in f32; a trajectory that does not decode has gmx = -inf = every x: its choice is unused)
+                    const float firstn = -wave_max(first != 0x7fffffff ? -(float)first : -3.0e38f);
+                    bn[j] = firstn < 1.0e9f ? (int)firstn : 0;
+                    tot[j] = want_p ? wave_sum(part) : 1.0f;
+                }
+                ELG_STAMP(sc_, 13);
+                // ---- stage 4: the choice and its probability
+#pragma unroll
+                for (int j = 0; j < NOWN; ++j) {
+                    if (!dec[j]) continue;
+                    const int q = wave + 8 * j;
+                    const float* scr = sSc + q * SP;
+                    const unsigned long long* mkw = sMaskW + q * NCH;
+                    const unsigned long long* slw = sSlotW + q * NCH;
+                    const float inv = 1.0f / tot[j];
+                    float* frow = (A.full_probs && t < A.dump_T) ? A.full_probs + (bm[j] * A.dump_T + t) * N1 : nullptr;
+                    if (frow)                                                   // tests: probabilities / clipped logits / scores before the clip
+                        for (int n = ln; n < N1; n += 64) {
+                            const bool masked = (mkw[n >> 6] >> (n & 63)) & 1ull, slot = (slw[n >> 6] >> (n & 63)) & 1ull;
+                            const float sv = scr[n] + (slot ? 0.f : dflt);
+                            const float x = masked ? ELG_NEG_INF : A.clip * fast_tanh(sv);
+                            frow[n] = A.dump_logits == 2 ? (masked ? ELG_NEG_INF : sv) : A.dump_logits == 1 ? x : (masked ? 0.f : __expf(x - gmx[j]) * inv);
+                        }
+                    int s_ = 0;
+                    if (A.mode == ELG_MODE_FORCED) s_ = (A.forced && t < A.Tforced) ? A.forced[bm[j] * A.Tforced + t] : 0;
+                    else if (A.mode == ELG_MODE_GREEDY) s_ = bn[j];
+                    else {
+                        // inverse CDF in node order (second pass, lane = node of a 64-node chunk so that the scan runs in node order)
+                        const float uni = A.uniforms ? A.uniforms[bm[j] * A.Tmax + t] : philox_uniform(A.seed, (unsigned)bm[j], (unsigned)t);
+                        const float target = uni * tot[j];
+                        float run = 0.f;
+                        int found = -1, lastpos = 0;
+#pragma unroll 1
+                        for (int ch = 0; ch < NCH && found < 0; ++ch) {
+                            const int n = ln + 64 * ch;
+                            float e = 0.f;
+                            if (!((mkw[ch] >> ln) & 1ull)) e = __expf(A.clip * fast_tanh(scr[n] + (((slw[ch] >> ln) & 1ull) ? 0.f : dflt)) - gmx[j]);
+                            const float cs_ = wave_scan_incl(e, ln) + run;
+                            run = readlane(cs_, 63);
+                            const unsigned long long pos = __ballot(e > 0.f);
+                            const unsigned long long hit = __ballot(e > 0.f && cs_ > target);
+                            if (hit) found = 64 * ch + (int)__builtin_ctzll(hit);
+                            if (pos) lastpos = 64 * ch + 63 - (int)__builtin_clzll(pos);
+                        }
+                        s_ = found >= 0 ? found : lastpos;
+                    }
+                    s_ = __builtin_amdgcn_readfirstlane(s_);
+                    const bool smasked = (mkw[s_ >> 6] >> (s_ & 63)) & 1ull, sslot = (slw[s_ >> 6] >> (s_ & 63)) & 1ull;
+                    if (want_p) {
+                        const float xs = smasked ? ELG_NEG_INF : A.clip * fast_tanh(scr[s_] + (sslot ? 0.f : dflt));
+                        const float p_ = (xs > ELG_NEG_INF) ? __expf(xs - gmx[j]) * inv : 0.f;
+                        pr[j] = i2f(__builtin_amdgcn_readfirstlane(f2i(p_)));
+                    }
+                    sel[j] = s_;
+                }
+                wave_lds_fence();
+                ELG_STAMP(sc_, 14);
+                // ---- stage 5: the slot words are all-zero between steps
+#pragma unroll
+                for (int j = 0; j < NOWN; ++j)
+                    if (dec[j] && snid[j] >= 0) atomicAnd(sSlotW + (wave + 8 * j) * NCH + (snid[j] >> 6), ~(1ull << (snid[j] & 63)));
+            }
             ELG_STAMP(sc_, 6);
         }
         auto advance = [&](MtTraj& s1, bool ac, int q, size_t bmq, int sl, float pp) {
@@ -3335,6 +3500,8 @@ __global__ __launch_bounds__(512) void rollout_fwd_xm_kernel(const elg_rollout_a
                 const int nblk = NP >> 8, tail = (NP & 255) ? 1 : 0;          // (NP = 64 NW: a last partial block of 64 / 128 / 192 nodes)
                 float mrun_l = ELG_NEG_INF, srun = 0.f;
                 int bn = 0x7fffffff;
+                // (a greedy construction without the chosen probabilities -- elg_rollout_args.probs == NULL -- needs the arg max only)
+                const bool want_p = A.probs != nullptr || A.full_probs != nullptr || A.mode != ELG_MODE_GREEDY;
                 for (int blk = 0; blk < nblk + tail; ++blk) {
                     float x[4] = {ELG_NEG_INF, ELG_NEG_INF, ELG_NEG_INF, ELG_NEG_INF};
                     if (256 * blk + 4 * lane < NP) logits4(blk, x);
@@ -3342,10 +3509,10 @@ __global__ __launch_bounds__(512) void rollout_fwd_xm_kernel(const elg_rollout_a
                     if (bm_ > mrun_l) {                                         // strictly greater: the first maximum wins (node order)
 #pragma unroll
                         for (int i = 3; i >= 0; --i) if (x[i] == bm_) bn = 256 * blk + 4 * lane + i;
-                        srun *= __expf(mrun_l - bm_);                           // exp(-inf) = 0 for the first finite block
+                        if (want_p) srun *= __expf(mrun_l - bm_);               // exp(-inf) = 0 for the first finite block
                         mrun_l = bm_;
                     }
-                    if (mrun_l > ELG_NEG_INF) {
+                    if (want_p && mrun_l > ELG_NEG_INF) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) srun += __expf(x[i] - mrun_l);
                     }
@@ -3357,7 +3524,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_xm_kernel(const elg_rollout_a
                     const float firstn = -wave_max(cand);
                     bn = firstn < 1.0e9f ? (int)firstn : 0;
                 }
-                const float tot = wave_sum(mrun_l > ELG_NEG_INF ? srun * __expf(mrun_l - gmx) : 0.f);
+                const float tot = want_p ? wave_sum(mrun_l > ELG_NEG_INF ? srun * __expf(mrun_l - gmx) : 0.f) : 1.0f;
                 const float inv = 1.0f / tot;
                 float* frow = (A.full_probs && t < A.dump_T) ? A.full_probs + (bmq * A.dump_T + t) * N1 : nullptr;
                 if (frow)                                                       // tests: probabilities / clipped logits / scores before the clip

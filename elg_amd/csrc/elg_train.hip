@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256) void rollout_stats_kernel(const int* __restric
         __syncthreads();
         if (threadIdx.x == 0) atomicMax(stats, max(max(smax[0], smax[1]), max(smax[2], smax[3])));
     }
+    if (!probs) return;                                    // a greedy rollout without probabilities: the length only
     for (int m = threadIdx.x; m < M; m += 256) {
         const int len = min(tl[m], t1);
         for (int t = t0; t < len; ++t)
@@ -193,7 +194,7 @@ extern "C" int elg_check_feasible(const int64_t* pi, int64_t m_stride, const flo
 
 extern "C" int elg_rollout_stats(const int32_t* tlen, const float* probs, int B, int M, int Tcap, int32_t* stats,
                                  int32_t* zero_steps, void* stream) {
-    if (!tlen || !probs || !stats || B <= 0 || M <= 0 || Tcap <= 0) return fail(ELG_EINVAL, "rollout_stats: bad arguments");
+    if (!tlen || !stats || B <= 0 || M <= 0 || Tcap <= 0) return fail(ELG_EINVAL, "rollout_stats: bad arguments");
     // ~1024 workgroups: the time axis in slices of >= 8 steps
     const int slices = max(1, min((Tcap + 7) / 8, (1024 + B - 1) / B));
     const int tper = (Tcap + slices - 1) / slices;

@@ -401,7 +401,7 @@ def rollout_stats_launch(res: "RolloutResult"):
     chosen probability is exactly 0], zero_steps[t] = 1 for the steps where that happened; block = stats followed by two
     zeroed int32 (room for the feasibility flags: one zero fill and one read-back for both).  No host sync."""
     B, M = res.tlen.shape
-    Tcap = res.probs.shape[1]
+    Tcap = res.actions.shape[2]
     buf = torch.zeros(4 + Tcap, dtype=torch.int32, device=res.tlen.device)     # stats | room for two feasibility flags | steps
     stats, zsteps = buf[:2], buf[4:]
     with torch.cuda.device(res.tlen.device):
@@ -421,7 +421,7 @@ def rollout_stats(res: "RolloutResult") -> tuple:
 @dataclass
 class RolloutResult:
     actions: torch.Tensor           # (B,M,Tcap) int32 (slice [:, :, :T])
-    probs: torch.Tensor             # (B,Tcap,M) f32
+    probs: Optional[torch.Tensor]   # (B,Tcap,M) f32; None when the caller asked for none (greedy evaluation, N1 > 128)
     reward: torch.Tensor            # (B,M) f32 = -length on the scaled coordinates
     tlen: torch.Tensor              # (B,M) int32
     full_probs: Optional[torch.Tensor] = None
@@ -475,14 +475,20 @@ def _rows_fit(B, M, N1, Tcap, dev) -> bool:
 
 def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mode: int, *, forced=None, seed: int = 0,
                     uniforms=None, dump_T: int = 0, geometry=None, Tcap: Optional[int] = None,
-                    train: bool = False, variant: int = 0, dump: str = "probs", precision: Optional[int] = None) -> RolloutResult:
-    """Run every trajectory to completion in one persistent launch (reference CVRP/utils.py:7-29)."""
+                    train: bool = False, variant: int = 0, dump: str = "probs", precision: Optional[int] = None,
+                    need_probs: bool = True) -> RolloutResult:
+    """Run every trajectory to completion in one persistent launch (reference CVRP/utils.py:7-29).  need_probs = False (greedy
+    only: the reference's greedy rollout returns no probabilities, utils.py:24-25) leaves RolloutResult.probs None; the kernels for
+    N1 > 128 then skip the softmax normaliser of every step (the cooperative kernel's production instantiation writes them anyway)."""
     dev = prob.xy.device
     _need_cuda(prob.xy, "the problem")
     B, N1 = prob.B, prob.N1
     Tcap = Tcap or max_steps(prob.kind, N1)
     actions = torch.zeros(B, M, Tcap, device=dev, dtype=torch.int32)       # finished -> depot (0)
-    probs = torch.ones(B, Tcap, M, device=dev, dtype=torch.float32)        # ... with probability 1
+    if not need_probs and (mode != L.MODE_GREEDY or train or dump_T > 0):
+        raise ValueError("need_probs=False is for greedy inference rollouts")
+    need_probs = need_probs or N1 <= 128
+    probs = torch.ones(B, Tcap, M, device=dev, dtype=torch.float32) if need_probs else None      # finished -> probability 1
     reward = torch.empty(B, M, device=dev, dtype=torch.float32)
     tlen = torch.empty(B, M, device=dev, dtype=torch.int32)
     full = torch.zeros(B, M, dump_T, N1, device=dev, dtype=torch.float32) if dump_T > 0 else None

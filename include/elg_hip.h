@@ -132,7 +132,9 @@ typedef struct elg_rollout_args {
     float* st_len;          /* (B,M)                                                            */
     uint64_t* st_vis;       /* (B,M,ceil(N1/64)) visited bitmask                                */
     int32_t* actions;       /* (B,M,Tmax) out                                                   */
-    float* probs;           /* (B,Tmax,M) out, probability of the chosen node                   */
+    float* probs;           /* (B,Tmax,M) out, probability of the chosen node; NULL: not wanted -- a greedy construction
+                               with N1 > 128 then forms no softmax normaliser (the reference's greedy rollout returns no
+                               probabilities: CVRPModel.py:70-73, utils.py:24-25)                                    */
     float* reward;          /* (B,M) out, -tour length on `xy`                                  */
     int32_t* tlen;          /* (B,M) out, number of steps taken                                 */
     float* full_probs;      /* (B,M,dump_T,N1) out or NULL: whole probability rows (tests)      */
@@ -359,7 +361,7 @@ int elg_check_feasible(const int64_t* pi, int64_t m_stride, const float* demand,
 
 /* After elg_rollout_fwd: stats[0] = max over tlen (the T of utils.rollout's outputs), stats[1] = 1 if a chosen
  * probability of a decoded step is exactly 0 (CVRPModel.py:67-68 then adds 1e-6 to that step).  stats: 2 x int32,
- * caller zeroes.  tlen (B,M), probs (B,Tcap,M).  zero_steps (Tcap x int32, caller zeroes) or NULL: [t] = 1 for the
+ * caller zeroes.  tlen (B,M), probs (B,Tcap,M) or NULL (stats[1] and zero_steps stay 0).  zero_steps (Tcap x int32, caller zeroes) or NULL: [t] = 1 for the
  * steps in which that happened. */
 int elg_rollout_stats(const int32_t* tlen, const float* probs, int B, int M, int Tcap, int32_t* stats,
                       int32_t* zero_steps, void* stream);

@@ -220,3 +220,25 @@ def test_streaming_kernel_needs_its_workspace():
     a.scratch = None
     rc = lib.elg_rollout_fwd(C.byref(a), eng._stream())
     assert rc == L.ELG_EINVAL and b"scratch" in lib.elg_last_error()
+
+
+@pytest.mark.parametrize("variant,precision", [(0, 0), (0, 1), (3, 0), (3, 1)], ids=["streaming_f32", "streaming_bf16", "xm_f32", "xm_bf16"])
+def test_greedy_without_probabilities_builds_the_same_tours(variant, precision):
+    """need_probs = False (what the greedy `rollout` of the evaluation paths passes: the reference's greedy rollout returns no
+    probabilities, CVRP/utils.py:24-25) skips the softmax normaliser in the kernels for N1 > 128: same tours, same rewards."""
+    gc, L, eng = _imports()
+    N, B, M = 200, 2, 40
+    mp, cfg, xy, dem = _cvrp_case(N, B, 11)
+    P = gc.weights("cvrp", 11, mp, 1.0)
+    enc = orc.encoder_forward(P, cfg, xy, dem)
+    prob = gc.make_problem(xy, dem, L.PROBLEM_CVRP)
+    pol = gc.make_policy(P, cfg, enc.to(gc.DEV), L.PROBLEM_CVRP)
+    starts = torch.arange(1, M + 1, dtype=torch.int32)
+    a = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, variant=variant, precision=precision)
+    b = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, variant=variant, precision=precision, need_probs=False)
+    assert b.probs is None and a.probs is not None
+    assert torch.equal(a.actions, b.actions) and torch.equal(a.reward, b.reward) and torch.equal(a.tlen, b.tlen)
+    T, zero = eng.rollout_stats(b)
+    assert T == int(a.tlen.max()) and not zero
+    with pytest.raises(ValueError):
+        eng.rollout_forward(prob, pol, M, starts, L.MODE_SAMPLE, need_probs=False)

@@ -40,11 +40,11 @@ torch.cuda.synchronize()
 nb = int((dbg.view(-1, 8, 16).abs().sum((1, 2)) > 0).sum())
 acc = dbg.view(-1, 8, 16)[:nb].cpu()
 names = ["owners: prepare (query, stores)", "barrier 1", "glimpse", "barrier 2", "pointer || local policy", "barrier 3",
-         "owners: choose (rest)", "owners: advance", "loop barrier", "prepare: mask build", "prepare: k-NN walk + slot features",
-         "choose: row read", "choose: finish_step"]
-a = acc[:, :, :13].mean((0, 1)); tot = float(a.sum())
+         "choose: slot-word restore", "owners: advance", "loop barrier", "prepare: mask build", "prepare: k-NN walk + slot features",
+         "choose: slot terms", "choose: the pass", "choose: lane merge", "choose: choice + probability"]
+a = acc[:, :, :15].mean((0, 1)); tot = float(a.sum())
 T = float(res.tlen.max())
 print(f"{nb} workgroups, {tot / T:.0f} cycles per step (max T {T:.0f});", "  ".join(f"{n} {100 * float(v) / tot:.1f}%" for n, v in zip(names, a)))
 for w in (0, 7):
-    a = acc[:, w, :13].mean(0); tot = float(a.sum())
+    a = acc[:, w, :15].mean(0); tot = float(a.sum())
     print(f"wave {w}:", "  ".join(f"{100 * float(v) / tot:.1f}%" for v in a))
