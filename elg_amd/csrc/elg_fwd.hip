@@ -783,6 +783,85 @@ __device__ __attribute__((noinline)) void co_local16_call(const float* sT, const
     co_local16(sT, la, sXrows, sXrows + CO_XU, CO_XP, lo, hi);
 }
 
+// The two stages as out-of-line calls for rollout_fwd_mt_kernel (round 4): head unit (h, group) -- attention of local head h over the
+// slots of a 16-trajectory group and its 8 channels of o' (the stages lh_score / lh_exp / lh_norm / lh_mfma of the cooperative kernel
+// in a row) -- at the start of the glimpse phase on the waves that finish that phase first, the tail on one wave per group in the
+// pointer phase: the single-wave chain of co_local16 was the critical path of the pointer phase there too.
+__device__ __attribute__((noinline)) void co_local_head_call(const float* sT, const float* sXrows, float* sO1, int h, int lo, int hi) {
+    const float* LX = sXrows + lo * CO_XP;
+    const int dt = h >> 1;
+    f32x4c lf[3][3], lal[3];
+    bool lmsk[3][4];
+    float lmx = ELG_NEG_INF, lden = 0.f, lF[3] = {0.f, 0.f, 0.f};
+    f32x4c lP = {0.f, 0.f, 0.f, 0.f};
+    const float4 la4 = *reinterpret_cast<const float4*>(sT + CL_LA + 4 * h);
+#pragma unroll
+    for (int jt = 0; jt < 3; ++jt) {
+        const int4 sl = *reinterpret_cast<const int4*>(LX + CO_XS + 16 * jt + 4 * hi);
+        lmsk[jt][0] = sl.x < 0; lmsk[jt][1] = sl.y < 0; lmsk[jt][2] = sl.z < 0; lmsk[jt][3] = sl.w < 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float4 tq = *reinterpret_cast<const float4*>(LX + CO_XF + k * ELG_SLOT_STRIDE + 16 * jt + 4 * hi);
+            lf[k][jt] = f32x4c{tq.x, tq.y, tq.z, tq.w};
+        }
+        const float4 lt4 = *reinterpret_cast<const float4*>(sT + CL_LTT + h * 48 + 16 * jt + 4 * hi);
+        const float ltv[4] = {lt4.x, lt4.y, lt4.z, lt4.w};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            float x = ltv[v];
+            x = fmaf(la4.x, lf[0][jt][v], x);
+            x = fmaf(la4.y, lf[1][jt][v], x);
+            x = fmaf(la4.z, lf[2][jt][v], x);
+            x = lmsk[jt][v] ? ELG_NEG_INF : x;
+            lal[jt][v] = x;
+            lmx = fmaxf(lmx, x);
+        }
+    }
+    lmx = quarters_max(lmx);
+#pragma unroll
+    for (int jt = 0; jt < 3; ++jt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float e = lmsk[jt][v] ? 0.f : __expf(lal[jt][v] - lmx);
+            lal[jt][v] = e;
+            lden += e;
+        }
+    lden = quarters_sum(lden);
+    const float lrden = lden > 0.f ? 1.0f / lden : 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 3; ++jt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float a = lal[jt][v] * lrden;
+            lal[jt][v] = a;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) lF[k] = fmaf(a, lf[k][jt][v], lF[k]);
+        }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) lF[k] = quarters_sum(lF[k]);
+#pragma unroll
+    for (int jt = 0; jt < 3; ++jt) {
+        const float4 a4 = *reinterpret_cast<const float4*>(sT + CL_LCVT + (16 * dt + lo) * CL_Q + 16 * jt + 4 * hi);
+        lP = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, lal[jt][0], lP, 0, 0, 0);
+        lP = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, lal[jt][1], lP, 0, 0, 0);
+        lP = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, lal[jt][2], lP, 0, 0, 0);
+        lP = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, lal[jt][3], lP, 0, 0, 0);
+    }
+    // rows 4 hi + v of the 16-channel tile dt: channels 8 (h & 1) .. + 7 belong to head h
+    if ((hi >= 2) == bool(h & 1)) {
+        float xo[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float4 lav = *reinterpret_cast<const float4*>(sT + CL_LAV + 4 * (16 * dt + 4 * hi + v));
+            xo[v] = fmaf(lav.z, lF[2], fmaf(lav.y, lF[1], fmaf(lav.x, lF[0], lP[v])));
+        }
+        *reinterpret_cast<float4*>(sO1 + (dt * 64 + 16 * hi + lo) * 4) = make_float4(xo[0], xo[1], xo[2], xo[3]);
+    }
+}
+__device__ __attribute__((noinline)) void co_local_tail_call(const float* sT, float* sXrows, const float* sO1, int lo, int hi) {
+    co_local_tail(sT, sXrows, sO1, sXrows + CO_XU, CO_XP, lo, hi);
+}
+
 template <bool TSP>
 __device__ __forceinline__ void co_store_state(int* sS, const Traj<2>& st, int lane) {
     if (lane == 0) {
@@ -2244,6 +2323,10 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                 }
                 __syncthreads();        // every head has its queries: the rows are free for the term planes of o (cheap: the waves
                                         // left the previous barrier a few instructions ago)
+                // local policy, stage 1: head unit (group w >> 2, head w & 3) on wave w; o' waits in the per-wave scratch area
+                // (free between the owners' phases) for the tail in the pointer phase
+                if (A.has_local && wave < 4 * NG)
+                    co_local_head_call(sT, sX + (wave >> 2) * 16 * CO_XP, sdem + ((N1 + 3) & ~3) + (wave >> 2) * 512, wave & 3, lo, hi);
                 if constexpr (BF) {
                     // ---- bf16 mode: one instruction per score tile, one per PAIR of node tiles for the output
                     u32x4 qb1[NG];
@@ -2409,10 +2492,10 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
             ELG_STAMP(sc_, 2);
             __syncthreads();
             ELG_STAMP(sc_, 3);
-            // ================= pointer: node tiles over the waves; local policy of group g: wave 7 - g =================
-            // (co_local16 costs about what three node tiles do: its wave joins the tile round-robin three rounds late)
-            const int nloc = A.has_local ? NG : 0, W0 = 8 - nloc, skip = nloc ? 3 * W0 : 0;
-            if (wave >= W0) co_local16_call(sT, A.loc, sX + (7 - wave) * 16 * CO_XP, lo, hi);
+            // ================= pointer: node tiles over the waves; local-policy tail of group g: wave 7 - g =================
+            // (the tail costs about what one node tile does: its wave joins the tile round-robin one round late)
+            const int nloc = A.has_local ? NG : 0, W0 = 8 - nloc, skip = nloc ? W0 : 0;
+            if (wave >= W0) co_local_tail_call(sT, sX + (7 - wave) * 16 * CO_XP, sdem + ((N1 + 3) & ~3) + (7 - wave) * 512, lo, hi);
             {
                 // s^T[node][trajectory] = sum over the channels of PK[node][c] o[trajectory][c] on v_mfma_f32_16x16x32_bf16:
                 // per 32 channels the six term products a1 b1, a1 b2, a2 b1, a2 b2, a1 b3, a3 b1 (24 instructions of 16 cycles per
