@@ -1980,9 +1980,9 @@ __device__ __forceinline__ void mt_fill_additive(const unsigned long long* mkw, 
 }
 
 // env_update() with the visited words in LDS (same roundings: one fp32 subtraction for the load, dist2d for the length)
+// (sxy = xy[sel]: requested by the caller for all of the wave's trajectories before the first of them is updated)
 template <int NCH, bool TSP>
-__device__ __forceinline__ void mt_env_update(MtTraj& st, unsigned long long* vis, const Inst& I, int N1, int sel, int lane) {
-    const float2 sxy = *reinterpret_cast<const float2*>(I.xy + 2 * sel);
+__device__ __forceinline__ void mt_env_update(MtTraj& st, unsigned long long* vis, const Inst& I, int N1, int sel, int lane, float2 sxy) {
     const float sx = i2f(__builtin_amdgcn_readfirstlane(f2i(sxy.x))), sy = i2f(__builtin_amdgcn_readfirstlane(f2i(sxy.y)));
     if (st.cnt > 0) st.len += dist2d(st.cx, st.cy, sx, sy);
     st.cx = sx; st.cy = sy;
@@ -2760,11 +2760,14 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                         s_ = found >= 0 ? found : lastpos;
                     }
                     s_ = __builtin_amdgcn_readfirstlane(s_);
-                    const bool smasked = (mkw[s_ >> 6] >> (s_ & 63)) & 1ull, sslot = (slw[s_ >> 6] >> (s_ & 63)) & 1ull;
                     if (want_p) {
-                        const float xs = smasked ? ELG_NEG_INF : A.clip * fast_tanh(scr[s_] + (sslot ? 0.f : dflt));
-                        const float p_ = (xs > ELG_NEG_INF) ? __expf(xs - gmx[j]) * inv : 0.f;
-                        pr[j] = i2f(__builtin_amdgcn_readfirstlane(f2i(p_)));
+                        if (A.mode == ELG_MODE_GREEDY) pr[j] = inv;         // the arg max: x = gmx, exp(0) = 1 (an open node always exists)
+                        else {
+                            const bool smasked = (mkw[s_ >> 6] >> (s_ & 63)) & 1ull, sslot = (slw[s_ >> 6] >> (s_ & 63)) & 1ull;
+                            const float xs = smasked ? ELG_NEG_INF : A.clip * fast_tanh(scr[s_] + (sslot ? 0.f : dflt));
+                            const float p_ = (xs > ELG_NEG_INF) ? __expf(xs - gmx[j]) * inv : 0.f;
+                            pr[j] = i2f(__builtin_amdgcn_readfirstlane(f2i(p_)));
+                        }
                     }
                     sel[j] = s_;
                 }
@@ -2777,21 +2780,29 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
             }
             ELG_STAMP(sc_, 6);
         }
-        auto advance = [&](MtTraj& s1, bool ac, int q, size_t bmq, int sl, float pp) {
-            if (!ac) return;
-            const int m = m_base + q;
-            if (first_move) {
-                if (A.mode == ELG_MODE_FORCED) sl = (A.forced && t < A.Tforced) ? __builtin_amdgcn_readfirstlane(A.forced[bmq * A.Tforced + t]) : 0;
-                else sl = (!TSP && t == 0) ? 0 : __builtin_amdgcn_readfirstlane(A.starts[m]);
-            }
-            if (lane == 0) {
-                if (A.actions) A.actions[bmq * A.Tmax + t] = sl;
-                if (A.probs) A.probs[((size_t)b * A.Tmax + t) * A.M + m] = pp;
-            }
-            mt_env_update<NCH, TSP>(s1, sVis + q * NCH, I, N1, sl, lane);
-        };
+        // environment transition (in stages over the wave's trajectories: the coordinates of the chosen nodes come from L2)
+        float2 sxy[NOWN];
 #pragma unroll
-        for (int j = 0; j < NOWN; ++j) advance(st[j], act[j], wave + 8 * j, bm[j], sel[j], pr[j]);
+        for (int j = 0; j < NOWN; ++j) {
+            sxy[j] = make_float2(0.f, 0.f);
+            if (!act[j]) continue;
+            if (first_move) {
+                if (A.mode == ELG_MODE_FORCED) sel[j] = (A.forced && t < A.Tforced) ? __builtin_amdgcn_readfirstlane(A.forced[bm[j] * A.Tforced + t]) : 0;
+                else sel[j] = (!TSP && t == 0) ? 0 : __builtin_amdgcn_readfirstlane(A.starts[m_base + wave + 8 * j]);
+            }
+            sxy[j] = *reinterpret_cast<const float2*>(I.xy + 2 * sel[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NOWN; ++j) {
+            if (!act[j]) continue;
+            if (lane == 0) {
+                if (A.actions) A.actions[bm[j] * A.Tmax + t] = sel[j];
+                if (A.probs) A.probs[((size_t)b * A.Tmax + t) * A.M + m_base + wave + 8 * j] = pr[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NOWN; ++j)
+            if (act[j]) mt_env_update<NCH, TSP>(st[j], sVis + (wave + 8 * j) * NCH, I, N1, sel[j], lane, sxy[j]);
         ELG_STAMP(sc_, 7);
     }
 #ifdef ELG_STAMPS
