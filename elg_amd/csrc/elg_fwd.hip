@@ -524,8 +524,23 @@ struct StampCtx {};
 #define ELG_STAMP(c, i)
 #endif
 
-constexpr int CO_QP = 132;      // pitch of the query / glimpse-output exchange rows (conflict-free column reads)
-constexpr int CO_SP = 116;      // pitch of the score exchange rows
+#ifndef ELG_CO_QP
+#define ELG_CO_QP 132
+#endif
+#ifndef ELG_CO_SP
+#define ELG_CO_SP 116
+#endif
+#ifndef ELG_CO_XPAD
+#define ELG_CO_XPAD 4
+#endif
+#ifndef ELG_CL_P
+#define ELG_CL_P 36
+#endif
+#ifndef ELG_CL_Q
+#define ELG_CL_Q 52
+#endif
+constexpr int CO_QP = ELG_CO_QP;      // pitch of the query / glimpse-output exchange rows (conflict-free column reads)
+constexpr int CO_SP = ELG_CO_SP;      // pitch of the score exchange rows
 constexpr int CO_NT = 7;        // node tiles of 16
 constexpr int CO_MAXTR = 32;    // trajectories in lockstep per workgroup
 
@@ -534,13 +549,13 @@ constexpr int CO_MAXTR = 32;    // trajectories in lockstep per workgroup
 // the TRAJECTORY on the lane -- the local policy's feature / slot-code fragments, 16 lanes x ds_read_b128 -- were 16-way bank
 // conflicts; 292 = 4 (mod 32) spreads the sixteen 16-byte pieces over all 64 banks.  PMC: SQ_LDS_BANK_CONFLICT was 45 % of
 // SQ_LDS_IDX_ACTIVE in the cooperative kernel.)
-constexpr int CO_XP = 6 * ELG_SLOT_STRIDE + 4;
+constexpr int CO_XP = 6 * ELG_SLOT_STRIDE + ELG_CO_XPAD;
 constexpr int CO_XF = 0, CO_XS = 3 * ELG_SLOT_STRIDE, CO_XPEN = 4 * ELG_SLOT_STRIDE, CO_XU = 5 * ELG_SLOT_STRIDE;
 // ---- folded local-policy tables staged in LDS with conflict-free pitches (same images as csrc/elg_local.hip)
 // Every MFMA operand that comes from a table is one ds_read_b128 (four k-steps at once): lcv is kept transposed ([d][52]: a
 // lane's four values are consecutive slots), lpe / lwc row-major with pitch 36 (consecutive channels), lt transposed per head,
 // lAv / lWe padded to four floats per channel.  Pitches 36 / 52 keep the 16 lanes of a b128 group on distinct banks.
-constexpr int CL_P = 36, CL_Q = 52;
+constexpr int CL_P = ELG_CL_P, CL_Q = ELG_CL_Q;
 constexpr int CL_LCVT = 0;                              // [32 d][52]   lcv[j][d] transposed
 constexpr int CL_LPE = CL_LCVT + 32 * CL_Q;             // [48 j][36]
 constexpr int CL_LWC = CL_LPE + 48 * CL_P;              // [32][36]

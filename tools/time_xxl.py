@@ -11,8 +11,9 @@ cfg = yaml.safe_load(open(os.path.join(ROOT, "elg_amd/CVRP/config.yml")))
 dev = "cuda:0"
 torch.manual_seed(1)
 model = CVRPModel(**cfg["model_params"]); model.decoder.add_local_policy(dev); model.to(dev).eval()
-inst = vrplib_io.read_instance(os.path.join(gu.GOLDEN_DIR, "vrplib", "XXL", name + ".vrp"))
-env = CVRPEnv(1000, dev)
+sub = "X" if name.startswith("X-") else "XXL"
+inst = vrplib_io.read_instance(os.path.join(gu.GOLDEN_DIR, "vrplib", sub, name + ".vrp"))
+env = CVRPEnv(min(1000, len(inst["demand"]) - 1), dev)
 
 
 def ev():
@@ -28,9 +29,9 @@ for rep in range(2):
     with torch.no_grad():
         model.pre_forward(rs)
         e2 = ev()
-        starts = torch.arange(1, 1001, dtype=torch.int32)
-        res = eng.rollout_forward(env.problem, model.decoder.policy, 1000, starts, L.MODE_GREEDY)
+        starts = torch.arange(1, env.multi_width + 1, dtype=torch.int32)
+        res = eng.rollout_forward(env.problem, model.decoder.policy, env.multi_width, starts, L.MODE_GREEDY)
     e3 = ev()
     torch.cuda.synchronize()
-    print(f"{name} N1 = {env.problem.N1}: load + neighbour tables {e0.elapsed_time(e1) / 1e3:.2f} s, encoder + tables {e1.elapsed_time(e2) / 1e3:.2f} s, "
-          f"rollout {e2.elapsed_time(e3) / 1e3:.2f} s ({int(res.tlen.max())} steps, mean cost {float((-res.reward).mean()):.0f})")
+    print(f"{name} N1 = {env.problem.N1}: load + neighbour tables {e0.elapsed_time(e1) :.1f} ms, encoder + tables {e1.elapsed_time(e2) :.1f} ms, "
+          f"rollout {e2.elapsed_time(e3) :.1f} ms ({int(res.tlen.max())} steps, mean cost {float((-res.reward).mean()):.0f})")
