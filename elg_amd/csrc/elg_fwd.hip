@@ -583,148 +583,11 @@ __device__ __forceinline__ void co_stage_local(const float* __restrict__ loc, fl
     for (int i = tid; i < 16; i += nthreads) sT[CL_LA + i] = (i & 3) < 3 ? loc[ELG_LOC_LA + 3 * (i >> 2) + (i & 3)] : 0.f;
 }
 
-// Local policy of 16 lockstep trajectories at once (models.py:133-166, folded as in elg_rollout.h::local_policy):
-// feature-major tiles X[slot 16 jt + 4 hi + v][trajectory lo]; the three table contractions (alpha -> o', o' -> g',
-// g' -> u) are MFMAs whose D tiles are the next B operands.  Reads the trajectories' slot blocks, writes u_j.
-__device__ __forceinline__ void co_local16(const float* __restrict__ sT, const float (&la)[ELG_LH][3], const float* sXrows,
-                                           float* sUrows, int upitch, int lo, int hi) {
-    constexpr int JT = 3;
-    const float* X = sXrows + lo * CO_XP;                           // this lane's trajectory
-    const bool up = hi >= 2;
-    const f32x4c z4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4c o1[2], g1[2];
-    // two heads at a time (the 16 channels of d-tile dt belong to heads 2 dt and 2 dt + 1): 24 live weights, not 48
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-        f32x4c f1[3][JT];                                             // re-read per head pair: not live across the MFMAs
-        bool msk[JT][4];
-#pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
-            const int4 sl = *reinterpret_cast<const int4*>(X + CO_XS + 16 * jt + 4 * hi);
-            msk[jt][0] = sl.x < 0; msk[jt][1] = sl.y < 0; msk[jt][2] = sl.z < 0; msk[jt][3] = sl.w < 0;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float4 t = *reinterpret_cast<const float4*>(X + CO_XF + k * ELG_SLOT_STRIDE + 16 * jt + 4 * hi);
-                f1[k][jt] = f32x4c{t.x, t.y, t.z, t.w};
-            }
-        }
-        f32x4c al[2][JT];
-        float F[2][3];
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int h = 2 * dt + hh;
-            float mx = ELG_NEG_INF;
-#pragma unroll
-            for (int jt = 0; jt < JT; ++jt) {
-                const float4 lt4 = *reinterpret_cast<const float4*>(sT + CL_LTT + h * 48 + 16 * jt + 4 * hi);
-                const float ltv[4] = {lt4.x, lt4.y, lt4.z, lt4.w};
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    float sc = ltv[v];
-                    sc = fmaf(la[h][0], f1[0][jt][v], sc);
-                    sc = fmaf(la[h][1], f1[1][jt][v], sc);
-                    sc = fmaf(la[h][2], f1[2][jt][v], sc);
-                    sc = msk[jt][v] ? ELG_NEG_INF : sc;
-                    al[hh][jt][v] = sc;
-                    mx = fmaxf(mx, sc);
-                }
-            }
-            mx = quarters_max(mx);
-            float den = 0.f;
-#pragma unroll
-            for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const float e = msk[jt][v] ? 0.f : __expf(al[hh][jt][v] - mx);
-                    al[hh][jt][v] = e;
-                    den += e;
-                }
-            den = quarters_sum(den);
-            float fk[3] = {0.f, 0.f, 0.f};
-            const float rden = den > 0.f ? 1.0f / den : 0.f;        // one IEEE division per head instead of twelve
-#pragma unroll
-            for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const float a = al[hh][jt][v] * rden;
-                    al[hh][jt][v] = a;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) fk[k] = fmaf(a, f1[k][jt][v], fk[k]);
-                }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                fk[k] = quarters_sum(fk[k]);
-                F[hh][k] = fk[k];
-            }
-        }
-        f32x4c Pa = z4, Pb = z4;
-#pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
-            const float4 a4 = *reinterpret_cast<const float4*>(sT + CL_LCVT + (16 * dt + lo) * CL_Q + 16 * jt + 4 * hi);
-            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                Pa = __builtin_amdgcn_mfma_f32_16x16x4f32(av[v], al[0][jt][v], Pa, 0, 0, 0);
-                Pb = __builtin_amdgcn_mfma_f32_16x16x4f32(av[v], al[1][jt][v], Pb, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int d = 16 * dt + 4 * hi + v;
-            float x = up ? Pb[v] : Pa[v];
-            const float4 lav = *reinterpret_cast<const float4*>(sT + CL_LAV + 4 * d);
-            x = fmaf(lav.x, up ? F[1][0] : F[0][0], x);
-            x = fmaf(lav.y, up ? F[1][1] : F[0][1], x);
-            x = fmaf(lav.z, up ? F[1][2] : F[0][2], x);
-            o1[dt][v] = x;
-        }
-    }
-    float w[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int dq = 0; dq < 2; ++dq) {
-        const float4 bc4 = *reinterpret_cast<const float4*>(sT + CL_LBC + 16 * dq + 4 * hi);
-        f32x4c acc = {bc4.x, bc4.y, bc4.z, bc4.w};
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            const float4 w4 = *reinterpret_cast<const float4*>(sT + CL_LWC + (16 * dq + lo) * CL_P + 16 * dt + 4 * hi);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, o1[dt][0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, o1[dt][1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, o1[dt][2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, o1[dt][3], acc, 0, 0, 0);
-        }
-        g1[dq] = acc;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const float4 we = *reinterpret_cast<const float4*>(sT + CL_LWE + 4 * (16 * dq + 4 * hi + v));
-            w[0] = fmaf(acc[v], we.x, w[0]); w[1] = fmaf(acc[v], we.y, w[1]); w[2] = fmaf(acc[v], we.z, w[2]);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { w[k] = quarters_sum(w[k]); }
-#pragma unroll
-    for (int jt = 0; jt < JT; ++jt) {
-        f32x4c acc = z4;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            const float4 p4 = *reinterpret_cast<const float4*>(sT + CL_LPE + (16 * jt + lo) * CL_P + 16 * dt + 4 * hi);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p4.x, g1[dt][0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p4.y, g1[dt][1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p4.z, g1[dt][2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p4.w, g1[dt][3], acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float4 t = *reinterpret_cast<const float4*>(X + CO_XF + k * ELG_SLOT_STRIDE + 16 * jt + 4 * hi);
-            acc[0] = fmaf(w[k], t.x, acc[0]); acc[1] = fmaf(w[k], t.y, acc[1]);
-            acc[2] = fmaf(w[k], t.z, acc[2]); acc[3] = fmaf(w[k], t.w, acc[3]);
-        }
-        *reinterpret_cast<float4*>(sUrows + lo * upitch + 16 * jt + 4 * hi) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
-// co_local16 in two stages for the cooperative kernel, where the single-wave chain (~12 K cycles) was the critical path of the
-// pointer phase:
+// The local policy of 16 lockstep trajectories (models.py:133-166, folded as in elg_rollout.h::local_policy) on the matrix cores, in two
+// stages -- feature-major tiles X[slot 16 jt + 4 hi + v][trajectory lo]; the three table contractions (alpha -> o', o' -> g', g' -> u)
+// are MFMAs whose D tiles are the next B operands.  (A single-wave chain of all of it, ~12 K cycles, was the critical path of the
+// pointer phase in every kernel that had it.)
 //   head units      one (head h, 16-trajectory group) unit: attention of head h over the slots and its 8 channels of o'
 //                   (12 MFMAs).  The eight units of a workgroup run on the eight waves inside the GLIMPSE phase, their stages
 //                   written between the glimpse's MFMA loops (rollout_fwd_coop_kernel: lh_score / lh_exp / lh_norm / lh_mfma),
@@ -787,21 +650,10 @@ __device__ __forceinline__ void co_local_tail(const float* __restrict__ sT, cons
     }
 }
 
-// out-of-line instance for rollout_fwd_mt_kernel: one wave calls it between phases, and its ~250 live registers must not
-// shape the register allocation of that kernel's streaming loops
-__device__ __attribute__((noinline)) void co_local16_call(const float* sT, const float* __restrict__ loc, float* sXrows, int lo, int hi) {
-    float la[ELG_LH][3];
-#pragma unroll
-    for (int h = 0; h < ELG_LH; ++h)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) la[h][k] = loc[ELG_LOC_LA + 3 * h + k];
-    co_local16(sT, la, sXrows, sXrows + CO_XU, CO_XP, lo, hi);
-}
-
 // The two stages as out-of-line calls for rollout_fwd_mt_kernel (round 4): head unit (h, group) -- attention of local head h over the
 // slots of a 16-trajectory group and its 8 channels of o' (the stages lh_score / lh_exp / lh_norm / lh_mfma of the cooperative kernel
 // in a row) -- at the start of the glimpse phase on the waves that finish that phase first, the tail on one wave per group in the
-// pointer phase: the single-wave chain of co_local16 was the critical path of the pointer phase there too.
+// pointer phase (out of line: their ~250 live registers must not shape the register allocation of the streaming loops).
 __device__ __attribute__((noinline)) void co_local_head_call(const float* sT, const float* sXrows, float* sO1, int h, int lo, int hi) {
     const float* LX = sXrows + lo * CO_XP;
     const int dt = h >> 1;
@@ -2266,7 +2118,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                         bool smask = !cust[j];
                         if (!TSP && ln == 0) smask = mk0[j] & 1u;                         // depot slot carries the depot's mask
                         const int code = smask ? (snid[j] >= 0 ? -2 : -1) : snid[j];
-                        if (A.has_local && ln < ELG_SLOT_STRIDE) {        // slot block for co_local16 (layout of the coop kernel)
+                        if (A.has_local && ln < ELG_SLOT_STRIDE) {        // slot block of the local policy (layout of the coop kernel)
                             float* X = sX + q * CO_XP;
                             X[CO_XF + ln] = f0; X[CO_XF + ELG_SLOT_STRIDE + ln] = f1; X[CO_XF + 2 * ELG_SLOT_STRIDE + ln] = f2;
                             reinterpret_cast<int*>(X)[CO_XS + ln] = code;
@@ -3282,7 +3134,12 @@ __global__ __launch_bounds__(512) void rollout_fwd_xm_kernel(const elg_rollout_a
         st[j].cur = 0; st[j].first = 0; st[j].cnt = 0; st[j].fin = has[j] ? 0 : 1; st[j].nvis = 0;
         st[j].load = 1.0f; st[j].len = 0.f; st[j].cx = 0.f; st[j].cy = 0.f;
     }
+    const int lane_k = lane;
     for (int t = 0; t < step_cap && t < A.Tmax; ++t) {
+        // (opaque per step: what the owners' phases derive from the lane id is re-formed here instead of living in registers across
+        // the matrix phases, where the f32-parity instantiation has none to spare)
+        int lane = lane_k;
+        asm volatile("" : "+v"(lane));
         const bool first_move = (!TSP && t <= 1) || (TSP && t == 0);
         bool act[NOWN], dec[NOWN];
         bool any = false;
@@ -3307,22 +3164,39 @@ __global__ __launch_bounds__(512) void rollout_fwd_xm_kernel(const elg_rollout_a
                 float f0 = 0.f, f1 = 0.f, f2 = 0.f;
                 int scode = -1;
                 if (dc) {
-                    const float lim = __fadd_rn(s1.load, 1e-6f);
-                    for (int ch = 0; ch < NW; ++ch) {                   // CVRPEnv.py:214-232 / TSPEnv.py:120
-                        const int n = lane + 64 * ch;
-                        bool mm = true;
-                        if (n < N1) {
-                            mm = (vis[ch] >> lane) & 1ull;
-                            if (!TSP) {
-                                mm = mm || (lim < sdem[n]);
-                                if (n == 0 && s1.fin) mm = false;
-                            }
+                    // the mask of the step as words (the streaming kernel's mt_mask_words with runtime loops, NW <= 128: lane c
+                    // assembles the words c and c + 64 = visited | ballot(demand > load) | nodes past N1; CVRPEnv.py:214-232 /
+                    // TSPEnv.py:120), then the additive row (0 open / -inf closed) 16 bytes per lane
+                    int lc = lane;
+                    asm volatile("" : "+v"(lc));
+                    unsigned long long w0 = lc < NW ? vis[lc] : 0ull, w1 = lc + 64 < NW ? vis[lc + 64] : 0ull;
+                    if (!TSP) {
+                        const float lim = __fadd_rn(s1.load, 1e-6f);
+                        unsigned l0 = 0u, h0 = 0u, l1 = 0u, h1 = 0u;
+#pragma unroll 2
+                        for (int ch = 0; ch < NW; ++ch) {               // (nodes past N1 read the scratch behind the demand row: closed below)
+                            const unsigned long long bal = __ballot(lim < sdem[lc + 64 * ch]);
+                            const bool mine = lc == (ch & 63);
+                            if (ch < 64) { l0 = mine ? (unsigned)bal : l0; h0 = mine ? (unsigned)(bal >> 32) : h0; }
+                            else { l1 = mine ? (unsigned)bal : l1; h1 = mine ? (unsigned)(bal >> 32) : h1; }
                         }
-                        srow[n] = mm ? ELG_NEG_INF : 0.f;
-                        const unsigned long long bal = __ballot(mm);
-                        if (lane == 0) mkw[ch] = bal;
+                        w0 |= ((unsigned long long)h0 << 32) | l0;
+                        w1 |= ((unsigned long long)h1 << 32) | l1;
                     }
+                    {
+                        const int r0 = N1 - 64 * lc, r1 = r0 - 4096;    // nodes of the words lc / lc + 64 that exist
+                        w0 |= r0 >= 64 ? 0ull : (r0 <= 0 ? ~0ull : ~((1ull << r0) - 1ull));
+                        w1 |= r1 >= 64 ? 0ull : (r1 <= 0 ? ~0ull : ~((1ull << r1) - 1ull));
+                    }
+                    if (!TSP && lc == 0 && s1.fin) w0 &= ~1ull;
+                    if (lc < NW) mkw[lc] = w0;
+                    if (lc + 64 < NW) mkw[lc + 64] = w1;
                     wave_lds_fence();
+                    for (int n0 = 4 * lc; n0 < NP; n0 += 256) {
+                        const unsigned bits = (unsigned)(mkw[n0 >> 6] >> (n0 & 63));
+                        *reinterpret_cast<float4*>(srow + n0) = make_float4((bits & 1u) ? ELG_NEG_INF : 0.f, (bits & 2u) ? ELG_NEG_INF : 0.f,
+                                                                            (bits & 4u) ? ELG_NEG_INF : 0.f, (bits & 8u) ? ELG_NEG_INF : 0.f);
+                    }
                     const int cb = (lane & 31) * 4;
                     q4 = *reinterpret_cast<const float4*>(Q1 + (size_t)s1.cur * ELG_E + cb);
                     if (TSP) {
@@ -3379,11 +3253,11 @@ __global__ __launch_bounds__(512) void rollout_fwd_xm_kernel(const elg_rollout_a
                         addval = pen;
                     }
                 } else {
-                    for (int ch = 0; ch < NW; ++ch) srow[lane + 64 * ch] = ELG_NEG_INF;     // not decoding: every node closed
-                    if (lane == 0)
-                        for (int ch = 0; ch < NW; ++ch) mkw[ch] = ~0ull;
+                    for (int n0 = 4 * lane; n0 < NP; n0 += 256)                             // not decoding: every node closed
+                        *reinterpret_cast<float4*>(srow + n0) = make_float4(ELG_NEG_INF, ELG_NEG_INF, ELG_NEG_INF, ELG_NEG_INF);
+                    for (int c = lane; c < NW; c += 64) mkw[c] = ~0ull;
                 }
-                if (A.has_local && lane < ELG_SLOT_STRIDE) {            // slot block for co_local16 (layout of the cooperative kernel)
+                if (A.has_local && lane < ELG_SLOT_STRIDE) {            // slot block of the local policy (layout of the cooperative kernel)
                     float* X = sX + q * CO_XP;
                     X[CO_XF + lane] = f0; X[CO_XF + ELG_SLOT_STRIDE + lane] = f1; X[CO_XF + 2 * ELG_SLOT_STRIDE + lane] = f2;
                     reinterpret_cast<int*>(X)[CO_XS + lane] = scode;
@@ -3405,6 +3279,8 @@ __global__ __launch_bounds__(512) void rollout_fwd_xm_kernel(const elg_rollout_a
                 float mrun = -1e30f, lrun = 0.f;
                 f32x4c o = {0.f, 0.f, 0.f, 0.f}, o2 = {0.f, 0.f, 0.f, 0.f};
                 __syncthreads();        // every head has its queries: the rows are free for the term planes of o
+                // local policy, stage 1: the four head units on the waves that finish the glimpse first (as in the streaming kernel)
+                if (A.has_local && wave < 4) co_local_head_call(sT, sX, sdem + ((N1 + 3) & ~3), wave & 3, lo, hi);
                 auto softmax_update = [&](f32x4c (&S)[TU]) {
                     float tm = ELG_NEG_INF;
 #pragma unroll
@@ -3513,9 +3389,9 @@ __global__ __launch_bounds__(512) void rollout_fwd_xm_kernel(const elg_rollout_a
                     *reinterpret_cast<uint2*>(sOb + (tm * NTR + lo) * OBP + 8 * wave + 2 * hi) = make_uint2(po[2 * tm], po[2 * tm + 1]);
             }
             __syncthreads();
-            // ================= pointer: node tiles over the waves; the local policy on wave 7 =================
-            const int nloc = A.has_local ? 1 : 0, W0 = 8 - nloc, skip = nloc ? 3 * W0 : 0;
-            if (wave >= W0) co_local16_call(sT, A.loc, sX, lo, hi);
+            // ================= pointer: node tiles over the waves; the local policy's tail on wave 7 =================
+            const int nloc = A.has_local ? 1 : 0, W0 = 8 - nloc, skip = nloc ? W0 : 0;
+            if (wave >= W0) co_local_tail_call(sT, sX, sdem + ((N1 + 3) & ~3), lo, hi);
             {
                 int nt = (wave < W0 ? wave : skip + wave);
                 float* orow = rows + (size_t)lo * NP + 4 * hi;
@@ -3604,7 +3480,8 @@ __global__ __launch_bounds__(512) void rollout_fwd_xm_kernel(const elg_rollout_a
                     const unsigned bits = (unsigned)(mkw[n0 >> 6] >> (n0 & 63)) & 0xFu;     // NP is a multiple of 64: n0 < NP
                     const float svv[4] = {sv.x, sv.y, sv.z, sv.w};
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) x[i] = ((bits >> i) & 1u) ? ELG_NEG_INF : A.clip * fast_tanh(svv[i] + dflt);
+                    for (int i = 0; i < 4; ++i)       // the closed bit as a 0 / -1 word -> + (-inf): no select for the compiler to branch on
+                        x[i] = fmaf(A.clip, fast_tanh(svv[i] + dflt), i2f(__builtin_amdgcn_sbfe((int)bits, i, 1) & (int)0xff800000u));
                 };
                 const int nblk = NP >> 8, tail = (NP & 255) ? 1 : 0;          // (NP = 64 NW: a last partial block of 64 / 128 / 192 nodes)
                 float mrun_l = ELG_NEG_INF, srun = 0.f;
