@@ -2456,61 +2456,12 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
             __syncthreads();
             ELG_STAMP(sc_, 5);
             // ================= owners: clip, mask, softmax, choice =================
-            auto choose = [&](bool dc, int q, size_t bmq, int sn, float addval, int& sl, float& pp) {
-                if (!dc) return;
-                unsigned long long mk[NCH];
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    const unsigned long long x = sMaskW[q * NCH + c];
-                    mk[c] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(x >> 32)) << 32) |
-                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)x);
-                }
-                float* srow = sSc + q * SP;
-                float s[NCH];
-#pragma unroll
-                for (int ch = 0; ch < NCH; ++ch) {
-                    const int n = lane + 64 * ch;
-                    s[ch] = (n < N1) ? srow[n] : 0.f;
-                }
-                wave_lds_fence();
-                ELG_STAMP(sc_, 11);
-                int fsel = 0;
-                if (A.forced && t < A.Tforced) fsel = __builtin_amdgcn_readfirstlane(A.forced[bmq * A.Tforced + t]);
-                float uni = 0.f;
-                if (A.mode == ELG_MODE_SAMPLE)
-                    uni = A.uniforms ? A.uniforms[bmq * A.Tmax + t] : philox_uniform(A.seed, (unsigned)bmq, (unsigned)t);
-                float* frow = (A.full_probs && t < A.dump_T) ? A.full_probs + (bmq * A.dump_T + t) * N1 : nullptr;
-                if (A.has_local && lane < ELG_SLOT_STRIDE) addval += sX[q * CO_XP + CO_XU + lane] * A.inv_ens;
-                // finish_step scatters through a node-indexed scratch row: the score row itself (the scores are in registers now)
-                // (TRAIN: the softmax x clip Jacobian row comes back in registers and is stored here -- finish_step's own row
-                // stores, inlined into this kernel, run into a code-generation error of the address-space cast of `srow`)
-                float pcj[NCH + 1];
-                const FwdOut fo = finish_step<NCH, TSP, false>(A, N1, lane, srow, mk, s, sn, addval, fsel, uni, frow, (size_t)b, 0, 0,
-                                                               TRAIN ? pcj : nullptr);
-                ELG_STAMP(sc_, 12);
-                if (TRAIN) {
-                    const size_t rrow = (size_t)b * Rcap + (size_t)t * A.M + m_base + q;
-                    float* rPC = A.trPC + rrow * N1;
-#pragma unroll
-                    for (int ch = 0; ch < NCH; ++ch) {
-                        const int n = lane + 64 * ch;
-                        if (n < N1) rPC[n] = pcj[ch];
-                    }
-                    if (lane == 0) A.trCsel[rrow] = pcj[NCH];
-                }
-                sl = __builtin_amdgcn_readfirstlane(fo.sel);
-                pp = i2f(__builtin_amdgcn_readfirstlane(f2i(fo.p)));
-            };
-            if constexpr (TRAIN) {
-#pragma unroll
-                for (int j = 0; j < NOWN; ++j) choose(dec[j], wave + 8 * j, bm[j], snid[j], addv[j], sel[j], pr[j]);
-            } else {
-                // Inference (round 4): ONE pass over the score row, 16 bytes per lane (lane l: nodes 256 c + 4 l .. + 3), the clipped
-                // logit x = clip tanh(s + xi | s + slot term) formed on the fly, per-lane online softmax (running maximum, sum of
-                // exp(x - max), first arg max), merged over the wave at the end.  The slot lanes put s + (penalty + local score)
+            {
+                // (round 4) ONE read of the score row, 16 bytes per lane (lane l: nodes 256 c + 4 l .. + 3): the clipped logits
+                // x = clip tanh(s + xi | s + slot term) of a trajectory stay in registers, from which the maximum, the first arg max, the
+                // normaliser and (training) the softmax x clip Jacobian row are taken.  The slot lanes put s + (penalty + local score)
                 // into the row themselves and flag the node in the slot words, so every value is the sum finish_step forms; the
-                // first maximum in node order wins (models.py:405-420).  Written in STAGES over the wave's trajectories: the phase
-                // is a chain of LDS round trips and wave reductions, and the trajectories' chains are independent.
+                // first maximum in node order wins (models.py:405-420).  Written in STAGES over the wave's trajectories.
                 int ln = lane;
                 asm volatile("" : "+v"(ln));
                 const float dflt = A.has_penalty ? A.xi : 0.f;
@@ -2535,6 +2486,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                 // as bit fields turned into 0 / -1 words (v_bfe_i32) -- no compare, no branch: a select on the closed bit invites the
                 // compiler to branch around the tanh per element
                 float xv[NOWN][NCH], mrun_l[NOWN];
+                float thv[NOWN][TRAIN ? NCH : 1];                               // tanh of the node's score: the training rows' clip Jacobian
                 float clipv = A.clip;
                 asm volatile("" : "+v"(clipv));                                 // (a vector register: the scalar one is spilled)
 #pragma unroll
@@ -2557,7 +2509,9 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                         for (int i = 0; i < 4; ++i) {
                             const int closed = __builtin_amdgcn_sbfe((int)mb, i, 1), slot = __builtin_amdgcn_sbfe((int)sbt, i, 1);     // 0 / -1
                             const float v = svv[i] + i2f(~slot & f2i(dflt));                  // s + xi, or the slot lanes' s + slot term
-                            const float x = fmaf(clipv, fast_tanh(v), i2f(closed & (int)0xff800000u));   // + (-inf) on a closed node
+                            const float th = fast_tanh(v);
+                            const float x = fmaf(clipv, th, i2f(closed & (int)0xff800000u));             // + (-inf) on a closed node
+                            if (TRAIN) thv[j][4 * c + i] = th;
                             xv[j][4 * c + i] = x;
                             mrun_l[j] = fmaxf(mrun_l[j], x);
                         }
@@ -2637,6 +2591,23 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                         }
                     }
                     sel[j] = s_;
+                    if (TRAIN) {
+                        // p[n] clip (1 - tanh^2): everything the backward needs of the clip / softmax Jacobian (row r = t M + m), and
+                        // the clip Jacobian at the chosen node
+                        const size_t rrow = (size_t)b * Rcap + (size_t)t * A.M + m_base + q;
+                        float* rPC = A.trPC + rrow * N1;
+#pragma unroll
+                        for (int c = 0; c < NCH / 4; ++c)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int n = 256 * c + 4 * ln + i;
+                                const float th = thv[j][4 * c + i];
+                                if (n < N1) rPC[n] = __expf(xv[j][4 * c + i] - gmx[j]) * inv * (A.clip * (1.f - th * th));
+                            }
+                        const bool sslot = (slw[s_ >> 6] >> (s_ & 63)) & 1ull;
+                        const float ths = fast_tanh(scr[s_] + (sslot ? 0.f : dflt));
+                        if (ln == 0) A.trCsel[rrow] = A.clip * (1.f - ths * ths);
+                    }
                 }
                 wave_lds_fence();
                 ELG_STAMP(sc_, 14);
