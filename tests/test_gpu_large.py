@@ -242,3 +242,47 @@ def test_greedy_without_probabilities_builds_the_same_tours(variant, precision):
     assert T == int(a.tlen.max()) and not zero
     with pytest.raises(ValueError):
         eng.rollout_forward(prob, pol, M, starts, L.MODE_SAMPLE, need_probs=False)
+
+
+@pytest.mark.parametrize("flags", [dict(ensemble=False), dict(distance_penalty=False), dict(ensemble=False, distance_penalty=False),
+                                   dict(euclidean=True)], ids=["no_local", "no_penalty", "neither", "euclidean"])
+@pytest.mark.parametrize("problem", ["cvrp", "tsp"])
+def test_streaming_kernel_ablation_flags_against_the_one_wavefront_kernel(problem, flags):
+    """model_params `ensemble` / `distance_penalty` / `euclidean` at N + 1 > 128 (reference models.py:355-413, TSP/models.py:
+    262-300): the streaming kernel's staged owners (slot blocks as walk scratch with the local policy, the wave's scratch
+    without it) and the N1 > 1024 kernel against the one-wavefront kernel -- whose flags are pinned on reference fixtures in
+    test_gpu_variants -- on its own greedy tours: scores before the clip and probabilities."""
+    gc, L, eng = _imports()
+    N, B, M = 150, 2, 20
+    kind = L.PROBLEM_CVRP if problem == "cvrp" else L.PROBLEM_TSP
+    if problem == "cvrp":
+        mp, cfg, xy, dem = _cvrp_case(N, B, 23)
+        P = gc.weights("cvrp", 23, mp, 1.0)
+        enc = orc.encoder_forward(P, cfg, xy, dem)
+        starts = torch.arange(1, M + 1, dtype=torch.int32)
+    else:
+        mp = dict(gu.TSP_MODEL_PARAMS)
+        cfg = orc.ModelCfg.from_model_params(mp, "tsp")
+        xy = torch.from_numpy(np.random.default_rng(23).random((B, N, 2), dtype=np.float32))
+        dem = None
+        P = gc.weights("tsp", 23, mp, 1.0)
+        enc = orc.encoder_forward(P, cfg, xy, None)
+        starts = torch.arange(M, dtype=torch.int32)
+    for k, v in flags.items():
+        setattr(cfg, k, v)
+    prob = gc.make_problem(xy, dem, kind)
+    pol = gc.make_policy(P, cfg, enc.to(gc.DEV), kind)
+    assert pol.has_local == bool(cfg.ensemble) and pol.has_penalty == bool(cfg.distance_penalty)
+    ref = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, variant=1)
+    T = int(ref.tlen.max())
+    for variant in (0, 3):
+        got = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, variant=variant)
+        assert torch.equal(got.actions, ref.actions), f"variant {variant}: other tours"
+        np.testing.assert_allclose(got.probs[:, :T].cpu().numpy(), ref.probs[:, :T].cpu().numpy(), rtol=5e-4, atol=1e-7)
+        for what in ("scores",):
+            a = eng.rollout_forward(prob, pol, M, starts, L.MODE_FORCED, forced=ref.actions, dump_T=T, variant=variant, dump=what).full_probs
+            b_ = eng.rollout_forward(prob, pol, M, starts, L.MODE_FORCED, forced=ref.actions, dump_T=T, variant=1, dump=what).full_probs
+            fin = torch.isfinite(b_)
+            assert torch.equal(fin, torch.isfinite(a))
+            err = float(((a - b_)[fin]).abs().max() / max(1.0, float(b_[fin].abs().max())))
+            assert err < 1e-4, (variant, what, err)
