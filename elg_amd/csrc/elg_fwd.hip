@@ -776,14 +776,19 @@ __device__ __forceinline__ void co_finish4(const elg_rollout_args& A, int N1, in
         int sn[3];
         float add[3], cur[3];
 #pragma unroll
-        for (int c3 = 0; c3 < 3; ++c3) {
+        for (int c3 = 0; c3 < 3; ++c3) {                 // (unconditional reads, selected afterwards: all 32 slot blocks exist)
             const int j = lo + 16 * c3;
-            const int code = qok ? reinterpret_cast<const int*>(X)[CO_XS + j] : -1;
+            const int code_r = reinterpret_cast<const int*>(X)[CO_XS + j];
+            const float add_r = X[CO_XPEN + j] + X[CO_XU + j] * A.inv_ens - dflt;
+            const int code = qok ? code_r : -1;
             sn[c3] = (code == -2) ? 0 : code;
-            add[c3] = qok ? X[CO_XPEN + j] + X[CO_XU + j] * A.inv_ens - dflt : 0.f;
+            add[c3] = qok ? add_r : 0.f;
         }
 #pragma unroll
-        for (int c3 = 0; c3 < 3; ++c3) cur[c3] = sn[c3] >= 0 ? sSc[q * CO_SP + sn[c3]] : 0.f;
+        for (int c3 = 0; c3 < 3; ++c3) {
+            const float c_r = sSc[q * CO_SP + max(sn[c3], 0)];
+            cur[c3] = sn[c3] >= 0 ? c_r : 0.f;
+        }
 #pragma unroll
         for (int c3 = 0; c3 < 3; ++c3)
             if (sn[c3] >= 0) sSc[q * CO_SP + sn[c3]] = cur[c3] + add[c3];
@@ -797,16 +802,25 @@ __device__ __forceinline__ void co_finish4(const elg_rollout_args& A, int N1, in
     const size_t r = (size_t)t * A.M + m;
     float e[NK], th[NK];
     float mx = ELG_NEG_INF;
+    {
+        // branch-free (round 4): the closed bit of node lo + 16 k as a 0 / -1 word (two 64-bit shifts per lane instead of seven;
+        // nodes past N1 are closed in the mask words), all score reads issued together, tanh for every lane and the closed ones
+        // masked afterwards -- `if (!masked)` around the LDS read + tanh chain was seven serialised divergent regions.  Same values
+        // for the open nodes; a closed node gets th = 0, x = -inf as before (whatever its score slot holds).
+        const unsigned long long x0 = w0 >> lo, x1 = w1 >> lo;
+        const int wd[4] = {(int)(unsigned)x0, (int)(unsigned)(x0 >> 32), (int)(unsigned)x1, (int)(unsigned)(x1 >> 32)};
+        float sv[NK];
 #pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        const int n = lo + 16 * k;
-        const unsigned long long w = (k < 4) ? w0 : w1;
-        const bool masked = (n >= N1) || ((w >> (n & 63)) & 1ull);
-        float x = ELG_NEG_INF;
-        th[k] = 0.f;
-        if (!masked) { th[k] = fast_tanh(sSc[q * CO_SP + n] + dflt); x = A.clip * th[k]; }
-        e[k] = x;
-        mx = fmaxf(mx, x);
+        for (int k = 0; k < NK; ++k) sv[k] = sSc[q * CO_SP + lo + 16 * k];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int closed = __builtin_amdgcn_sbfe(wd[k >> 1], 16 * (k & 1), 1);          // bit lo + 16 k of (w0, w1)
+            const float t = fast_tanh(sv[k] + dflt);
+            th[k] = i2f(f2i(t) & ~closed);
+            const float x = i2f((f2i(A.clip * t) & ~closed) | (closed & (int)0xff800000u));
+            e[k] = x;
+            mx = fmaxf(mx, x);
+        }
     }
     mx = row16_max(mx);
     float part = 0.f;
@@ -987,17 +1001,20 @@ __device__ __forceinline__ void co_advance4(const elg_rollout_args& A, const Ins
     const size_t r1 = (size_t)(t + 1) * A.M + m;
     const float lim = __fadd_rn(st.load, 1e-6f);
     unsigned long long w0 = 0ull, w1 = 0ull;
+    // (branch-free: the visited bits of the lane's seven nodes from two 64-bit shifts, the demands read up front -- a node past N1
+    // reads LDS behind the demand row and is closed whatever it finds; `nxt` implies the trajectory is not finished, so the
+    // finished-depot exception of build_mask() cannot apply here)
+    const unsigned long long y0 = st.v0 >> lo, y1 = st.v1 >> lo;
+    const unsigned vw[4] = {(unsigned)y0, (unsigned)(y0 >> 32), (unsigned)y1, (unsigned)(y1 >> 32)};
+    float dk[CO_NT];
+#pragma unroll
+    for (int k = 0; k < CO_NT; ++k) dk[k] = TSP ? 0.f : I.dem[lo + 16 * k];
 #pragma unroll
     for (int k = 0; k < CO_NT; ++k) {
         const int n = lo + 16 * k;
-        bool mm = true;
-        if (n < N1 && nxt) {
-            mm = ((k < 4 ? st.v0 : st.v1) >> (n & 63)) & 1ull;
-            if (!TSP) {
-                mm = mm || (lim < I.dem[n]);
-                if (n == 0 && st.fin) mm = false;
-            }
-        }
+        bool m1 = (vw[k >> 1] >> (16 * (k & 1))) & 1u;
+        if (!TSP) m1 = m1 || (lim < dk[k]);
+        const bool mm = !(n < N1 && nxt) || m1;
         // the glimpse takes the mask as the C operand of its S = K q^T MFMAs (0 for an open node, -inf for a closed one):
         // written into the trajectory's SCORE row, which is free from here until the pointer phase of the next step
         // refills it (one select + one LDS store per lane and chunk instead of three VALU per score in every head's wave)
@@ -1080,24 +1097,30 @@ __device__ __forceinline__ void co_advance4(const elg_rollout_args& A, const Ins
     for (int c3 = 0; c3 < 3; ++c3) {
         const int j = lo + 16 * c3;
         const bool cust = nxt && (j >= S0) && (j < S0 + kk);
-        float sd = 0.f, sth = 0.f;
-        int snid = -1;
-        if (cust) { sd = X[CO_XF + j]; sth = X[CO_XF + ELG_SLOT_STRIDE + j]; snid = Xi[CO_XS + j]; }
+        // (branch-free: the slot's three words are read whether or not the lane holds a customer and the quotients formed for every
+        // lane -- selected afterwards; three divergent regions with LDS reads and IEEE divisions inside serialised the slots)
+        const float sd_r = X[CO_XF + j], sth_r = X[CO_XF + ELG_SLOT_STRIDE + j];
+        const int snid_r = Xi[CO_XS + j];
+        const float sd = cust ? sd_r : 0.f, sth = cust ? sth_r : 0.f;
+        int snid = cust ? snid_r : -1;
         if (!TSP && j == 0 && nxt && (LEAN || A.has_penalty || A.has_local)) snid = 0;          // depot slot
         float pen = 0.f;
-        if ((LEAN || A.has_penalty) && cust) {
-            if (TSP) pen = -(sd / (dmax + 1e-6f));
-            else pen = (dmax != 0.f) ? -(sd / dmax) : -sd;
+        if (LEAN || A.has_penalty) {
+            float pq;
+            if (TSP) pq = -(sd / (dmax + 1e-6f));
+            else pq = (dmax != 0.f) ? -(sd / dmax) : -sd;
+            pen = cust ? pq : 0.f;
         }
         float f0 = 0.f, f1 = 0.f, f2 = 0.f;
-        if (cust) {
-            f0 = sd / nf;
-            f1 = sth;
+        {
+            const int sidx = cust ? snid_r : 0;                          // (a node of the instance whatever the slot holds)
+            float g0 = sd / nf, g1 = sth;
             if (!LEAN && A.euclidean) {                                 // models.py:95-125: relative (x, y) / norm
-                f0 = __fsub_rn(I.xy[2 * snid], st.cx) / nf;
-                f1 = __fsub_rn(I.xy[2 * snid + 1], st.cy) / nf;
+                g0 = __fsub_rn(I.xy[2 * sidx], st.cx) / nf;
+                g1 = __fsub_rn(I.xy[2 * sidx + 1], st.cy) / nf;
             }
-            if (!TSP) f2 = I.dem[snid] / st.load;
+            const float g2 = TSP ? 0.f : I.dem[sidx] / st.load;
+            f0 = cust ? g0 : 0.f; f1 = cust ? g1 : 0.f; f2 = cust ? g2 : 0.f;
         }
         bool smask = !cust;
         if (!TSP && j == 0) smask = depot_closed;
