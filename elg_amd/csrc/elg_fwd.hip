@@ -1058,7 +1058,10 @@ __device__ __forceinline__ void co_advance4(const elg_rollout_args& A, const Ins
     if (want_nbr) {
         // candidate flags, their in-row ranks (DPP scan) and the row totals of all seven chunks are independent of each other:
         // only the running offset `found` chains them (two integer adds per chunk)
-        int cI[CO_NT], inc[CO_NT], tot[CO_NT];
+        // (round 4: the in-row rank and the row total from ONE ballot per chunk -- the row's 16 bits of it, two population counts --
+        // instead of a DPP scan and a DPP all-reduce, 16 operations per chunk)
+        int cI[CO_NT], exc[CO_NT], tot[CO_NT];
+        const unsigned below = (1u << lo) - 1u;
 #pragma unroll
         for (int k = 0; k < CO_NT; ++k) {
             const int i = lo + 16 * k;
@@ -1067,17 +1070,15 @@ __device__ __forceinline__ void co_advance4(const elg_rollout_args& A, const Ins
             bool cand = valid && !(((nid < 64 ? w0 : w1) >> (nid & 63)) & 1ull);
             if (!TSP) cand = cand && (nid != 0);
             cI[k] = cand ? 1 : 0;
-            int sc_ = cI[k];
-            sc_ += dpp_i<0x111>(sc_); sc_ += dpp_i<0x112>(sc_); sc_ += dpp_i<0x114>(sc_); sc_ += dpp_i<0x118>(sc_);
-            inc[k] = sc_;
-            int tt = cI[k];
-            tt += dpp_i<0xB1>(tt); tt += dpp_i<0x4E>(tt); tt += dpp_i<0x141>(tt); tt += dpp_i<0x140>(tt);   // row all-reduce
-            tot[k] = tt;
+            const unsigned long long bal = __ballot(cand);
+            const unsigned rowbits = (unsigned)(bal >> (16 * tq)) & 0xFFFFu;
+            exc[k] = __popc(rowbits & below);
+            tot[k] = __popc(rowbits);
         }
         int found = 0;
 #pragma unroll
         for (int k = 0; k < CO_NT; ++k) {
-            const int rank = found + inc[k] - cI[k];
+            const int rank = found + exc[k];
             if (cI[k] && rank < A.K) {
                 X[CO_XF + S0 + rank] = nb_d[k];
                 X[CO_XF + ELG_SLOT_STRIDE + S0 + rank] = nb_th[k];
