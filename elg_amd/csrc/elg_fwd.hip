@@ -950,11 +950,13 @@ __device__ __forceinline__ void co_advance4(const elg_rollout_args& A, const Ins
     const bool want_nbr = LEAN || A.has_penalty || A.has_local;
     float4 q1a, q1c, q2a = make_float4(0.f, 0.f, 0.f, 0.f), q2c = q2a;
     {
-        const float* q1 = I.Q1 + (size_t)cur_n * ELG_E + 8 * lo;
+        // (32-bit element offsets from the instance's uniform bases: scalar base + vector offset addressing instead of a 64-bit
+        // multiply-add chain per load -- an instance's tables are far below 4 GB)
+        const float* q1 = I.Q1 + (unsigned)(cur_n * ELG_E + 8 * lo);
         q1a = *reinterpret_cast<const float4*>(q1);
         q1c = *reinterpret_cast<const float4*>(q1 + 4);
         if (TSP) {
-            const float* q2 = I.Q2 + (size_t)first_n * ELG_E + 8 * lo;
+            const float* q2 = I.Q2 + (unsigned)(first_n * ELG_E + 8 * lo);
             q2a = *reinterpret_cast<const float4*>(q2);
             q2c = *reinterpret_cast<const float4*>(q2 + 4);
         }
@@ -962,13 +964,13 @@ __device__ __forceinline__ void co_advance4(const elg_rollout_args& A, const Ins
     int nb_id[CO_NT];
     float nb_d[CO_NT], nb_th[CO_NT];
     if (want_nbr) {
-        const size_t row = (size_t)cur_n * N1;
+        const unsigned row = (unsigned)(cur_n * N1);
 #pragma unroll
         for (int k = 0; k < CO_NT; ++k) {
-            const int ic = min(lo + 16 * k, N1 - 1);
-            nb_id[k] = I.nidx[row + ic];
-            nb_d[k] = I.ndist[row + ic];
-            nb_th[k] = I.ntheta[row + ic];
+            const unsigned e = row + (unsigned)min(lo + 16 * k, N1 - 1);
+            nb_id[k] = I.nidx[e];
+            nb_d[k] = I.ndist[e];
+            nb_th[k] = I.ntheta[e];
         }
     } else {
 #pragma unroll
