@@ -539,6 +539,12 @@ struct StampCtx {};
 #ifndef ELG_CL_Q
 #define ELG_CL_Q 52
 #endif
+// load through a uniform base pointer + a 32-bit BYTE offset: base + zext(offset) is what the scalar-base + vector-offset form of
+// global_load takes; an ELEMENT offset (shifted left in 64 bits) costs a 64-bit shift-add per load
+template <typename T>
+__device__ __forceinline__ T ld_off(const void* base, unsigned byte_off) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
 constexpr int CO_QP = ELG_CO_QP;      // pitch of the query / glimpse-output exchange rows (conflict-free column reads)
 constexpr int CO_SP = ELG_CO_SP;      // pitch of the score exchange rows
 constexpr int CO_NT = 7;        // node tiles of 16
@@ -952,13 +958,13 @@ __device__ __forceinline__ void co_advance4(const elg_rollout_args& A, const Ins
     {
         // (32-bit element offsets from the instance's uniform bases: scalar base + vector offset addressing instead of a 64-bit
         // multiply-add chain per load -- an instance's tables are far below 4 GB)
-        const float* q1 = I.Q1 + (unsigned)(cur_n * ELG_E + 8 * lo);
-        q1a = *reinterpret_cast<const float4*>(q1);
-        q1c = *reinterpret_cast<const float4*>(q1 + 4);
+        const unsigned o1 = 4u * (unsigned)(cur_n * ELG_E + 8 * lo);
+        q1a = ld_off<float4>(I.Q1, o1);
+        q1c = ld_off<float4>(I.Q1, o1 + 16u);
         if (TSP) {
-            const float* q2 = I.Q2 + (unsigned)(first_n * ELG_E + 8 * lo);
-            q2a = *reinterpret_cast<const float4*>(q2);
-            q2c = *reinterpret_cast<const float4*>(q2 + 4);
+            const unsigned o2 = 4u * (unsigned)(first_n * ELG_E + 8 * lo);
+            q2a = ld_off<float4>(I.Q2, o2);
+            q2c = ld_off<float4>(I.Q2, o2 + 16u);
         }
     }
     int nb_id[CO_NT];
@@ -967,10 +973,10 @@ __device__ __forceinline__ void co_advance4(const elg_rollout_args& A, const Ins
         const unsigned row = (unsigned)(cur_n * N1);
 #pragma unroll
         for (int k = 0; k < CO_NT; ++k) {
-            const unsigned e = row + (unsigned)min(lo + 16 * k, N1 - 1);
-            nb_id[k] = I.nidx[e];
-            nb_d[k] = I.ndist[e];
-            nb_th[k] = I.ntheta[e];
+            const unsigned e = 4u * (row + (unsigned)min(lo + 16 * k, N1 - 1));
+            nb_id[k] = ld_off<int>(I.nidx, e);
+            nb_d[k] = ld_off<float>(I.ndist, e);
+            nb_th[k] = ld_off<float>(I.ntheta, e);
         }
     } else {
 #pragma unroll
@@ -1206,12 +1212,12 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
         {   /* one 16-byte load: channels 4 hi .. 4 hi + 3 (the MFMA visits the 16 channels in the order 4 hi + kk) */ \
             /* rows past N1 re-read row N1 - 1 (finite): their nodes are closed in every mask, so S is replaced by -inf */ \
             /* and the weight that multiplies the V row is exactly 0 -- no zeroing of the operands needed              */ \
-            const float4 k4_ = *reinterpret_cast<const float4*>(gK + (unsigned)(min(n, N1 - 1) * ELG_E + 4 * hi_t));   \
+            const float4 k4_ = ld_off<float4>(gK, 4u * (unsigned)(min(n, N1 - 1) * ELG_E + 4 * hi_t));                     \
             kop[nt][0] = k4_.x; kop[nt][1] = k4_.y; kop[nt][2] = k4_.z; kop[nt][3] = k4_.w;                 \
         }                                                                                                   \
         _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                                     \
             const int n2 = 16 * nt + 4 * hi_t + v;                                                          \
-            vop[nt][v] = gV[(unsigned)(min(n2, N1 - 1) * ELG_E + lo_t)];                                    \
+            vop[nt][v] = ld_off<float>(gV, 4u * (unsigned)(min(n2, N1 - 1) * ELG_E + lo_t));                               \
         }                                                                                                   \
     }
     // bf16 mode: kopb[nt] = K[n = 16 nt + lo][16 h + 4 hi + j], j < 4, in k-slots (hi, 0..3); k-slots (hi, 4..7) are zero (the head
@@ -1221,14 +1227,14 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
 #define ELG_CO_LOAD_KV_BF()                                                                                 \
     _Pragma("unroll") for (int nt = 0; nt < CO_NT; ++nt) {                                                  \
         const int n = 16 * nt + lo_t;                                                                       \
-        const float4 k4_ = *reinterpret_cast<const float4*>(gK + (unsigned)(min(n, N1 - 1) * ELG_E + 4 * hi_t));   \
+        const float4 k4_ = ld_off<float4>(gK, 4u * (unsigned)(min(n, N1 - 1) * ELG_E + 4 * hi_t));                     \
         kopb[nt] = u32x4{pk_bf16(k4_.x, k4_.y), pk_bf16(k4_.z, k4_.w), 0u, 0u};                             \
     }                                                                                                       \
     _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                                         \
         float va_[4], vb_[4];                                                                               \
         _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                                     \
-            va_[v] = gV[(unsigned)(min(32 * p + 4 * hi_t + v, N1 - 1) * ELG_E + lo_t)];                     \
-            vb_[v] = gV[(unsigned)(min(32 * p + 16 + 4 * hi_t + v, N1 - 1) * ELG_E + lo_t)];                \
+            va_[v] = ld_off<float>(gV, 4u * (unsigned)(min(32 * p + 4 * hi_t + v, N1 - 1) * ELG_E + lo_t));                \
+            vb_[v] = ld_off<float>(gV, 4u * (unsigned)(min(32 * p + 16 + 4 * hi_t + v, N1 - 1) * ELG_E + lo_t));                \
         }                                                                                                   \
         vopb[p] = u32x4{pk_bf16(va_[0], va_[1]), pk_bf16(va_[2], va_[3]), pk_bf16(vb_[0], vb_[1]), pk_bf16(vb_[2], vb_[3])}; \
     }
