@@ -2122,11 +2122,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                         if (!go[j]) continue;
                         const int k = found[j] < A.K ? found[j] : A.K;
                         cust[j] = (ln >= S0) && (ln < S0 + k);
-                        {   // (unconditional reads, selected afterwards: lanes 48 .. 63 read the next region of the block / scratch)
-                            const float sd_r = lds[W[j] + oD + ln], sth_r = lds[W[j] + oT + ln];
-                            const int sn_r = reinterpret_cast<const int*>(lds)[W[j] + oN + ln];
-                            sd[j] = cust[j] ? sd_r : 0.f; sth[j] = cust[j] ? sth_r : 0.f; snid[j] = cust[j] ? sn_r : snid[j];
-                        }
+                        if (cust[j]) { sd[j] = lds[W[j] + oD + ln]; sth[j] = lds[W[j] + oT + ln]; snid[j] = reinterpret_cast<const int*>(lds)[W[j] + oN + ln]; }
                         if (k > 0) dmax[j] = lds[W[j] + oD + S0 + k - 1];
                     }
                     wave_lds_fence();
@@ -2135,28 +2131,21 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
                         if (!go[j]) continue;
                         const int q = wave + 8 * j;
                         if (!TSP && ln == 0) snid[j] = 0;                                 // depot slot
-                        // (the quotients are formed for every lane and selected afterwards: IEEE divisions inside divergent regions
-                        // serialised the wave's trajectories)
                         float pen = 0.f;
-                        if (A.has_penalty) {
-                            float pq;
-                            if (TSP) pq = -(sd[j] / (dmax[j] + 1e-6f));                   // TSP/models.py:290
-                            else pq = (dmax[j] != 0.f) ? -(sd[j] / dmax[j]) : -sd[j];     // models.py:379-405 (no epsilon)
-                            pen = cust[j] ? pq : 0.f;
+                        if (A.has_penalty && cust[j]) {
+                            if (TSP) pen = -(sd[j] / (dmax[j] + 1e-6f));                  // TSP/models.py:290
+                            else pen = (dmax[j] != 0.f) ? -(sd[j] / dmax[j]) : -sd[j];    // models.py:379-405 (no epsilon)
                         }
                         addv[j] = pen;
                         const float nf = dmax[j] + 1e-6f;                                 // models.py:79 / TSP :72
                         float f0 = 0.f, f1 = 0.f, f2 = 0.f;
-                        {
-                            const int sidx = cust[j] ? snid[j] : 0;                       // a node of the instance for every lane
-                            float g0, g1;
+                        if (cust[j]) {
                             if (A.euclidean) {                                            // models.py:95-125: relative (x, y) / norm
                                 const float cx = I.xy[2 * st[j].cur], cy = I.xy[2 * st[j].cur + 1];
-                                g0 = __fsub_rn(I.xy[2 * sidx], cx) / nf;
-                                g1 = __fsub_rn(I.xy[2 * sidx + 1], cy) / nf;
-                            } else { g0 = sd[j] / nf; g1 = sth[j]; }
-                            const float g2 = TSP ? 0.f : sdem[sidx] / st[j].load;         // CVRPEnv.py:315-316
-                            f0 = cust[j] ? g0 : 0.f; f1 = cust[j] ? g1 : 0.f; f2 = cust[j] ? g2 : 0.f;
+                                f0 = __fsub_rn(I.xy[2 * snid[j]], cx) / nf;
+                                f1 = __fsub_rn(I.xy[2 * snid[j] + 1], cy) / nf;
+                            } else { f0 = sd[j] / nf; f1 = sth[j]; }
+                            if (!TSP) f2 = sdem[snid[j]] / st[j].load;                    // CVRPEnv.py:315-316
                         }
                         bool smask = !cust[j];
                         if (!TSP && ln == 0) smask = mk0[j] & 1u;                         // depot slot carries the depot's mask
