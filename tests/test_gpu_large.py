@@ -286,3 +286,78 @@ def test_streaming_kernel_ablation_flags_against_the_one_wavefront_kernel(proble
             assert torch.equal(fin, torch.isfinite(a))
             err = float(((a - b_)[fin]).abs().max() / max(1.0, float(b_[fin].abs().max())))
             assert err < 1e-4, (variant, what, err)
+
+
+@pytest.mark.parametrize("problem,N1", [("cvrp", 129), ("cvrp", 193), ("cvrp", 256), ("cvrp", 257), ("cvrp", 512), ("cvrp", 513), ("cvrp", 1024),
+                                        ("tsp", 129), ("tsp", 256), ("tsp", 257), ("tsp", 512), ("tsp", 513), ("tsp", 1024)])
+def test_streaming_kernel_at_the_chunk_boundaries(problem, N1):
+    """Node counts at the edges of the streaming kernel's 4 / 8 / 16 mask-word instantiations (N1 = 64 k, 64 k + 1): the word-based
+    mask build (tail bits of the last word, nodes past N1), the 256-node blocks of the choice pass and the 16 / 32 trajectories
+    per workgroup against the one-wavefront kernel -- greedy tours, chosen probabilities, rewards.  (Random encodings: the
+    decoder's arithmetic does not care where they come from.)"""
+    gc, L, eng = _imports()
+    kind = L.PROBLEM_CVRP if problem == "cvrp" else L.PROBLEM_TSP
+    B, M = 2, 40                                              # 40 trajectories: 3 workgroups of 16, or 2 of 32 in the wide configuration
+    g = torch.Generator().manual_seed(1000 + N1)
+    xy = torch.rand(B, N1, 2, generator=g)
+    if problem == "cvrp":
+        mp = dict(gu.CVRP_MODEL_PARAMS)
+        dem = torch.randint(1, 10, (B, N1), generator=g).float() / 60.0
+        dem[:, 0] = 0.0
+        P = gc.weights("cvrp", 3, mp, 1.0)
+        starts = torch.arange(1, M + 1, dtype=torch.int32)
+    else:
+        mp = dict(gu.TSP_MODEL_PARAMS)
+        dem = None
+        P = gc.weights("tsp", 3, mp, 1.0)
+        starts = torch.arange(M, dtype=torch.int32)
+    cfg = orc.ModelCfg.from_model_params(mp, problem)
+    enc = 0.3 * torch.randn(B, N1, 128, generator=g)
+    prob = gc.make_problem(xy, dem, kind)
+    pol = gc.make_policy(P, cfg, enc.to(gc.DEV), kind)
+    ref = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, variant=1)
+    T = int(ref.tlen.max())
+    got = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, variant=0)
+    assert torch.equal(got.tlen, ref.tlen)
+    same = (got.actions == ref.actions).all(dim=2)            # (near-ties of two logits may fork a greedy tour: compare what did not fork)
+    assert same.float().mean().item() >= 0.9, f"{(~same).sum().item()} of {same.numel()} tours differ"
+    gp, rp = got.probs[:, :T].permute(0, 2, 1)[same].cpu().numpy(), ref.probs[:, :T].permute(0, 2, 1)[same].cpu().numpy()
+    np.testing.assert_allclose(gp, rp, rtol=2e-3, atol=1e-7)
+    np.testing.assert_allclose(got.reward[same].cpu().numpy(), ref.reward[same].cpu().numpy(), rtol=1e-6)
+    nop = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, variant=0, need_probs=False)
+    assert torch.equal(nop.actions, got.actions)
+
+
+@pytest.mark.parametrize("problem,N1", [("cvrp", 1025), ("cvrp", 1089), ("cvrp", 2049), ("tsp", 1025), ("tsp", 1345)])
+def test_matrix_core_xl_kernel_at_the_chunk_boundaries(problem, N1):
+    """The N1 > 1024 kernel (rollout_fwd_xm_kernel: runtime chunk loops, two mask words per lane, 256-node blocks with a partial
+    last block) against the one-wavefront N1 > 1024 kernel (variant 2) just past the streaming kernel's range and at word counts
+    that are not multiples of four: greedy tours that did not fork, chosen probabilities, rewards."""
+    gc, L, eng = _imports()
+    kind = L.PROBLEM_CVRP if problem == "cvrp" else L.PROBLEM_TSP
+    B, M = 1, 24
+    g = torch.Generator().manual_seed(2000 + N1)
+    xy = torch.rand(B, N1, 2, generator=g)
+    if problem == "cvrp":
+        mp = dict(gu.CVRP_MODEL_PARAMS)
+        dem = torch.randint(1, 10, (B, N1), generator=g).float() / 200.0
+        dem[:, 0] = 0.0
+        P = gc.weights("cvrp", 3, mp, 1.0)
+        starts = torch.arange(1, M + 1, dtype=torch.int32)
+    else:
+        mp = dict(gu.TSP_MODEL_PARAMS)
+        dem = None
+        P = gc.weights("tsp", 3, mp, 1.0)
+        starts = torch.arange(M, dtype=torch.int32)
+    cfg = orc.ModelCfg.from_model_params(mp, problem)
+    enc = 0.3 * torch.randn(B, N1, 128, generator=g)
+    prob = gc.make_problem(xy, dem, kind)
+    pol = gc.make_policy(P, cfg, enc.to(gc.DEV), kind)
+    ref = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, variant=2)
+    got = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, variant=0)
+    T = int(ref.tlen.max())
+    same = (got.actions == ref.actions).all(dim=2)
+    assert same.float().mean().item() >= 0.8, f"{(~same).sum().item()} of {same.numel()} tours differ"
+    gp, rp = got.probs[:, :T].permute(0, 2, 1)[same].cpu().numpy(), ref.probs[:, :T].permute(0, 2, 1)[same].cpu().numpy()
+    np.testing.assert_allclose(gp, rp, rtol=4e-3, atol=1e-7)
+    np.testing.assert_allclose(got.reward[same].cpu().numpy(), ref.reward[same].cpu().numpy(), rtol=1e-6)
