@@ -17,19 +17,13 @@
 // the B operand of O^T = V^T P^T (online softmax over chunks of 128 keys, any N1).  Its backward (N1 <= 128) keeps
 // Q, K, V, dO of the (instance, head) in LDS and forms the score tile in both orientations, so that dQ (rows on lanes)
 // and dK / dV (keys on lanes) each accumulate in registers of the wave that owns them: no atomics, no transposes.
-#include "elg_common.h"
-#include "../../include/elg_hip.h"
-#include <string>
+#include "elg_enc_internal.h"
 
 extern "C" __attribute__((visibility("hidden"))) int elg_gemm_f32_alpha(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
                                   int ldb, int ldc, int transA, int transB, int relu, int split_k, float* a_rowsum,
                                   float alpha, void* stream);
 
 namespace elg {
-int fail(int code, const std::string& msg);
-int launch_status(const char* what);
-
-using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 enum { EPI_STORE = 0, EPI_RELU = 1, EPI_NORM = 2, EPI_ADD = 3, EPI_RELUMASK = 4, EPI_ADDBIAS = 5, EPI_ADD_NORMBWD = 6 };
 enum { W_NK = 0, W_KN = 1, W_NK_SCALAR = 2 };
@@ -820,15 +814,6 @@ __global__ __launch_bounds__(256) void enc_attn_bwd_large_kernel(const float* __
 // 64 x 64 block of dW as 2 x 2 MFMA tiles (rows / columns interleaved by two), a workgroup 128 x 128, and the row range is
 // split over gridDim.y workgroups that accumulate with f32 atomics (the per-layer split-K GEMMs this replaces issued ~4x
 // more atomics and ran 40 launches of ~22 us).
-struct DwJob {
-    const float* dY; const float* X; float* dW; float* db;
-    int ldy, ldx, ldw, M, N, tile0; float alpha;
-};
-constexpr int DW_MAX_JOBS = 48;
-struct DwBatch {
-    DwJob job[DW_MAX_JOBS];
-    int njobs, ntiles, rows, rows_per_split;
-};
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 __global__ __launch_bounds__(256) void enc_dw_kernel(const DwBatch bt) {
@@ -910,52 +895,43 @@ __global__ __launch_bounds__(256) void enc_dw_kernel(const DwBatch bt) {
     }
 }
 
-struct DwList {
-    DwBatch bt;
-    long rows;
-    hipStream_t s;
-    DwList(long rows_, hipStream_t s_) : rows(rows_), s(s_) { bt.njobs = 0; bt.ntiles = 0; }
-    int add(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, int M, int N, float* db, float alpha) {
-        if (bt.njobs >= DW_MAX_JOBS) {
-            const int rc = launch();
-            if (rc != ELG_OK) return rc;
-        }
-        if ((M & 127) || (N & 127) || (ldy & 1) || (ldx & 1)) return fail(ELG_EINVAL, "encoder bwd: dW shapes must be multiples of 128");
-        DwJob& j = bt.job[bt.njobs++];
-        j.dY = dY; j.X = X; j.dW = dW; j.db = db; j.ldy = ldy; j.ldx = ldx; j.ldw = ldw; j.M = M; j.N = N; j.alpha = alpha;
-        j.tile0 = bt.ntiles;
-        bt.ntiles += (M >> 7) * (N >> 7);
-        return ELG_OK;
+int DwList::add(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, int M, int N, float* db, float alpha) {
+    if (bt.njobs >= DW_MAX_JOBS) {
+        const int rc = launch();
+        if (rc != ELG_OK) return rc;
     }
-    int launch() {
-        if (bt.njobs == 0) return ELG_OK;
-        // row split: ~4 workgroups per CU overall (measured at the bench shape: 2048 workgroups 306 us, 1024 271 us, 512 281 us,
-        // 256 301 us), at least 128 rows each
-        int splits = (int)max(1L, min(rows / 128, (long)((1024 + bt.ntiles - 1) / bt.ntiles)));
-        int rps = (int)((rows + splits - 1) / splits);
-        rps = (rps + 15) / 16 * 16;
-        splits = (int)((rows + rps - 1) / rps);
-        bt.rows = (int)rows; bt.rows_per_split = rps;
-        (void)hipGetLastError();
-        hipLaunchKernelGGL(enc_dw_kernel, dim3(bt.ntiles, splits), dim3(256), 0, s, bt);
-        bt.njobs = 0; bt.ntiles = 0;
-        return launch_status("enc_dw");
-    }
-};
+    if ((M & 127) || (N & 127) || (ldy & 1) || (ldx & 1)) return fail(ELG_EINVAL, "encoder bwd: dW shapes must be multiples of 128");
+    DwJob& j = bt.job[bt.njobs++];
+    j.dY = dY; j.X = X; j.dW = dW; j.db = db; j.ldy = ldy; j.ldx = ldx; j.ldw = ldw; j.M = M; j.N = N; j.alpha = alpha;
+    j.tile0 = bt.ntiles;
+    bt.ntiles += (M >> 7) * (N >> 7);
+    return ELG_OK;
+}
+int DwList::launch() {
+    if (bt.njobs == 0) return ELG_OK;
+    // row split: ~4 workgroups per CU overall (measured at the bench shape: 2048 workgroups 306 us, 1024 271 us, 512 281 us,
+    // 256 301 us), at least 128 rows each
+    int splits = (int)max(1L, min(rows / 128, (long)((1024 + bt.ntiles - 1) / bt.ntiles)));
+    int rps = (int)((rows + splits - 1) / splits);
+    rps = (rps + 15) / 16 * 16;
+    splits = (int)((rows + rps - 1) / rps);
+    bt.rows = (int)rows; bt.rows_per_split = rps;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(enc_dw_kernel, dim3(bt.ntiles, splits), dim3(256), 0, s, bt);
+    bt.njobs = 0; bt.ntiles = 0;
+    return launch_status("enc_dw");
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // workspace layout (floats)
-struct EncWs {
-    long R, X0, tmp, layer0, layer_stride;
-    long oQKV, oO, oLSE, oXH1, oRS1, oX1, oH, oXH2, oRS2, oXout, total;
-};
-static EncWs enc_ws(int B, int N1, int n_layers, int ff, int save) {
+EncWs enc_ws(int B, int N1, int n_layers, int ff, int save) {
     EncWs w;
     if (n_layers == 0) { w = EncWs{}; w.R = (long)B * N1; return w; }
     w.R = (long)B * N1;
     long o = 0;
     w.X0 = o; o += w.R * ELG_E;
     w.tmp = o; o += w.R * ELG_E;
+    w.P = o; o += (N1 <= 128) ? w.R * ELG_E * (ff >> 7) : 0;        // FFN2 partial sums of the fused path (one per hidden slice)
     w.layer0 = o;
     long p = 0;
     w.oQKV = p; p += w.R * 3 * ELG_E;
@@ -971,6 +947,33 @@ static EncWs enc_ws(int B, int N1, int n_layers, int ff, int save) {
     w.layer_stride = save ? p : 0;
     w.total = w.layer0 + (save ? p * n_layers : p);
     return w;
+}
+
+EncWs2 enc_ws2(int B, int N1, int n_layers, int ff) {
+    EncWs2 w{};
+    w.R = (long)B * N1;
+    long o = 0;
+    w.gX = o; o += w.R * ELG_E;
+    w.gO = o; o += w.R * ELG_E;
+    w.gT = o; o += w.R * ELG_E;
+    w.lay0 = o; w.lay_stride = w.R * (5 * ELG_E + ff); o += w.lay_stride * n_layers;
+    w.delta = o; o += (N1 > 128) ? (long)B * 8 * N1 : 0;
+    if (N1 <= 128) {
+        w.PX = o; o += ENC_PX * w.R * ELG_E;
+        w.P1 = o; o += (long)(ff >> 7) * w.R * ELG_E;
+        w.WT = o; w.wt_stride = 4L * ELG_E * ELG_E + 2L * ELG_E * ff; o += w.wt_stride * n_layers;
+    }
+    w.total = o;
+    return w;
+}
+
+int launch_fold_small_bwd(const float* enc, const float* gpb, const float* gwl, float* gbc, float* gWq_last, long rows, float scale,
+                          hipStream_t s) {
+    const int rpb = 64;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(enc_fold_small_bwd_kernel, dim3(gpb ? (unsigned)((rows + rpb - 1) / rpb) : 1u), dim3(512), 0, s, enc, gpb, gwl, gbc,
+                       gWq_last, rows, rpb, scale);
+    return launch_status("enc_fold_small_bwd");
 }
 
 static EncGemm gemm_base(const float* A, int lda, int N, int K, long rows, int N1, bool aligned) {
@@ -999,8 +1002,8 @@ extern "C" int64_t elg_encoder_ws_floats(int B, int N1, int n_layers, int ff_hid
 extern "C" int64_t elg_encoder_bwd_ws_floats(int B, int N1, int n_layers, int ff_hidden) {
     if (B <= 0 || N1 <= 0 || n_layers <= 0 || ff_hidden <= 0) return 0;
     // d x / d att / d x1 (shared) + per layer: dS2, dH, dS1, dQKV (kept until the grouped weight-gradient launch)
-    // + delta[b, h, n] of the N1 > 128 attention backward
-    return (int64_t)B * N1 * (3 * ELG_E + (int64_t)n_layers * (5 * ELG_E + ff_hidden)) + (N1 > 128 ? (int64_t)B * 8 * N1 : 0);
+    // + delta[b, h, n] of the N1 > 128 attention backward | the fused path's partial sums and transposed weights
+    return enc_ws2(B, N1, n_layers, ff_hidden).total;
 }
 
 static int check_enc_args(const elg_encoder_args* a) {
@@ -1033,6 +1036,7 @@ extern "C" int elg_encoder_fwd(const elg_encoder_args* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const int B = a->B, N1 = a->N1, FF = a->ff_hidden;
     const bool tsp = a->problem == ELG_PROBLEM_TSP;
+    if (enc_fused_ok(a)) return enc_fused_fwd(a, s);
     const EncWs w = enc_ws(B, N1, a->n_layers, FF, a->save);
     const long R = w.R;
     const bool aligned = N1 <= 128;
@@ -1137,18 +1141,20 @@ extern "C" int elg_encoder_bwd(const elg_encoder_bwd_args* ba, void* stream) {
     const long R = w.R;
     if (!ba->ws2 || ba->ws2_floats < elg_encoder_bwd_ws_floats(B, N1, a->n_layers, FF)) return fail(ELG_EINVAL, "encoder bwd: scratch too small");
     const elg_enc_weights& G = ba->G;
-    float* gX = ba->ws2;
-    float* gO = gX + R * ELG_E;
-    float* gT = gO + R * ELG_E;
-    float* lay2 = gT + R * ELG_E;
-    const long lay2_stride = R * (5 * ELG_E + FF);
+    const EncWs2 w2 = enc_ws2(B, N1, a->n_layers, FF);
+    float* gX = ba->ws2 + w2.gX;
+    float* gO = ba->ws2 + w2.gO;
+    float* gT = ba->ws2 + w2.gT;
+    float* lay2 = ba->ws2 + w2.lay0;
+    const long lay2_stride = w2.lay_stride;
     float* ws = a->ws;
     DwList dw(R, s);
+    if (enc_fused_ok(a)) return enc_fused_bwd(ba, dw, s);
     const float inv_sqrt_e = 0.08838834764831845f;
     // N1 <= 128: row block = instance, the norm backwards ride in GEMM epilogues.  N1 > 128: 128-row blocks, the add & norm
     // backwards are the stand-alone kernel (per (instance, channel) over the node axis), attention backward from global memory
     const bool aligned = N1 <= 128;
-    float* delta = lay2 + lay2_stride * a->n_layers;
+    float* delta = ba->ws2 + w2.delta;
     // ---- d enc from the decoder tables (autograd of set_kv / fold_decoder_tables)
     bool have = false;          // gX holds a value
     if (ba->g_enc) {
@@ -1204,11 +1210,7 @@ extern "C" int elg_encoder_bwd(const elg_encoder_bwd_args* ba, void* stream) {
     } else if (ba->gpb) return fail(ELG_EINVAL, "encoder bwd: gpb without gPK");
     if (ba->gpb || (ba->gwl && !tsp)) {
         if (ba->gpb) ENC_TRY(need(G.dec_bc, "d bc"))
-        const int rpb = 64;
-        (void)hipGetLastError();
-        hipLaunchKernelGGL(enc_fold_small_bwd_kernel, dim3(ba->gpb ? (unsigned)((R + rpb - 1) / rpb) : 1u), dim3(512), 0, s, a->enc,
-                           ba->gpb, tsp ? nullptr : ba->gwl, (float*)G.dec_bc, (float*)G.dec_Wq_last, R, rpb, inv_sqrt_e);
-        ENC_TRY(launch_status("enc_fold_small_bwd"))
+        ENC_TRY(launch_fold_small_bwd(a->enc, ba->gpb, tsp ? nullptr : ba->gwl, (float*)G.dec_bc, (float*)G.dec_Wq_last, R, inv_sqrt_e, s))
     }
     if (!have) return fail(ELG_EINVAL, "encoder bwd: no cotangent given");
     // ---- layers, last to first
