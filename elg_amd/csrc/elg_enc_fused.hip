@@ -156,28 +156,47 @@ __device__ __forceinline__ void colsum_get(float4 (&r)[8], const float* stat, in
     }
 }
 
-// sum of np partial buffers (pstride floats apart) at the lane's 8 fragments, added to acc.  All loads of up to four partials
-// are in flight together (a loop over a runtime np that waits per partial cost one exposed round trip each), and the S
-// workgroups of an instance walk the buffers in ROTATED order (`rot` = the workgroup's part index): they run at the same time
-// on one XCD and ask for the same lines -- in the same order all of them wait on the same ~64 outstanding misses per CU
-// (measured: 260 KB per workgroup arrived at 8 B/clk, a 36 K-cycle prologue); rotated, each is the first toucher of a quarter
-// and finds the rest in L2.  (The order of the f32 adds then differs between the parts of an instance by design: the
-// activation they each form agrees to rounding, ~1e-7 relative.)
-__device__ __forceinline__ void add_partials(float4 (&acc)[8], const float* P, const long pstride, const int np, const size_t off,
-                                             const int rot) {
+// ---- activation tiles come from memory in LOAD layout and are turned into the MFMA fragment layout through LDS.
+// Measured (tools/_bench/ldbench.hip): a CU's vector-memory path delivers cache LINES, not bytes -- ~7 cycles per 128-byte line
+// touched when the line is in L2, ~14 when it comes from the memory side (everything another kernel has just written), whatever
+// the lanes use of it.  The fragment map (lane (lo, hi): row lo, 16 bytes at column 16 t + 4 hi) touches 16 half lines per
+// instruction, i.e. every line of the tile twice: 5 - 7 tiles per prologue cost 35 - 42 K cycles in the first version, more than
+// the kernels' MFMA time.  Load layout: instruction t, lane l: row 2 t + (l >> 5), 16 bytes at column 4 (l & 31) -- two whole
+// rows = 8 whole lines per instruction.  Sums of tiles (partials + residual + bias) are formed in load layout (element-wise), then
+// ONE pass through a wave-private LDS buffer (16 x TP floats, written as rows, read back as fragments) re-maps the result.
+constexpr int TP = 136;             // row pitch of the transpose buffer (= 8 mod 64: conflict-free fragment reads)
+constexpr int TBUF = 16 * TP;       // floats per wave
+
+struct TileAddr {                   // per-lane element offsets of the 8 load-layout slots of the wave's tile (rows past N1 clamped)
+    size_t off[8];
+};
+__device__ __forceinline__ TileAddr tile_addr(const int b, const int N1, const int wave, const int lane, const int ld) {
+    TileAddr a;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int r = min(16 * wave + 2 * t + (lane >> 5), N1 - 1);
+        a.off[t] = ((size_t)b * N1 + r) * ld + 4 * (lane & 31);
+    }
+    return a;
+}
+__device__ __forceinline__ void tile_ld(float4 (&v)[8], const float* src, const TileAddr& a) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t] = ld4(src + a.off[t]);
+}
+__device__ __forceinline__ void tile_add(float4 (&acc)[8], const float4 (&v)[8]) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = add4(acc[t], v[t]);
+}
+// acc += sum of np tiles pstride floats apart; up to four in flight together (a loop that waits per tile costs one exposed round
+// trip each); slots past np re-read the last tile with weight 0
+__device__ __forceinline__ void tile_add_partials(float4 (&acc)[8], const float* P, const long pstride, const int np, const TileAddr& a) {
     for (int q0 = 0; q0 < np; q0 += 4) {
         float4 v[4][8];
-        const int nq = min(4, np - q0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tile_ld(v[j], P + (size_t)min(q0 + j, np - 1) * pstride, a);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int q = (j < nq) ? (j + rot) % nq : nq - 1;        // slots past np re-read a buffer with weight 0
-            const float* p = P + (size_t)(q0 + q) * pstride + off;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) v[j][t] = ld4(p + 16 * t);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float wq = j < nq ? 1.f : 0.f;
+            const float wq = q0 + j < np ? 1.f : 0.f;
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 acc[t].x = fmaf(wq, v[j][t].x, acc[t].x); acc[t].y = fmaf(wq, v[j][t].y, acc[t].y);
@@ -185,6 +204,15 @@ __device__ __forceinline__ void add_partials(float4 (&acc)[8], const float* P, c
             }
         }
     }
+}
+// load layout -> fragment layout (x[t] = row lo, columns 16 t + 4 hi ..) through the wave's own buffer sT
+__device__ __forceinline__ void to_frag(const float4 (&v)[8], float4 (&x)[8], float* sT, const int lane, const int lo, const int hi) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) st4(sT + (2 * t + (lane >> 5)) * TP + 4 * (lane & 31), v[t]);
+    wave_lds_fence();
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = ld4(sT + lo * TP + 16 * t + 4 * hi);
+    wave_lds_fence();
 }
 // 1 / sqrt(v): v_rsq_f32 (1 ulp) -- the per-channel statistics are recomputed by every lane that holds the channel, and the
 // correctly rounded sqrt + division sequences were ~700 VALU instructions per lane and norm
@@ -211,10 +239,11 @@ struct EncPro {
 };
 
 // all waves of the workgroup call this (it contains barriers); `stat` = 2 x 8 x 128 floats of LDS
-__device__ __forceinline__ void enc_prologue(const EncPro& p, float4 (&x)[8], float* stat, const int b, const int N1, const int rot,
-                                             const int wave, const int lo, const int hi, const bool act, const int nact) {
+__device__ __forceinline__ void enc_prologue(const EncPro& p, float4 (&x)[8], float* stat, float* sT, const int b, const int N1,
+                                             const bool writer, const int wave, const int lane, const bool act, const int nact) {
+    const int lo = lane & 15, hi = lane >> 4;
     const int row = 16 * wave + lo;
-    const bool rvalid = row < N1, writer = rot == 0;
+    const bool rvalid = row < N1;
     const size_t grow = (size_t)b * N1 + min(row, N1 - 1);
     if (p.mode != 1) {
         if (!act) return;
@@ -251,8 +280,9 @@ __device__ __forceinline__ void enc_prologue(const EncPro& p, float4 (&x)[8], fl
                 x[t] = make_float4(o[0], o[1], o[2], o[3]);
             }
         } else {
-#pragma unroll
-            for (int t = 0; t < 8; ++t) x[t] = ld4(p.xout + grow * ELG_E + 16 * t + 4 * hi);
+            float4 v[8];
+            tile_ld(v, p.xout, tile_addr(b, N1, wave, lane, ELG_E));
+            to_frag(v, x, sT, lane, lo, hi);
             return;                                        // (mode 2: xout is the INPUT, nothing to write)
         }
         if (writer && rvalid && p.xout) {
@@ -263,9 +293,16 @@ __device__ __forceinline__ void enc_prologue(const EncPro& p, float4 (&x)[8], fl
     }
     float4 s[8];
     if (act) {
+        {
+            const TileAddr ta = tile_addr(b, N1, wave, lane, ELG_E);
+            float4 v[8];
+            tile_ld(v, p.res, ta);
+            const float4 bb = ld4(p.bias + 4 * (lane & 31));
 #pragma unroll
-        for (int t = 0; t < 8; ++t) s[t] = add4(ld4(p.bias + 16 * t + 4 * hi), ld4(p.res + grow * ELG_E + 16 * t + 4 * hi));
-        add_partials(s, p.P, p.pstride, p.np, grow * ELG_E + 4 * hi, rot);
+            for (int t = 0; t < 8; ++t) v[t] = add4(v[t], bb);
+            tile_add_partials(v, p.P, p.pstride, p.np, ta);
+            to_frag(v, s, sT, lane, lo, hi);
+        }
         if (!rvalid) {
 #pragma unroll
             for (int t = 0; t < 8; ++t) s[t] = zero4();
@@ -326,6 +363,7 @@ __global__ __launch_bounds__(512) void enc_f1_kernel(const EncF1 g) {
     float* sK = sW + 96 * WP128;                         // [2][ROWS][KP]
     float* sVT = sK + 2 * ROWS * KP;                     // [2][16][PT]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* sT = sK + wave * TBUF;                        // the prologue's transpose buffers share the K / V region (a barrier apart)
     const int lo = lane & 15, hi = lane >> 4;
     int b, c;
     map_block(blockIdx.x, g.B, 4, b, c);
@@ -344,7 +382,7 @@ __global__ __launch_bounds__(512) void enc_f1_kernel(const EncF1 g) {
     }
     float4 x[8];
     STAMP(0, 0)
-    enc_prologue(g.pro, x, stat, b, N1, c, wave, lo, hi, act, nact);
+    enc_prologue(g.pro, x, stat, sT, b, N1, c == 0, wave, lane, act, nact);
     STAMP(0, 1)
     stage_commit<6>(wr, sW, tid);
     __syncthreads();
@@ -436,6 +474,7 @@ __global__ __launch_bounds__(512) void enc_f2_kernel(const EncF2 g) {
     float* sA = stat + 2 * 8 * ELG_E;                    // two weight stages of 64 rows
     float* sB = sA + 64 * WP128;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* sT = sB + 64 * WP128 + wave * TBUF;
     const int lo = lane & 15, hi = lane >> 4;
     int b, c;
     map_block(blockIdx.x, g.B, g.FF >> 7, b, c);
@@ -452,18 +491,12 @@ __global__ __launch_bounds__(512) void enc_f2_kernel(const EncF2 g) {
     stage_fetch<4>(wr, g.Wc, ELG_E, tid);
     float4 o[8], s[8];
     if (act) {
-        // (the instance's workgroups ask for the two tiles in different orders: see add_partials)
-        if (c & 1) {
-#pragma unroll
-            for (int t = 0; t < 8; ++t) s[t] = ld4(g.Xin + grow * ELG_E + 16 * t + 4 * hi);      // the residual
-#pragma unroll
-            for (int t = 0; t < 8; ++t) o[t] = ld4(g.O + grow * ELG_E + 16 * t + 4 * hi);
-        } else {
-#pragma unroll
-            for (int t = 0; t < 8; ++t) o[t] = ld4(g.O + grow * ELG_E + 16 * t + 4 * hi);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) s[t] = ld4(g.Xin + grow * ELG_E + 16 * t + 4 * hi);
-        }
+        const TileAddr ta = tile_addr(b, N1, wave, lane, ELG_E);
+        float4 v[8], w[8];
+        tile_ld(v, g.O, ta);
+        tile_ld(w, g.Xin, ta);                           // the residual
+        to_frag(v, o, sT, lane, lo, hi);
+        to_frag(w, s, sT, lane, lo, hi);
     }
     stage_commit<4>(wr, sA, tid);
     __syncthreads();
@@ -595,6 +628,7 @@ __global__ __launch_bounds__(512) void enc_f3_kernel(const EncF3 g) {
     float* sA = stat + 2 * 8 * ELG_E;
     float* sB = sA + 64 * WP128;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* sT = sB + 64 * WP128 + wave * TBUF;
     const int lo = lane & 15, hi = lane >> 4;
     int b, c;
     map_block(blockIdx.x, g.B, max(g.ntab, 1), b, c);
@@ -609,7 +643,7 @@ __global__ __launch_bounds__(512) void enc_f3_kernel(const EncF3 g) {
     float4 wr[4];
     if (g.ntab) stage_fetch_any(wr, W, sm, sk, tid);
     float4 x[8];
-    enc_prologue(g.pro, x, stat, b, N1, c, wave, lo, hi, act, nact);
+    enc_prologue(g.pro, x, stat, sT, b, N1, c == 0, wave, lane, act, nact);
     if (g.ntab == 0) return;
     stage_commit_any(wr, sA, sk, tid);
     __syncthreads();
@@ -673,18 +707,27 @@ struct EncBPro {
     float* dout;                         // ds, written by the workgroup c = 0 (the weight-gradient launch reads it)
 };
 
-__device__ __forceinline__ void enc_bprologue(const EncBPro& p, float4 (&ds)[8], float* stat, const int b, const int N1, const int rot,
-                                              const int wave, const int lo, const int hi, const bool act, const int nact) {
+__device__ __forceinline__ void enc_bprologue(const EncBPro& p, float4 (&ds)[8], float* stat, float* sT, const int b, const int N1,
+                                              const bool writer, const int wave, const int lane, const bool act, const int nact) {
+    const int lo = lane & 15, hi = lane >> 4;
     const int row = 16 * wave + lo;
-    const bool rvalid = row < N1, writer = rot == 0;
+    const bool rvalid = row < N1;
     const size_t grow = (size_t)b * N1 + min(row, N1 - 1);
     float4 d[8], xh[8];
     if (act) {
+        {
+            const TileAddr ta = tile_addr(b, N1, wave, lane, ELG_E);
+            float4 v[8], w[8];
+            tile_ld(w, p.xhat, ta);
+            if (p.base) tile_ld(v, p.base, ta);
+            else {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) xh[t] = ld4(p.xhat + grow * ELG_E + 16 * t + 4 * hi);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) d[t] = p.base ? ld4(p.base + grow * ELG_E + 16 * t + 4 * hi) : zero4();
-        add_partials(d, p.P, p.pstride, p.np, grow * ELG_E + 4 * hi, rot);
+                for (int t = 0; t < 8; ++t) v[t] = zero4();
+            }
+            tile_add_partials(v, p.P, p.pstride, p.np, ta);
+            to_frag(w, xh, sT, lane, lo, hi);
+            to_frag(v, d, sT, lane, lo, hi);
+        }
         float4 dx[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -733,6 +776,7 @@ __global__ __launch_bounds__(512) void enc_b0_kernel(const EncB0 g) {
     float* sA = lds;
     float* sB = sA + 64 * WP128;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* sT = sB + 64 * WP128 + wave * TBUF;
     const int lo = lane & 15, hi = lane >> 4;
     int b, c;
     map_block(blockIdx.x, g.B, g.ntab, b, c);
@@ -749,8 +793,9 @@ __global__ __launch_bounds__(512) void enc_b0_kernel(const EncB0 g) {
     stage_fetch_any(wr, W, sm, sk, tid);
     float4 x[8];
     if (act) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) x[t] = ld4(G + grow * ELG_E + 16 * t + 4 * hi);
+        float4 v[8];
+        tile_ld(v, G, tile_addr(b, N1, wave, lane, ELG_E));
+        to_frag(v, x, sT, lane, lo, hi);
     }
     stage_commit_any(wr, sA, sk, tid);
     __syncthreads();
@@ -791,6 +836,7 @@ __global__ __launch_bounds__(512) void enc_b1_kernel(const EncB1 g) {
     float* sA = stat + 2 * 8 * ELG_E;
     float* sB = sA + 64 * WP128;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* sT = sB + 64 * WP128 + wave * TBUF;
     const int lo = lane & 15, hi = lane >> 4;
     int b, c;
     map_block(blockIdx.x, g.B, g.FF >> 7, b, c);
@@ -805,12 +851,13 @@ __global__ __launch_bounds__(512) void enc_b1_kernel(const EncB1 g) {
     stage_fetch<4>(wr, W2Tc, ELG_E, tid);
     float4 ds[8];
     STAMP(3, 0)
-    enc_bprologue(g.pro, ds, stat, b, N1, c, wave, lo, hi, act, nact);
+    enc_bprologue(g.pro, ds, stat, sT, b, N1, c == 0, wave, lane, act, nact);
     STAMP(3, 1)
     float4 hm[8];
     if (act) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) hm[t] = ld4(g.H + grow * g.FF + 128 * c + 16 * t + 4 * hi);
+        float4 v[8];
+        tile_ld(v, g.H + 128 * c, tile_addr(b, N1, wave, lane, g.FF));
+        to_frag(v, hm, sT, lane, lo, hi);
     }
     stage_commit<4>(wr, sA, tid);
     __syncthreads();
@@ -872,7 +919,8 @@ template <int NT>
 constexpr int b2_attn_floats() {
     constexpr int ROWS = NT * 16, PT = ROWS + 4;
     constexpr int attn = 4 * 2 * ROWS * 20 + 3 * 2 * 16 * PT + 2 * 2 * ROWS;
-    return attn > 2 * 64 * WP96 ? attn : 2 * 64 * WP96;
+    constexpr int other = 8 * TBUF > 2 * 64 * WP96 ? 8 * TBUF : 2 * 64 * WP96;
+    return attn > other ? attn : other;
 }
 
 template <int NT>
@@ -893,6 +941,7 @@ __global__ __launch_bounds__(512) void enc_b2_kernel(const EncB2 g) {
     float* sA = sQ;                                      // after the attention: two stages of the input-gradient weights (64 x WP96)
     float* sB = sA + 64 * WP96;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* sT = sQ + wave * TBUF;                        // before it: the prologue's transpose buffers
     const int lo = lane & 15, hi = lane >> 4;
     int b, c;
     map_block(blockIdx.x, g.B, 4, b, c);
@@ -905,7 +954,7 @@ __global__ __launch_bounds__(512) void enc_b2_kernel(const EncB2 g) {
     stage_fetch<2>(wc, g.WcT + (size_t)(32 * c) * ELG_E, ELG_E, tid);
     float4 dy[8];
     STAMP(4, 0)
-    enc_bprologue(g.pro, dy, stat, b, N1, c, wave, lo, hi, act, nact);
+    enc_bprologue(g.pro, dy, stat, sT, b, N1, c == 0, wave, lane, act, nact);
     STAMP(4, 1)
     stage_commit<2>(wc, sWc, tid);
     __syncthreads();
@@ -1132,11 +1181,13 @@ static int launch1(K kern, DynLds& optin, const char* what, int grid, size_t lds
 }
 constexpr size_t LDS_STAT = sizeof(float) * 2 * 8 * ELG_E;
 constexpr size_t LDS_2STAGE = sizeof(float) * 2 * 64 * WP128;
+constexpr size_t LDS_TBUF = sizeof(float) * 8 * TBUF;
 
 template <int NT>
 static int launch_f1_t(const EncF1& g, hipStream_t s) {
     constexpr int ROWS = NT * 16, PT = ROWS + 4;
-    constexpr size_t lds = LDS_STAT + sizeof(float) * (96 * WP128 + 2 * ROWS * 20 + 2 * 16 * PT);
+    constexpr int kv = 2 * ROWS * 20 + 2 * 16 * PT;
+    constexpr size_t lds = LDS_STAT + sizeof(float) * (96 * WP128 + (kv > 8 * TBUF ? kv : 8 * TBUF));
     static DynLds optin;
     return launch1(enc_f1_kernel<NT>, optin, "enc_f1", g.B * 4, lds, s, g);
 }
@@ -1149,19 +1200,19 @@ static int launch_f1(const EncF1& g, hipStream_t s) {
 }
 static int launch_f2(const EncF2& g, hipStream_t s) {
     static DynLds optin;
-    return launch1(enc_f2_kernel, optin, "enc_f2", g.B * (g.FF >> 7), LDS_STAT + LDS_2STAGE, s, g);
+    return launch1(enc_f2_kernel, optin, "enc_f2", g.B * (g.FF >> 7), LDS_STAT + LDS_2STAGE + LDS_TBUF, s, g);
 }
 static int launch_f3(const EncF3& g, hipStream_t s) {
     static DynLds optin;
-    return launch1(enc_f3_kernel, optin, "enc_f3", g.B * (g.ntab > 0 ? g.ntab : 1), LDS_STAT + LDS_2STAGE, s, g);
+    return launch1(enc_f3_kernel, optin, "enc_f3", g.B * (g.ntab > 0 ? g.ntab : 1), LDS_STAT + LDS_2STAGE + LDS_TBUF, s, g);
 }
 static int launch_b0(const EncB0& g, hipStream_t s) {
     static DynLds optin;
-    return launch1(enc_b0_kernel, optin, "enc_b0", g.B * g.ntab, LDS_2STAGE, s, g);
+    return launch1(enc_b0_kernel, optin, "enc_b0", g.B * g.ntab, LDS_2STAGE + LDS_TBUF, s, g);
 }
 static int launch_b1(const EncB1& g, hipStream_t s) {
     static DynLds optin;
-    return launch1(enc_b1_kernel, optin, "enc_b1", g.B * (g.FF >> 7), LDS_STAT + LDS_2STAGE, s, g);
+    return launch1(enc_b1_kernel, optin, "enc_b1", g.B * (g.FF >> 7), LDS_STAT + LDS_2STAGE + LDS_TBUF, s, g);
 }
 template <int NT>
 static int launch_b2_t(const EncB2& g, hipStream_t s) {

@@ -52,7 +52,8 @@ int main() {
     const long bstride = 64L * 112 * 128 * 4;            // floats between partial buffers (>= all instances), generous
     const size_t n = (size_t)bstride * 6;
     float *src, *out; unsigned long long* cyc;
-    hipMalloc(&src, n * 4); hipMalloc(&out, (size_t)NWG * 512 * 16); hipMalloc(&cyc, NWG * 8 * 2 * 8);
+    if (hipMalloc(&src, n * 4) != hipSuccess || hipMalloc(&out, (size_t)NWG * 512 * 16) != hipSuccess || hipMalloc(&cyc, NWG * 8 * 2 * 8) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    printf("src %p out %p cyc %p\n", (void*)src, (void*)out, (void*)cyc); fflush(stdout);
     std::vector<unsigned long long> h(NWG * 8 * 2);
     for (int mode = 0; mode < 3; ++mode)
         for (int share : {0, 4})
@@ -63,14 +64,14 @@ int main() {
                     for (int rep = 0; rep < 3; ++rep) {
                         hipLaunchKernelGGL(fill, dim3(2048), dim3(256), 0, 0, src, n);       // rewrite: the reads below start L2-cold
                         hipLaunchKernelGGL(ldbench, dim3(NWG), dim3(512), 0, 0, src, out, cyc, mode, nbuf, bstride, share, rot);
-                        hipDeviceSynchronize();
+                        if (hipDeviceSynchronize() != hipSuccess) { printf("sync failed\n"); return 1; }
                         hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
                         double a = 0, b = 0;
                         for (int w = 0; w < NWG; ++w) for (int k = 0; k < 7; ++k) { a += h[(w * 8 + k) * 2]; b += h[(w * 8 + k) * 2 + 1]; }
                         s0 = a / (NWG * 7); s1 = b / (NWG * 7);
                     }
                     const double bytes = nbuf * 7 * 16 * 512.0;        // per workgroup
-                    printf("mode %d share %d rot %d nbuf %d: cold %.0f cyc (%.1f B/clk/CU)  warm %.0f cyc (%.1f B/clk/CU)\n", mode, share, rot,
+                    fflush(stdout); printf("mode %d share %d rot %d nbuf %d: cold %.0f cyc (%.1f B/clk/CU)  warm %.0f cyc (%.1f B/clk/CU)\n", mode, share, rot,
                            nbuf, s0, bytes / s0, s1, bytes / s1);
                 }
     return 0;
