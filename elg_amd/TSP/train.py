@@ -52,9 +52,10 @@ def softmax(x):
     return e / e.sum(axis=0)
 
 
-def test_rollout(loader, env, model):
-    """reference TSP/train.py:20-38: mean over batches of the best-of-POMO greedy tour length."""
-    total, batches = 0.0, 0
+def test_rollout(loader, env, model, weighted=False):
+    """reference TSP/train.py:20-38: mean over batches of the best-of-POMO greedy tour length.
+    weighted: return (sum of the instances' lengths, instances) -- a rank's share of a sharded validation."""
+    total, batches, cost_sum, count = 0.0, 0, 0.0, 0
     for batch in loader:
         env.load_random_problems(batch)
         reset_state, _, _ = env.reset()
@@ -63,9 +64,12 @@ def test_rollout(loader, env, model):
             model.pre_forward(reset_state)
             solutions, _, rewards = rollout(model=model, env=env, eval_type='greedy')
         check_feasible(solutions[0:1])
-        total += float(-rewards.max(1)[0].mean())
+        best = -rewards.max(1)[0]
+        total += float(best.mean())
         batches += 1
-    return total / max(batches, 1)
+        cost_sum += float(best.double().sum())
+        count += int(best.numel())
+    return (cost_sum, count) if weighted else total / max(batches, 1)
 
 
 def validate(model, multiple_width, device, mixed=True, data_dir='data'):
@@ -76,8 +80,22 @@ def validate(model, multiple_width, device, mixed=True, data_dir='data'):
                 ('tsp_mixed100_1000_seed1234.pkl', 1000, 1000)]
     else:
         sets = [('tsp_100_val.pkl', 1000, 500), ('tsp_200_val.pkl', 1000, 500), ('tsp_500_val.pkl', 100, 10)]
-    return [test_rollout(DataLoader(TSPDataset(os.path.join(data_dir, f), num_samples=n), batch_size=bs), env, model)
-            for f, n, bs in sets]
+    rank, world = parallel.collective_world()
+    if world <= 1:
+        return [test_rollout(DataLoader(TSPDataset(os.path.join(data_dir, f), num_samples=n), batch_size=bs), env, model)
+                for f, n, bs in sets]
+    # data parallel: every rank evaluates the instances rank, rank + world, ... of each set; the cost sums are added over the ranks
+    def local_sums():                     # no collective in here: a rank that fails must still reach the guard's exchange
+        sums = []
+        for f, n, bs in sets:
+            rows = TSPDataset(os.path.join(data_dir, f), num_samples=n)
+            mine = [rows[i] for i in range(rank, len(rows), world)]
+            s_, c_ = test_rollout(DataLoader(mine, batch_size=max(1, -(-bs // world))), env, model, weighted=True) if mine else (0.0, 0)
+            sums += [s_, float(c_)]
+        return sums
+    # a rank that raises makes every rank raise here, instead of leaving the others in the sum below until its timeout
+    tot = parallel.sum_over_ranks(parallel.guarded(local_sums))
+    return [tot[2 * i] / max(tot[2 * i + 1], 1.0) for i in range(len(sets))]
 
 
 def train(model, training, T, start_steps, train_steps, mixed, train_batch_size, problem_size, distribution,
@@ -107,16 +125,15 @@ def train(model, training, T, start_steps, train_steps, mixed, train_batch_size,
         batch = generate_tsp_data(batch_size=train_batch_size // world, problem_size=problem_size, distribution=distribution_)
         train_step(model, env, optimizer, batch, scale_norm, bucket, world)
         if (i + 1) % log_step == 0:
-            val_info = None
+            # every rank evaluates its share of the validation sets (a rank that fails takes the others down with it: validate())
+            val_info = validate(model, multiple_width, device, mixed)
             if rank == 0:
-                val_info = validate(model, multiple_width, device, mixed)
                 fileLogger.log(val_info)
                 if logger is not None:
                     logger.log({'val_100_cost': val_info[0], 'val_200_cost': val_info[1], 'val_500_cost': val_info[2]}, step=i)
                 torch.save({'step': i, 'model_state_dict': model.state_dict(), 'optimizer_state_dict': optimizer.state_dict()},
                            dir_path + '/model_epoch_{}.pt'.format(int((i + 1) / log_step)))
-            if mixed:
-                val_info = parallel.broadcast_object(val_info)       # the gaps drive every rank's next draws
+            if mixed:                                                # the gaps drive every rank's next draws (same on every rank)
                 opts = np.array([7.753418, 3.667576, 6.729566])      # reference solver means (TSP/train.py:148)
                 gaps = (np.array(val_info) - opts) / opts
 

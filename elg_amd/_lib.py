@@ -84,7 +84,7 @@ class LocalWeights(C.Structure):
 
 class EncoderArgs(C.Structure):
     _fields_ = [("problem", C.c_int32), ("B", C.c_int32), ("N1", C.c_int32), ("n_layers", C.c_int32),
-                ("ff_hidden", C.c_int32), ("save", C.c_int32), ("eps", C.c_float), ("pad0", C.c_int32),
+                ("ff_hidden", C.c_int32), ("save", C.c_int32), ("eps", C.c_float), ("precision", C.c_int32),
                 ("xy", _vp), ("demand", _vp), ("W", EncWeights),
                 ("enc", _vp), ("K", _vp), ("V", _vp), ("PK", _vp), ("pb", _vp), ("Q1", _vp), ("Q2", _vp), ("wl", _vp),
                 ("ws", _vp), ("ws_floats", C.c_int64)]

@@ -1153,7 +1153,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             float aw[4], ds1[4];
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                aw[v] = __builtin_amdgcn_exp2f(TS == 1 ? fmaf(S[v], cs, -lsv[v]) : S[v]);
+                // (argument clamped at 0: a live row has s log2(e)/4 - lse <= 0; a row the rollout did not write at this step keeps q / lse
+                //  of an earlier batch, its exp2 could overflow and inf * 0 -- its dA and dO are 0 -- would poison dK / dV / dQ)
+                aw[v] = __builtin_amdgcn_exp2f(fminf(TS == 1 ? fmaf(S[v], cs, -lsv[v]) : S[v], 0.f));
                 ds1[v] = aw[v] * dA[v];                            // 4 dS: node 16 nt + lo, row 4 hi + v
             }
             const u32x4 dsq = bf_single(ds1[0], ds1[1], ds1[2], ds1[3]);
@@ -1446,7 +1448,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             float aw[4], ds1[4];
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                aw[v] = __builtin_amdgcn_exp2f(S[v]);
+                aw[v] = __builtin_amdgcn_exp2f(fminf(S[v], 0.f));   // (clamped: rows of an earlier batch must stay finite, see the bf16 kernel)
                 ds1[v] = aw[v] * dA[v];                            // 4 dS: node 16 nt + lo, row 4 hi + v
             }
 #pragma unroll

@@ -1010,6 +1010,7 @@ static int check_enc_args(const elg_encoder_args* a) {
     if (!a) return fail(ELG_EINVAL, "encoder: null args");
     if (a->B <= 0 || a->N1 < 4) return fail(ELG_EINVAL, "encoder: need B > 0, N1 >= 4");
     if (a->n_layers < 0 || a->n_layers > ELG_ENC_MAX_LAYERS) return fail(ELG_EINVAL, "encoder: 0 .. 8 layers");
+    if (a->precision != 0 && a->precision != 1) return fail(ELG_EINVAL, "encoder: precision 0 (f32) or 1 (bf16 GEMM operands)");
     if (a->n_layers == 0) {          // set_kv only: `enc` is an input
         if (!a->enc || !a->K) return fail(ELG_EINVAL, "encoder: n_layers = 0 needs enc (input) and the table buffers");
         return ELG_OK;

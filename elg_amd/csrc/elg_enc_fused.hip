@@ -23,6 +23,7 @@
 //
 // Launches per training step at 6 layers: forward 13 (was 36), backward 16 + the grouped weight-gradient launch (was 39).
 #include "elg_enc_internal.h"
+#include "elg_bf16.h"
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -70,26 +71,69 @@ __device__ __forceinline__ void map_block(int bid, int B, int S, int& b, int& c)
 constexpr int WP128 = 136;          // LDS row pitch (floats) of a K = 128 weight image
 constexpr int WP96 = 104;           //                           K = 96
 
+// ---- bf16 mode (elg_encoder_args.precision = 1; BASELINE configs[1] "bf16"): every GEMM of the encoder and of its backward on
+// v_mfma_f32_16x16x32_bf16 -- both operands rounded to bf16 (round to nearest even, v_cvt_pk_bf16_f32), f32 accumulation;
+// bias, residual, instance norm, softmax and everything saved for the backward stay f32 (oracle: oracle/elg_oracle.py
+// encoder_forward(precision="bf16")).  The instruction contracts 32 k per issue, 8 per lane: k-slot (hi, j).  The D^T tiles that
+// chain the GEMMs hold 4 consecutive channels per lane and tile, so a 32-wide k chunk = two tiles, and slot (hi, j) stands for
+// channel 32 kc + 4 hi + j (j < 4, tile 2 kc) resp. 32 kc + 16 + 4 hi + j - 4 (j >= 4, tile 2 kc + 1) in BOTH operands: the
+// weight image is written in that order (one ds_read_b128 per lane, tile and chunk), the activation operand is the two tiles'
+// registers packed.  Image row = K bf16 + 16 (pitch = 8 mod 64 dwords: conflict-free fragment reads).
+constexpr int WPB128 = 72;          // dwords per row of a K = 128 bf16 weight image
+constexpr int WPB96 = 56;           //                      K = 96
+// dword offset inside an image row of the 4 channels 4 p .. 4 p + 3 (p = 16-byte piece of the f32 row)
+__device__ __forceinline__ int bf_piece_off(const int p) { return 16 * (p >> 3) + 4 * (p & 3) + 2 * ((p >> 2) & 1); }
+__device__ __forceinline__ u32x4 pack8(const float4 a, const float4 b) {
+    return u32x4{pk_bf16(a.x, a.y), pk_bf16(a.z, a.w), pk_bf16(b.x, b.y), pk_bf16(b.z, b.w)};
+}
+
 // out[j] (D^T tiles: out[j][i] = y[row lo][16 j + 4 hi + i]) = sum_k W(16 j + lo, k) x[row lo][k]: NCT column tiles from the
 // LDS image sW, the wave's activation tile `in` held as KC chunks of 16 k (in[kc] = x[row lo][16 kc + 4 hi ..]).
-template <int NCT, int KC, int PITCH>
+template <bool BF, int NCT, int KC, int PITCH>
 __device__ __forceinline__ void mma_lds(const float* sW, const float4 (&in)[KC], f32x4* out, const int lo, const int hi) {
-    const float* p = sW + lo * PITCH + 4 * hi;
 #pragma unroll
     for (int j = 0; j < NCT; ++j) out[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (BF) {
+        static_assert((KC & 1) == 0, "bf16: k in chunks of 32");
+        constexpr int PB = PITCH == WP128 ? WPB128 : WPB96;
+        const unsigned* p = reinterpret_cast<const unsigned*>(sW) + lo * PB + 4 * hi;
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) {
-        float4 a[NCT];
+        for (int kc = 0; kc < KC / 2; ++kc) {
+            const u32x4 bop = pack8(in[2 * kc], in[2 * kc + 1]);
+            u32x4 a[NCT];
 #pragma unroll
-        for (int j = 0; j < NCT; ++j) a[j] = ld4(p + j * (16 * PITCH) + 16 * kc);
+            for (int j = 0; j < NCT; ++j) a[j] = *reinterpret_cast<const u32x4*>(p + j * (16 * PB) + 16 * kc);
 #pragma unroll
-        for (int j = 0; j < NCT; ++j) out[j] = mfma4(a[j].x, in[kc].x, out[j]);
+            for (int j = 0; j < NCT; ++j) out[j] = mfma_bf(a[j], bop, out[j]);
+        }
+    } else {
+        const float* p = sW + lo * PITCH + 4 * hi;
 #pragma unroll
-        for (int j = 0; j < NCT; ++j) out[j] = mfma4(a[j].y, in[kc].y, out[j]);
+        for (int kc = 0; kc < KC; ++kc) {
+            float4 a[NCT];
 #pragma unroll
-        for (int j = 0; j < NCT; ++j) out[j] = mfma4(a[j].z, in[kc].z, out[j]);
+            for (int j = 0; j < NCT; ++j) a[j] = ld4(p + j * (16 * PITCH) + 16 * kc);
 #pragma unroll
-        for (int j = 0; j < NCT; ++j) out[j] = mfma4(a[j].w, in[kc].w, out[j]);
+            for (int j = 0; j < NCT; ++j) out[j] = mfma4(a[j].x, in[kc].x, out[j]);
+#pragma unroll
+            for (int j = 0; j < NCT; ++j) out[j] = mfma4(a[j].y, in[kc].y, out[j]);
+#pragma unroll
+            for (int j = 0; j < NCT; ++j) out[j] = mfma4(a[j].z, in[kc].z, out[j]);
+#pragma unroll
+            for (int j = 0; j < NCT; ++j) out[j] = mfma4(a[j].w, in[kc].w, out[j]);
+        }
+    }
+}
+
+// one piece (4 channels of a row) of a weight stage into the image
+template <bool BF, int PITCH>
+__device__ __forceinline__ void image_put(float* dst, const int row, const int piece, const float4 v) {
+    if constexpr (BF) {
+        constexpr int PB = PITCH == WP128 ? WPB128 : WPB96;
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned*>(dst) + row * PB + bf_piece_off(piece)) =
+            make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
+    } else {
+        st4(dst + row * PITCH + 4 * piece, v);
     }
 }
 
@@ -102,12 +146,12 @@ __device__ __forceinline__ void stage_fetch(float4 (&r)[NF4], const float* src, 
         r[i] = ld4(src + (size_t)(idx >> 5) * ld + 4 * (idx & 31));
     }
 }
-template <int NF4>
+template <bool BF, int NF4>
 __device__ __forceinline__ void stage_commit(const float4 (&r)[NF4], float* dst, const int tid) {
 #pragma unroll
     for (int i = 0; i < NF4; ++i) {
         const int idx = tid + 512 * i;
-        st4(dst + (idx >> 5) * WP128 + 4 * (idx & 31), r[i]);
+        image_put<BF, WP128>(dst, idx >> 5, idx & 31, r[i]);
     }
 }
 // the same for a weight given as W(m, k) = src[m sm + k sk] (the decoder tables and their backward: nn.Linear weights used
@@ -127,12 +171,13 @@ __device__ __forceinline__ void stage_fetch_any(float4 (&r)[4], const float* src
         }
     }
 }
+template <bool BF>
 __device__ __forceinline__ void stage_commit_any(const float4 (&r)[4], float* dst, const int sk, const int tid) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int idx = tid + 512 * i;
-        if (sk == 1) st4(dst + (idx >> 5) * WP128 + 4 * (idx & 31), r[i]);
-        else st4(dst + (idx & 63) * WP128 + 4 * (idx >> 6), r[i]);
+        if (sk == 1) image_put<BF, WP128>(dst, idx >> 5, idx & 31, r[i]);
+        else image_put<BF, WP128>(dst, idx & 63, idx >> 6, r[i]);
     }
 }
 
@@ -354,7 +399,7 @@ struct EncF1 {
     int B, N1;
 };
 
-template <int NT>
+template <int NT, bool BF>
 __global__ __launch_bounds__(512) void enc_f1_kernel(const EncF1 g) {
     constexpr int ROWS = NT * 16, KP = 20, PT = ROWS + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -384,12 +429,12 @@ __global__ __launch_bounds__(512) void enc_f1_kernel(const EncF1 g) {
     STAMP(0, 0)
     enc_prologue(g.pro, x, stat, sT, b, N1, c == 0, wave, lane, act, nact);
     STAMP(0, 1)
-    stage_commit<6>(wr, sW, tid);
+    stage_commit<BF, 6>(wr, sW, tid);
     __syncthreads();
     STAMP(0, 2)
     f32x4 qkv[6];                                        // q0 q1 k0 k1 v0 v1
     if (act) {
-        mma_lds<6, 8, WP128>(sW, x, qkv, lo, hi);
+        mma_lds<BF, 6, 8, WP128>(sW, x, qkv, lo, hi);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (g.QKV && rvalid) {
@@ -419,14 +464,19 @@ __global__ __launch_bounds__(512) void enc_f1_kernel(const EncF1 g) {
     for (int u = 0; u < 2; ++u) {
         f32x4 S[NT];
         float mx = ELG_NEG_INF;
+        const u32x4 qb = {pk_bf16(qkv[u][0], qkv[u][1]), pk_bf16(qkv[u][2], qkv[u][3]), 0u, 0u};     // (BF) k-slots (hi, 4..7) empty
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
             const float4 ka = ld4(sK + (u * ROWS + 16 * kt + lo) * KP + 4 * hi);
             f32x4 sc = {0.f, 0.f, 0.f, 0.f};
-            sc = mfma4(ka.x, qkv[u][0], sc);
-            sc = mfma4(ka.y, qkv[u][1], sc);
-            sc = mfma4(ka.z, qkv[u][2], sc);
-            sc = mfma4(ka.w, qkv[u][3], sc);
+            if constexpr (BF) {
+                sc = mfma_bf(u32x4{pk_bf16(ka.x, ka.y), pk_bf16(ka.z, ka.w), 0u, 0u}, qb, sc);
+            } else {
+                sc = mfma4(ka.x, qkv[u][0], sc);
+                sc = mfma4(ka.y, qkv[u][1], sc);
+                sc = mfma4(ka.z, qkv[u][2], sc);
+                sc = mfma4(ka.w, qkv[u][3], sc);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 sc[i] = (16 * kt + 4 * hi + i < N1) ? sc[i] * 0.25f : ELG_NEG_INF;      // key 16 kt + 4 hi + i, query row lo
@@ -437,15 +487,34 @@ __global__ __launch_bounds__(512) void enc_f1_kernel(const EncF1 g) {
         mx = quarters_max(mx);
         float l = 0.f;
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (BF) {
+            // two key tiles per instruction: k-slot (hi, j) = key 16 (2 p) + 4 hi + j, (hi, 4 + j) = key 16 (2 p + 1) + 4 hi + j;
+            // the numerators go in rounded to bf16, the normaliser is the sum of the unrounded ones
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            const float4 vt = ld4(sVT + (u * 16 + lo) * PT + 16 * kt + 4 * hi);
-            const float vv[4] = {vt.x, vt.y, vt.z, vt.w};
+            for (int pr = 0; pr < (NT + 1) / 2; ++pr) {
+                const int t0 = 2 * pr, t1 = 2 * pr + 1;
+                const float4 v0 = ld4(sVT + (u * 16 + lo) * PT + 16 * t0 + 4 * hi);
+                const float4 v1 = t1 < NT ? ld4(sVT + (u * 16 + lo) * PT + 16 * t1 + 4 * hi) : zero4();
+                float e0[4], e1[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float p = __expf(S[kt][i] - mx);
-                l += p;
-                o = mfma4(vv[i], p, o);
+                for (int i = 0; i < 4; ++i) {
+                    e0[i] = __expf(S[t0][i] - mx);
+                    e1[i] = t1 < NT ? __expf(S[t1 < NT ? t1 : t0][i] - mx) : 0.f;
+                    l += e0[i] + e1[i];
+                }
+                o = mfma_bf(pack8(v0, v1), u32x4{pk_bf16(e0[0], e0[1]), pk_bf16(e0[2], e0[3]), pk_bf16(e1[0], e1[1]), pk_bf16(e1[2], e1[3])}, o);
+            }
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                const float4 vt = ld4(sVT + (u * 16 + lo) * PT + 16 * kt + 4 * hi);
+                const float vv[4] = {vt.x, vt.y, vt.z, vt.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float p = __expf(S[kt][i] - mx);
+                    l += p;
+                    o = mfma4(vv[i], p, o);
+                }
             }
         }
         l = quarters_sum(l);
@@ -468,6 +537,7 @@ struct EncF2 {
     float eps;
 };
 
+template <bool BF>
 __global__ __launch_bounds__(512) void enc_f2_kernel(const EncF2 g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* stat = lds;                                   // 2 x 8 x 128
@@ -498,19 +568,19 @@ __global__ __launch_bounds__(512) void enc_f2_kernel(const EncF2 g) {
         to_frag(v, o, sT, lane, lo, hi);
         to_frag(w, s, sT, lane, lo, hi);
     }
-    stage_commit<4>(wr, sA, tid);
+    stage_commit<BF, 4>(wr, sA, tid);
     __syncthreads();
     STAMP(1, 1)
     f32x4 a[8];
     stage_fetch<4>(wr, g.Wc + 64 * ELG_E, ELG_E, tid);
-    if (act) mma_lds<4, 8, WP128>(sA, o, a, lo, hi);
+    if (act) mma_lds<BF, 4, 8, WP128>(sA, o, a, lo, hi);
     STAMP(1, 2)
-    stage_commit<4>(wr, sB, tid);
+    stage_commit<BF, 4>(wr, sB, tid);
     __syncthreads();
     STAMP(1, 3)
     stage_fetch<4>(wr, W1c, ELG_E, tid);
     if (act) {
-        mma_lds<4, 8, WP128>(sB, o, a + 4, lo, hi);
+        mma_lds<BF, 4, 8, WP128>(sB, o, a + 4, lo, hi);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             s[t] = add4(add4(f4(a[t]), ld4(g.bc + 16 * t + 4 * hi)), s[t]);
@@ -519,7 +589,7 @@ __global__ __launch_bounds__(512) void enc_f2_kernel(const EncF2 g) {
         colsum_put(s, stat, wave, lo, hi);
     }
     STAMP(1, 4)
-    stage_commit<4>(wr, sA, tid);
+    stage_commit<BF, 4>(wr, sA, tid);
     __syncthreads();
     STAMP(1, 5)
     const float inv_n = 1.0f / (float)N1;
@@ -561,15 +631,15 @@ __global__ __launch_bounds__(512) void enc_f2_kernel(const EncF2 g) {
     // ---- h = relu(x1 W1_c^T + b1_c)
     STAMP(1, 7)
     stage_fetch<4>(wr, W1c + 64 * ELG_E, ELG_E, tid);
-    if (act) mma_lds<4, 8, WP128>(sA, x1, a, lo, hi);
+    if (act) mma_lds<BF, 4, 8, WP128>(sA, x1, a, lo, hi);
     STAMP(1, 8)
-    stage_commit<4>(wr, sB, tid);
+    stage_commit<BF, 4>(wr, sB, tid);
     __syncthreads();
     STAMP(1, 9)
     stage_fetch<4>(wr, W2c, g.FF, tid);
     float4 h[8];
     if (act) {
-        mma_lds<4, 8, WP128>(sB, x1, a + 4, lo, hi);
+        mma_lds<BF, 4, 8, WP128>(sB, x1, a + 4, lo, hi);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const float4 bb = ld4(g.bf1 + 128 * c + 16 * t + 4 * hi);
@@ -578,17 +648,17 @@ __global__ __launch_bounds__(512) void enc_f2_kernel(const EncF2 g) {
         }
     }
     STAMP(1, 10)
-    stage_commit<4>(wr, sA, tid);
+    stage_commit<BF, 4>(wr, sA, tid);
     __syncthreads();
     STAMP(1, 11)
     // ---- partial[c] = h W2_c^T
     stage_fetch<4>(wr, W2c + (size_t)64 * g.FF, g.FF, tid);
-    if (act) mma_lds<4, 8, WP128>(sA, h, a, lo, hi);
-    stage_commit<4>(wr, sB, tid);
+    if (act) mma_lds<BF, 4, 8, WP128>(sA, h, a, lo, hi);
+    stage_commit<BF, 4>(wr, sB, tid);
     __syncthreads();
     STAMP(1, 12)
     if (act) {
-        mma_lds<4, 8, WP128>(sB, h, a + 4, lo, hi);
+        mma_lds<BF, 4, 8, WP128>(sB, h, a + 4, lo, hi);
         STAMP(1, 13)
         if (rvalid) {
             float* op = g.P + c * g.pstride + grow * ELG_E + 4 * hi;
@@ -622,6 +692,7 @@ __device__ __forceinline__ T pick5(const T (&p)[5], int i) {
     return r;
 }
 
+template <bool BF>
 __global__ __launch_bounds__(512) void enc_f3_kernel(const EncF3 g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* stat = lds;
@@ -645,15 +716,15 @@ __global__ __launch_bounds__(512) void enc_f3_kernel(const EncF3 g) {
     float4 x[8];
     enc_prologue(g.pro, x, stat, sT, b, N1, c == 0, wave, lane, act, nact);
     if (g.ntab == 0) return;
-    stage_commit_any(wr, sA, sk, tid);
+    stage_commit_any<BF>(wr, sA, sk, tid);
     __syncthreads();
     stage_fetch_any(wr, W + (size_t)64 * sm, sm, sk, tid);
     f32x4 a[8];
-    if (act) mma_lds<4, 8, WP128>(sA, x, a, lo, hi);
-    stage_commit_any(wr, sB, sk, tid);
+    if (act) mma_lds<BF, 4, 8, WP128>(sA, x, a, lo, hi);
+    stage_commit_any<BF>(wr, sB, sk, tid);
     __syncthreads();
     if (!act) return;
-    mma_lds<4, 8, WP128>(sB, x, a + 4, lo, hi);
+    mma_lds<BF, 4, 8, WP128>(sB, x, a + 4, lo, hi);
     const float alpha = pick5(g.alpha, c);
     float* out = pick5(g.out, c);
     if (rvalid) {
@@ -771,6 +842,7 @@ struct EncB0 {
     int ntab, B, N1;
 };
 
+template <bool BF>
 __global__ __launch_bounds__(512) void enc_b0_kernel(const EncB0 g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sA = lds;
@@ -797,15 +869,15 @@ __global__ __launch_bounds__(512) void enc_b0_kernel(const EncB0 g) {
         tile_ld(v, G, tile_addr(b, N1, wave, lane, ELG_E));
         to_frag(v, x, sT, lane, lo, hi);
     }
-    stage_commit_any(wr, sA, sk, tid);
+    stage_commit_any<BF>(wr, sA, sk, tid);
     __syncthreads();
     stage_fetch_any(wr, W + (size_t)64 * sm, sm, sk, tid);
     f32x4 a[8];
-    if (act) mma_lds<4, 8, WP128>(sA, x, a, lo, hi);
-    stage_commit_any(wr, sB, sk, tid);
+    if (act) mma_lds<BF, 4, 8, WP128>(sA, x, a, lo, hi);
+    stage_commit_any<BF>(wr, sB, sk, tid);
     __syncthreads();
     if (!act) return;
-    mma_lds<4, 8, WP128>(sB, x, a + 4, lo, hi);
+    mma_lds<BF, 4, 8, WP128>(sB, x, a + 4, lo, hi);
     if (!rvalid) return;
     const float gp = (c == g.pb_tab && g.gpb) ? g.gpb[grow] * alpha : 0.f;
     float* o = g.PX + c * g.pstride + grow * ELG_E + 4 * hi;
@@ -830,6 +902,7 @@ struct EncB1 {
     int B, N1, FF;
 };
 
+template <bool BF>
 __global__ __launch_bounds__(512) void enc_b1_kernel(const EncB1 g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* stat = lds;
@@ -859,20 +932,20 @@ __global__ __launch_bounds__(512) void enc_b1_kernel(const EncB1 g) {
         tile_ld(v, g.H + 128 * c, tile_addr(b, N1, wave, lane, g.FF));
         to_frag(v, hm, sT, lane, lo, hi);
     }
-    stage_commit<4>(wr, sA, tid);
+    stage_commit<BF, 4>(wr, sA, tid);
     __syncthreads();
     STAMP(3, 2)
     f32x4 a[8];
     stage_fetch<4>(wr, W2Tc + 64 * ELG_E, ELG_E, tid);
-    if (act) mma_lds<4, 8, WP128>(sA, ds, a, lo, hi);
+    if (act) mma_lds<BF, 4, 8, WP128>(sA, ds, a, lo, hi);
     STAMP(3, 3)
-    stage_commit<4>(wr, sB, tid);
+    stage_commit<BF, 4>(wr, sB, tid);
     __syncthreads();
     STAMP(3, 4)
     stage_fetch<4>(wr, W1Tc, g.FF, tid);
     float4 dh[8];
     if (act) {
-        mma_lds<4, 8, WP128>(sB, ds, a + 4, lo, hi);
+        mma_lds<BF, 4, 8, WP128>(sB, ds, a + 4, lo, hi);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             dh[t] = make_float4(hm[t].x > 0.f ? a[t][0] : 0.f, hm[t].y > 0.f ? a[t][1] : 0.f, hm[t].z > 0.f ? a[t][2] : 0.f,
@@ -881,16 +954,16 @@ __global__ __launch_bounds__(512) void enc_b1_kernel(const EncB1 g) {
         }
     }
     STAMP(3, 5)
-    stage_commit<4>(wr, sA, tid);
+    stage_commit<BF, 4>(wr, sA, tid);
     __syncthreads();
     STAMP(3, 6)
     stage_fetch<4>(wr, W1Tc + (size_t)64 * g.FF, g.FF, tid);
-    if (act) mma_lds<4, 8, WP128>(sA, dh, a, lo, hi);
-    stage_commit<4>(wr, sB, tid);
+    if (act) mma_lds<BF, 4, 8, WP128>(sA, dh, a, lo, hi);
+    stage_commit<BF, 4>(wr, sB, tid);
     __syncthreads();
     STAMP(3, 7)
     if (act) {
-        mma_lds<4, 8, WP128>(sB, dh, a + 4, lo, hi);
+        mma_lds<BF, 4, 8, WP128>(sB, dh, a + 4, lo, hi);
         STAMP(3, 8)
         if (rvalid) {
             float* o = g.P1 + c * g.pstride + grow * ELG_E + 4 * hi;
@@ -923,7 +996,7 @@ constexpr int b2_attn_floats() {
     return attn > other ? attn : other;
 }
 
-template <int NT>
+template <int NT, bool BF>
 __global__ __launch_bounds__(512) void enc_b2_kernel(const EncB2 g) {
     constexpr int ROWS = NT * 16, KP = 20, PT = ROWS + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -956,14 +1029,14 @@ __global__ __launch_bounds__(512) void enc_b2_kernel(const EncB2 g) {
     STAMP(4, 0)
     enc_bprologue(g.pro, dy, stat, sT, b, N1, c == 0, wave, lane, act, nact);
     STAMP(4, 1)
-    stage_commit<2>(wc, sWc, tid);
+    stage_commit<BF, 2>(wc, sWc, tid);
     __syncthreads();
     STAMP(4, 2)
     float4 q4[2], k4[2], v4[2], d4[2];
     float lr[2], del[2];
     if (act) {
         f32x4 dO[2];
-        mma_lds<2, 8, WP128>(sWc, dy, dO, lo, hi);
+        mma_lds<BF, 2, 8, WP128>(sWc, dy, dO, lo, hi);
         const float mk = rvalid ? 1.f : 0.f;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -1024,7 +1097,7 @@ __global__ __launch_bounds__(512) void enc_b2_kernel(const EncB2 g) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int idx = tid + 512 * i, r = idx / 24, pc = idx - r * 24;
-            st4(dst + r * WP96 + 4 * pc, wr[i]);
+            image_put<BF, WP96>(dst, r, pc, wr[i]);
         }
     };
     fetch3(0);
@@ -1032,9 +1105,76 @@ __global__ __launch_bounds__(512) void enc_b2_kernel(const EncB2 g) {
     if (act) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
+            f32x4 dq = {0.f, 0.f, 0.f, 0.f}, dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (BF) {
+                // bf16 operands: the 16-channel contractions fill k-slots (hi, 0..3) only; the contractions over keys / rows take two
+                // tiles per instruction (slots (hi, j) = tile 2 p, (hi, 4 + j) = tile 2 p + 1).  p is recomputed from the scores of
+                // bf16(q) . bf16(k), as the forward formed them.
+                auto half = [](const float4 v) { return u32x4{pk_bf16(v.x, v.y), pk_bf16(v.z, v.w), 0u, 0u}; };
+                const u32x4 qb = half(q4[u]), db = half(d4[u]), kb = half(k4[u]), vb = half(v4[u]);
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                // ---- rows on lanes: dQ of the wave's row tile
+#pragma unroll
+                for (int pr = 0; pr < (NT + 1) / 2; ++pr) {
+                    float dsv[2][4];
+                    float4 kT[2];
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const int kt = 2 * pr + h2;
+                        if (kt < NT) {
+                            const f32x4 S = mfma_bf(half(ld4(sK + (u * ROWS + 16 * kt + lo) * KP + 4 * hi)), qb, z);
+                            const f32x4 dP = mfma_bf(half(ld4(sV + (u * ROWS + 16 * kt + lo) * KP + 4 * hi)), db, z);
+                            kT[h2] = ld4(sKT + (u * 16 + lo) * PT + 16 * kt + 4 * hi);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int key = 16 * kt + 4 * hi + i;
+                                const float p = key < N1 ? __expf(S[i] * 0.25f - lr[u]) : 0.f;
+                                dsv[h2][i] = p * (dP[i] - del[u]) * 0.25f;
+                            }
+                        } else {
+                            kT[h2] = zero4();
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) dsv[h2][i] = 0.f;
+                        }
+                    }
+                    dq = mfma_bf(pack8(kT[0], kT[1]), u32x4{pk_bf16(dsv[0][0], dsv[0][1]), pk_bf16(dsv[0][2], dsv[0][3]),
+                                                            pk_bf16(dsv[1][0], dsv[1][1]), pk_bf16(dsv[1][2], dsv[1][3])}, dq);
+                }
+                // ---- keys on lanes: dK, dV of the wave's key tile
+#pragma unroll
+                for (int pr = 0; pr < (NT + 1) / 2; ++pr) {
+                    float pv[2][4], dsv[2][4];
+                    float4 dT[2], qT[2];
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const int rt = 2 * pr + h2;
+                        if (rt < NT) {
+                            const f32x4 S = mfma_bf(half(ld4(sQ + (u * ROWS + 16 * rt + lo) * KP + 4 * hi)), kb, z);
+                            const f32x4 dP = mfma_bf(half(ld4(sD + (u * ROWS + 16 * rt + lo) * KP + 4 * hi)), vb, z);
+                            const float4 l4 = ld4(sL + u * ROWS + 16 * rt + 4 * hi);
+                            const float4 e4 = ld4(sDel + u * ROWS + 16 * rt + 4 * hi);
+                            dT[h2] = ld4(sDT + (u * 16 + lo) * PT + 16 * rt + 4 * hi);
+                            qT[h2] = ld4(sQT + (u * 16 + lo) * PT + 16 * rt + 4 * hi);
+                            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, ev[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                pv[h2][i] = rvalid ? __expf(S[i] * 0.25f - lv[i]) : 0.f;
+                                dsv[h2][i] = pv[h2][i] * (dP[i] - ev[i]) * 0.25f;
+                            }
+                        } else {
+                            dT[h2] = zero4(); qT[h2] = zero4();
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { pv[h2][i] = 0.f; dsv[h2][i] = 0.f; }
+                        }
+                    }
+                    dv = mfma_bf(pack8(dT[0], dT[1]), u32x4{pk_bf16(pv[0][0], pv[0][1]), pk_bf16(pv[0][2], pv[0][3]),
+                                                            pk_bf16(pv[1][0], pv[1][1]), pk_bf16(pv[1][2], pv[1][3])}, dv);
+                    dk = mfma_bf(pack8(qT[0], qT[1]), u32x4{pk_bf16(dsv[0][0], dsv[0][1]), pk_bf16(dsv[0][2], dsv[0][3]),
+                                                            pk_bf16(dsv[1][0], dsv[1][1]), pk_bf16(dsv[1][2], dsv[1][3])}, dk);
+                }
+            } else {
             // ---- rows on lanes: dQ of the wave's row tile
             const float qB[4] = {q4[u].x, q4[u].y, q4[u].z, q4[u].w}, dB[4] = {d4[u].x, d4[u].y, d4[u].z, d4[u].w};
-            f32x4 dq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
                 const float4 kA = ld4(sK + (u * ROWS + 16 * kt + lo) * KP + 4 * hi);
@@ -1060,7 +1200,6 @@ __global__ __launch_bounds__(512) void enc_b2_kernel(const EncB2 g) {
             }
             // ---- keys on lanes: dK, dV of the wave's key tile
             const float kB[4] = {k4[u].x, k4[u].y, k4[u].z, k4[u].w}, vB[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
-            f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int rt = 0; rt < NT; ++rt) {
                 const float4 qA = ld4(sQ + (u * ROWS + 16 * rt + lo) * KP + 4 * hi);
@@ -1088,6 +1227,7 @@ __global__ __launch_bounds__(512) void enc_b2_kernel(const EncB2 g) {
                     dk = mfma4(qTv[i], dsv, dk);
                 }
             }
+            }
             gin[u] = f4(dq); gin[2 + u] = f4(dk); gin[4 + u] = f4(dv);
             if (rvalid) {
                 float* o = g.dQKV + grow * (3 * ELG_E) + 32 * c + 16 * u + 4 * hi;
@@ -1105,12 +1245,12 @@ __global__ __launch_bounds__(512) void enc_b2_kernel(const EncB2 g) {
     STAMP(4, 7)
     fetch3(64);
     f32x4 a[8];
-    if (act) mma_lds<4, 6, WP96>(sA, gin, a, lo, hi);
+    if (act) mma_lds<BF, 4, 6, WP96>(sA, gin, a, lo, hi);
     commit3(sB);
     __syncthreads();
     STAMP(4, 8)
     if (act) {
-        mma_lds<4, 6, WP96>(sB, gin, a + 4, lo, hi);
+        mma_lds<BF, 4, 6, WP96>(sB, gin, a + 4, lo, hi);
         STAMP(4, 9)
         if (rvalid) {
             float* o = g.P2 + c * g.pstride + grow * ELG_E + 4 * hi;
@@ -1183,55 +1323,67 @@ constexpr size_t LDS_STAT = sizeof(float) * 2 * 8 * ELG_E;
 constexpr size_t LDS_2STAGE = sizeof(float) * 2 * 64 * WP128;
 constexpr size_t LDS_TBUF = sizeof(float) * 8 * TBUF;
 
-template <int NT>
+template <int NT, bool BF>
 static int launch_f1_t(const EncF1& g, hipStream_t s) {
     constexpr int ROWS = NT * 16, PT = ROWS + 4;
     constexpr int kv = 2 * ROWS * 20 + 2 * 16 * PT;
     constexpr size_t lds = LDS_STAT + sizeof(float) * (96 * WP128 + (kv > 8 * TBUF ? kv : 8 * TBUF));
     static DynLds optin;
-    return launch1(enc_f1_kernel<NT>, optin, "enc_f1", g.B * 4, lds, s, g);
+    return launch1(enc_f1_kernel<NT, BF>, optin, "enc_f1", g.B * 4, lds, s, g);
 }
-static int launch_f1(const EncF1& g, hipStream_t s) {
+template <bool BF>
+static int launch_f1_b(const EncF1& g, hipStream_t s) {
     const int nt = (g.N1 + 15) / 16;
-    if (nt <= 2) return launch_f1_t<2>(g, s);
-    if (nt <= 4) return launch_f1_t<4>(g, s);
-    if (nt <= 7) return launch_f1_t<7>(g, s);
-    return launch_f1_t<8>(g, s);
+    if (nt <= 2) return launch_f1_t<2, BF>(g, s);
+    if (nt <= 4) return launch_f1_t<4, BF>(g, s);
+    if (nt <= 7) return launch_f1_t<7, BF>(g, s);
+    return launch_f1_t<8, BF>(g, s);
 }
-static int launch_f2(const EncF2& g, hipStream_t s) {
+static int launch_f1(const EncF1& g, bool bf, hipStream_t s) { return bf ? launch_f1_b<true>(g, s) : launch_f1_b<false>(g, s); }
+template <bool BF>
+static int launch_f2_b(const EncF2& g, hipStream_t s) {
     static DynLds optin;
-    return launch1(enc_f2_kernel, optin, "enc_f2", g.B * (g.FF >> 7), LDS_STAT + LDS_2STAGE + LDS_TBUF, s, g);
+    return launch1(enc_f2_kernel<BF>, optin, "enc_f2", g.B * (g.FF >> 7), LDS_STAT + LDS_2STAGE + LDS_TBUF, s, g);
 }
-static int launch_f3(const EncF3& g, hipStream_t s) {
+static int launch_f2(const EncF2& g, bool bf, hipStream_t s) { return bf ? launch_f2_b<true>(g, s) : launch_f2_b<false>(g, s); }
+template <bool BF>
+static int launch_f3_b(const EncF3& g, hipStream_t s) {
     static DynLds optin;
-    return launch1(enc_f3_kernel, optin, "enc_f3", g.B * (g.ntab > 0 ? g.ntab : 1), LDS_STAT + LDS_2STAGE + LDS_TBUF, s, g);
+    return launch1(enc_f3_kernel<BF>, optin, "enc_f3", g.B * (g.ntab > 0 ? g.ntab : 1), LDS_STAT + LDS_2STAGE + LDS_TBUF, s, g);
 }
-static int launch_b0(const EncB0& g, hipStream_t s) {
+static int launch_f3(const EncF3& g, bool bf, hipStream_t s) { return bf ? launch_f3_b<true>(g, s) : launch_f3_b<false>(g, s); }
+template <bool BF>
+static int launch_b0_b(const EncB0& g, hipStream_t s) {
     static DynLds optin;
-    return launch1(enc_b0_kernel, optin, "enc_b0", g.B * g.ntab, LDS_2STAGE + LDS_TBUF, s, g);
+    return launch1(enc_b0_kernel<BF>, optin, "enc_b0", g.B * g.ntab, LDS_2STAGE + LDS_TBUF, s, g);
 }
-static int launch_b1(const EncB1& g, hipStream_t s) {
+static int launch_b0(const EncB0& g, bool bf, hipStream_t s) { return bf ? launch_b0_b<true>(g, s) : launch_b0_b<false>(g, s); }
+template <bool BF>
+static int launch_b1_b(const EncB1& g, hipStream_t s) {
     static DynLds optin;
-    return launch1(enc_b1_kernel, optin, "enc_b1", g.B * (g.FF >> 7), LDS_STAT + LDS_2STAGE + LDS_TBUF, s, g);
+    return launch1(enc_b1_kernel<BF>, optin, "enc_b1", g.B * (g.FF >> 7), LDS_STAT + LDS_2STAGE + LDS_TBUF, s, g);
 }
-template <int NT>
+static int launch_b1(const EncB1& g, bool bf, hipStream_t s) { return bf ? launch_b1_b<true>(g, s) : launch_b1_b<false>(g, s); }
+template <int NT, bool BF>
 static int launch_b2_t(const EncB2& g, hipStream_t s) {
     constexpr size_t lds = LDS_STAT + sizeof(float) * (32 * WP128 + b2_attn_floats<NT>());
     static_assert(lds <= 160 * 1024, "enc_b2: LDS image over 160 KB");
     static DynLds optin;
-    return launch1(enc_b2_kernel<NT>, optin, "enc_b2", g.B * 4, lds, s, g);
+    return launch1(enc_b2_kernel<NT, BF>, optin, "enc_b2", g.B * 4, lds, s, g);
 }
-static int launch_b2(const EncB2& g, hipStream_t s) {
+template <bool BF>
+static int launch_b2_b(const EncB2& g, hipStream_t s) {
     const int nt = (g.N1 + 15) / 16;
-    if (nt <= 2) return launch_b2_t<2>(g, s);
-    if (nt <= 4) return launch_b2_t<4>(g, s);
-    if (nt <= 7) return launch_b2_t<7>(g, s);
-    return launch_b2_t<8>(g, s);
+    if (nt <= 2) return launch_b2_t<2, BF>(g, s);
+    if (nt <= 4) return launch_b2_t<4, BF>(g, s);
+    if (nt <= 7) return launch_b2_t<7, BF>(g, s);
+    return launch_b2_t<8, BF>(g, s);
 }
+static int launch_b2(const EncB2& g, bool bf, hipStream_t s) { return bf ? launch_b2_b<true>(g, s) : launch_b2_b<false>(g, s); }
 
 int enc_fused_fwd(const elg_encoder_args* a, hipStream_t s) {
     const int B = a->B, N1 = a->N1, FF = a->ff_hidden, NS = FF >> 7, NL = a->n_layers;
-    const bool tsp = a->problem == ELG_PROBLEM_TSP;
+    const bool tsp = a->problem == ELG_PROBLEM_TSP, bf = a->precision == 1;
     const EncWs w = enc_ws(B, N1, NL, FF, a->save);
     const long R = w.R;
     float* ws = a->ws;
@@ -1260,12 +1412,12 @@ int enc_fused_fwd(const elg_encoder_args* a, hipStream_t s) {
         f1.Wq = L.Wq; f1.Wk = L.Wk; f1.Wv = L.Wv;
         f1.QKV = a->save ? lb + w.oQKV : nullptr; f1.O = lb + w.oO; f1.LSE = a->save ? lb + w.oLSE : nullptr;
         f1.B = B; f1.N1 = N1;
-        ENCF_TRY(launch_f1(f1, s))
+        ENCF_TRY(launch_f1(f1, bf, s))
         EncF2 f2{};
         f2.O = lb + w.oO; f2.Xin = xin_of(l); f2.Wc = L.Wc; f2.bc = L.bc; f2.g1 = L.g1; f2.b1 = L.b1; f2.W1 = L.W1; f2.bf1 = L.bf1;
         f2.W2 = L.W2; f2.X1 = lb + w.oX1; f2.XH1 = a->save ? lb + w.oXH1 : nullptr; f2.RS1 = a->save ? lb + w.oRS1 : nullptr;
         f2.H = a->save ? lb + w.oH : nullptr; f2.P = ws + w.P; f2.pstride = R * ELG_E; f2.B = B; f2.N1 = N1; f2.FF = FF; f2.eps = a->eps;
-        ENCF_TRY(launch_f2(f2, s))
+        ENCF_TRY(launch_f2(f2, bf, s))
     }
     EncF3 f3{};
     if (NL > 0) f3.pro = norm_pro(NL - 1, a->enc);
@@ -1289,13 +1441,13 @@ int enc_fused_fwd(const elg_encoder_args* a, hipStream_t s) {
         f3.ntab = n; f3.bc = a->W.dec_bc; f3.pb = a->pb; f3.pb_scale = inv_sqrt_e;
         if (!tsp) { f3.wl_src = a->W.dec_Wq_last; f3.wl = a->wl; }
     } else if (NL == 0) return ELG_OK;
-    return launch_f3(f3, s);
+    return launch_f3(f3, bf, s);
 }
 
 int enc_fused_bwd(const elg_encoder_bwd_args* ba, DwList& dw, hipStream_t s) {
     const elg_encoder_args* a = &ba->fwd;
     const int B = a->B, N1 = a->N1, FF = a->ff_hidden, NS = FF >> 7, NL = a->n_layers;
-    const bool tsp = a->problem == ELG_PROBLEM_TSP;
+    const bool tsp = a->problem == ELG_PROBLEM_TSP, bf = a->precision == 1;
     const EncWs w = enc_ws(B, N1, NL, FF, 1);
     const EncWs2 w2 = enc_ws2(B, N1, NL, FF);
     const long R = w.R;
@@ -1364,7 +1516,7 @@ int enc_fused_bwd(const elg_encoder_bwd_args* ba, DwList& dw, hipStream_t s) {
         } else if (ba->gpb) return fail(ELG_EINVAL, "encoder bwd: gpb without gPK");
         b0.ntab = n; b0.PX = s2 + w2.PX; b0.pstride = R * ELG_E; b0.B = B; b0.N1 = N1;
         if (n == 0 && !ba->g_enc) return fail(ELG_EINVAL, "encoder bwd: no cotangent given");
-        if (n > 0) ENCF_TRY(launch_b0(b0, s))
+        if (n > 0) ENCF_TRY(launch_b0(b0, bf, s))
     }
     if (ba->gpb || (ba->gwl && !tsp)) {
         if (ba->gpb) ENCF_TRY(need(G.dec_bc, "d bc"))
@@ -1389,7 +1541,7 @@ int enc_fused_bwd(const elg_encoder_bwd_args* ba, DwList& dw, hipStream_t s) {
         b1.pro.dout = gS;
         b1.W2T = wt + 4 * ELG_E * ELG_E + ELG_E * FF; b1.W1T = wt + 4 * ELG_E * ELG_E; b1.H = lb + w.oH; b1.gH = gH;
         b1.P1 = s2 + w2.P1; b1.pstride = R * ELG_E; b1.B = B; b1.N1 = N1; b1.FF = FF;
-        ENCF_TRY(launch_b1(b1, s))
+        ENCF_TRY(launch_b1(b1, bf, s))
         ENCF_TRY(dw.add(gS, ELG_E, lb + w.oH, FF, (float*)GL.W2, FF, ELG_E, FF, (float*)GL.bf2, 1.f))
         ENCF_TRY(dw.add(gH, FF, lb + w.oX1, ELG_E, (float*)GL.W1, ELG_E, FF, ELG_E, (float*)GL.bf1, 1.f))
         EncB2 b2{};
@@ -1399,7 +1551,7 @@ int enc_fused_bwd(const elg_encoder_bwd_args* ba, DwList& dw, hipStream_t s) {
         b2.WqT = wt; b2.WkT = wt + ELG_E * ELG_E; b2.WvT = wt + 2 * ELG_E * ELG_E; b2.WcT = wt + 3 * ELG_E * ELG_E;
         b2.QKV = lb + w.oQKV; b2.O = lb + w.oO; b2.LSE = lb + w.oLSE; b2.dQKV = dQKV; b2.P2 = s2 + w2.PX; b2.pstride = R * ELG_E;
         b2.B = B; b2.N1 = N1;
-        ENCF_TRY(launch_b2(b2, s))
+        ENCF_TRY(launch_b2(b2, bf, s))
         ENCF_TRY(dw.add(gY, ELG_E, lb + w.oO, ELG_E, (float*)GL.Wc, ELG_E, ELG_E, ELG_E, (float*)GL.bc, 1.f))
         ENCF_TRY(dw.add(dQKV, 3 * ELG_E, Xin, ELG_E, (float*)GL.Wq, ELG_E, ELG_E, ELG_E, nullptr, 1.f))
         ENCF_TRY(dw.add(dQKV + ELG_E, 3 * ELG_E, Xin, ELG_E, (float*)GL.Wk, ELG_E, ELG_E, ELG_E, nullptr, 1.f))

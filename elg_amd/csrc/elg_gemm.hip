@@ -166,7 +166,7 @@ static int gemm_launch(const float* A, const float* B, float* C, const float* bi
     return launch_status("gemm_f32");
 }
 
-extern "C" int elg_gemm_f32_alpha(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+extern "C" __attribute__((visibility("hidden"))) int elg_gemm_f32_alpha(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                                   int lda, int ldb, int ldc, int transA, int transB, int relu, int split_k, float* a_rowsum,
                                   float alpha, void* stream) {
     const long st[6] = {0, 0, 0, 0, 0, 0};

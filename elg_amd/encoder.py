@@ -69,13 +69,22 @@ class _Workspace:
         return ws
 
 
+def _precision(precision) -> int:
+    """0 = f32 (parity mode), 1 = the bf16 throughput mode (elg_encoder_args.precision); None: the engine's mode
+    (engine.FWD_PRECISION / ELG_FWD_MODE, the switch the rollout obeys)."""
+    if precision is None:
+        from . import engine as _eng          # (lazy: engine does not import this module)
+        precision = _eng.FWD_PRECISION
+    return int(precision)
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
 class _EncodeFold(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, kind, n_layers, ff, eps, train, xy, demand, *params):
+    def forward(ctx, kind, n_layers, ff, eps, train, precision, xy, demand, *params):
         dev = xy.device
         B, N1, _ = xy.shape
         tsp = kind == L.PROBLEM_TSP
@@ -84,6 +93,7 @@ class _EncodeFold(torch.autograd.Function):
         ws = _Workspace.get((B, N1, n_layers, ff, train, str(dev)), n_ws, dev)
         a = L.EncoderArgs()
         a.problem, a.B, a.N1, a.n_layers, a.ff_hidden, a.save, a.eps = kind, B, N1, n_layers, ff, int(train), eps
+        a.precision = precision
         a.xy, a.demand = _ptr(xy), _ptr(demand)
         _fill_weights(a.W, kind, n_layers, [p.data_ptr() for p in params])
         enc, K, V, PK, Q1 = (torch.empty(B, N1, E, device=dev) for _ in range(5))
@@ -142,11 +152,11 @@ class _EncodeFold(torch.autograd.Function):
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             L.check(lib.elg_encoder_bwd(C.byref(ba), stream), "elg_encoder_bwd")
-        return (None, None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, None, *grads)
 
 
 def encode_and_fold(kind: int, xy: torch.Tensor, demand: Optional[torch.Tensor], params: Sequence[torch.Tensor],
-                    n_layers: int, ff_hidden: int, eps: float = 1e-5):
+                    n_layers: int, ff_hidden: int, eps: float = 1e-5, precision=None):
     """-> (encoded_nodes, tables) with tables = {K, V, PK, pb, Q1, Q2, wl} (engine.Policy layout).  GPU only."""
     if not xy.is_cuda:
         raise RuntimeError("elg_amd: the encoder runs on the GPU only -- the HIP path has no CPU fallback")
@@ -156,12 +166,12 @@ def encode_and_fold(kind: int, xy: torch.Tensor, demand: Optional[torch.Tensor],
     xy = xy.contiguous().float()
     demand = None if demand is None else demand.contiguous().float()
     train = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-    enc, K, V, PK, pb, Q1, Q2, wl = _EncodeFold.apply(kind, n_layers, ff_hidden, eps, train, xy, demand, *params)
+    enc, K, V, PK, pb, Q1, Q2, wl = _EncodeFold.apply(kind, n_layers, ff_hidden, eps, train, _precision(precision), xy, demand, *params)
     return enc, dict(K=K, V=V, PK=PK, pb=pb, Q1=Q1, Q2=Q2, wl=wl)
 
 
 def encode_only(kind: int, xy: torch.Tensor, demand: Optional[torch.Tensor], enc_params: Sequence[torch.Tensor],
-                n_layers: int, ff_hidden: int, eps: float = 1e-5) -> torch.Tensor:
+                n_layers: int, ff_hidden: int, eps: float = 1e-5, precision=None) -> torch.Tensor:
     """Encoder without the decoder tables (inference): `enc_params` = the encoder.* entries of parameter_names()."""
     if not xy.is_cuda:
         raise RuntimeError("elg_amd: the encoder runs on the GPU only -- the HIP path has no CPU fallback")
@@ -173,6 +183,7 @@ def encode_only(kind: int, xy: torch.Tensor, demand: Optional[torch.Tensor], enc
     ws = _Workspace.get((B, N1, n_layers, ff_hidden, False, str(dev)), int(lib.elg_encoder_ws_floats(B, N1, n_layers, ff_hidden, 0)), dev)
     a = L.EncoderArgs()
     a.problem, a.B, a.N1, a.n_layers, a.ff_hidden, a.save, a.eps = kind, B, N1, n_layers, ff_hidden, 0, eps
+    a.precision = _precision(precision)
     a.xy, a.demand = _ptr(xy), _ptr(demand)
     ptrs = [p.data_ptr() for p in enc_params] + [0] * (6 if kind == L.PROBLEM_TSP else 5)
     _fill_weights(a.W, kind, n_layers, ptrs)
@@ -183,7 +194,7 @@ def encode_only(kind: int, xy: torch.Tensor, demand: Optional[torch.Tensor], enc
     return enc
 
 
-def fold_only(kind: int, enc: torch.Tensor, dec_params: Sequence[torch.Tensor]) -> Dict[str, torch.Tensor]:
+def fold_only(kind: int, enc: torch.Tensor, dec_params: Sequence[torch.Tensor], precision=None) -> Dict[str, torch.Tensor]:
     """`decoder.set_kv(encoded_nodes)` on given encodings (reference models.py:300-308, TSP/models.py:231-241), inference
     only: the table part of elg_encoder_fwd (n_layers = 0).  dec_params = the decoder.* entries of parameter_names()."""
     if not enc.is_cuda:
@@ -194,6 +205,7 @@ def fold_only(kind: int, enc: torch.Tensor, dec_params: Sequence[torch.Tensor]) 
     tsp = kind == L.PROBLEM_TSP
     a = L.EncoderArgs()
     a.problem, a.B, a.N1, a.n_layers, a.ff_hidden, a.save, a.eps = kind, B, N1, 0, 512, 0, 1e-5
+    a.precision = _precision(precision)
     ptrs = [0] * (2 if tsp else 4) + [p.data_ptr() for p in dec_params]
     _fill_weights(a.W, kind, 0, ptrs)
     K, V, PK, Q1 = (torch.empty(B, N1, E, device=dev) for _ in range(4))

@@ -175,6 +175,46 @@ def broadcast_object(obj, src: int = 0):
     return obj
 
 
+def collective_world() -> tuple:
+    """(rank, world) of the process group the collectives run in; (0, 1) without one."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def sum_over_ranks(values) -> list:
+    """Element-wise SUM over the ranks of a short list of numbers (float64; identity without a process group)."""
+    _, world = collective_world()
+    if world <= 1:
+        return [float(v) for v in values]
+    t = torch.tensor(list(values), dtype=torch.float64, device="cuda" if _device_collectives() else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.cpu()]
+
+
+def guarded(fn):
+    """Run fn() -- rank-local work WITHOUT collectives (a rank's share of a sharded validation) -- on every rank, then exchange
+    an error flag: if ANY rank raised, every rank raises here, before the collective that would combine the results -- a rank
+    that fails must not leave the others sitting in that collective until its timeout (600 s).  The failing rank re-raises its
+    own exception, the others a RuntimeError naming it."""
+    _, world = collective_world()
+    if world <= 1:
+        return fn()
+    err, out = None, None
+    try:
+        out = fn()
+    except BaseException as e:          # noqa: BLE001 -- the flag must be exchanged whatever went wrong
+        err = e
+    box = [None] * world
+    dist.all_gather_object(box, None if err is None else f"{type(err).__name__}: {err}")
+    if err is not None:
+        raise err
+    bad = [(r, m) for r, m in enumerate(box) if m is not None]
+    if bad:
+        raise RuntimeError(f"rank {bad[0][0]} failed in a collective phase: {bad[0][1]}")
+    return out
+
+
 def ranks_seen() -> int:
     """World size as the data path sees it: an all-reduce of ones (1 without a process group)."""
     if not (dist.is_available() and dist.is_initialized()):

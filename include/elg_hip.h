@@ -104,9 +104,11 @@ typedef struct elg_rollout_args {
                                (N1 <= 1024); training goes through elg_rollout_bwd's replay (N1 <= 1024)                */
     int32_t Kens[ELG_MAX_ENS];
     int32_t precision;      /* 0: f32 (the parity mode: every product exact f32).  1: bf16 throughput mode (BASELINE configs[1]): the
-                               glimpse score / output and pointer products of the cooperative kernel (N1 <= 112) take bf16 operands
-                               on v_mfma_f32_16x16x32_bf16 with f32 accumulation; softmax, masks, local policy, environment stay
-                               f32.  Other kernels ignore it (they compute in f32).                                      */
+                               glimpse score / output and pointer products take bf16 operands on v_mfma_f32_16x16x32_bf16 with f32
+                               accumulation; softmax, masks, local policy, environment stay f32.  Honoured by the cooperative kernel
+                               (N1 <= 112; training and evaluation), the streaming kernel (128 < N1 <= 1024, evaluation) and the
+                               N1 > 1024 kernel (evaluation); the one-wavefront kernels and the N1 > 128 training forward compute in
+                               f32 whatever it says.                                                                     */
     uint64_t seed;          /* sampling seed (Philox key)                                       */
     const float* Kmat;      /* (B,N1,128) decoder.Wk enc                                        */
     const float* Vmat;      /* (B,N1,128) decoder.Wv enc                                        */
@@ -305,7 +307,11 @@ typedef struct elg_encoder_args {
     int32_t ff_hidden;      /* model_params.ff_hidden_dim (multiple of 64)                                         */
     int32_t save;           /* 1: keep every layer's activations in `ws` for elg_encoder_bwd (training)            */
     float eps;              /* InstanceNorm1d eps (1e-5)                                                           */
-    int32_t pad0;
+    int32_t precision;      /* 0: f32 (the parity mode).  1: bf16 throughput mode (BASELINE configs[1]), N1 <= 128 only (larger
+                               instances compute in f32 whatever it says): every GEMM of the encoder, of the tables and of
+                               their backward takes bf16 operands on v_mfma_f32_16x16x32_bf16 with f32 accumulation; bias,
+                               residual, instance norm, softmax, the saved activations and the weight gradients stay f32.  The
+                               backward must be given the forward's value.                                                */
     const float* xy;        /* (B,N1,2)                                                                            */
     const float* demand;    /* (B,N1) CVRP (depot entry unused); TSP: NULL                                         */
     elg_enc_weights W;

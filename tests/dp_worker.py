@@ -103,7 +103,26 @@ def two_ranks(out_path):
     opt2.step()
     torch.cuda.synchronize()
     after2 = _flat(model2)
+    # ---- sharded validation (train.validate under data parallelism): each rank evaluates the instances rank, rank + world, ...
+    # of every set; against the one-process evaluation of the same sets (test_rollout, no collective), and identical on both ranks
+    import pickle, tempfile
+    import numpy as np
+    from torch.utils.data import DataLoader
+    from elg_amd.CVRP import train as T_
+    from elg_amd.CVRP.generate_data import VRPDataset
+    vdir = tempfile.mkdtemp()
+    rs = np.random.RandomState(99)                                      # the same files on every rank
+    for kind in ("uniform", "cluster", "mixed"):
+        rows = [(rs.rand(2).tolist(), rs.rand(20, 2).tolist(), rs.randint(1, 10, 20).astype(float).tolist(), 30.0) for _ in range(7)]
+        pickle.dump(rows, open(os.path.join(vdir, f"vrp_{kind}100_1000_seed1234.pkl"), "wb"))
+    sharded = T_.validate(model, 20, dev, True, data_dir=vdir)
+    venv = CVRPEnv(multi_width=20, device=dev)
+    whole = [T_.test_rollout(DataLoader(VRPDataset(os.path.join(vdir, f"vrp_{k}100_1000_seed1234.pkl"), num_samples=1000), batch_size=1000),
+                             venv, model) for k in ("uniform", "cluster", "mixed")]
+    mark("sharded validation done")
+    model.train()
     res = {
+        "validate_sharded": sharded, "validate_whole": whole,
         "rank": rank, "world": world, "grad_scale": opt.grad_scale, "staged_on_host": bool(captured["on_host"]),
         "bucket_calls": bucket.calls,
         "allreduce_err": float((summed.cpu() - ref_sum).abs().max()),

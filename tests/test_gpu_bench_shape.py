@@ -7,7 +7,7 @@
 * the bench launch geometry (64 instances x pomo 100 -> tiles = 4, 256 workgroups of 25 lockstep trajectories) diffed against
   the oracle's probabilities on two of its instances.
 
-Worst observed values go to gpurun_out/parity_r04.json (copied to profiles/)."""
+Worst observed values go to gpurun_out/parity_r05.json (copied to profiles/)."""
 import random
 
 import numpy as np
@@ -169,3 +169,65 @@ def test_side_stream_local_backward_equals_the_inline_launch(monkeypatch):
         worst = max(worst, err)
         assert err <= 2e-4, (k, err)            # (two runs of the SAME path differ by ~3e-5: float atomics)
     gc.record_parity("side_stream_local_bwd/grad_rel_diff", worst)
+
+
+@pytest.mark.parametrize("problem,N", [("cvrp", 120), ("tsp", 127), ("cvrp", 112), ("tsp", 113)])
+def test_product_train_step_in_the_112_to_128_node_band(problem, N):
+    """112 < N + 1 <= 128: too wide for the cooperative kernel (its operand images hold 7 node tiles), still inside the
+    one-instance-per-row-block encoder and the N1 <= 128 decoder backward -- the product step takes the one-wavefront training
+    forward with STORED glimpse weights there (engine.rollout_forward: trA), a path the fixed-size tests reach only through
+    parametrisations.  Whole product step (pre_forward -> sampled rollout -> POMO loss -> backward) against the oracle's autograd
+    in float64 on the same tours: chosen probabilities 5e-4, decoder / local-policy gradients 1e-3 of the tensor's maximum."""
+    from elg_amd import engine as eng
+    if problem == "cvrp":
+        from elg_amd.CVRP.CVRPEnv import CVRPEnv as Env
+        from elg_amd.CVRP.train import pomo_loss
+        from elg_amd.CVRP.utils import rollout
+        mp = dict(gu.CVRP_MODEL_PARAMS)
+        depot, loc, demand = gu.golden_cvrp_problem(500 + N, 1, N, 50.0)
+        batch = dict(depot=torch.from_numpy(depot), loc=torch.from_numpy(loc), demand=torch.from_numpy(demand))
+        xy = torch.from_numpy(np.concatenate([depot, loc], 1))
+        dem = torch.from_numpy(np.concatenate([np.zeros((1, 1), np.float32), demand], 1))
+    else:
+        from elg_amd.TSP.TSPEnv import TSPEnv as Env
+        from elg_amd.TSP.train import pomo_loss
+        from elg_amd.TSP.utils import rollout
+        mp = dict(gu.TSP_MODEL_PARAMS)
+        xy = torch.from_numpy(gu.golden_tsp_problem(500 + N, 1, N))
+        batch, dem = xy, None
+    cfg = orc.ModelCfg.from_model_params(mp, problem)
+    M = 12
+    model = gc.load_model(problem, 29, mp, 1.0).train()
+    env = Env(multi_width=M, device=DEV)
+    env.load_random_problems(batch)
+    rs, _, _ = env.reset()
+    model.pre_forward(rs)
+    torch.manual_seed(5)
+    random.seed(5)
+    acts, probs, rew = rollout(model, env, 'sample')
+    assert probs.requires_grad
+    rew_n = rew + 0.3 * torch.randn(1, M, device=rew.device)
+    J = pomo_loss(probs, rew_n, True) if problem == "cvrp" else pomo_loss(probs, rew_n)
+    J.backward()
+    got = {k: v.grad.detach().cpu().double() for k, v in model.named_parameters()}
+    P = {k: v.double().requires_grad_(True) for k, v in gc.weights(problem, 29, mp, 1.0).items()}
+    a = acts.cpu().long()
+    if problem == "cvrp":
+        out = orc.rollout_cvrp(P, cfg, xy.double(), dem.double(), M, starts=a[0, :, 1], forced=a)
+    else:
+        out = orc.rollout_tsp(P, cfg, xy.double(), M, starts=a[0, :, 0], forced=a)
+    ref_p = out["probs"].detach()
+    pe = float(((probs.detach().cpu().double()[:, :ref_p.shape[1]] - ref_p).abs() / ref_p).max())
+    assert pe <= 5e-4, f"chosen probabilities off by {pe:.2e}"
+    Jo = orc.pomo_loss(out["probs"], rew_n.cpu().double(), True, guard_zero=(problem == "tsp"))
+    Jo.backward()
+    worst = 0.0
+    for k, p in P.items():
+        if not k.startswith("decoder.") or p.grad is None:
+            continue
+        err = float((got[k] - p.grad).abs().max()) / float(p.grad.abs().max())
+        worst = max(worst, err)
+        assert err <= 1e-3, f"{k}: {err:.3e} of the tensor maximum"
+    gc.record_parity(f"band_112_128/{problem}_n{N}_decoder_local_grad_over_tensor_max", worst)
+    gc.record_parity(f"band_112_128/{problem}_n{N}_chosen_prob_rel", pe)
+    print(problem, N, f"decoder/local gradients {worst:.2e} of the tensor maximum, chosen probabilities {pe:.2e}")

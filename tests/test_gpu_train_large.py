@@ -193,3 +193,63 @@ def test_saved_rows_workspace_is_reused_across_batches(poison):
     worst, n_ex = _grad_check(got, {k: v.grad for k, v in P.items()}, _kink_units(P, cfg, xy, dem))
     gc.record_parity(f"train_large_rows_reused_poison{int(poison)}_grad_over_limit", worst)
     eng.TrainRows._cache.clear()
+
+
+@pytest.mark.parametrize("mode", ["f32", "split_bf16", "bf16_mode"])
+def test_cooperative_saved_rows_workspace_poisoned_between_batches(mode):
+    """The same hazard at the cooperative kernel's sizes (N + 1 <= 112: glimpse_bwd_f32n_kernel / glimpse_bwd_bf16_kernel recompute
+    exp2(q . K - lse) on every saved row): a finished trajectory's rows keep q / lse of an earlier batch; poisoned in between, they
+    must not reach the gradients (the exp2 argument is clamped at 0, their dA / dO are 0).  Gradients of the second batch against
+    the oracle's, as in the test above."""
+    from elg_amd import engine as eng
+    from elg_amd.CVRP.CVRPEnv import CVRPEnv
+    from elg_amd.CVRP.train import pomo_loss
+    from elg_amd.CVRP.utils import rollout
+    eng.TrainRows._cache.clear()
+    N, M, B = 50, 16, 2
+    mp = dict(gu.CVRP_MODEL_PARAMS)
+    cfg = orc.ModelCfg.from_model_params(mp, "cvrp")
+    model = gc.load_model("cvrp", 17, mp, gain=1.0).train()
+    env = CVRPEnv(multi_width=M, device=DEV)
+    torch.manual_seed(12)
+    random.seed(12)
+    old = (eng.BWD_MFMA_MODE, eng.FWD_PRECISION)
+    eng.BWD_MFMA_MODE = {"f32": 0, "split_bf16": 2, "bf16_mode": 0}[mode]
+    eng.FWD_PRECISION = 1 if mode == "bf16_mode" else 0
+    try:
+        for step, (seed, cap) in enumerate([(411, 25.0), (412, 80.0)]):
+            depot, loc_xy, demand = gu.golden_cvrp_problem(seed, B, N, cap)
+            batch = dict(depot=torch.from_numpy(depot), loc=torch.from_numpy(loc_xy), demand=torch.from_numpy(demand))
+            env.load_random_problems(batch)
+            rs, _, _ = env.reset()
+            for p in model.parameters():
+                p.grad = None
+            model.pre_forward(rs)
+            acts, probs, rew = rollout(model, env, 'sample')
+            rew_n = rew + 0.3 * torch.randn(B, M, device=rew.device)
+            J = pomo_loss(probs, rew_n, True)
+            J.backward()
+            ws = [w for k, w in eng.TrainRows._cache.items() if k[2] <= 128]
+            assert len(ws) == 1, "both steps must share one saved-rows workspace"
+            if step == 0:
+                T0 = acts.shape[2]
+                ws[0].Q.fill_(3.0e18)
+                ws[0].Lse.fill_(-3.0e38)
+                ws[0].Mask.zero_()
+                ws[0].O.fill_(1.0e18)
+    finally:
+        eng.BWD_MFMA_MODE, eng.FWD_PRECISION = old
+    got = {k: v.grad for k, v in model.named_parameters()}
+    assert all(torch.isfinite(g).all().item() for g in got.values()), "a dead row reached the gradients"
+    if mode == "bf16_mode":
+        return                                            # (its gradients are pinned in test_gpu_backward against the bf16 oracle)
+    xy = torch.from_numpy(np.concatenate([depot, loc_xy], 1))
+    dem = torch.from_numpy(np.concatenate([np.zeros((B, 1), np.float32), demand], 1))
+    P = {k: v.clone().requires_grad_(True) for k, v in gc.weights("cvrp", 17, mp, 1.0).items()}
+    a = acts.cpu()
+    out = orc.rollout_cvrp(P, cfg, xy, dem, M, starts=a[0, :, 1], forced=a)
+    Jo = orc.pomo_loss(out["probs"], rew_n.cpu(), True)
+    Jo.backward()
+    worst, n_ex = _grad_check(got, {k: v.grad for k, v in P.items()}, _kink_units(P, cfg, xy, dem))
+    gc.record_parity(f"train_coop_rows_poisoned_{mode}_grad_over_limit", worst)
+    eng.TrainRows._cache.clear()

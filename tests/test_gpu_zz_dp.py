@@ -91,6 +91,10 @@ def test_two_ranks_share_one_gradient(tmp_path):
         assert r["step_moved"] > 0
         assert r["vs_single_process_adam"] == 0.0                          # = Adam on the averaged gradient, bit for bit
     assert res[0]["param_checksum"] == res[1]["param_checksum"]             # replicas identical after the step
+    # sharded validate(): the same means on both ranks, equal to the one-process evaluation of the same sets
+    assert res[0]["validate_sharded"] == res[1]["validate_sharded"]
+    for a, b in zip(res[0]["validate_sharded"], res[0]["validate_whole"]):
+        assert abs(a - b) <= 1e-6 * abs(b), (res[0]["validate_sharded"], res[0]["validate_whole"])
 
 
 def test_rccl_allreduce_in_the_training_step(tmp_path):

@@ -432,3 +432,73 @@ def test_oracle_ensemble_of_local_policies(tag):
         ref = fx[f"{tag}_grad_{n}"]
         got = P[n].grad.numpy()
         assert np.abs(got - ref).max() <= 1e-3 * max(np.abs(ref).max(), 1e-6), n
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the folded decode and the bf16 restatement (round 5): the oracle of the engine's bf16 throughput mode
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("problem,tag", [("cvrp", "n50"), ("cvrp", "n100"), ("tsp", "n20")])
+def test_oracle_folded_decode_against_reference_internals(problem, tag):
+    """fold_tables + the folded glimpse / pointer (what precision="bf16" is defined on) against the REFERENCE's recorded score
+    before the clip and logits at the f32 bar, and against the oracle's unfolded path: the regrouping changes nothing."""
+    lg = gu.load_golden(f"r02_{problem}_logits_{tag}.npz")
+    fx = gu.load_golden(f"{problem}_rollout_{str(lg['src'])}.npz")
+    acts = torch.from_numpy(fx["actions"].astype(np.int64))
+    if problem == "cvrp":
+        cfg, P, xy, dem, B, N, M = _cvrp_setup(fx, torch.float32)
+        enc = orc.encoder_forward(P, cfg, xy, dem)
+        kw = dict(starts=acts[0, :, 1], forced=acts, enc=enc, keep_parts=True)
+        run = lambda **k: orc.rollout_cvrp(P, cfg, xy, dem, M, **kw, **k)
+        t0 = 2
+    else:
+        cfg, P, xy, B, N, M = _tsp_setup(fx, torch.float32)
+        enc = orc.encoder_forward(P, cfg, xy)
+        kw = dict(starts=acts[0, :, 0], forced=acts, enc=enc, keep_parts=True)
+        run = lambda **k: orc.rollout_tsp(P, cfg, xy, M, **kw, **k)
+        t0 = 1
+    plain, folded = run(), run(tables=orc.fold_tables(P, cfg, enc))
+    for i, t in enumerate(lg["steps"]):
+        open_ = np.isfinite(lg["logits"][i])
+        s = folded["parts"][int(t) - t0]["s"].numpy()
+        assert logit_errors(s, lg["pre_clip"][i], open_) <= LOGIT_RTOL
+        assert logit_errors(cfg.logit_clipping * np.tanh(s), lg["logits"][i], open_, cfg.logit_clipping) <= LOGIT_RTOL
+        assert logit_errors(s, plain["parts"][int(t) - t0]["s"].numpy(), open_) <= 2e-5
+    np.testing.assert_allclose(folded["probs"].numpy(), plain["probs"].numpy(), rtol=2e-4)
+
+
+def test_oracle_bf16_restatement_is_a_value_substitution(monkeypatch):
+    """precision="bf16": (i) with the rounding switched off it IS the folded f32 path, values and gradients (the substitution
+    plumbing adds nothing of its own); (ii) with it on, the scores move by the size of a bf16 rounding (between 1e-5 and 1e-1 of
+    max(|s|, 1)), the gradient stays finite and close to the f32 one; (iii) the rounded values may come from other tables
+    (tables_val) without touching the derivative's graph."""
+    fx = gu.load_golden("cvrp_rollout_n20.npz")
+    acts = torch.from_numpy(fx["actions"].astype(np.int64))
+    cfg, P, xy, dem, B, N, M = _cvrp_setup(fx, torch.float64)
+
+    def grads(precision, tv=False):
+        Pd = {k: v.clone().requires_grad_(k.startswith("decoder.")) for k, v in P.items()}
+        enc = orc.encoder_forward(P, cfg, xy, dem).detach().requires_grad_(True)
+        t = orc.fold_tables(Pd, cfg, enc)
+        tvd = {k: (None if v is None else v.detach().float()) for k, v in t.items()} if tv else None
+        out = orc.rollout_cvrp(Pd, cfg, xy, dem, M, starts=acts[0, :, 1], forced=acts, enc=enc, keep_parts=True, tables=t,
+                               tables_val=tvd, precision=precision)
+        torch.log(out["probs"]).sum().backward()
+        return out, {**{k: v.grad for k, v in Pd.items() if v.grad is not None}, "enc": enc.grad}
+    o32, g32 = grads("f32")
+    with monkeypatch.context() as m:
+        m.setattr(orc, "_bf16", lambda x: x.detach())
+        oid, gid = grads("bf16")
+    assert torch.allclose(oid["probs"], o32["probs"], rtol=1e-12, atol=0)
+    for k in g32:
+        assert torch.allclose(gid[k], g32[k], rtol=1e-9, atol=1e-12), k
+    ob, gb = grads("bf16")
+    ot, gt = grads("bf16", tv=True)
+    dev = max(float(((a["s"] - b["s"])[torch.isfinite(a["s"])].abs() / a["s"][torch.isfinite(a["s"])].abs().clamp_min(1.0)).max())
+              for a, b in zip(o32["parts"], ob["parts"]))
+    assert 1e-5 < dev < 1e-1, dev
+    for k in g32:
+        assert torch.isfinite(gb[k]).all() and torch.isfinite(gt[k]).all()
+        rel = float((gb[k] - g32[k]).norm() / g32[k].norm().clamp_min(1e-30))
+        assert rel < 0.2, (k, rel)
+    # float64 tables rounded through f32 (what tables_val carries) round to the same bf16 values except at f32 rounding boundaries
+    assert float((ot["probs"] - ob["probs"]).abs().max()) < 1e-2

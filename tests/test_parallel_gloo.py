@@ -98,3 +98,50 @@ def test_curriculum_choice_is_rank0s_on_every_rank():
     # without a process group the helper is the identity
     from elg_amd import parallel
     assert parallel.broadcast_object("x") == "x"
+
+
+def _guard_worker(rank, world, port, out, fail_rank):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from elg_amd import parallel
+    parallel.init_distributed("gloo", timeout_s=60.0)
+    # a sharded evaluation: every rank sums its own instances, the sums meet in sum_over_ranks
+    costs = [3.0, 5.0, 7.0, 11.0, 13.0]
+    mine = costs[rank::world]
+
+    def phase():                                            # rank-local, no collective (as validate()'s local_sums)
+        if rank == fail_rank:
+            raise ValueError("boom on this rank")
+        return [sum(mine), float(len(mine))]
+    try:
+        tot = parallel.sum_over_ranks(parallel.guarded(phase))
+        out[rank] = ("ok", tot[0] / tot[1])
+    except Exception as e:                                  # noqa: BLE001
+        out[rank] = (type(e).__name__, str(e))
+    torch.distributed.destroy_process_group()
+
+
+def _run_guard(fail_rank):
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_guard_worker, args=(r, 2, port, out, fail_rank)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0, "a rank hung or died instead of raising"
+    return dict(out)
+
+
+def test_sharded_validation_sum_and_error_guard_world2():
+    """validate() under data parallelism: each rank evaluates its share, the sums are added over the ranks and every rank gets
+    the same mean; a rank that raises inside the phase makes EVERY rank raise right after it (no rank is left waiting in the next
+    collective for the 600 s timeout)."""
+    ok = _run_guard(fail_rank=-1)
+    assert ok[0] == ok[1] == ("ok", (3.0 + 5.0 + 7.0 + 11.0 + 13.0) / 5.0)
+    bad = _run_guard(fail_rank=1)
+    assert bad[1] == ("ValueError", "boom on this rank")                      # the failing rank: its own exception
+    assert bad[0][0] == "RuntimeError" and "rank 1 failed" in bad[0][1] and "boom" in bad[0][1]
+    from elg_amd import parallel
+    assert parallel.guarded(lambda: 42) == 42 and parallel.sum_over_ranks([1, 2.5]) == [1.0, 2.5]
