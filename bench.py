@@ -431,8 +431,8 @@ def main():
                         "2-term split-bf16 linear products; encoder (N1 <= 128) forward and backward GEMMs + self-attention on bf16 "
                         "operands (elg_encoder_args.precision = 1), weight gradients, pointer and local-policy backward f32",
                 "tolerance": "pinned on the oracle's bf16 restatement (oracle/elg_oracle.py precision='bf16'): "
-                             "tests/test_gpu_logits.py::test_bf16_mode_* -- scores before the clip within 1e-4 max(|ref|, 1) of it on >= 99.8 % "
-                             "of the open nodes (the rest: bf16 rounding boundaries, <= 2e-2), and within 2 x the observed distance "
+                             "tests/test_gpu_logits.py::test_bf16_mode_* -- scores before the clip within 1e-4 max(|ref|, 1) of it on >= 99 % "
+                             "of the open nodes (the rest: bf16 rounding boundaries, <= 2e-3), and within 2 x the observed distance "
                              "of the reference's f32 scores per fixture (1.4e-2 at CVRP-100); "
                              "tests/test_gpu_backward.py::test_bf16_mode_training_gradients -- every gradient entry within 1e-3 of "
                              "the tensor's largest against the same oracle in float64"}

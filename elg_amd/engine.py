@@ -456,7 +456,7 @@ BWD_MFMA_MODE = int(os.environ.get("ELG_BWD_MFMA_MODE", "0"))
 # kernels and the training forward above 128 nodes compute in f32 whatever the mode.  Tolerance of the mode, as tested
 # (tests/test_gpu_logits.py::test_bf16_mode_*, tests/test_gpu_backward.py::test_bf16_mode_training_gradients): pinned on the
 # oracle's bf16 restatement (the same operands rounded) at the f32 bar -- scores before the clip within 1e-4 max(|ref|, 1) on
-# >= 99.8 % of the open nodes, gradients within 1e-3 of the tensor's largest entry -- and within 1.4e-2 max(|ref|, 1) of the
+# >= 99 % of the open nodes (<= 2e-3 on the rest), gradients within 1e-3 of the tensor's largest entry -- and within 1.4e-2 max(|ref|, 1) of the
 # reference's f32 scores at CVRP-100 (per-fixture bounds in the test); greedy tours differ from the f32 ones in a few per
 # cent of the steps.
 FWD_PRECISION = {"f32": 0, "fp32": 0, "bf16": 1}[os.environ.get("ELG_FWD_MODE", "f32").lower()]

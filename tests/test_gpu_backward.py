@@ -100,10 +100,12 @@ def _run(problem, tag, loss_kind, geometry=None, train=False, precision=0, bf16_
         Jb.backward()
         refb = {k: v.grad.clone() for k, v in P64.items() if v.grad is not None}
         refb["enc"] = enc64.grad.clone()
-        pe = float(((pr.detach().cpu().double() - ob["probs"].detach()).abs() / ob["probs"].detach()).max())
+        rel_p = ((pr.detach().cpu().double() - ob["probs"].detach()).abs() / ob["probs"].detach()).flatten()
+        pe, p_frac = float(rel_p.max()), float((rel_p <= 2e-3).double().mean())
         pe32 = float(((pr.detach().cpu() - out["probs"].detach()).abs() / out["probs"].detach()).max())
-        print(problem, tag, f"bf16 mode: chosen probabilities vs the bf16 oracle {pe:.2e} (vs the f32 oracle {pe32:.2e})")
+        print(problem, tag, f"bf16 mode: chosen probabilities vs the bf16 oracle: {p_frac:.4f} within 2e-3, worst {pe:.2e} (vs the f32 oracle {pe32:.2e})")
         gc.record_parity(f"bf16_mode/{problem}_{tag}_chosen_prob_rel_vs_bf16_oracle", pe)
+        gc.record_parity(f"bf16_mode/{problem}_{tag}_chosen_prob_fraction_within_2e-3_of_bf16_oracle", p_frac)
         gc.record_parity(f"bf16_mode/{problem}_{tag}_chosen_prob_rel_vs_f32_oracle", pe32)
         Jg = loss_fn(pr)
         Jg.backward()
@@ -111,17 +113,24 @@ def _run(problem, tag, loss_kind, geometry=None, train=False, precision=0, bf16_
         got["enc"] = enc_g.grad
         assert set(got) == set(refb)
         prob_rel, grad_rel = bf16_bounds
-        assert pe <= prob_rel, f"chosen probability off the bf16 oracle by {pe:.3e} (bound {prob_rel})"
-        # every entry within grad_rel of the tensor's largest entry (+ the f32 floor of _grad_check)
+        # (a score on a bf16 rounding boundary moves by up to 4e-4 -- test_gpu_logits -- and the clip's factor 50 makes that 2 % of a
+        # single probability: almost all of them agree to 2e-3, the rest are bounded)
+        assert p_frac >= 0.99 and pe <= prob_rel, f"chosen probabilities off the bf16 oracle: {p_frac:.4f} within 2e-3, worst {pe:.3e}"
+        # every gradient entry within grad_rel of the tensor's largest entry (+ the f32 floor of _grad_check), and the tensor clearly
+        # closer to the bf16 oracle than to the f32 one
         rms = max(float(v.norm()) / np.sqrt(v.numel()) for v in refb.values())
-        worst = {}
+        worst, closer = {}, {}
         for k, r in refb.items():
             g = got[k].detach().cpu().double()
             worst[k] = float((g - r).abs().max()) / (float(r.abs().max()) + 2.0 * rms)
+            closer[k] = float((g - r).norm() / (g - ref[k].double()).norm().clamp_min(1e-30))
         gc.record_parity(f"bf16_mode/{problem}_{tag}_grad_err_over_max_vs_bf16_oracle", max(worst.values()))
-        print(problem, tag, "bf16 mode, gradient error / tensor max:", {k.split(".")[-1] if "." in k else k: f"{v:.1e}" for k, v in worst.items()})
+        gc.record_parity(f"bf16_mode/{problem}_{tag}_grad_l2_to_bf16_oracle_over_l2_to_f32_oracle", max(closer.values()))
+        print(problem, tag, "bf16 mode, gradient error / tensor max:", {k.split(".")[-1] if "." in k else k: f"{v:.1e}" for k, v in worst.items()},
+              " L2 distance to the bf16 oracle / to the f32 oracle:", f"{max(closer.values()):.2f}")
         bad = {k: v for k, v in worst.items() if v > grad_rel}
         assert not bad, f"gradients off the bf16 oracle: {bad} (bound {grad_rel})"
+        assert max(closer.values()) < 0.5, closer
         return
     np.testing.assert_allclose(pr.detach().cpu().numpy(), out["probs"].detach().numpy(), rtol=5e-4)
     Jg = loss_fn(pr)
@@ -158,13 +167,14 @@ def test_tsp_backward(tag, train):
     _run("tsp", tag, "pomo", train=train)
 
 
-@pytest.mark.parametrize("problem,tag,bounds", [("cvrp", "n100", (5e-3, 1e-3)), ("tsp", "n50", (5e-3, 1e-3)), ("cvrp", "n50", (5e-3, 1e-3))])
+@pytest.mark.parametrize("problem,tag,bounds", [("cvrp", "n100", (6e-2, 1e-2)), ("tsp", "n50", (6e-2, 1e-2)), ("cvrp", "n50", (6e-2, 1e-2))])
 def test_bf16_mode_training_gradients(problem, tag, bounds):
     """The bf16 throughput mode end to end (elg_rollout_args.precision = 1 forward -> elg_decoder_bwd mode 3, whose score
     recompute rounds q and K as the forward did): chosen probabilities and REINFORCE gradients against the oracle's bf16
     restatement in float64 (same rounded operands, derivatives of the f32 formulas at the forward's values) -- bounds =
-    (worst relative error of a chosen probability, worst gradient entry error over the tensor's largest entry).  A backward that
-    is inconsistent with its forward (the f32 backward on a bf16 forward, a head's sign) is off by per cents to factors."""
+    (worst relative error of a chosen probability, worst gradient entry error over the tensor's largest entry); 99 % of the chosen
+    probabilities within 2e-3; every gradient tensor at least twice as close (L2) to the bf16 oracle as to the f32 one.  A backward
+    that is inconsistent with its forward (the f32 backward on a bf16 forward, a head's sign) is off by per cents to factors."""
     _run(problem, tag, "pomo", train=True, precision=1, bf16_bounds=bounds)
 
 

@@ -134,18 +134,24 @@ def test_large_instance_logits(variant):
 #      entry rounds the other way than on the GPU: scores before the clip within 1e-4 max(|ref|, 1) -- the f32 bar -- on at least
 #      BF16_FRAC of the open nodes.  The remainder is what a rounding boundary does: the kernel's q / numerator / glimpse-output
 #      values differ from the oracle's in the last f32 bit (fma order, v_exp_f32), and where such a value sits on a bf16 rounding
-#      boundary one operand moves by a whole bf16 ulp (2^-8 relative) -- those entries are bounded by BF16_FLIP, an order of
-#      magnitude under the mode's distance to the f32 reference.  A wrong kernel (a head's sign, a missing rounding) moves every
+#      boundary one operand moves by a whole bf16 ulp (2^-8 relative) -- those entries are bounded by BF16_FLIP (observed <= 4e-4),
+#      one to two orders of magnitude under the mode's distance to the f32 reference.  A wrong kernel (a head's sign, a missing rounding) moves every
 #      score and fails (1) outright.
 #  (2) against the REFERENCE's f32 logits, per fixture, bound = 2 x the observed deviation (bf16 operands carry 8 significand
 #      bits: a score s = sum_c a_c b_c moves by ~2^-9 |a||b| per term; the fixtures with amplified weights, whose tables are an
 #      order of magnitude larger than a trained model's, move most).
-BF16_FRAC = 0.998
-BF16_FLIP = 2e-2
-BF16_VS_REFERENCE = {"cvrp_n100": 1.4e-2, "cvrp_n20k8": 6e-2, "cvrp_n50": 1.2e-1, "tsp_n20": 6e-3, "tsp_n50": 4e-2}
+BF16_FRAC = 0.99
+BF16_FLIP = 2e-3
+# The node-streaming kernels (128 < N1: rollout_fwd_mt_kernel, rollout_fwd_xm_kernel) round the same operands, but their softmax is
+# ONLINE over chunks of nodes: a numerator is rounded to bf16 relative to the running maximum of its chunk and rescaled afterwards,
+# i.e. at other values than exp(s - global max) -- the oracle's restatement (the cooperative kernel's arithmetic) is then one
+# bf16 rounding of the numerators away: most scores still agree to 1e-4, all to BF16_FLIP_STREAMING (observed 1.5e-3).
+BF16_FRAC_STREAMING = 0.75
+BF16_FLIP_STREAMING = 4e-3
+BF16_VS_REFERENCE = {"cvrp_n150_streaming": 5e-2, "cvrp_n150_xm": 5e-2, "cvrp_n100": 1.4e-2, "cvrp_n20k8": 6e-2, "cvrp_n50": 1.2e-1, "tsp_n20": 6e-3, "tsp_n50": 4e-2}
 
 
-def _check_bf16(tag, lg, scores, logits, clip, steps, tlen, oracle_parts, first_step):
+def _check_bf16(tag, lg, scores, logits, clip, steps, tlen, oracle_parts=None, first_step=0, kernel="coop"):
     worst_s = worst_l = worst_o = 0.0
     n_open = n_ok = 0
     tl = tlen.cpu().numpy()
@@ -159,18 +165,22 @@ def _check_bf16(tag, lg, scores, logits, clip, steps, tlen, oracle_parts, first_
         ref_s = lg["pre_clip"][i]
         worst_s = max(worst_s, float((np.abs(got_s[open_] - ref_s[open_]) / np.maximum(np.abs(ref_s[open_]), 1.0)).max()))
         worst_l = max(worst_l, float((np.abs(got_l[open_] - ref_l[open_]) / clip).max()))
-        orc_s = oracle_parts[int(t) - first_step]["s"].numpy()
-        rel = np.abs(got_s[open_] - orc_s[open_]) / np.maximum(np.abs(orc_s[open_]), 1.0)
-        n_open += rel.size
-        n_ok += int((rel <= 1e-4).sum())
-        worst_o = max(worst_o, float(rel.max()))
-    frac = n_ok / max(n_open, 1)
-    gc.record_parity(f"logits_bf16/{tag}/coop/score_rel_vs_reference", worst_s)
-    gc.record_parity(f"logits_bf16/{tag}/coop/logit_over_clip_vs_reference", worst_l)
-    gc.record_parity(f"logits_bf16/{tag}/coop/score_rel_vs_bf16_oracle_worst", worst_o)
-    gc.record_parity(f"logits_bf16/{tag}/coop/fraction_within_1e-4_of_bf16_oracle", frac)
-    print(tag, f"bf16 mode: vs bf16 oracle {frac:.5f} of {n_open} scores within 1e-4, worst {worst_o:.2e};  vs reference: scores {worst_s:.2e}  logits/clip {worst_l:.2e}")
-    assert frac >= BF16_FRAC and worst_o <= BF16_FLIP, (tag, frac, worst_o)
+        if oracle_parts is not None:
+            orc_s = oracle_parts[int(t) - first_step]["s"].numpy()
+            rel = np.abs(got_s[open_] - orc_s[open_]) / np.maximum(np.abs(orc_s[open_]), 1.0)
+            n_open += rel.size
+            n_ok += int((rel <= 1e-4).sum())
+            worst_o = max(worst_o, float(rel.max()))
+    gc.record_parity(f"logits_bf16/{tag}/{kernel}/score_rel_vs_reference", worst_s)
+    gc.record_parity(f"logits_bf16/{tag}/{kernel}/logit_over_clip_vs_reference", worst_l)
+    if oracle_parts is not None:
+        frac = n_ok / max(n_open, 1)
+        gc.record_parity(f"logits_bf16/{tag}/{kernel}/score_rel_vs_bf16_oracle_worst", worst_o)
+        gc.record_parity(f"logits_bf16/{tag}/{kernel}/fraction_within_1e-4_of_bf16_oracle", frac)
+        print(tag, f"bf16 mode: vs bf16 oracle {frac:.5f} of {n_open} scores within 1e-4, worst {worst_o:.2e}")
+        lim = (BF16_FRAC, BF16_FLIP) if kernel == "coop" else (BF16_FRAC_STREAMING, BF16_FLIP_STREAMING)
+        assert frac >= lim[0] and worst_o <= lim[1], (tag, frac, worst_o)
+    print(tag, kernel, f"bf16 mode vs reference: scores {worst_s:.2e}  logits/clip {worst_l:.2e}")
     bound = BF16_VS_REFERENCE[tag]
     assert worst_s <= bound and worst_l <= bound, (tag, worst_s, worst_l, bound)
     assert worst_s > 1e-5, "the bf16 mode produced f32-exact scores: it did not run"
@@ -296,7 +306,10 @@ def test_bf16_mode_streaming_kernel_logits_and_tours():
         r = eng.rollout_forward(env.problem, pol, M, acts[0, :, 1], L.MODE_FORCED, forced=acts, dump_T=T, dump=what, precision=1)
         dumps[what] = r.full_probs
     np.testing.assert_allclose(r.reward.cpu().numpy(), lg["reward"], rtol=2e-6)          # the environment is exact in every mode
-    _check_bf16("cvrp_n150_streaming", lg, dumps["scores"], dumps["logits"], mp["logit_clipping"], lg["steps"], r.tlen)
+    xy = torch.from_numpy(np.concatenate([depot, loc], 1))
+    dem = torch.from_numpy(np.concatenate([np.zeros((B, 1), np.float32), demand], 1))
+    parts = _oracle_bf16_parts("cvrp", mp, wseed, 1.0, pol, model.encoded_nodes, xy, dem, M, acts.long())
+    _check_bf16("cvrp_n150_streaming", lg, dumps["scores"], dumps["logits"], mp["logit_clipping"], lg["steps"], r.tlen, parts, 2, "streaming")
     cost = {}
     for prec in (0, 1):
         g = eng.rollout_forward(env.problem, pol, M, acts[0, :, 1], L.MODE_GREEDY, precision=prec)
@@ -328,6 +341,9 @@ def test_bf16_mode_xm_kernel_logits():
         r = eng.rollout_forward(env.problem, pol, M, acts[0, :, 1], L.MODE_FORCED, forced=acts, dump_T=T, dump=what, precision=1, variant=3)
         dumps[what] = r.full_probs
     np.testing.assert_allclose(r.reward.cpu().numpy(), lg["reward"], rtol=2e-6)
-    _check_bf16("cvrp_n150_xm", lg, dumps["scores"], dumps["logits"], mp["logit_clipping"], lg["steps"], r.tlen)
+    xy = torch.from_numpy(np.concatenate([depot, loc], 1))
+    dem = torch.from_numpy(np.concatenate([np.zeros((B, 1), np.float32), demand], 1))
+    parts = _oracle_bf16_parts("cvrp", mp, wseed, 1.0, pol, model.encoded_nodes, xy, dem, M, acts.long())
+    _check_bf16("cvrp_n150_xm", lg, dumps["scores"], dumps["logits"], mp["logit_clipping"], lg["steps"], r.tlen, parts, 2, "xm")
     cost = {p: float((-eng.rollout_forward(env.problem, pol, M, acts[0, :, 1], L.MODE_GREEDY, precision=p, variant=3).reward).mean()) for p in (0, 1)}
     assert abs(cost[1] - cost[0]) <= 0.02 * cost[0], cost
