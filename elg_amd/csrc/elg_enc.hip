@@ -18,6 +18,7 @@
 // Q, K, V, dO of the (instance, head) in LDS and forms the score tile in both orientations, so that dQ (rows on lanes)
 // and dK / dV (keys on lanes) each accumulate in registers of the wave that owns them: no atomics, no transposes.
 #include "elg_enc_internal.h"
+#include <cstdlib>
 
 extern "C" __attribute__((visibility("hidden"))) int elg_gemm_f32_alpha(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
                                   int ldb, int ldc, int transA, int transB, int relu, int split_k, float* a_rowsum,
@@ -832,11 +833,40 @@ __global__ __launch_bounds__(256) void enc_dw_kernel(const DwBatch bt) {
         }
     const int tile = blockIdx.x - tile0, ntn = N >> 7;
     const int mt = tile / ntn, nt = tile - mt * ntn;
-    const int m0 = mt * 128 + (wave >> 1) * 64, n0 = nt * 128 + (wave & 1) * 64;
+    const int mw = (wave >> 1) * 64, nw = (wave & 1) * 64;             // the wave's 64 x 64 block inside the 128 x 128 tile
+    const int m0 = mt * 128 + mw, n0 = nt * 128 + nw;
     const int kbeg = blockIdx.y * bt.rows_per_split, kend = min(bt.rows, kbeg + bt.rows_per_split);
     if (kbeg >= kend) return;
-    const float* ap = dY + m0 + 2 * li;
-    const float* bp = X + n0 + 2 * li;
+    // Round 5: the operands go through LDS in chunks of 16 rows.  Read straight from global memory (round 2), the two waves that
+    // share a 64-column block of an operand both fetched it, and a CU's vector-memory path delivers cache LINES at a fixed pace
+    // (~7 cycles per 128-byte line from L2, ~14 from the memory side: DESIGN 4.2) -- 32 line touches per k-step of a workgroup
+    // against 4 x 64 cycles of MFMA per wave, with 4 workgroups per CU: the kernel sat at 37 % of the matrix pipe whatever the
+    // prefetch depth.  Now a chunk's 16 x 128 floats per operand are loaded once per workgroup as whole lines (two 16-byte loads per
+    // thread and operand, issued one chunk ahead), and a wave's fragments (rows 2 s + q, columns 2 li, 2 li + 1 of its block)
+    // are conflict-free ds_read_b64.
+    __shared__ __attribute__((aligned(16))) float sA[2][16 * 128], sB[2][16 * 128];
+    const int tid = threadIdx.x;
+    const float* gA = dY + mt * 128;
+    const float* gB = X + nt * 128;
+    float4 ra[2], rb[2];
+    auto fetch = [&](int r0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i, r = r0 + (idx >> 5), rc = min(r, kend - 1);
+            float4 a_ = *reinterpret_cast<const float4*>(gA + (size_t)rc * ldy + 4 * (idx & 31));
+            if (r >= kend) a_ = make_float4(0.f, 0.f, 0.f, 0.f);          // rows past the split: zero dY (X may be anything finite)
+            ra[i] = a_;
+            rb[i] = *reinterpret_cast<const float4*>(gB + (size_t)rc * ldx + 4 * (idx & 31));
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            *reinterpret_cast<float4*>(&sA[buf][(idx >> 5) * 128 + 4 * (idx & 31)]) = ra[i];
+            *reinterpret_cast<float4*>(&sB[buf][(idx >> 5) * 128 + 4 * (idx & 31)]) = rb[i];
+        }
+    };
     f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -845,54 +875,71 @@ __global__ __launch_bounds__(256) void enc_dw_kernel(const DwBatch bt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     float bsum0 = 0.f, bsum1 = 0.f;
-    constexpr int U = 8;                               // MFMA k-steps (2 rows each) per batch of loads
-    float2 av[U], bv[U];
-#define DW_LOAD(K0, AV, BV)                                                                            \
-    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                    \
-        const int r_ = (K0) + 2 * u + kq;                                                              \
-        const int rc_ = min(r_, kend - 1);                                                             \
-        const float mk_ = r_ < kend ? 1.f : 0.f;                                                       \
-        float2 a_ = *reinterpret_cast<const float2*>(ap + (size_t)rc_ * ldy);                          \
-        a_.x *= mk_; a_.y *= mk_;                                                                      \
-        AV[u] = a_;                                                                                    \
-        BV[u] = *reinterpret_cast<const float2*>(bp + (size_t)rc_ * ldx);                              \
-    }
-    float2 an[U], bn[U];
-    DW_LOAD(kbeg, av, bv)
-    DW_LOAD(min(kbeg + 2 * U, kend - 1), an, bn)
-    for (int k = kbeg; k < kend; k += 2 * U) {
-        // two batches in flight: the batch after next is requested before this one is consumed
-        float2 a2[U], b2[U];
-        const int kn = min(k + 4 * U, kend - 1);       // the last prefetches re-read in-range rows, unused
-        DW_LOAD(kn, a2, b2)
+    fetch(kbeg);
+    commit(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k = kbeg; k < kend; k += 16) {
+        const bool more = k + 16 < kend;                               // (uniform)
+        if (more) fetch(k + 16);
+        const float* pa = &sA[buf][kq * 128 + mw + 2 * li];
+        const float* pb = &sB[buf][kq * 128 + nw + 2 * li];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u].x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u].y, acc[1][1], 0, 0, 0);
-            bsum0 += av[u].x; bsum1 += av[u].y;
+        for (int s2 = 0; s2 < 8; ++s2) {
+            const float2 av = *reinterpret_cast<const float2*>(pa + s2 * 256);
+            const float2 bv = *reinterpret_cast<const float2*>(pb + s2 * 256);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[1][1], 0, 0, 0);
+            bsum0 += av.x; bsum1 += av.y;
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) { av[u] = an[u]; bv[u] = bn[u]; an[u] = a2[u]; bn[u] = b2[u]; }
+        if (more) commit(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
     }
-#undef DW_LOAD
     // C/D layout of 32x32: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); tile (a, b) holds
-    // dW[m0 + 2 row + a][n0 + 2 col + b]
+    // dW[m0 + 2 row + a][n0 + 2 col + b].  The split's 128 x 128 partial goes to the scratch tile [split][tile][128][128] with
+    // plain stores (a lane's two neighbouring columns as one 8-byte store: 256 contiguous bytes per row and half wave);
+    // enc_dw_reduce_kernel adds the splits in a fixed order.  (Rounds 2 - 4 added the partials with f32 atomics: 17.5 M of them
+    // per launch, each 4 bytes at an 8-byte stride -- ~2.2 M memory-side requests that a micro-benchmark prices at ~0.1 ms of the
+    // kernel's 0.27, and a summation order that changed from run to run.)
+    float* sc = bt.scratch + ((size_t)blockIdx.y * bt.ntiles + blockIdx.x) * (128 * 128);
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * kq;
-                atomicAdd(dW + (size_t)(m0 + 2 * row + a) * ldw + n0 + 2 * li + b, acc[a][b][r] * alpha);
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * kq;
+            *reinterpret_cast<float2*>(sc + (mw + 2 * row + a) * 128 + nw + 2 * li) = make_float2(acc[a][0][r] * alpha, acc[a][1][r] * alpha);
+        }
     if (db && nt == 0 && (wave & 1) == 0) {
         bsum0 = x32_sum(bsum0);
         bsum1 = x32_sum(bsum1);
         if (kq == 0) { atomicAdd(db + m0 + 2 * li, bsum0); atomicAdd(db + m0 + 2 * li + 1, bsum1); }
     }
+}
+
+// dW tile += sum over the row splits of the scratch tiles, split 0 first.  grid (ntiles, 16), 256 threads x 16 bytes.
+__global__ __launch_bounds__(256) void enc_dw_reduce_kernel(const DwBatch bt, const int splits) {
+    int j = 0;
+    for (int t = 1; t < bt.njobs; ++t) j = (int)blockIdx.x >= bt.job[t].tile0 ? t : j;
+    float* dW = nullptr; int ldw = 0, N = 0, tile0 = 0;
+#pragma unroll
+    for (int t = 0; t < DW_MAX_JOBS; ++t)
+        if (t == j) { dW = bt.job[t].dW; ldw = bt.job[t].ldw; N = bt.job[t].N; tile0 = bt.job[t].tile0; }
+    const int tile = blockIdx.x - tile0, ntn = N >> 7;
+    const int mt = tile / ntn, nt = tile - mt * ntn;
+    const int e = (blockIdx.y * 256 + threadIdx.x) * 4;                 // element of the 128 x 128 tile
+    const int row = e >> 7, col = e & 127;
+    const float* sc = bt.scratch + (size_t)blockIdx.x * (128 * 128) + e;
+    const size_t stride = (size_t)bt.ntiles * (128 * 128);
+    float4 acc = *reinterpret_cast<const float4*>(sc);
+    for (int sp = 1; sp < splits; ++sp) {
+        const float4 v = *reinterpret_cast<const float4*>(sc + sp * stride);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float* o = dW + (size_t)(mt * 128 + row) * ldw + nt * 128 + col;    // (ldw may be odd: Wq_last is (128,129))
+    o[0] += acc.x; o[1] += acc.y; o[2] += acc.z; o[3] += acc.w;
 }
 
 int DwList::add(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, int M, int N, float* db, float alpha) {
@@ -909,15 +956,26 @@ int DwList::add(const float* dY, int ldy, const float* X, int ldx, float* dW, in
 }
 int DwList::launch() {
     if (bt.njobs == 0) return ELG_OK;
-    // row split: ~4 workgroups per CU overall (measured at the bench shape: 2048 workgroups 306 us, 1024 271 us, 512 281 us,
-    // 256 301 us), at least 128 rows each
-    int splits = (int)max(1L, min(rows / 128, (long)((1024 + bt.ntiles - 1) / bt.ntiles)));
+    // row split: ~3 workgroups per CU overall, at least 128 rows each (measured at the bench shape with the partial tiles going to
+    // scratch: 256 workgroups 272 us, 486 / 512 -- one generation of the two that fit a CU -- 221 / 223, 768 191, 1024 194; the
+    // kernel holds the matrix pipe at ~60 % whichever way the rows are cut)
+    static const int target = [] {
+        const char* e = std::getenv("ELG_DW_WGS");
+        if (e && atoi(e) > 0) return atoi(e);
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return 3 * cus;
+    }();
+    int splits = (int)max(1L, min(rows / 128, (long)(target / bt.ntiles)));
     int rps = (int)((rows + splits - 1) / splits);
     rps = (rps + 15) / 16 * 16;
     splits = (int)((rows + rps - 1) / rps);
     bt.rows = (int)rows; bt.rows_per_split = rps;
+    if (!scratch || (long)splits * bt.ntiles * (128 * 128) > scratch_floats) return fail(ELG_EINVAL, "encoder bwd: weight-gradient scratch too small");
+    bt.scratch = scratch;
     (void)hipGetLastError();
     hipLaunchKernelGGL(enc_dw_kernel, dim3(bt.ntiles, splits), dim3(256), 0, s, bt);
+    hipLaunchKernelGGL(enc_dw_reduce_kernel, dim3(bt.ntiles, 16), dim3(256), 0, s, bt, splits);
     bt.njobs = 0; bt.ntiles = 0;
     return launch_status("enc_dw");
 }
@@ -963,6 +1021,8 @@ EncWs2 enc_ws2(int B, int N1, int n_layers, int ff) {
         w.P1 = o; o += (long)(ff >> 7) * w.R * ELG_E;
         w.WT = o; w.wt_stride = 4L * ELG_E * ELG_E + 2L * ELG_E * ff; o += w.wt_stride * n_layers;
     }
+    // partial tiles of the grouped weight-gradient launch: splits * ntiles <= 1024 + ntiles, ntiles <= 12 per layer + 5 table jobs
+    w.DW = o; w.dw_floats = (1024L + 12L * n_layers + 5) * (128 * 128); o += w.dw_floats;
     w.total = o;
     return w;
 }
@@ -1149,7 +1209,7 @@ extern "C" int elg_encoder_bwd(const elg_encoder_bwd_args* ba, void* stream) {
     float* lay2 = ba->ws2 + w2.lay0;
     const long lay2_stride = w2.lay_stride;
     float* ws = a->ws;
-    DwList dw(R, s);
+    DwList dw(R, s, ba->ws2 + w2.DW, w2.dw_floats);
     if (enc_fused_ok(a)) return enc_fused_bwd(ba, dw, s);
     const float inv_sqrt_e = 0.08838834764831845f;
     // N1 <= 128: row block = instance, the norm backwards ride in GEMM epilogues.  N1 > 128: 128-row blocks, the add & norm

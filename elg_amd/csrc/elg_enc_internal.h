@@ -20,7 +20,7 @@ EncWs enc_ws(int B, int N1, int n_layers, int ff, int save);
 
 // scratch layout of elg_encoder_bwd (floats)
 struct EncWs2 {
-    long R, gX, gO, gT, lay0, lay_stride, delta, PX, P1, WT, wt_stride, total;
+    long R, gX, gO, gT, lay0, lay_stride, delta, PX, P1, WT, wt_stride, DW, dw_floats, total;
     // per layer (offsets from lay0 + l * lay_stride): gS (R,128) | gH (R,ff) | gY (R,128) | dQKV (R,384)
     // per layer of WT (offsets from WT + l * wt_stride): WqT | WkT | WvT | WcT (128,128 each) | W1T (128,ff) | W2T (ff,128)
 };
@@ -36,12 +36,16 @@ constexpr int DW_MAX_JOBS = 48;
 struct DwBatch {
     DwJob job[DW_MAX_JOBS];
     int njobs, ntiles, rows, rows_per_split;
+    float* scratch;                   // [split][tile][128][128] partial tiles
 };
 struct DwList {
     DwBatch bt;
     long rows;
     hipStream_t s;
-    DwList(long rows_, hipStream_t s_) : rows(rows_), s(s_) { bt.njobs = 0; bt.ntiles = 0; }
+    float* scratch; long scratch_floats;
+    DwList(long rows_, hipStream_t s_, float* scratch_, long scratch_floats_) : rows(rows_), s(s_), scratch(scratch_), scratch_floats(scratch_floats_) {
+        bt.njobs = 0; bt.ntiles = 0; bt.scratch = nullptr;
+    }
     int add(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, int M, int N, float* db, float alpha);
     int launch();
 };
