@@ -340,11 +340,11 @@ __device__ __forceinline__ void enc_prologue(const EncPro& p, float4 (&x)[8], fl
     if (act) {
         {
             const TileAddr ta = tile_addr(b, N1, wave, lane, ELG_E);
+            // (the residual x1 and the FFN2 bias are already in partial 0: its producer, the slice c = 0 of enc_f2, has x1 in
+            //  registers -- one tile less to fetch here, in every workgroup of the instance)
             float4 v[8];
-            tile_ld(v, p.res, ta);
-            const float4 bb = ld4(p.bias + 4 * (lane & 31));
 #pragma unroll
-            for (int t = 0; t < 8; ++t) v[t] = add4(v[t], bb);
+            for (int t = 0; t < 8; ++t) v[t] = zero4();
             tile_add_partials(v, p.P, p.pstride, p.np, ta);
             to_frag(v, s, sT, lane, lo, hi);
         }
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(512) void enc_f1_kernel(const EncF1 g) {
 // ------------------------------------------------------------------------------------------------------------------
 // F2: x1 = InstanceNorm(x + combine(att)) ; partial[c] = relu(x1 W1_c^T + b1_c) W2_c^T   (hidden slice c).  grid B x (ff / 128).
 struct EncF2 {
-    const float *O, *Xin, *Wc, *bc, *g1, *b1, *W1, *bf1, *W2;
+    const float *O, *Xin, *Wc, *bc, *g1, *b1, *W1, *bf1, *W2, *bf2;
     float *X1, *XH1, *RS1, *H, *P;      // X1 always (the next prologue's residual); XH1 / RS1 / H when saving (else NULL)
     long pstride;
     int B, N1, FF;
@@ -663,7 +663,11 @@ __global__ __launch_bounds__(512) void enc_f2_kernel(const EncF2 g) {
         if (rvalid) {
             float* op = g.P + c * g.pstride + grow * ELG_E + 4 * hi;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) st4(op + 16 * t, f4(a[t]));
+            for (int t = 0; t < 8; ++t) {
+                float4 v = f4(a[t]);
+                if (writer) v = add4(add4(v, ld4(g.bf2 + 16 * t + 4 * hi)), x1[t]);       // partial 0 carries the bias and the residual
+                st4(op + 16 * t, v);
+            }
         }
     }
     STAMP(1, 14)
@@ -838,6 +842,7 @@ __device__ __forceinline__ void enc_bprologue(const EncBPro& p, float4 (&ds)[8],
 struct EncB0 {
     const float* G[5]; const float* W[5]; int sm[5], sk[5]; float alpha[5];
     int pb_tab; const float* gpb; const float* bc;
+    const float* g_enc;                  // d loss / d enc itself (or NULL): added to partial 0
     float* PX; long pstride;
     int ntab, B, N1;
 };
@@ -888,6 +893,7 @@ __global__ __launch_bounds__(512) void enc_b0_kernel(const EncB0 g) {
             const float4 bb = ld4(g.bc + 16 * t + 4 * hi);
             v.x = fmaf(gp, bb.x, v.x); v.y = fmaf(gp, bb.y, v.y); v.z = fmaf(gp, bb.z, v.z); v.w = fmaf(gp, bb.w, v.w);
         }
+        if (c == 0 && g.g_enc) v = add4(v, ld4(g.g_enc + grow * ELG_E + 16 * t + 4 * hi));
         st4(o + 16 * t, v);
     }
 }
@@ -968,7 +974,7 @@ __global__ __launch_bounds__(512) void enc_b1_kernel(const EncB1 g) {
         if (rvalid) {
             float* o = g.P1 + c * g.pstride + grow * ELG_E + 4 * hi;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) st4(o + 16 * t, f4(a[t]));
+            for (int t = 0; t < 8; ++t) st4(o + 16 * t, c == 0 ? add4(f4(a[t]), ds[t]) : f4(a[t]));     // partial 0 carries the residual path dS2
         }
     }
 }
@@ -1255,7 +1261,7 @@ __global__ __launch_bounds__(512) void enc_b2_kernel(const EncB2 g) {
         if (rvalid) {
             float* o = g.P2 + c * g.pstride + grow * ELG_E + 4 * hi;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) st4(o + 16 * t, f4(a[t]));
+            for (int t = 0; t < 8; ++t) st4(o + 16 * t, c == 0 ? add4(f4(a[t]), dy[t]) : f4(a[t]));     // partial 0 carries the residual path dY
         }
     }
 }
@@ -1270,7 +1276,7 @@ __global__ __launch_bounds__(512) void enc_embed_bwd2_kernel(const float* __rest
     const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     float v[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // node w0 w1 w2 b | depot w0 w1 b
     for (long r = r0 + q; r < r1; r += 4) {
-        float gx = base[r * ELG_E + c];
+        float gx = base ? base[r * ELG_E + c] : 0.f;
         for (int k = 0; k < np; ++k) gx += P[k * pstride + r * ELG_E + c];
         const float x = xy[r * 2], y = xy[r * 2 + 1];
         if (gWd && (r % N1) == 0) { v[4] = fmaf(gx, x, v[4]); v[5] = fmaf(gx, y, v[5]); v[6] += gx; }
@@ -1393,7 +1399,7 @@ int enc_fused_fwd(const elg_encoder_args* a, hipStream_t s) {
         EncPro p{};
         const elg_enc_layer& L = a->W.layer[l];
         p.mode = 1; p.np = NS; p.P = ws + w.P; p.pstride = R * ELG_E;
-        p.res = lay(l) + w.oX1; p.bias = L.bf2; p.gamma = L.g2; p.beta = L.b2;
+        p.res = nullptr; p.bias = nullptr; p.gamma = L.g2; p.beta = L.b2;        // (x1 + bias ride in partial 0)
         p.xhat = a->save ? lay(l) + w.oXH2 : nullptr; p.rstd = a->save ? lay(l) + w.oRS2 : nullptr; p.xout = xout;
         p.eps = a->eps;
         return p;
@@ -1415,7 +1421,7 @@ int enc_fused_fwd(const elg_encoder_args* a, hipStream_t s) {
         ENCF_TRY(launch_f1(f1, bf, s))
         EncF2 f2{};
         f2.O = lb + w.oO; f2.Xin = xin_of(l); f2.Wc = L.Wc; f2.bc = L.bc; f2.g1 = L.g1; f2.b1 = L.b1; f2.W1 = L.W1; f2.bf1 = L.bf1;
-        f2.W2 = L.W2; f2.X1 = lb + w.oX1; f2.XH1 = a->save ? lb + w.oXH1 : nullptr; f2.RS1 = a->save ? lb + w.oRS1 : nullptr;
+        f2.W2 = L.W2; f2.bf2 = L.bf2; f2.X1 = lb + w.oX1; f2.XH1 = a->save ? lb + w.oXH1 : nullptr; f2.RS1 = a->save ? lb + w.oRS1 : nullptr;
         f2.H = a->save ? lb + w.oH : nullptr; f2.P = ws + w.P; f2.pstride = R * ELG_E; f2.B = B; f2.N1 = N1; f2.FF = FF; f2.eps = a->eps;
         ENCF_TRY(launch_f2(f2, bf, s))
     }
@@ -1514,7 +1520,7 @@ int enc_fused_bwd(const elg_encoder_bwd_args* ba, DwList& dw, hipStream_t s) {
             tab(ba->gPK, a->W.dec_Wc, ELG_E, 1, inv_sqrt_e);
             ENCF_TRY(dw.add(a->enc, ELG_E, ba->gPK, ELG_E, (float*)G.dec_Wc, ELG_E, ELG_E, ELG_E, nullptr, inv_sqrt_e))
         } else if (ba->gpb) return fail(ELG_EINVAL, "encoder bwd: gpb without gPK");
-        b0.ntab = n; b0.PX = s2 + w2.PX; b0.pstride = R * ELG_E; b0.B = B; b0.N1 = N1;
+        b0.ntab = n; b0.PX = s2 + w2.PX; b0.pstride = R * ELG_E; b0.B = B; b0.N1 = N1; b0.g_enc = ba->g_enc;
         if (n == 0 && !ba->g_enc) return fail(ELG_EINVAL, "encoder bwd: no cotangent given");
         if (n > 0) ENCF_TRY(launch_b0(b0, bf, s))
     }
@@ -1523,7 +1529,7 @@ int enc_fused_bwd(const elg_encoder_bwd_args* ba, DwList& dw, hipStream_t s) {
         ENCF_TRY(launch_fold_small_bwd(a->enc, ba->gpb, tsp ? nullptr : ba->gwl, (float*)G.dec_bc, (float*)G.dec_Wq_last, R, inv_sqrt_e, s))
     }
     // ---- layers, last to first
-    const float* base = ba->g_enc;
+    const float* base = b0.ntab > 0 ? nullptr : ba->g_enc;      // (with table cotangents, d enc itself rides in partial 0)
     int np = b0.ntab;
     for (int l = NL - 1; l >= 0; --l) {
         const elg_enc_layer& GL = G.layer[l];
@@ -1545,7 +1551,8 @@ int enc_fused_bwd(const elg_encoder_bwd_args* ba, DwList& dw, hipStream_t s) {
         ENCF_TRY(dw.add(gS, ELG_E, lb + w.oH, FF, (float*)GL.W2, FF, ELG_E, FF, (float*)GL.bf2, 1.f))
         ENCF_TRY(dw.add(gH, FF, lb + w.oX1, ELG_E, (float*)GL.W1, ELG_E, FF, ELG_E, (float*)GL.bf1, 1.f))
         EncB2 b2{};
-        b2.pro.base = gS; b2.pro.P = s2 + w2.P1; b2.pro.pstride = R * ELG_E; b2.pro.np = NS;
+        b2.pro.base = nullptr;                                   // (dS2 rides in partial 0)
+        b2.pro.P = s2 + w2.P1; b2.pro.pstride = R * ELG_E; b2.pro.np = NS;
         b2.pro.xhat = lb + w.oXH1; b2.pro.rstd = lb + w.oRS1; b2.pro.gamma = L.g1; b2.pro.dgamma = (float*)GL.g1; b2.pro.dbeta = (float*)GL.b1;
         b2.pro.dout = gY;
         b2.WqT = wt; b2.WkT = wt + ELG_E * ELG_E; b2.WvT = wt + 2 * ELG_E * ELG_E; b2.WcT = wt + 3 * ELG_E * ELG_E;
@@ -1556,7 +1563,7 @@ int enc_fused_bwd(const elg_encoder_bwd_args* ba, DwList& dw, hipStream_t s) {
         ENCF_TRY(dw.add(dQKV, 3 * ELG_E, Xin, ELG_E, (float*)GL.Wq, ELG_E, ELG_E, ELG_E, nullptr, 1.f))
         ENCF_TRY(dw.add(dQKV + ELG_E, 3 * ELG_E, Xin, ELG_E, (float*)GL.Wk, ELG_E, ELG_E, ELG_E, nullptr, 1.f))
         ENCF_TRY(dw.add(dQKV + 2 * ELG_E, 3 * ELG_E, Xin, ELG_E, (float*)GL.Wv, ELG_E, ELG_E, ELG_E, nullptr, 1.f))
-        base = gY;
+        base = nullptr;                                        // (dY rides in partial 0)
         np = 4;
     }
     // ---- input embeddings: d x0 = dY(layer 0) + the four partials

@@ -14,6 +14,11 @@
 // TSP/models.py:48-110,244-303).
 #include "elg_rollout.h"
 #include "elg_bf16.h"
+// diagnostic builds only (tools/exp_rollout_stores.sh): -DELG_EXP_SKIP=<bits> compiles saved-row stores of the cooperative kernel out
+// (1 trQ, 2 trSlot / trF, 4 trO, 8 trPC / trCsel) to TIME the launch without them; the shipped library is built with 0.
+#ifndef ELG_EXP_SKIP
+#define ELG_EXP_SKIP 0
+#endif
 #include <string>
 
 namespace elg {
@@ -916,7 +921,7 @@ __device__ __forceinline__ void co_finish4(const elg_rollout_args& A, int N1, in
     pe = row16_sum(pe);
     if (TRAIN) {
         pj = row16_sum(pj);
-        if (act) {
+        if (act && !(ELG_EXP_SKIP & 8)) {
             float* rPC = A.trPC + (b * Rcap + r) * N1;
 #pragma unroll
             for (int k = 0; k < NK; ++k)
@@ -1052,7 +1057,7 @@ __device__ __forceinline__ void co_advance4(const elg_rollout_args& A, const Ins
         if (!nxt) { a = make_float4(0.f, 0.f, 0.f, 0.f); c = a; }
         *reinterpret_cast<float4*>(sQ + q * CO_QP + 8 * lo) = a;
         *reinterpret_cast<float4*>(sQ + q * CO_QP + 8 * lo + 4) = c;
-        if (TRAIN && nxt) {
+        if (TRAIN && nxt && !(ELG_EXP_SKIP & 1)) {
             *reinterpret_cast<float4*>(A.trQ + (b * Rcap + r1) * ELG_E + 8 * lo) = a;
             *reinterpret_cast<float4*>(A.trQ + (b * Rcap + r1) * ELG_E + 8 * lo + 4) = c;
         }
@@ -1138,7 +1143,7 @@ __device__ __forceinline__ void co_advance4(const elg_rollout_args& A, const Ins
         Xi[CO_XS + j] = ssave;
         X[CO_XPEN + j] = pen;
         X[CO_XU + j] = 0.f;
-        if (TRAIN && nxt && (LEAN || A.trSlot)) {
+        if (TRAIN && nxt && (LEAN || A.trSlot) && !(ELG_EXP_SKIP & 2)) {
             A.trSlot[(b * Rcap + r1) * ELG_SLOT_STRIDE + j] = ssave;
             if (LEAN || A.trF) {
                 float* fr = A.trF + (b * Rcap + r1) * (3 * ELG_SLOT_STRIDE) + j;
@@ -1489,7 +1494,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_coop_kernel(const elg_rollout
                                                       (o[rt][2] + o2[rt][2]) * inv, (o[rt][3] + o2[rt][3]) * inv);
                         // O^T[d = 4 hi_t + v][traj = lo_t] -> this head's 16 channels of the trajectory's exchange row
                         *reinterpret_cast<float4*>(sQ + traj * CO_QP + 16 * wave + 4 * hi_t) = ov;
-                        if (TRAIN && live) *reinterpret_cast<float4*>(A.trO + ((size_t)b * Rcap + r) * ELG_E + 16 * wave + 4 * hi_t) = ov;
+                        if (TRAIN && live && !(ELG_EXP_SKIP & 4)) *reinterpret_cast<float4*>(A.trO + ((size_t)b * Rcap + r) * ELG_E + 16 * wave + 4 * hi_t) = ov;
                     }
                 }
                 ELG_STAMP(sc, 0);

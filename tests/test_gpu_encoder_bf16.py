@@ -145,7 +145,7 @@ def test_bf16_encoder_every_product_with_its_own_inputs(problem, B, N1):
         e = torch.exp(s - mx)
         den = e.sum(-1, keepdim=True)
         o_ref = ((bf(e) @ bf(vh)) / den).transpose(1, 2).reshape(B, N1, E)
-        _close("attention", O, o_ref, TOL, worst, flips=(0.995, 5e-3))                 # (v_exp_f32 vs exp: a numerator on a rounding boundary now and then)
+        _close("attention", O, o_ref, TOL, worst, flips=(0.98, 5e-3))                 # (v_exp_f32 vs exp: a numerator on a rounding boundary now and then)
         _close("lse", LSE, (mx + torch.log(den))[..., 0], TOL, worst)
         s1 = Xin + bf(O) @ bf(P[p + "multi_head_combine.weight"]).T + P[p + "multi_head_combine.bias"]
         x1_ref, xh1_ref, rs1_ref = _norm(s1, P[p + n1 + ".norm.weight"], P[p + n1 + ".norm.bias"])
@@ -192,7 +192,7 @@ def test_bf16_encoder_every_product_with_its_own_inputs(problem, B, N1):
         ds = pr * (dP - (dO * oh).sum(-1, keepdim=True)) / 4.0
         dq, dk, dv = bf(ds) @ bf(kh), bf(ds).transpose(2, 3) @ bf(qh), bf(pr).transpose(2, 3) @ bf(dO)
         dqkv_ref = torch.cat([x.transpose(1, 2).reshape(B, N1, E) for x in (dq, dk, dv)], 2)
-        _close("dQKV", dQKV, dqkv_ref, TOL, worst, flips=(0.995, 2e-2))
+        _close("dQKV", dQKV, dqkv_ref, TOL, worst, flips=(0.98, 2e-2))
         Wqkv = torch.cat([P[p + w] for w in ("Wq.weight", "Wk.weight", "Wv.weight")], 0)
         d = gY + bf(dQKV) @ bf(Wqkv)
         # the weight gradients: f32 products of the saved f32 activations and the kept cotangents
