@@ -176,3 +176,23 @@ def test_vrplib_n1001_properties():
         # the softmax runs over ten times the nodes of the 5e-4 cases and its logits carry logit_clipping = 50)
         np.testing.assert_allclose(got, ref, rtol=2e-3, atol=1e-12)
     gc.record_parity("fullsize/vrplib_n1001_aug8_pomo1000_chosen_prob_rel", worst)
+    # The same comparison in the unit north_star's bar is stated in: the scores before the clip of the streaming kernel AT N1 = 1001
+    # (the 1e-4 logit checks of test_gpu_logits stop at 151 nodes), teacher-forced on the two trajectories, first 60 decode steps,
+    # against the oracle's.  A probability 9e-4 off at this size is a score ~2e-5 off times the clip's factor 50.
+    import dataclasses
+    pol = model.decoder.policy
+    worst_s, DT = 0.0, 60
+    for b in (0, 5):
+        pol_b = dataclasses.replace(pol, tables={k: (v if v is None or v.dim() == 1 else v[b:b + 1].contiguous()) for k, v in pol.tables.items()})
+        prob_b = gc.make_problem(xy[b:b + 1], dm[b:b + 1], L.PROBLEM_CVRP)
+        forced = a[b:b + 1][:, sel].to(torch.int32)
+        r = eng.rollout_forward(prob_b, pol_b, 2, forced[0, :, 1], L.MODE_FORCED, forced=forced, dump_T=DT, dump="scores")
+        out = orc.rollout_cvrp(Pw, cfg, xy[b:b + 1], dm[b:b + 1], 2, starts=a[b, sel, 1], forced=a[b:b + 1][:, sel], keep_parts=True, keep_probs=True, max_steps=DT)
+        for t in range(2, DT):
+            ref_s = out["parts"][t - 2]["s"].numpy()[0]
+            got_s = r.full_probs[0, :, t].cpu().numpy()
+            open_ = out["full_probs"][t - 2][0].numpy() > 0            # (the oracle's open nodes; the environment is bit-exact)
+            worst_s = max(worst_s, float((np.abs(got_s[open_] - ref_s[open_]) / np.maximum(np.abs(ref_s[open_]), 1.0)).max()))
+    gc.record_parity("fullsize/vrplib_n1001_scores_before_clip_rel", worst_s)
+    print(f"X-n1001: scores before the clip vs the oracle {worst_s:.2e}, chosen probabilities {worst:.2e}")
+    assert worst_s <= 1e-4, worst_s
