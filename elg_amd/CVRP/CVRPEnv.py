@@ -90,6 +90,19 @@ class CVRPEnv:
 
     def load_random_problems(self, batch, aug_factor=1):
         """reference CVRPEnv.py:125-150."""
+        if aug_factor == 1 and not any(batch[k].is_cuda for k in ('loc', 'demand', 'depot')):
+            # a training batch from the host generator: depot | customers and 0 | demands are joined on the HOST (26 KB) and reach the
+            # device as two copies -- instead of three copies, two concatenations and a zero fill queued in front of the encoder
+            depot_h = batch['depot'].float()
+            if depot_h.dim() == 2:
+                depot_h = depot_h[:, None, :]
+            node_h, dem_h = batch['loc'].float(), batch['demand'].float()
+            self.vrplib = False
+            self.batch_size = node_h.shape[0]
+            self.depot_node_xy = eng.h2d(torch.cat((depot_h, node_h), dim=1), self.device)
+            dem = eng.h2d(torch.cat((torch.zeros(self.batch_size, 1), dem_h), dim=1), self.device)
+            self._finish_load(self.depot_node_xy[:, :1, :], dem)
+            return
         node = eng.h2d(batch['loc'].float(), self.device)
         demand = eng.h2d(batch['demand'].float(), self.device)
         depot = eng.h2d(batch['depot'].float(), self.device)

@@ -31,9 +31,10 @@ def softmax(x):
     return e / e.sum(axis=0)
 
 
-def pomo_loss(probs, rewards, scale_norm=True):
-    """reference train.py:112-121: shared baseline = mean reward over the POMO trajectories of an instance."""
-    return eng.pomo_loss(probs, rewards, scale_norm)     # csrc/elg_train.hip; GPU tensors only (no CPU path)
+def pomo_loss(probs, rewards, scale_norm=True, zero_steps=None):
+    """reference train.py:112-121: shared baseline = mean reward over the POMO trajectories of an instance.
+    zero_steps: utils.rollout_train's device flags of the steps with a chosen probability of exactly 0 (the reference's +1e-6)."""
+    return eng.pomo_loss(probs, rewards, scale_norm, zero_steps=zero_steps)     # csrc/elg_train.hip; GPU tensors only (no CPU path)
 
 
 _NOTED = set()
@@ -79,7 +80,7 @@ def train_step(model, env, optimizer, batch, scale_norm=True, bucket=None, world
     ro = rollout_train(model, env, reset_state.node_demand[0] if check else None)
     try:
         optimizer.zero_grad()
-        J = pomo_loss(ro.probs, ro.reward, scale_norm)
+        J = pomo_loss(ro.probs_raw, ro.reward, scale_norm, zero_steps=ro.zero_steps)
         J.backward()
         if bucket is not None:
             bucket.allreduce(world)

@@ -50,9 +50,20 @@ class TrainRollout:
     waits for the rollout's length and the feasibility flags, which were copied to the host right behind the rollout -- by
     then the backward is already queued, so the GPU never idles on the host -- and returns the actions (B, M, T)."""
 
-    def __init__(self, env, res, probs, fetch, checked):
-        self.env, self.res, self.probs, self.reward = env, res, probs, res.reward
+    def __init__(self, env, res, probs, fetch, checked, zero_steps=None):
+        self.env, self.res, self.reward = env, res, res.reward
+        # chosen probabilities as the kernels produced them + the steps on which one of them was exactly 0 (device flags): the
+        # loss kernel adds the reference's 1e-6 there (train.pomo_loss(..., zero_steps=)); `probs` forms the sum for other callers
+        self.probs_raw, self.zero_steps = probs, zero_steps
+        self._probs = None
         self._fetch, self._checked = fetch, checked
+
+    @property
+    def probs(self):
+        if self._probs is None:
+            self._probs = self.probs_raw if self.zero_steps is None else \
+                torch.add(self.probs_raw, self.zero_steps[None, :, None], alpha=1e-6)      # exact + 0.0 unless a chosen probability was 0
+        return self._probs
 
     def finish(self):
         vals = self._fetch.get()
@@ -87,8 +98,7 @@ def rollout_train(model, env, check_demand=None):
     fetch = eng.HostFetch(block)
     Tcap = res.probs.shape[1]
     probs = eng.chosen_probs(env.problem, pol, M, res, Tcap, T_dev=stats)
-    probs = torch.add(probs, zsteps[None, :, None], alpha=1e-6)      # exact + 0.0 unless a chosen probability was 0
-    return TrainRollout(env, res, probs, fetch, check_demand is not None)
+    return TrainRollout(env, res, probs, fetch, check_demand is not None, zero_steps=zsteps)
 
 
 def augment_xy_data_by_8_fold(problems):

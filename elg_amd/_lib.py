@@ -97,7 +97,7 @@ class EncoderBwdArgs(C.Structure):
 
 EXPORTS = ["elg_version", "elg_last_error", "elg_aug8", "elg_dist_matrix", "elg_nbr_tables", "elg_route_length",
            "elg_rollout_fwd", "elg_rollout_bwd", "elg_glimpse_rows_bwd", "elg_glimpse_bwd_fused", "elg_gemm_f32",
-           "elg_gemm_f32_batched", "elg_pomo_loss", "elg_adam_step", "elg_local_bwd_rows",
+           "elg_gemm_f32_batched", "elg_pomo_loss", "elg_pomo_loss_grad", "elg_adam_step", "elg_local_bwd_rows",
            "elg_add_instnorm_fwd", "elg_add_instnorm_bwd",
            "elg_encoder_ws_floats", "elg_encoder_fwd", "elg_encoder_bwd_ws_floats", "elg_encoder_bwd",
            "elg_local_fold_fwd", "elg_local_fold_bwd", "elg_check_feasible", "elg_rollout_stats", "elg_decoder_bwd",
@@ -137,6 +137,7 @@ def lib() -> C.CDLL:
         L.elg_gemm_f32_batched.argtypes = [f, f, f, i, i, i, i, i, i, i, i, i, i, i64, i64, i64, i64, i64, i64, fl, f]
         L.elg_gemm_f32_batched.restype = C.c_int
         L.elg_pomo_loss.argtypes = [f, f, i, i, i, i64, i64, f, f, f, f, f, f]
+        L.elg_pomo_loss_grad.argtypes = [f, f, f, i, i, i, i64, i64, C.c_float, f, f, f]
         L.elg_add_instnorm_fwd.argtypes = [f, f, f, f, f, f, f, i, i, i, fl, f]
         L.elg_add_instnorm_bwd.argtypes = [f, f, f, f, f, f, f, i, i, i, f]
         L.elg_local_bwd_rows.argtypes = [f, f, f, f, f, i, i, i64, i, f, i, i, f]
@@ -165,7 +166,7 @@ def lib() -> C.CDLL:
         L.elg_encoder_bwd.restype = C.c_int
         for n in ("elg_aug8", "elg_dist_matrix", "elg_nbr_tables", "elg_route_length", "elg_rollout_fwd",
                   "elg_rollout_bwd", "elg_glimpse_rows_bwd", "elg_glimpse_bwd_fused", "elg_gemm_f32",
-                  "elg_pomo_loss", "elg_adam_step", "elg_local_bwd_rows",
+                  "elg_pomo_loss", "elg_pomo_loss_grad", "elg_adam_step", "elg_local_bwd_rows",
                   "elg_add_instnorm_fwd", "elg_add_instnorm_bwd"):
             getattr(L, n).restype = C.c_int
         _lib = L

@@ -204,6 +204,59 @@ extern "C" int elg_rollout_stats(const int32_t* tlen, const float* probs, int B,
     return launch_status("rollout_stats");
 }
 
+// The scaled POMO loss of a CVRP training step AND its gradient w.r.t. the chosen probabilities in one launch (elg_pomo_loss_grad):
+// p' = p + 1e-6 [a chosen probability of step t was exactly 0]   (CVRPModel.py:67-68, as rollout_train applies it),
+// J_b = inv_count sum_m (-adv / max adv) sum_t log p',   g[b,t,m] = inv_count (-adv / max adv) / p'.
+// Same arithmetic and summation order as pomo_loss_kernel + the element-wise chain it replaces (the +1e-6 add, J's scale, the three
+// element-wise kernels of the autograd backward: five launches of 6 - 12 us in front of the decoder backward).
+__global__ __launch_bounds__(1024) void pomo_loss_grad_kernel(const float* __restrict__ probs, const float* __restrict__ reward,
+                                                              const int* __restrict__ zsteps, int T, int M, long long p_bstride,
+                                                              long long p_tstride, float inv_count, float* __restrict__ Jterm,
+                                                              float* __restrict__ gprob) {
+    __shared__ float red[16];
+    __shared__ float part[1024];
+    __shared__ float coef[1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* pb = probs + (size_t)b * p_bstride;
+    int MP = 1;
+    while (MP < M && MP < 1024) MP <<= 1;
+    const int G = 1024 / MP, g = tid / MP, mc = tid - g * MP;
+    float rsum = 0.f;
+    for (int m = tid; m < M; m += 1024) rsum += reward[(size_t)b * M + m];
+    const float mean = block_sum(rsum, red, tid, 1024) / (float)M;
+    float amax = ELG_NEG_INF;
+    for (int m = tid; m < M; m += 1024) amax = fmaxf(amax, reward[(size_t)b * M + m] - mean);
+    amax = block_max(amax, red, tid, 1024);
+    float jr = 0.f;
+    for (int m0 = 0; m0 < M; m0 += MP) {
+        const int m = m0 + mc;
+        float lp = 0.f;
+        if (m < M)
+            for (int t = g; t < T; t += G) lp += logf(pb[(size_t)t * p_tstride + m] + (zsteps && zsteps[t] ? 1e-6f : 0.f));
+        __syncthreads();
+        part[tid] = lp;
+        __syncthreads();
+        if (g == 0 && m < M) {
+            float tot = part[mc];
+            for (int k = 1; k < G; ++k) tot += part[k * MP + mc];
+            const float adv = reward[(size_t)b * M + m] - mean;
+            jr = fmaf(-adv, tot, jr);
+            coef[mc] = -adv / amax;
+        }
+        __syncthreads();
+        // the gradient rows of these MP trajectories
+        if (m < M) {
+            const float cf = coef[mc] * inv_count;
+            for (int t = g; t < T; t += G) {
+                const float pv = pb[(size_t)t * p_tstride + m] + (zsteps && zsteps[t] ? 1e-6f : 0.f);
+                gprob[((size_t)b * T + t) * M + m] = cf / pv;
+            }
+        }
+    }
+    jr = block_sum(jr, red, tid, 1024);
+    if (tid == 0) Jterm[b] = (jr / amax) * inv_count;
+}
+
 extern "C" int elg_pomo_loss(const float* probs, const float* reward, int B, int T, int M, int64_t probs_bstride,
                              int64_t probs_tstride, float* J_raw, float* J_scaled, float* adv_max, float* coef_raw,
                              float* coef_scaled, void* stream) {
@@ -214,6 +267,17 @@ extern "C" int elg_pomo_loss(const float* probs, const float* reward, int B, int
     hipLaunchKernelGGL(pomo_loss_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, probs, reward, T, M,
                        (long long)probs_bstride, (long long)probs_tstride, J_raw, J_scaled, adv_max, coef_raw, coef_scaled);
     return launch_status("pomo_loss");
+}
+
+extern "C" int elg_pomo_loss_grad(const float* probs, const float* reward, const int32_t* zero_steps, int B, int T, int M,
+                                  int64_t probs_bstride, int64_t probs_tstride, float inv_count, float* J_terms, float* gprob,
+                                  void* stream) {
+    if (B <= 0 || T <= 0 || M <= 0) return fail(ELG_EINVAL, "pomo_loss_grad: bad sizes");
+    if (!probs || !reward || !J_terms || !gprob) return fail(ELG_EINVAL, "pomo_loss_grad: null buffer");
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(pomo_loss_grad_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, probs, reward, zero_steps, T, M,
+                       (long long)probs_bstride, (long long)probs_tstride, inv_count, J_terms, gprob);
+    return launch_status("pomo_loss_grad");
 }
 
 extern "C" int elg_adam_step(float* param, float* const* param_table, const int64_t* offsets, int n_tensors,

@@ -827,10 +827,40 @@ class _PomoLoss(torch.autograd.Function):
         return (gout * ctx.scale) * c[:, None, :] / probs, None, None, None
 
 
-def pomo_loss(probs: torch.Tensor, rewards: torch.Tensor, scale_norm: bool = True, guard_zero: bool = False):
+class _PomoLossGrad(torch.autograd.Function):
+    """The scaled loss and its gradient in one launch (elg_pomo_loss_grad): the training step's path (CVRP, scale_norm, no
+    batch-wide guard).  zero_steps (Tcap int32 device flags, or None): the +1e-6 of CVRPModel.py:67-68 on the steps where a
+    chosen probability was exactly 0, applied inside the kernel instead of by an element-wise add in front of it."""
+    @staticmethod
+    def forward(ctx, probs, rewards, zero_steps):
+        B, T, M = probs.shape
+        if probs.stride(2) != 1:
+            probs = probs.contiguous()
+        rewards = rewards.contiguous().float()
+        dev = probs.device
+        jt = torch.empty(B, device=dev)
+        g = torch.empty(B, T, M, device=dev)
+        L.check(L.lib().elg_pomo_loss_grad(_ptr(probs), _ptr(rewards), _ptr(zero_steps), B, T, M, probs.stride(0), probs.stride(1),
+                                           1.0 / (B * M), _ptr(jt), _ptr(g), _stream()), "elg_pomo_loss_grad")
+        ctx.save_for_backward(g)
+        return jt.sum()
+
+    @staticmethod
+    def backward(ctx, gout):
+        (g,) = ctx.saved_tensors
+        return gout * g, None, None
+
+
+def pomo_loss(probs: torch.Tensor, rewards: torch.Tensor, scale_norm: bool = True, guard_zero: bool = False,
+              zero_steps: Optional[torch.Tensor] = None):
     """mean over (instance, trajectory) of -advantage * sum_t log p, advantage = reward - POMO mean
-    (reference CVRP/train.py:112-121; guard_zero = the TSP variant's batch-wide zero-normaliser check)."""
+    (reference CVRP/train.py:112-121; guard_zero = the TSP variant's batch-wide zero-normaliser check).
+    zero_steps: rollout_train's per-step flags "some chosen probability was exactly 0" -- p + 1e-6 on those steps."""
     _need_cuda(probs, "probs")
+    if scale_norm and not guard_zero and probs.dim() == 3:
+        return _PomoLossGrad.apply(probs.float(), rewards, None if zero_steps is None else zero_steps.contiguous())
+    if zero_steps is not None:
+        probs = torch.add(probs, zero_steps[None, :, None], alpha=1e-6)      # exact + 0.0 unless a chosen probability was 0
     return _PomoLoss.apply(probs.float(), rewards, bool(scale_norm), bool(guard_zero))
 
 

@@ -240,6 +240,14 @@ int elg_pomo_loss(const float* probs, const float* reward, int B, int T, int M, 
                   int64_t probs_tstride, float* J_raw, float* J_scaled, float* adv_max, float* coef_raw,
                   float* coef_scaled, void* stream);
 
+/* The scaled variant of that loss together with its gradient w.r.t. the chosen probabilities, for the CVRP training step
+ * (train.py:112-121 with scale_norm; the +1e-6 of CVRPModel.py:67-68 on the steps flagged in zero_steps (T int32, or NULL)):
+ *   J_terms[b] = inv_count * sum_m (-adv / max_m adv) sum_t log p',  gprob[b,t,m] = inv_count * (-adv / max adv) / p',
+ * p' = probs + 1e-6 zero_steps[t];  J = sum_b J_terms with inv_count = 1 / (B M) is the reference's .mean(); gprob is (B,T,M)
+ * contiguous.  One launch instead of the loss kernel + five element-wise framework kernels of its autograd chain. */
+int elg_pomo_loss_grad(const float* probs, const float* reward, const int32_t* zero_steps, int B, int T, int M,
+                       int64_t probs_bstride, int64_t probs_tstride, float inv_count, float* J_terms, float* gprob, void* stream);
+
 /* torch.optim.Adam update (L2 weight decay added to the gradient, bias correction; reference train.py:101) over n
  * floats in one launch.  grad / exp_avg / exp_avg_sq are flat.  Parameters: either flat (`param`), or left in place
  * and addressed through `param_table[k]` (device array of n_tensors device pointers) with element i of the flat

@@ -374,3 +374,34 @@ def test_rollout_stats_marks_the_steps_with_a_zero_probability():
     res.probs[1, 4, 7] = 0.5
     res.probs[0, 22, 11] = 0.5
     assert eng.rollout_stats(res) == (23, False)
+
+
+def test_fused_pomo_loss_and_gradient_equal_the_kernel_plus_autograd_chain():
+    """elg_pomo_loss_grad (the training step's path: scaled loss + d loss / d chosen probabilities in one launch, the +1e-6 of
+    the zero-probability steps inside it) against elg_pomo_loss + torch's element-wise chain, and against the oracle's
+    pomo_loss in float64."""
+    from elg_amd import engine as eng
+    from oracle import elg_oracle as orc
+    torch.manual_seed(3)
+    B, T, M = 5, 37, 23
+    probs0 = torch.rand(B, T, M).clamp_min(0.02)
+    probs0[1, 4, 7] = 0.0                                   # a chosen probability of exactly 0 at step 4 ...
+    z = torch.zeros(T, dtype=torch.int32)
+    z[4] = 1                                                # ... flagged by elg_rollout_stats
+    rew = torch.randn(B, M)
+    out = {}
+    for fused in (True, False):
+        p = probs0.clone().to(DEV).requires_grad_(True)
+        if fused:
+            J = eng.pomo_loss(p, rew.to(DEV), True, zero_steps=z.to(DEV))
+        else:
+            J = eng._PomoLoss.apply(torch.add(p, z.to(DEV)[None, :, None], alpha=1e-6), rew.to(DEV), True, False)
+        J.backward()
+        out[fused] = (float(J.detach()), p.grad.cpu())
+    p64 = (probs0.double() + 1e-6 * z.double()[None, :, None]).requires_grad_(True)
+    Jo = orc.pomo_loss(p64, rew.double(), True)
+    Jo.backward()
+    assert abs(out[True][0] - out[False][0]) <= 1e-6 * abs(out[False][0])
+    assert abs(out[True][0] - float(Jo.detach())) <= 2e-5 * abs(float(Jo.detach()))
+    np.testing.assert_allclose(out[True][1].numpy(), out[False][1].numpy(), rtol=2e-6, atol=0)
+    np.testing.assert_allclose(out[True][1].numpy(), p64.grad.numpy(), rtol=2e-5, atol=0)
