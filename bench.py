@@ -429,7 +429,7 @@ def main():
                 "mode": "rollout: glimpse scores / output and pointer scores on bf16 operands (v_mfma_f32_16x16x32_bf16, f32 "
                         "accumulation), softmax / masks / local policy / environment f32; glimpse backward: bf16-forward scores + "
                         "2-term split-bf16 linear products; encoder (N1 <= 128) forward and backward GEMMs + self-attention on bf16 "
-                        "operands (elg_encoder_args.precision = 1), weight gradients, pointer and local-policy backward f32",
+                        "operands (elg_encoder_args.precision = 1, weight gradients included), pointer and local-policy backward f32",
                 "tolerance": "pinned on the oracle's bf16 restatement (oracle/elg_oracle.py precision='bf16'): "
                              "tests/test_gpu_logits.py::test_bf16_mode_* -- scores before the clip within 1e-4 max(|ref|, 1) of it on >= 99 % "
                              "of the open nodes (the rest: bf16 rounding boundaries, <= 2e-3), and within 2 x the observed distance "

@@ -18,6 +18,7 @@
 // Q, K, V, dO of the (instance, head) in LDS and forms the score tile in both orientations, so that dQ (rows on lanes)
 // and dK / dV (keys on lanes) each accumulate in registers of the wave that owns them: no atomics, no transposes.
 #include "elg_enc_internal.h"
+#include "elg_bf16.h"
 #include <cstdlib>
 
 extern "C" __attribute__((visibility("hidden"))) int elg_gemm_f32_alpha(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
@@ -884,15 +885,37 @@ __global__ __launch_bounds__(256) void enc_dw_kernel(const DwBatch bt) {
         if (more) fetch(k + 16);
         const float* pa = &sA[buf][kq * 128 + mw + 2 * li];
         const float* pb = &sB[buf][kq * 128 + nw + 2 * li];
+        if (bt.bf16) {
+            // bf16 mode (elg_encoder_args.precision = 1): the chunk's 16 rows are ONE k-step of v_mfma_f32_32x32x16_bf16 -- lane (li, q)
+            // supplies rows 8 q .. 8 q + 7 of its two columns per operand, rounded to bf16; f32 accumulation; the bias sums stay f32
+            const float* qa = &sA[buf][(8 * kq) * 128 + mw + 2 * li];
+            const float* qb = &sB[buf][(8 * kq) * 128 + nw + 2 * li];
+            float2 av[8], bv[8];
 #pragma unroll
-        for (int s2 = 0; s2 < 8; ++s2) {
-            const float2 av = *reinterpret_cast<const float2*>(pa + s2 * 256);
-            const float2 bv = *reinterpret_cast<const float2*>(pb + s2 * 256);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[1][1], 0, 0, 0);
-            bsum0 += av.x; bsum1 += av.y;
+            for (int j = 0; j < 8; ++j) {
+                av[j] = *reinterpret_cast<const float2*>(qa + j * 128);
+                bv[j] = *reinterpret_cast<const float2*>(qb + j * 128);
+                bsum0 += av[j].x; bsum1 += av[j].y;
+            }
+            const u32x4 a0 = {pk_bf16(av[0].x, av[1].x), pk_bf16(av[2].x, av[3].x), pk_bf16(av[4].x, av[5].x), pk_bf16(av[6].x, av[7].x)};
+            const u32x4 a1 = {pk_bf16(av[0].y, av[1].y), pk_bf16(av[2].y, av[3].y), pk_bf16(av[4].y, av[5].y), pk_bf16(av[6].y, av[7].y)};
+            const u32x4 b0 = {pk_bf16(bv[0].x, bv[1].x), pk_bf16(bv[2].x, bv[3].x), pk_bf16(bv[4].x, bv[5].x), pk_bf16(bv[6].x, bv[7].x)};
+            const u32x4 b1 = {pk_bf16(bv[0].y, bv[1].y), pk_bf16(bv[2].y, bv[3].y), pk_bf16(bv[4].y, bv[5].y), pk_bf16(bv[6].y, bv[7].y)};
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, b0), acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, b1), acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, b0), acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, b1), acc[1][1], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) {
+                const float2 av = *reinterpret_cast<const float2*>(pa + s2 * 256);
+                const float2 bv = *reinterpret_cast<const float2*>(pb + s2 * 256);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.y, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.x, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[1][1], 0, 0, 0);
+                bsum0 += av.x; bsum1 += av.y;
+            }
         }
         if (more) commit(buf ^ 1);
         __syncthreads();
@@ -1210,6 +1233,7 @@ extern "C" int elg_encoder_bwd(const elg_encoder_bwd_args* ba, void* stream) {
     const long lay2_stride = w2.lay_stride;
     float* ws = a->ws;
     DwList dw(R, s, ba->ws2 + w2.DW, w2.dw_floats);
+    dw.bt.bf16 = (a->precision == 1 && enc_fused_ok(a)) ? 1 : 0;          // the bf16 mode's weight gradients (N1 <= 128)
     if (enc_fused_ok(a)) return enc_fused_bwd(ba, dw, s);
     const float inv_sqrt_e = 0.08838834764831845f;
     // N1 <= 128: row block = instance, the norm backwards ride in GEMM epilogues.  N1 > 128: 128-row blocks, the add & norm

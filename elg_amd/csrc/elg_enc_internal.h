@@ -37,6 +37,7 @@ struct DwBatch {
     DwJob job[DW_MAX_JOBS];
     int njobs, ntiles, rows, rows_per_split;
     float* scratch;                   // [split][tile][128][128] partial tiles
+    int bf16;                         // 1: operands rounded to bf16, v_mfma_f32_32x32x16_bf16 (the encoder's bf16 mode)
 };
 struct DwList {
     DwBatch bt;
@@ -44,7 +45,7 @@ struct DwList {
     hipStream_t s;
     float* scratch; long scratch_floats;
     DwList(long rows_, hipStream_t s_, float* scratch_, long scratch_floats_) : rows(rows_), s(s_), scratch(scratch_), scratch_floats(scratch_floats_) {
-        bt.njobs = 0; bt.ntiles = 0; bt.scratch = nullptr;
+        bt.njobs = 0; bt.ntiles = 0; bt.scratch = nullptr; bt.bf16 = 0;
     }
     int add(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, int M, int N, float* db, float alpha);
     int launch();

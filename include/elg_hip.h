@@ -318,7 +318,8 @@ typedef struct elg_encoder_args {
     int32_t precision;      /* 0: f32 (the parity mode).  1: bf16 throughput mode (BASELINE configs[1]), N1 <= 128 only (larger
                                instances compute in f32 whatever it says): every GEMM of the encoder, of the tables and of
                                their backward takes bf16 operands on v_mfma_f32_16x16x32_bf16 with f32 accumulation; bias,
-                               residual, instance norm, softmax, the saved activations and the weight gradients stay f32.  The
+                               residual, instance norm, softmax, the saved activations and the bias gradients stay f32 (the weight
+                               gradients are bf16 products of the saved f32 activations with f32 accumulation).  The
                                backward must be given the forward's value.                                                */
     const float* xy;        /* (B,N1,2)                                                                            */
     const float* demand;    /* (B,N1) CVRP (depot entry unused); TSP: NULL                                         */

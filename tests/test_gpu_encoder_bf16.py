@@ -195,11 +195,13 @@ def test_bf16_encoder_every_product_with_its_own_inputs(problem, B, N1):
         _close("dQKV", dQKV, dqkv_ref, TOL, worst, flips=(0.98, 2e-2))
         Wqkv = torch.cat([P[p + w] for w in ("Wq.weight", "Wk.weight", "Wv.weight")], 0)
         d = gY + bf(dQKV) @ bf(Wqkv)
-        # the weight gradients: f32 products of the saved f32 activations and the kept cotangents
+        # the weight gradients: bf16 products (f32 accumulation) of the saved f32 activations and the kept cotangents; bias
+        # gradients: f32 column sums
         R2 = lambda x: x.reshape(-1, x.shape[-1])
-        for name, ref in ((ff + ".W2.weight", R2(gS).T @ R2(H)), (ff + ".W1.weight", R2(gH).T @ R2(X1)),
-                          ("multi_head_combine.weight", R2(gY).T @ R2(O)), ("Wq.weight", R2(dQKV[..., :E]).T @ R2(Xin)),
-                          ("Wk.weight", R2(dQKV[..., E:2 * E]).T @ R2(Xin)), ("Wv.weight", R2(dQKV[..., 2 * E:]).T @ R2(Xin)),
+        RB = lambda x: bf(x).reshape(-1, x.shape[-1])
+        for name, ref in ((ff + ".W2.weight", RB(gS).T @ RB(H)), (ff + ".W1.weight", RB(gH).T @ RB(X1)),
+                          ("multi_head_combine.weight", RB(gY).T @ RB(O)), ("Wq.weight", RB(dQKV[..., :E]).T @ RB(Xin)),
+                          ("Wk.weight", RB(dQKV[..., E:2 * E]).T @ RB(Xin)), ("Wv.weight", RB(dQKV[..., 2 * E:]).T @ RB(Xin)),
                           (ff + ".W2.bias", R2(gS).sum(0)), (ff + ".W1.bias", R2(gH).sum(0)), ("multi_head_combine.bias", R2(gY).sum(0))):
             # (the biases in front of an instance norm have an exactly-zero true gradient -- the norm removes the per-channel mean, the
             # column sums of dS2 / dY cancel --: measured against 1e-2 of the largest gradient entry of the model)
