@@ -164,3 +164,50 @@ def test_local_fold_kernels_match_torch_restatement(problem, positional):
     for k in lp64:
         r = lp64[k].grad.numpy()
         np.testing.assert_allclose(lpg[k].grad.cpu().numpy(), r, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(r).max()), err_msg=k)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 5: shapes the fused per-instance kernels (csrc/elg_enc_fused.hip) treat differently from the defaults -- batches that
+# are not a multiple of 8 (the XCD-aware block map has a remainder branch; the bench's 64 never takes it, batches < 8 only
+# take it), hidden widths of 2 and 8 slices (ff_hidden_dim 256 / 1024: the partial-sum prologue walks more than four buffers),
+# 2 and 8 layers -- forward against the oracle and every gradient against float64 autograd
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("problem,B,N1,layers,ff", [("cvrp", 13, 101, 6, 512), ("cvrp", 9, 51, 2, 1024), ("tsp", 17, 100, 3, 256),
+                                                    ("cvrp", 8, 21, 8, 512), ("tsp", 11, 128, 2, 128)])
+def test_fused_encoder_other_batches_layers_and_hidden_widths(problem, B, N1, layers, ff):
+    mp = dict(gu.CVRP_MODEL_PARAMS if problem == "cvrp" else gu.TSP_MODEL_PARAMS)
+    mp["encoder_layer_num"], mp["ff_hidden_dim"] = layers, ff
+    cfg = orc.ModelCfg.from_model_params(mp, problem)
+    P = gc.weights(problem, 13, mp)
+    g = torch.Generator().manual_seed(13)
+    xy = torch.rand(B, N1, 2, generator=g)
+    dem = None
+    if problem == "cvrp":
+        dem = torch.cat([torch.zeros(B, 1), torch.randint(1, 10, (B, N1 - 1), generator=g).float() / 30.0], 1)
+    kind = L.PROBLEM_CVRP if problem == "cvrp" else L.PROBLEM_TSP
+    names = enc_host.parameter_names(kind, layers)
+    keys = ["enc", "K", "V", "PK", "pb", "Q1"] + (["Q2"] if problem == "tsp" else [])
+    cot = {k: torch.randn(B, N1, generator=g) if k == "pb" else torch.randn(B, N1, 128, generator=g) for k in keys}
+
+    def oracle(dt):
+        Pd = {k: v.detach().clone().to(dt).requires_grad_(True) for k, v in P.items()}
+        e, t = _oracle_tables(Pd, cfg, xy.to(dt), None if dem is None else dem.to(dt), kind)
+        t = dict(t, enc=e)
+        sum((t[k] * cot[k].to(dt)).sum() for k in keys).backward()
+        return {k: t[k].detach() for k in keys}, {n: Pd[n].grad.double().numpy() for n in names}
+    out64, g64 = oracle(torch.float64)
+    _, g32 = oracle(torch.float32)
+    params = [P[n].detach().clone().to(DEV).contiguous().requires_grad_(True) for n in names]
+    enc, t = enc_host.encode_and_fold(kind, xy.to(DEV), None if dem is None else dem.to(DEV), params, layers, ff)
+    t = dict(t, enc=enc)
+    for k in keys:
+        err = float((t[k].detach().cpu().double() - out64[k]).abs().max() / out64[k].abs().max())
+        assert err < 3e-5, (k, err)
+    sum((t[k] * cot[k].to(DEV)).sum() for k in keys).backward()
+    gmax = max(np.abs(v).max() for v in g64.values())
+    for n, p in zip(names, params):
+        ref, got = g64[n], p.grad.cpu().double().numpy()
+        err, err32 = np.abs(got - ref).max(), np.abs(g32[n] - ref).max()
+        # (err32 = what f32 rounding alone costs the oracle on this tensor: with 8 hidden slices the partial sums are added in two
+        #  batches of four -- another f32 order, up to 6 x err32 observed on the depot embedding of the 2-layer / 1024-wide case)
+        assert err <= max(1e-4 * np.abs(ref).max(), 8.0 * err32, 1e-6 * gmax), (n, err, err32)
