@@ -5,8 +5,8 @@
 // Why: with one kernel per GEMM a layer was 5 launches forward and 5 backward, each a single generation of workgroups whose
 // duration is its slowest wave's latency chain (load the row block, 3.5 us of MFMA, epilogue) -- 15-36 us per launch for
 // 1-4 us of matrix work.  Here a WAVE owns one tile of 16 rows (nodes) of one instance for a whole sub-layer and
-// every product is formed TRANSPOSED, D^T = W x^T: the weight rows are the MFMA's A operand (lane lo = output channel, one
-// 16-byte global load per lane and 16 k), the wave's activation tile is the B operand (lane lo = row).  The D registers of
+// every product is formed TRANSPOSED, D^T = W x^T: the weight rows are the MFMA's A operand (lane lo = output channel; staged
+// through LDS for the whole workgroup, see below), the wave's activation tile is the B operand (lane lo = row).  The D registers of
 // such a product, acc[i] = y[row lo][channel 16 ct + 4 hi + i], are exactly the B-operand fragment of chunk ct of the NEXT
 // product -- so QKV -> attention, combine -> norm -> FFN1 -> ReLU -> FFN2 and their backward chains run from registers: no
 // activation goes through LDS or memory between the GEMMs of a kernel.  What crosses waves is only what the math makes
@@ -19,7 +19,9 @@
 // where the add & instance norm (resp. its backward) runs as well -- every workgroup of the instance repeats that cheap
 // element-wise prologue (the norm needs all rows and the next GEMM all channels), the workgroup c = 0 writes its result
 // for the backward.  The combine GEMM in front of the first norm is repeated by the S feed-forward workgroups for the same
-// reason (+1/3 of that kernel's MFMAs, -1 launch and one round trip per layer).
+// reason (+1/3 of that kernel's MFMAs, -1 launch and one round trip per layer).  Partial 0 also carries the residual path (its
+// producer has x1 / dS2 / dY in registers), so a consumer fetches S tiles, not S + 1.
+// precision = 1 (template parameter BF): the same kernels with every MFMA operand rounded to bf16 (see mma_lds).
 //
 // Launches per training step at 6 layers: forward 13 (was 36), backward 16 + the grouped weight-gradient launch (was 39).
 #include "elg_enc_internal.h"
