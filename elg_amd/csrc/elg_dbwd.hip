@@ -12,6 +12,7 @@
 #include "elg_common.h"
 #include "../../include/elg_hip.h"
 #include "elg_bwd_internal.h"
+#include "elg_bf16.h"
 #include <string>
 
 namespace elg {
@@ -55,7 +56,11 @@ __global__ __launch_bounds__(256) void row_weights_kernel(const PtrBwd a) {
 // grid (splits, B), 512 threads: wave h owns channels 16 h .. 16 h + 15 of dO / dPK.  A thread stages 4 nodes of one row
 // of the dl tile (32 threads per row) and one 16-byte piece of the O tile; the next tile's values are fetched into
 // registers before the current tile's MFMAs.
-template <int NT>
+// BF (elg_decoder_bwd mfma_mode 3, the backward of a bf16 rollout): both products on v_mfma_f32_16x16x32_bf16 -- dl, PK and O
+// rounded to bf16 as operands, f32 accumulation (oracle: _PtrBF).  dO contracts over the nodes, two node tiles per instruction
+// (k-slot (hi, j) = node 16 (2 p) + 4 hi + j, (hi, 4 + j) = node 16 (2 p + 1) + 4 hi + j); dPK contracts over the tile's 16 rows,
+// k-slots (hi, 4..7) empty.  11 instructions of 16 cycles per tile instead of 56 of 32: the kernel is then bound by its 1.3 GB of rows.
+template <int NT, bool BF>
 __global__ __launch_bounds__(512, 4) void pointer_bwd_kernel(const PtrBwd a) {
     // pitches = 4 x odd (mod 64 floats): the fragment reads / stores that put the ROW on the lane (16 lanes x 16 bytes at one
     // pitch apart) then cover all 64 banks; 120 and 144 were 2- and 4-way conflicts (PMC: 43 % of the LDS-active cycles)
@@ -172,13 +177,28 @@ __global__ __launch_bounds__(512, 4) void pointer_bwd_kernel(const PtrBwd a) {
         slv[0] = slvn[0]; slv[1] = slvn[1];
         // dO^T[d][row] = sum_n PK[n][d] dl[row][n]   (D: lane holds d = 4 hi + i of row lo)
         f32x4 dot = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (BF) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const float4 d4 = *reinterpret_cast<const float4*>(sDL + lo * DLP + 16 * nt + 4 * hi);
-            dot = __builtin_amdgcn_mfma_f32_16x16x4f32(pk[nt][0], d4.x, dot, 0, 0, 0);
-            dot = __builtin_amdgcn_mfma_f32_16x16x4f32(pk[nt][1], d4.y, dot, 0, 0, 0);
-            dot = __builtin_amdgcn_mfma_f32_16x16x4f32(pk[nt][2], d4.z, dot, 0, 0, 0);
-            dot = __builtin_amdgcn_mfma_f32_16x16x4f32(pk[nt][3], d4.w, dot, 0, 0, 0);
+            for (int pr = 0; pr < (NT + 1) / 2; ++pr) {
+                const int t0 = 2 * pr, t1 = 2 * pr + 1;
+                const float4 d0 = *reinterpret_cast<const float4*>(sDL + lo * DLP + 16 * t0 + 4 * hi);
+                const float4 d1 = t1 < NT ? *reinterpret_cast<const float4*>(sDL + lo * DLP + 16 * (t1 < NT ? t1 : t0) + 4 * hi)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+                const u32x4 aop = {pk_bf16(pk[t0][0], pk[t0][1]), pk_bf16(pk[t0][2], pk[t0][3]),
+                                   t1 < NT ? pk_bf16(pk[t1 < NT ? t1 : t0][0], pk[t1 < NT ? t1 : t0][1]) : 0u,
+                                   t1 < NT ? pk_bf16(pk[t1 < NT ? t1 : t0][2], pk[t1 < NT ? t1 : t0][3]) : 0u};
+                const u32x4 bop = {pk_bf16(d0.x, d0.y), pk_bf16(d0.z, d0.w), pk_bf16(d1.x, d1.y), pk_bf16(d1.z, d1.w)};
+                dot = mfma_bf(aop, bop, dot);
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 d4 = *reinterpret_cast<const float4*>(sDL + lo * DLP + 16 * nt + 4 * hi);
+                dot = __builtin_amdgcn_mfma_f32_16x16x4f32(pk[nt][0], d4.x, dot, 0, 0, 0);
+                dot = __builtin_amdgcn_mfma_f32_16x16x4f32(pk[nt][1], d4.y, dot, 0, 0, 0);
+                dot = __builtin_amdgcn_mfma_f32_16x16x4f32(pk[nt][2], d4.z, dot, 0, 0, 0);
+                dot = __builtin_amdgcn_mfma_f32_16x16x4f32(pk[nt][3], d4.w, dot, 0, 0, 0);
+            }
         }
         *reinterpret_cast<float4*>(sDO + lo * OP + h * 16 + 4 * hi) = make_float4(dot[0], dot[1], dot[2], dot[3]);
         // dPK[n][d] += sum_row dl[row][n] O[row][d]   (D: lane holds node 16 nt + 4 hi + i, d = lo)
@@ -188,13 +208,18 @@ __global__ __launch_bounds__(512, 4) void pointer_bwd_kernel(const PtrBwd a) {
             float ov[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) ov[j] = sO[(4 * hi + j) * OP + h * 16 + lo];
+            const u32x4 ob = {pk_bf16(ov[0], ov[1]), pk_bf16(ov[2], ov[3]), 0u, 0u};          // (BF)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const float4 dT = *reinterpret_cast<const float4*>(sDLT + (16 * nt + lo) * TPD + 4 * hi);
-                dpk[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dT.x, ov[0], dpk[nt], 0, 0, 0);
-                dpk[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dT.y, ov[1], dpk[nt], 0, 0, 0);
-                dpk[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dT.z, ov[2], dpk[nt], 0, 0, 0);
-                dpk[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dT.w, ov[3], dpk[nt], 0, 0, 0);
+                if constexpr (BF) {
+                    dpk[nt] = mfma_bf(u32x4{pk_bf16(dT.x, dT.y), pk_bf16(dT.z, dT.w), 0u, 0u}, ob, dpk[nt]);
+                } else {
+                    dpk[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dT.x, ov[0], dpk[nt], 0, 0, 0);
+                    dpk[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dT.y, ov[1], dpk[nt], 0, 0, 0);
+                    dpk[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dT.z, ov[2], dpk[nt], 0, 0, 0);
+                    dpk[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dT.w, ov[3], dpk[nt], 0, 0, 0);
+                }
             }
         }
         __syncthreads();
@@ -513,10 +538,17 @@ extern "C" int elg_decoder_bwd(const elg_decoder_bwd_args* p, void* stream) {
     if (rc != ELG_OK) return rc;
     if (N1 > 128) return decoder_bwd_large(p, a, s);
     dim3 grid(a.splits, B), block(512);
-    if (nt <= 2) hipLaunchKernelGGL(pointer_bwd_kernel<2>, grid, block, 0, s, a);
-    else if (nt <= 4) hipLaunchKernelGGL(pointer_bwd_kernel<4>, grid, block, 0, s, a);
-    else if (nt <= 7) hipLaunchKernelGGL(pointer_bwd_kernel<7>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(pointer_bwd_kernel<8>, grid, block, 0, s, a);
+    if (p->mfma_mode == 3) {            // the backward of a bf16 rollout: the pointer's two products on bf16 operands too
+        if (nt <= 2) hipLaunchKernelGGL((pointer_bwd_kernel<2, true>), grid, block, 0, s, a);
+        else if (nt <= 4) hipLaunchKernelGGL((pointer_bwd_kernel<4, true>), grid, block, 0, s, a);
+        else if (nt <= 7) hipLaunchKernelGGL((pointer_bwd_kernel<7, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((pointer_bwd_kernel<8, true>), grid, block, 0, s, a);
+    } else {
+        if (nt <= 2) hipLaunchKernelGGL((pointer_bwd_kernel<2, false>), grid, block, 0, s, a);
+        else if (nt <= 4) hipLaunchKernelGGL((pointer_bwd_kernel<4, false>), grid, block, 0, s, a);
+        else if (nt <= 7) hipLaunchKernelGGL((pointer_bwd_kernel<7, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((pointer_bwd_kernel<8, false>), grid, block, 0, s, a);
+    }
     rc = launch_status("pointer_bwd");
     if (rc != ELG_OK) return rc;
     if (p->tables_frozen) return ELG_OK;          // nothing upstream of the pointer scores needs a gradient

@@ -3,7 +3,9 @@ optimiser's packed gradient buffer.  Writes its findings to a JSON file; prints 
 dumps every thread's stack if it is still alive after ELG_DP_WATCHDOG seconds, so that a hang names its place.
 
     dp_worker.py OUT two_ranks     gloo, world 2, both ranks on cuda:0 (RANK / WORLD_SIZE / MASTER_* from the env)
-    dp_worker.py OUT rccl_world1   nccl (= RCCL), world 1, ELG_FORCE_DIST=1: the all-reduce of the training step on RCCL"""
+    dp_worker.py OUT rccl_world1   nccl (= RCCL), world 1, ELG_FORCE_DIST=1: the all-reduce of the training step on RCCL
+    dp_worker.py OUT whole_step    a whole CVRP-100 train_step: world 2 (gloo, both ranks on cuda:0, 32 instances each) or,
+                                   without WORLD_SIZE > 1, one process over the same 64 instances"""
 import faulthandler
 import json
 import os
@@ -217,6 +219,72 @@ def rccl_world1(out_path):
     mark("done")
 
 
+def whole_step(out_path):
+    """A whole product train_step at CVRP-100 (POMO 100): two ranks x 32 instances against one process x the same 64 instances,
+    the same sampled trajectories (the engine's `uniforms` hook: the philox stream is keyed by the trajectory's index IN the
+    batch, so rank 1's instances would otherwise draw other numbers than instances 32..63 of the one process).  The loss is a
+    mean over instances and the advantage's baseline is per instance, so the ranks' averaged gradient IS the one-process
+    gradient; what differs is the order of the f32 sums over the rows (32 vs 64 instances per reduction)."""
+    import numpy as np
+    import golden_util as gu
+    from elg_amd import engine as eng
+    from elg_amd import parallel
+    from elg_amd.CVRP.CVRPEnv import CVRPEnv
+    from elg_amd.CVRP.generate_data import generate_vrp_data
+    from elg_amd.CVRP.train import train_step
+    from elg_amd.CVRP.utils import seed_everything
+    from elg_amd.optim import Adam
+    rank, world, _ = parallel.world_info()
+    if world > 1:
+        parallel.init_distributed(backend="gloo", timeout_s=90)
+        mark("process group up")
+    dev = "cuda:0"
+    N, M, Btot = 100, 100, 64
+    mp = dict(gu.CVRP_MODEL_PARAMS)
+    seed_everything(4242)                               # the same weights, instances and uniforms in every process
+    model = _new_model(mp, dev)
+    parallel.broadcast_parameters(model)
+    data = generate_vrp_data(Btot, N, {"data_type": "uniform"})
+    Tcap = eng.max_steps(eng.L.PROBLEM_CVRP, N + 1)
+    uni = torch.rand(Btot, M, Tcap)
+    per = Btot // world
+    sl = slice(rank * per, (rank + 1) * per)
+    batch = {k: v[sl] for k, v in data.items()}
+    orig_fwd = eng.rollout_forward
+
+    def fwd(*a, **kw):
+        kw["uniforms"] = uni[sl]
+        return orig_fwd(*a, **kw)
+    eng.rollout_forward = fwd
+    import elg_amd.CVRP.utils as U_
+    assert U_.eng is eng
+    env = CVRPEnv(multi_width=M, device=dev)
+    opt = Adam(model.parameters(), lr=1e-4, weight_decay=1e-6)
+    bucket = parallel.make_bucket(model.parameters(), opt)
+    assert (bucket is not None) == (world > 1)
+    before = _flat(model)
+    model.train()
+    J, rewards = train_step(model, env, opt, batch, True, bucket, world, check=True)
+    torch.cuda.synchronize()
+    eng.rollout_forward = orig_fwd
+    mark("train_step returned")
+    if world > 1:
+        grad = (opt.grad_flat.detach() * opt.grad_scale).cpu().numpy()       # the averaged gradient Adam applied
+    else:
+        grad = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
+    np.save(out_path + ".grad.npy", grad)
+    np.save(out_path + ".after.npy", _flat(model).cpu().numpy())
+    res = {"rank": rank, "world": world, "instances": per, "loss": float(J), "reward_sum": float(rewards.double().sum()),
+           "moved": float((_flat(model) - before).abs().max()), "bucket_calls": bucket.calls if bucket else 0}
+    with open(out_path, "w") as f:
+        json.dump(res, f)
+    mark("results written")
+    if world > 1:
+        parallel.barrier()
+        torch.distributed.destroy_process_group()
+    mark("done")
+
+
 if __name__ == "__main__":
-    {"two_ranks": two_ranks, "rccl_world1": rccl_world1}[sys.argv[2]](sys.argv[1])
+    {"two_ranks": two_ranks, "rccl_world1": rccl_world1, "whole_step": whole_step}[sys.argv[2]](sys.argv[1])
     faulthandler.cancel_dump_traceback_later()

@@ -1,6 +1,7 @@
 """The data-parallel path the product uses (parallel.GradBucket on elg_amd.optim.Adam's packed gradient buffer, 1/world
 folded into the Adam kernel) in fresh child processes:
 * two real ranks, both on cuda:0, gloo backend (RCCL refuses two ranks on one device);
+* a whole CVRP-100 training step, two ranks x 32 instances against one process x 64;
 * the RCCL branch itself: backend nccl at world size 1 (ELG_FORCE_DIST=1);
 * bench.py under the launcher the driver uses (`python -m torch.distributed.run`), with the RCCL all-reduce forced.
 The file sorts last (`zz`, and tests/conftest.py orders it last): nothing that starts processes or opens sockets runs in
@@ -95,6 +96,34 @@ def test_two_ranks_share_one_gradient(tmp_path):
     assert res[0]["validate_sharded"] == res[1]["validate_sharded"]
     for a, b in zip(res[0]["validate_sharded"], res[0]["validate_whole"]):
         assert abs(a - b) <= 1e-6 * abs(b), (res[0]["validate_sharded"], res[0]["validate_whole"])
+
+
+def test_whole_cvrp100_step_two_ranks_against_one_process(tmp_path):
+    """A whole CVRP-100 train_step (POMO 100): two gloo ranks x 32 instances against one process x the same 64 instances and
+    the same sampled trajectories.  Same tours (the rewards' sum is exact: every reward is the same f32), the averaged gradient
+    equal to the one-process gradient to the noise of the f32 row sums' order, the same Adam update."""
+    import numpy as np
+    port = _free_port()
+    outs = [str(tmp_path / f"w2_rank{r}.json") for r in range(2)] + [str(tmp_path / "w1.json")]
+    _check(_run_children(
+        [([sys.executable, WORKER, outs[r], "whole_step"],
+          _env({"RANK": str(r), "WORLD_SIZE": "2", "LOCAL_RANK": "0", "MASTER_PORT": port})) for r in range(2)],
+        tmp_path, "whole_step_rank"))
+    env1 = _env({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    env1.pop("ELG_FORCE_DIST", None)
+    _check(_run_children([([sys.executable, WORKER, outs[2], "whole_step"], env1)], tmp_path, "whole_step_single"))
+    r0, r1, one = (json.load(open(o)) for o in outs)
+    assert r0["world"] == 2 and r1["world"] == 2 and one["world"] == 1 and r0["instances"] == 32 and one["instances"] == 64
+    assert r0["bucket_calls"] == 1 and one["bucket_calls"] == 0
+    assert abs((r0["reward_sum"] + r1["reward_sum"]) - one["reward_sum"]) <= 1e-9 * abs(one["reward_sum"])     # the same tours
+    assert abs(0.5 * (r0["loss"] + r1["loss"]) - one["loss"]) <= 2e-5 * max(1.0, abs(one["loss"]))
+    g0, g1, g = (np.load(o + ".grad.npy").astype(np.float64) for o in outs)
+    assert np.array_equal(g0, g1)                                            # both ranks hold the same reduced bucket
+    scale = np.abs(g).max()
+    assert scale > 0 and np.abs(g0 - g).max() <= 2e-5 * scale, (np.abs(g0 - g).max(), scale)
+    a0, a1, a = (np.load(o + ".after.npy") for o in outs)
+    assert np.array_equal(a0, a1)
+    assert one["moved"] > 0 and np.abs(a0 - a).max() <= 0.05 * one["moved"]    # Adam: lr * m / sqrt(v), sign-stable where |g| >> noise
 
 
 def test_rccl_allreduce_in_the_training_step(tmp_path):
