@@ -18,14 +18,21 @@ from elg_amd import _lib as L
 from elg_amd import engine as eng
 
 
-@dataclass
 class Reset_State:
-    depot_xy: torch.Tensor = None        # (batch, 1, 2)
-    node_xy: torch.Tensor = None         # (batch, problem, 2)
-    node_demand: torch.Tensor = None     # (batch, problem)
-    dist: torch.Tensor = None            # (batch, problem+1, problem+1)
-    _xy: torch.Tensor = None             # (batch, problem+1, 2)   depot + customers, as the encoder kernel reads them
-    _demand: torch.Tensor = None         # (batch, problem+1)      demand[:, 0] = 0
+    """reference CVRPEnv.py:8-13.  `dist` (batch, problem+1, problem+1) is built on first read: the engine works from the
+    neighbour tables, and a training step that never looks at it should not pay a launch and 2.6 MB for it."""
+
+    def __init__(self):
+        self.depot_xy = None             # (batch, 1, 2)
+        self.node_xy = None              # (batch, problem, 2)
+        self.node_demand = None          # (batch, problem)
+        self._xy = None                  # (batch, problem+1, 2)   depot + customers, as the encoder kernel reads them
+        self._demand = None              # (batch, problem+1)      demand[:, 0] = 0
+        self._env = None
+
+    @property
+    def dist(self):
+        return None if self._env is None or self._env.depot_node_xy is None else self._env.dist
 
 
 @dataclass
@@ -61,6 +68,7 @@ class CVRPEnv:
         self.finished = None
         self.ninf_mask = None
         self.reset_state = Reset_State()
+        self.reset_state._env = self
         self.step_state = Step_State()
         self.problem = None                  # engine.Problem (coordinates, demands, neighbour tables)
         self._st = None
@@ -77,7 +85,6 @@ class CVRPEnv:
         self.problem = eng.Problem(L.PROBLEM_CVRP, self.depot_node_xy, self.depot_node_demand,
                                    eng.nbr_tables(self.depot_node_xy))
         self._dist = None
-        self.reset_state.dist = None
 
     @property
     def dist(self):
@@ -85,7 +92,6 @@ class CVRPEnv:
         neighbour tables (reference CVRPEnv.py:148)."""
         if self._dist is None:
             self._dist = eng.dist_matrix(self.depot_node_xy)
-            self.reset_state.dist = self._dist
         return self._dist
 
     def load_random_problems(self, batch, aug_factor=1):
@@ -159,8 +165,6 @@ class CVRPEnv:
         # the fused rollout (utils.rollout) never reads it, and ten small fills per reset are 1 % of a training step
         self._st_store = self._load = self._finished = self._ninf_mask = None
         self._needs_state = True
-        if self.reset_state.dist is None:
-            _ = self.dist
         return self.reset_state, None, False
 
     def _ensure_state(self):
