@@ -47,6 +47,8 @@ class Step_State:
 
 class CVRPEnv:
     def __init__(self, multi_width, device):
+        self._tours_lazy = None
+        self._selected_node_list = self._current_node = None
         self._needs_state = False
         self._st_store = self._load = self._finished = self._ninf_mask = None
         self.device = torch.device(device)
@@ -73,8 +75,39 @@ class CVRPEnv:
         self.problem = None                  # engine.Problem (coordinates, demands, neighbour tables)
         self._st = None
 
+    # `selected_node_list` (batch, multi, T) int64 / `current_node` as the reference's env holds them after a rollout.  A training
+    # step (utils.rollout_train) leaves the engine's int32 tours and their length here and the int64 tensors are formed on first
+    # read: nothing in a training step reads them, and the conversion is a 10 us launch per step.
+    @property
+    def selected_node_list(self):
+        if self._tours_lazy is not None:
+            tours, T = self._tours_lazy
+            self._tours_lazy = None
+            self._selected_node_list = tours[:, :, :T].long()
+            self._current_node = self._selected_node_list[:, :, -1]
+        return self._selected_node_list
+
+    @selected_node_list.setter
+    def selected_node_list(self, v):
+        self._tours_lazy = None
+        self._selected_node_list = v
+
+    @property
+    def current_node(self):
+        if self._tours_lazy is not None:
+            _ = self.selected_node_list
+        return self._current_node
+
+    @current_node.setter
+    def current_node(self, v):
+        self._current_node = v
+
+    def set_tours_lazy(self, tours_i32, T):
+        self._tours_lazy = (tours_i32, int(T))
+        self.selected_count = int(T)
+
     # ------------------------------------------------------------------ problem loading
-    def _finish_load(self, depot, demand_with_depot):
+    def _finish_load(self, depot, demand_with_depot, nbr=None):
         self.depot_node_xy = self.depot_node_xy.contiguous().float()
         self.depot_node_demand = demand_with_depot.contiguous().float()
         self.reset_state.depot_xy = depot
@@ -83,7 +116,7 @@ class CVRPEnv:
         self.reset_state._xy, self.reset_state._demand = self.depot_node_xy, self.depot_node_demand
         self.problem_size = self.depot_node_xy.shape[1] - 1
         self.problem = eng.Problem(L.PROBLEM_CVRP, self.depot_node_xy, self.depot_node_demand,
-                                   eng.nbr_tables(self.depot_node_xy))
+                                   nbr if nbr is not None else eng.nbr_tables(self.depot_node_xy))
         self._dist = None
 
     @property
@@ -105,9 +138,17 @@ class CVRPEnv:
             node_h, dem_h = batch['loc'].float(), batch['demand'].float()
             self.vrplib = False
             self.batch_size = node_h.shape[0]
-            self.depot_node_xy = eng.h2d(torch.cat((depot_h, node_h), dim=1), self.device)
-            dem = eng.h2d(torch.cat((torch.zeros(self.batch_size, 1), dem_h), dim=1), self.device)
-            self._finish_load(self.depot_node_xy[:, :1, :], dem)
+            xy_h = torch.cat((depot_h, node_h), dim=1)
+            dem_hh = torch.cat((torch.zeros(self.batch_size, 1), dem_h), dim=1)
+
+            def upload():                  # host data only: on the preparation stream, next to the previous step's backward
+                xy = eng.h2d(xy_h, self.device)
+                dem = eng.h2d(dem_hh, self.device)
+                nbr = eng.nbr_tables(xy)
+                return xy, dem, nbr.idx, nbr.dist, nbr.theta
+            xy, dem, idx, dist, theta = eng.on_prep_stream(self.device, upload)
+            self.depot_node_xy = xy
+            self._finish_load(xy[:, :1, :], dem, eng.NbrTables(idx, dist, theta))
             return
         node = eng.h2d(batch['loc'].float(), self.device)
         demand = eng.h2d(batch['demand'].float(), self.device)

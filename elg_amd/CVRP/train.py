@@ -31,10 +31,11 @@ def softmax(x):
     return e / e.sum(axis=0)
 
 
-def pomo_loss(probs, rewards, scale_norm=True, zero_steps=None):
+def pomo_loss(probs, rewards, scale_norm=True, zero_steps=None, T_dev=None):
     """reference train.py:112-121: shared baseline = mean reward over the POMO trajectories of an instance.
-    zero_steps: utils.rollout_train's device flags of the steps with a chosen probability of exactly 0 (the reference's +1e-6)."""
-    return eng.pomo_loss(probs, rewards, scale_norm, zero_steps=zero_steps)     # csrc/elg_train.hip; GPU tensors only (no CPU path)
+    zero_steps: utils.rollout_train's device flags of the steps with a chosen probability of exactly 0 (the reference's +1e-6);
+    T_dev: its device-resident step count (the padded steps behind it are not read)."""
+    return eng.pomo_loss(probs, rewards, scale_norm, zero_steps=zero_steps, T_dev=T_dev)     # csrc/elg_train.hip; GPU tensors only (no CPU path)
 
 
 _NOTED = set()
@@ -80,8 +81,8 @@ def train_step(model, env, optimizer, batch, scale_norm=True, bucket=None, world
     ro = rollout_train(model, env, reset_state.node_demand[0] if check else None)
     try:
         optimizer.zero_grad()
-        J = pomo_loss(ro.probs_raw, ro.reward, scale_norm, zero_steps=ro.zero_steps)
-        J.backward()
+        J = pomo_loss(ro.probs_raw, ro.reward, scale_norm, zero_steps=ro.zero_steps, T_dev=ro.T_dev)
+        J.backward(eng.unit_grad(J.device))          # = J.backward(), minus the fill and the product of the implicit cotangent
         if bucket is not None:
             bucket.allreduce(world)
         optimizer.step()

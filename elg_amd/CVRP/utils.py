@@ -50,8 +50,9 @@ class TrainRollout:
     waits for the rollout's length and the feasibility flags, which were copied to the host right behind the rollout -- by
     then the backward is already queued, so the GPU never idles on the host -- and returns the actions (B, M, T)."""
 
-    def __init__(self, env, res, probs, fetch, checked, zero_steps=None):
+    def __init__(self, env, res, probs, fetch, checked, zero_steps=None, T_dev=None):
         self.env, self.res, self.reward = env, res, res.reward
+        self.T_dev = T_dev                  # device int32: the longest trajectory's step count (probs beyond it are exactly 1)
         # chosen probabilities as the kernels produced them + the steps on which one of them was exactly 0 (device flags): the
         # loss kernel adds the reference's 1e-6 there (train.pomo_loss(..., zero_steps=)); `probs` forms the sum for other callers
         self.probs_raw, self.zero_steps = probs, zero_steps
@@ -65,18 +66,15 @@ class TrainRollout:
                 torch.add(self.probs_raw, self.zero_steps[None, :, None], alpha=1e-6)      # exact + 0.0 unless a chosen probability was 0
         return self._probs
 
-    def finish(self):
+    def finish(self, want_actions: bool = False):
         vals = self._fetch.get()
         T = int(vals[0])
-        actions = self.res.actions[:, :, :T].long()
-        env = self.env
-        env.selected_count = T
-        env.selected_node_list = actions
-        env.current_node = actions[:, :, -1]
+        # env.selected_node_list / current_node: formed from the engine's tours when somebody reads them (CVRPEnv.set_tours_lazy)
+        self.env.set_tours_lazy(self.res.actions, T)
         if self._checked:                                   # utils.check_feasible's assertions (reference utils.py:90-119)
             assert not vals[2], "Invalid tour"
             assert not vals[3], "Used more than capacity"
-        return actions
+        return self.env.selected_node_list if want_actions else None
 
 
 def rollout_train(model, env, check_demand=None):
@@ -98,7 +96,7 @@ def rollout_train(model, env, check_demand=None):
     fetch = eng.HostFetch(block)
     Tcap = res.probs.shape[1]
     probs = eng.chosen_probs(env.problem, pol, M, res, Tcap, T_dev=stats)
-    return TrainRollout(env, res, probs, fetch, check_demand is not None, zero_steps=zsteps)
+    return TrainRollout(env, res, probs, fetch, check_demand is not None, zero_steps=zsteps, T_dev=stats)
 
 
 def augment_xy_data_by_8_fold(problems):

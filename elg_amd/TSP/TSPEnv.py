@@ -46,10 +46,10 @@ class TSPEnv:
         self._needs_state = False
         self._dist = None
 
-    def _finish_load(self):
+    def _finish_load(self, nbr=None):
         self.problems = self.problems.contiguous().float()
         self.batch_size, self.problem_size = self.problems.shape[0], self.problems.shape[1]
-        self.problem = eng.Problem(L.PROBLEM_TSP, self.problems, None, eng.nbr_tables(self.problems))
+        self.problem = eng.Problem(L.PROBLEM_TSP, self.problems, None, nbr if nbr is not None else eng.nbr_tables(self.problems))
         self._dist = None
         dev = self.device
         self.BATCH_IDX = torch.arange(self.batch_size, device=dev)[:, None].expand(self.batch_size, self.pomo_size)
@@ -64,6 +64,17 @@ class TSPEnv:
     def load_random_problems(self, problems, aug_factor=1):
         """reference TSPEnv.py:53-67."""
         self.tsplib = False
+        if aug_factor == 1 and not problems.is_cuda:
+            host = problems.float()
+
+            def upload():                  # host data only: on the preparation stream, next to the previous step's backward
+                xy = eng.h2d(host, self.device)
+                nbr = eng.nbr_tables(xy)
+                return xy, nbr.idx, nbr.dist, nbr.theta
+            xy, idx, dist, theta = eng.on_prep_stream(self.device, upload)
+            self.problems = xy
+            self._finish_load(eng.NbrTables(idx, dist, theta))
+            return
         self.problems = eng.h2d(problems.float(), self.device)
         if aug_factor > 1:
             if aug_factor != 8:

@@ -137,7 +137,7 @@ def lib() -> C.CDLL:
         L.elg_gemm_f32_batched.argtypes = [f, f, f, i, i, i, i, i, i, i, i, i, i, i64, i64, i64, i64, i64, i64, fl, f]
         L.elg_gemm_f32_batched.restype = C.c_int
         L.elg_pomo_loss.argtypes = [f, f, i, i, i, i64, i64, f, f, f, f, f, f]
-        L.elg_pomo_loss_grad.argtypes = [f, f, f, i, i, i, i64, i64, C.c_float, f, f, f]
+        L.elg_pomo_loss_grad.argtypes = [f, f, f, i, i, i, i64, i64, C.c_float, f, f, f, f, f, f]
         L.elg_add_instnorm_fwd.argtypes = [f, f, f, f, f, f, f, i, i, i, fl, f]
         L.elg_add_instnorm_bwd.argtypes = [f, f, f, f, f, f, f, i, i, i, f]
         L.elg_local_bwd_rows.argtypes = [f, f, f, f, f, i, i, i64, i, f, i, i, f]

@@ -212,12 +212,16 @@ extern "C" int elg_rollout_stats(const int32_t* tlen, const float* probs, int B,
 __global__ __launch_bounds__(1024) void pomo_loss_grad_kernel(const float* __restrict__ probs, const float* __restrict__ reward,
                                                               const int* __restrict__ zsteps, int T, int M, long long p_bstride,
                                                               long long p_tstride, float inv_count, float* __restrict__ Jterm,
-                                                              float* __restrict__ gprob) {
+                                                              float* __restrict__ gprob, const int* __restrict__ T_dev,
+                                                              float* __restrict__ Jtotal, int* __restrict__ ticket) {
     __shared__ float red[16];
     __shared__ float part[1024];
     __shared__ float coef[1024];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* pb = probs + (size_t)b * p_bstride;
+    // steps past the rollout's longest trajectory hold probability 1 and no zero flag: log p' = 0 and g = coefficient / 1, exactly
+    // what the arithmetic below gives -- written without reading them (the buffer is padded to 2 N + 1 steps, a tour takes ~1.15 N)
+    const int Te = T_dev ? min(T, max(T_dev[0], 0)) : T;
     int MP = 1;
     while (MP < M && MP < 1024) MP <<= 1;
     const int G = 1024 / MP, g = tid / MP, mc = tid - g * MP;
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(1024) void pomo_loss_grad_kernel(const float* __res
         const int m = m0 + mc;
         float lp = 0.f;
         if (m < M)
-            for (int t = g; t < T; t += G) lp += logf(pb[(size_t)t * p_tstride + m] + (zsteps && zsteps[t] ? 1e-6f : 0.f));
+            for (int t = g; t < Te; t += G) lp += logf(pb[(size_t)t * p_tstride + m] + (zsteps && zsteps[t] ? 1e-6f : 0.f));
         __syncthreads();
         part[tid] = lp;
         __syncthreads();
@@ -247,14 +251,31 @@ __global__ __launch_bounds__(1024) void pomo_loss_grad_kernel(const float* __res
         // the gradient rows of these MP trajectories
         if (m < M) {
             const float cf = coef[mc] * inv_count;
-            for (int t = g; t < T; t += G) {
+            for (int t = g; t < Te; t += G) {
                 const float pv = pb[(size_t)t * p_tstride + m] + (zsteps && zsteps[t] ? 1e-6f : 0.f);
                 gprob[((size_t)b * T + t) * M + m] = cf / pv;
             }
+            for (int t = Te + g; t < T; t += G) gprob[((size_t)b * T + t) * M + m] = cf;
         }
     }
     jr = block_sum(jr, red, tid, 1024);
-    if (tid == 0) Jterm[b] = (jr / amax) * inv_count;
+    if (tid == 0) __hip_atomic_store(Jterm + b, (jr / amax) * inv_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (Jtotal) {
+        // the last workgroup to arrive adds the B terms in index order (the same bits whatever the arrival order) and re-arms the ticket
+        __shared__ int last;
+        if (tid == 0) {
+            __threadfence();
+            last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+        }
+        __syncthreads();
+        if (last && tid == 0) {
+            __threadfence();
+            float tot = 0.f;
+            for (int i = 0; i < (int)gridDim.x; ++i) tot += __hip_atomic_load(Jterm + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the workgroups sit on eight L2s)
+            Jtotal[0] = tot;
+            *ticket = 0;
+        }
+    }
 }
 
 extern "C" int elg_pomo_loss(const float* probs, const float* reward, int B, int T, int M, int64_t probs_bstride,
@@ -271,12 +292,13 @@ extern "C" int elg_pomo_loss(const float* probs, const float* reward, int B, int
 
 extern "C" int elg_pomo_loss_grad(const float* probs, const float* reward, const int32_t* zero_steps, int B, int T, int M,
                                   int64_t probs_bstride, int64_t probs_tstride, float inv_count, float* J_terms, float* gprob,
-                                  void* stream) {
+                                  const int32_t* T_dev, float* J_total, int32_t* ticket, void* stream) {
     if (B <= 0 || T <= 0 || M <= 0) return fail(ELG_EINVAL, "pomo_loss_grad: bad sizes");
     if (!probs || !reward || !J_terms || !gprob) return fail(ELG_EINVAL, "pomo_loss_grad: null buffer");
+    if ((J_total != nullptr) != (ticket != nullptr)) return fail(ELG_EINVAL, "pomo_loss_grad: J_total needs a ticket word (and vice versa)");
     (void)hipGetLastError();
     hipLaunchKernelGGL(pomo_loss_grad_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, probs, reward, zero_steps, T, M,
-                       (long long)probs_bstride, (long long)probs_tstride, inv_count, J_terms, gprob);
+                       (long long)probs_bstride, (long long)probs_tstride, inv_count, J_terms, gprob, T_dev, J_total, ticket);
     return launch_status("pomo_loss_grad");
 }
 

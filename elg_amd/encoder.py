@@ -115,6 +115,9 @@ class _EncodeFold(torch.autograd.Function):
             # piled up until a long run died with an out-of-memory error.
             ctx.keep = (xy, demand)
             ctx.save_for_backward(*params, enc)
+            # an output nobody differentiated (the training step never uses `enc` itself) arrives in backward as None, not as a
+            # zero tensor autograd would have to fill first: elg_encoder_bwd takes NULL for every cotangent that is absent
+            ctx.set_materialize_grads(False)
         return enc, K, V, PK, pb, Q1, Q2, wl
 
     @staticmethod

@@ -39,6 +39,34 @@ def _side_stream(dev) -> "torch.cuda.Stream":
     return _SIDE[key]
 
 
+# A training batch from the host generator depends on nothing the GPU has computed: its two uploads and the neighbour-table kernel
+# are issued on their own stream, where they run while the PREVIOUS step's backward still occupies the main stream (the host is a step
+# ahead of the GPU), instead of sitting between Adam and the encoder (two DMA round trips + one launch: ~55 us of a 4 - 5 ms step).
+PREP_STREAM = os.environ.get("ELG_PREP_STREAM", "1") not in ("", "0")
+_PREP = {}
+
+
+def on_prep_stream(dev, fn):
+    """fn() -> tuple of device tensors, built from HOST data only.  Runs fn on the device's preparation stream; the current stream
+    waits for it and the tensors are marked as used there (the allocator must not hand their memory out again while the current
+    stream still reads them)."""
+    if not PREP_STREAM:
+        return fn()
+    dev = torch.device(dev)
+    key = str(dev)
+    if key not in _PREP:
+        _PREP[key] = torch.cuda.Stream(device=dev)
+    main, prep = torch.cuda.current_stream(dev), _PREP[key]
+    with torch.cuda.stream(prep):
+        outs = fn()
+        ev = torch.cuda.Event()
+        ev.record(prep)
+    main.wait_event(ev)
+    for t in outs:
+        t.record_stream(main)
+    return outs
+
+
 class HostFetch:
     """A few device integers copied to pinned host memory behind the work queued so far; get() waits for that copy only,
     not for what was queued after it (a plain .tolist() would wait for the whole stream)."""
@@ -831,34 +859,55 @@ class _PomoLossGrad(torch.autograd.Function):
     """The scaled loss and its gradient in one launch (elg_pomo_loss_grad): the training step's path (CVRP, scale_norm, no
     batch-wide guard).  zero_steps (Tcap int32 device flags, or None): the +1e-6 of CVRPModel.py:67-68 on the steps where a
     chosen probability was exactly 0, applied inside the kernel instead of by an element-wise add in front of it."""
+    _tickets: Dict[str, torch.Tensor] = {}
+
     @staticmethod
-    def forward(ctx, probs, rewards, zero_steps):
+    def forward(ctx, probs, rewards, zero_steps, T_dev):
         B, T, M = probs.shape
         if probs.stride(2) != 1:
             probs = probs.contiguous()
         rewards = rewards.contiguous().float()
         dev = probs.device
-        jt = torch.empty(B, device=dev)
+        key = str(dev)
+        if key not in _PomoLossGrad._tickets:
+            _PomoLossGrad._tickets[key] = torch.zeros(1, dtype=torch.int32, device=dev)     # left zero by every launch
+        out = torch.empty(B + 1, device=dev)                   # J_terms | J
         g = torch.empty(B, T, M, device=dev)
         L.check(L.lib().elg_pomo_loss_grad(_ptr(probs), _ptr(rewards), _ptr(zero_steps), B, T, M, probs.stride(0), probs.stride(1),
-                                           1.0 / (B * M), _ptr(jt), _ptr(g), _stream()), "elg_pomo_loss_grad")
+                                           1.0 / (B * M), _ptr(out), _ptr(g), _ptr(T_dev), _ptr(out[B:]),
+                                           _ptr(_PomoLossGrad._tickets[key]), _stream()), "elg_pomo_loss_grad")
         ctx.save_for_backward(g)
-        return jt.sum()
+        return out[B]
 
     @staticmethod
     def backward(ctx, gout):
         (g,) = ctx.saved_tensors
-        return gout * g, None, None
+        if gout.data_ptr() == unit_grad(g.device).data_ptr():      # J.backward(unit_grad(dev)): the cotangent IS 1, nothing to scale
+            return g, None, None, None
+        return gout * g, None, None, None
+
+
+_UNIT: Dict[str, torch.Tensor] = {}
+
+
+def unit_grad(dev) -> torch.Tensor:
+    """The cached device scalar 1.0.  `J.backward(unit_grad(dev))` is `J.backward()` without the fill that creates the implicit
+    cotangent and -- for the fused POMO loss, which recognises this tensor -- without the element-wise product with it."""
+    key = str(torch.device(dev))
+    if key not in _UNIT:
+        _UNIT[key] = torch.ones((), device=dev)
+    return _UNIT[key]
 
 
 def pomo_loss(probs: torch.Tensor, rewards: torch.Tensor, scale_norm: bool = True, guard_zero: bool = False,
-              zero_steps: Optional[torch.Tensor] = None):
+              zero_steps: Optional[torch.Tensor] = None, T_dev: Optional[torch.Tensor] = None):
     """mean over (instance, trajectory) of -advantage * sum_t log p, advantage = reward - POMO mean
     (reference CVRP/train.py:112-121; guard_zero = the TSP variant's batch-wide zero-normaliser check).
     zero_steps: rollout_train's per-step flags "some chosen probability was exactly 0" -- p + 1e-6 on those steps."""
     _need_cuda(probs, "probs")
     if scale_norm and not guard_zero and probs.dim() == 3:
-        return _PomoLossGrad.apply(probs.float(), rewards, None if zero_steps is None else zero_steps.contiguous())
+        # T_dev (device int32, rollout_train's step count): the padded steps behind it hold probability 1 and are not read
+        return _PomoLossGrad.apply(probs.float(), rewards, None if zero_steps is None else zero_steps.contiguous(), T_dev)
     if zero_steps is not None:
         probs = torch.add(probs, zero_steps[None, :, None], alpha=1e-6)      # exact + 0.0 unless a chosen probability was 0
     return _PomoLoss.apply(probs.float(), rewards, bool(scale_norm), bool(guard_zero))

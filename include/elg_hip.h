@@ -244,9 +244,14 @@ int elg_pomo_loss(const float* probs, const float* reward, int B, int T, int M, 
  * (train.py:112-121 with scale_norm; the +1e-6 of CVRPModel.py:67-68 on the steps flagged in zero_steps (T int32, or NULL)):
  *   J_terms[b] = inv_count * sum_m (-adv / max_m adv) sum_t log p',  gprob[b,t,m] = inv_count * (-adv / max adv) / p',
  * p' = probs + 1e-6 zero_steps[t];  J = sum_b J_terms with inv_count = 1 / (B M) is the reference's .mean(); gprob is (B,T,M)
- * contiguous.  One launch instead of the loss kernel + five element-wise framework kernels of its autograd chain. */
+ * contiguous.  One launch instead of the loss kernel + five element-wise framework kernels of its autograd chain.
+ * T_dev (device int32, or NULL): the rollout's longest trajectory; the steps from there on hold probability 1 by contract and are
+ * not read (their gprob is the coefficient itself, as the division by 1 gives).  J_total (device float, or NULL) receives
+ * sum_b J_terms[b], added in index order by the last workgroup to finish; `ticket` is the int32 word that elects it -- zero before
+ * the first call, left zero by every call, required exactly when J_total is given. */
 int elg_pomo_loss_grad(const float* probs, const float* reward, const int32_t* zero_steps, int B, int T, int M,
-                       int64_t probs_bstride, int64_t probs_tstride, float inv_count, float* J_terms, float* gprob, void* stream);
+                       int64_t probs_bstride, int64_t probs_tstride, float inv_count, float* J_terms, float* gprob,
+                       const int32_t* T_dev, float* J_total, int32_t* ticket, void* stream);
 
 /* torch.optim.Adam update (L2 weight decay added to the gradient, bias correction; reference train.py:101) over n
  * floats in one launch.  grad / exp_avg / exp_avg_sq are flat.  Parameters: either flat (`param`), or left in place

@@ -172,6 +172,31 @@ def test_local_fold_kernels_match_torch_restatement(problem, positional):
 # take it), hidden widths of 2 and 8 slices (ff_hidden_dim 256 / 1024: the partial-sum prologue walks more than four buffers),
 # 2 and 8 layers -- forward against the oracle and every gradient against float64 autograd
 # ---------------------------------------------------------------------------------------------------------------------
+def _away_from_relu_kinks(P, cfg, xy, dem, tol=2e-5):
+    """Move the W1 biases of the hidden units whose pre-activation lies within `tol` of 0 at some node (by the oracle's float64
+    forward) until there is none.  Such a unit's ReLU may fall on the other side in an f32 forward with another summation order;
+    that is a legitimate difference which moves one row of the W1 gradient by a node's whole contribution and everything below it
+    by a little (found with B = 9, N1 = 51, ff = 1024: |pre| = 1.6e-7 and 1.0e-7 in the two layers, W1 rows off by 3 %, depot
+    embedding by 9 x the f32 oracle's own error).  The tests below want tight bounds on EVERY tensor, so their inputs avoid kinks."""
+    ff = "feed_forward" if cfg.problem == "cvrp" else "feedForward"
+    for it in range(40):
+        taps = {}
+        with torch.no_grad():
+            orc.encoder_forward({k: v.detach().double() for k, v in P.items()}, cfg, xy.double(), None if dem is None else dem.double(),
+                                taps=taps)
+        moved = False
+        for k in sorted(taps):
+            near = (taps[k].abs() < tol).flatten(0, 1).any(dim=0)
+            if bool(near.any()):
+                with torch.no_grad():
+                    P[k.replace("pre_relu", ff + ".W1") + ".bias"][near] += 1e-3 * (1 + it % 3)
+                moved = True
+                break                      # the layers above see other inputs now: look again
+        if not moved:
+            return P
+    raise AssertionError("could not move the pre-activations away from 0")
+
+
 @pytest.mark.parametrize("problem,B,N1,layers,ff", [("cvrp", 13, 101, 6, 512), ("cvrp", 9, 51, 2, 1024), ("tsp", 17, 100, 3, 256),
                                                     ("cvrp", 8, 21, 8, 512), ("tsp", 11, 128, 2, 128)])
 def test_fused_encoder_other_batches_layers_and_hidden_widths(problem, B, N1, layers, ff):
@@ -186,6 +211,7 @@ def test_fused_encoder_other_batches_layers_and_hidden_widths(problem, B, N1, la
         dem = torch.cat([torch.zeros(B, 1), torch.randint(1, 10, (B, N1 - 1), generator=g).float() / 30.0], 1)
     kind = L.PROBLEM_CVRP if problem == "cvrp" else L.PROBLEM_TSP
     names = enc_host.parameter_names(kind, layers)
+    P = _away_from_relu_kinks({k: v.detach().clone() for k, v in P.items()}, cfg, xy, dem)
     keys = ["enc", "K", "V", "PK", "pb", "Q1"] + (["Q2"] if problem == "tsp" else [])
     cot = {k: torch.randn(B, N1, generator=g) if k == "pb" else torch.randn(B, N1, 128, generator=g) for k in keys}
 

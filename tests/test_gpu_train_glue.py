@@ -330,7 +330,7 @@ def test_deferred_sync_rollout_matches_the_synchronous_sequence():
             ro = rollout_train(model, env, rs.node_demand[0])
             J = pomo_loss(ro.probs, ro.reward, True)
             J.backward()
-            sol, rew = ro.finish(), ro.reward
+            sol, rew = ro.finish(want_actions=True), ro.reward
             assert ro.probs.shape[1] >= sol.shape[2]
         else:
             sol, probs, rew = rollout(model, env, 'sample')
@@ -405,3 +405,22 @@ def test_fused_pomo_loss_and_gradient_equal_the_kernel_plus_autograd_chain():
     assert abs(out[True][0] - float(Jo.detach())) <= 2e-5 * abs(float(Jo.detach()))
     np.testing.assert_allclose(out[True][1].numpy(), out[False][1].numpy(), rtol=2e-6, atol=0)
     np.testing.assert_allclose(out[True][1].numpy(), p64.grad.numpy(), rtol=2e-5, atol=0)
+    # the training step's form: padded steps of probability 1 behind the device-resident step count are not read, the cotangent is the
+    # cached unit scalar (no product) -- the same loss and gradient, bit for bit, as the full walk with the implicit cotangent; twice
+    # (the ticket word that elects the workgroup adding the terms must come back to zero)
+    T2 = T + 9
+    pad = torch.ones(B, T2, M)
+    pad[:, :T] = probs0
+    z2 = torch.zeros(T2, dtype=torch.int32)
+    z2[4] = 1
+    Tdev = torch.tensor([T, 0], dtype=torch.int32, device=DEV)
+    got = []
+    for T_dev, unit in ((None, False), (Tdev, True), (Tdev, True)):
+        p = pad.clone().to(DEV).requires_grad_(True)
+        J = eng.pomo_loss(p, rew.to(DEV), True, zero_steps=z2.to(DEV), T_dev=T_dev)
+        J.backward(eng.unit_grad(DEV)) if unit else J.backward()
+        got.append((J.detach().cpu(), p.grad.cpu()))
+    for J2, g2 in got[1:]:
+        assert torch.equal(J2, got[0][0]) and torch.equal(g2, got[0][1])
+    assert abs(float(got[0][0]) - out[True][0]) <= 1e-6 * abs(out[True][0])
+    assert torch.equal(got[0][1][:, :T], out[True][1])

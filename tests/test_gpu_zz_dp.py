@@ -123,7 +123,11 @@ def test_whole_cvrp100_step_two_ranks_against_one_process(tmp_path):
     assert scale > 0 and np.abs(g0 - g).max() <= 2e-5 * scale, (np.abs(g0 - g).max(), scale)
     a0, a1, a = (np.load(o + ".after.npy") for o in outs)
     assert np.array_equal(a0, a1)
-    assert one["moved"] > 0 and np.abs(a0 - a).max() <= 0.05 * one["moved"]    # Adam: lr * m / sqrt(v), sign-stable where |g| >> noise
+    # Adam's first update is lr * g / (|g| + eps): +-lr whatever |g| is, so an entry whose gradient is summation noise around zero may
+    # move the other way.  Where the gradient is above that noise the two updates agree.
+    big = np.abs(g) >= 1e-3 * scale
+    assert one["moved"] > 0 and big.mean() > 0.3 and np.abs(a0 - a)[big].max() <= 0.05 * one["moved"], \
+        (big.mean(), np.abs(a0 - a)[big].max(), one["moved"])
 
 
 def test_rccl_allreduce_in_the_training_step(tmp_path):
