@@ -255,6 +255,34 @@ def secondary_workloads(dev):
         out["vrplib_X-n1001_rollout_ms"] = {"f32": round(ro_ms, 1), "bf16": round(ro_ms_bf, 1)}
         out["vrplib_X-n1001_us_per_decode_step"] = {"f32": round(1e3 * ro_ms / T_f32, 1), "bf16": round(1e3 * ro_ms_bf / steps["T"], 1)}
         out["vrplib_X-n1001_roofline"] = secondary_roofline(8, 1000, 1001, T_f32, ro_ms, tsp=False)
+    # the reference's own default batch (CVRP/config.yml:18 train_batch_size 120), the shape its full schedule runs at
+    # (tools/cvrp_full_schedule.py): 40 whole training steps after 5 warm-up steps, f32 and the bf16 mode
+    with open(os.path.join(ROOT, "elg_amd", "CVRP", "config.yml")) as f:
+        ccfg = yaml.load(f.read(), Loader=yaml.FullLoader)
+    from elg_amd.CVRP.generate_data import generate_vrp_data
+    from elg_amd.CVRP.train import train_step
+    from elg_amd.optim import Adam
+    m120 = CVRPModel(**ccfg["model_params"])
+    m120.decoder.add_local_policy(dev)
+    m120.to(dev).train()
+    e120 = CVRPEnv(100, dev)
+    o120 = Adam(m120.parameters(), lr=1e-4, weight_decay=1e-6)
+    dcfg = dict(ccfg["distribution"], data_type="uniform")
+
+    def leg120():
+        for _ in range(5):
+            train_step(m120, e120, o120, generate_vrp_data(120, 100, dcfg), True, check=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(40):
+            train_step(m120, e120, o120, generate_vrp_data(120, 100, dcfg), True, check=True)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 40
+    s32 = leg120()
+    sbf = with_bf16(leg120)
+    out["cvrp100_b120"] = {"instances_per_s": round(120 / s32, 1), "ms_per_step": round(s32 * 1e3, 3),
+                           "instances_per_s_bf16": round(120 / sbf, 1), "ms_per_step_bf16": round(sbf * 1e3, 3),
+                           "what": "whole training steps at the reference's default batch 120 (pomo 100, joint), 40 timed after 5 warm-up"}
     return out
 
 
@@ -429,7 +457,8 @@ def main():
                 "mode": "rollout: glimpse scores / output and pointer scores on bf16 operands (v_mfma_f32_16x16x32_bf16, f32 "
                         "accumulation), softmax / masks / local policy / environment f32; glimpse backward: bf16-forward scores + "
                         "2-term split-bf16 linear products; encoder (N1 <= 128) forward and backward GEMMs + self-attention on bf16 "
-                        "operands (elg_encoder_args.precision = 1, weight gradients included), pointer and local-policy backward f32",
+                        "operands (elg_encoder_args.precision = 1, weight gradients included), pointer backward on bf16 operands "
+                        "(pointer_bwd_kernel<NT, true>), local-policy forward and backward f32",
                 "tolerance": "pinned on the oracle's bf16 restatement (oracle/elg_oracle.py precision='bf16'): "
                              "tests/test_gpu_logits.py::test_bf16_mode_* -- scores before the clip within 1e-4 max(|ref|, 1) of it on >= 99 % "
                              "of the open nodes (the rest: bf16 rounding boundaries, <= 2e-3), and within 2 x the observed distance "

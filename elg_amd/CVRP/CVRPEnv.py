@@ -138,15 +138,23 @@ class CVRPEnv:
             node_h, dem_h = batch['loc'].float(), batch['demand'].float()
             self.vrplib = False
             self.batch_size = node_h.shape[0]
-            xy_h = torch.cat((depot_h, node_h), dim=1)
-            dem_hh = torch.cat((torch.zeros(self.batch_size, 1), dem_h), dim=1)
+            # ... into ONE pinned buffer by numpy slices (no torch CPU kernel: engine._host_copy says why) and to the device in ONE copy
+            B_, n1 = self.batch_size, node_h.shape[1] + 1
+            xy_h = torch.empty(B_, n1, 2)
+            dem_hh = torch.empty(B_, n1)
+            xy_n, dem_n = xy_h.numpy(), dem_hh.numpy()
+            xy_n[:, :1] = depot_h.numpy()
+            xy_n[:, 1:] = node_h.numpy()
+            dem_n[:, 0] = 0.0
+            dem_n[:, 1:] = dem_h.numpy()
 
             def upload():                  # host data only: on the preparation stream, next to the previous step's backward
-                xy = eng.h2d(xy_h, self.device)
-                dem = eng.h2d(dem_hh, self.device)
+                flat, (xy, dem) = eng.h2d_parts((xy_h, dem_hh), self.device)
                 nbr = eng.nbr_tables(xy)
-                return xy, dem, nbr.idx, nbr.dist, nbr.theta
-            xy, dem, idx, dist, theta = eng.on_prep_stream(self.device, upload)
+                return flat, nbr.idx, nbr.dist, nbr.theta
+            flat, idx, dist, theta = eng.on_prep_stream(self.device, upload)
+            nxy = (B_ * n1 * 2 + 63) // 64 * 64
+            xy, dem = flat[:B_ * n1 * 2].view(B_, n1, 2), flat[nxy:nxy + B_ * n1].view(B_, n1)
             self.depot_node_xy = xy
             self._finish_load(xy[:, :1, :], dem, eng.NbrTables(idx, dist, theta))
             return

@@ -85,6 +85,42 @@ class HostFetch:
 _PINNED = {}
 
 
+def _host_copy(dst: torch.Tensor, src: torch.Tensor):
+    """dst[...] = src between host tensors WITHOUT torch's intra-op thread pool (numpy: one thread).  A CPU tensor op over more than
+    32 768 elements wakes all of torch's OpenMP threads (128 on the GPU box); in a container with a CPU quota (16 CPUs there) their
+    spin-waiting exhausts the quota and the kernel throttles the whole process for the rest of the 100 ms period -- measured as a
+    40 - 60 ms stall in every third training step at batches >= 180 (depot | customers = B x 101 x 2 > 32 768 floats), in whatever
+    call the main thread happened to be; gone with OMP_NUM_THREADS=1 and with this copy.  tools/time_b120_geometry.py."""
+    if dst.dtype == src.dtype and dst.dtype != torch.bfloat16:
+        dst.numpy()[...] = src.detach().numpy()
+    else:
+        dst.copy_(src)
+
+
+def h2d_parts(parts, dev, pad: int = 64):
+    """Several host float32 tensors -> ONE pinned staging buffer (each part starts at a multiple of `pad` floats) -> ONE asynchronous
+    copy -> device views of the parts' shapes.  The parts are written into the staging buffer by numpy slices (see _host_copy)."""
+    offs, n = [], 0
+    for p in parts:
+        offs.append(n)
+        n += (p.numel() + pad - 1) // pad * pad
+    key = (("parts", n), torch.float32, str(dev))
+    ent = _PINNED.get(key)
+    if ent is None:
+        ent = _PINNED[key] = [torch.zeros(n, dtype=torch.float32).pin_memory(), None]
+    buf, ev = ent
+    if ev is not None:
+        ev.synchronize()                        # the previous copy out of this buffer has completed
+    host = buf.numpy()
+    for p, o in zip(parts, offs):
+        host[o:o + p.numel()] = p.detach().float().contiguous().numpy().reshape(-1)
+    flat = buf.to(dev, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    ent[1] = ev
+    return flat, [flat[o:o + p.numel()].view(p.shape) for p, o in zip(parts, offs)]
+
+
 def h2d(t: torch.Tensor, dev) -> torch.Tensor:
     """Host -> HBM copy that does not stall the host behind the work already queued on the stream: the tensor is
     staged in a cached pinned buffer and copied asynchronously (a pageable .to(device) blocks until every kernel
@@ -99,7 +135,7 @@ def h2d(t: torch.Tensor, dev) -> torch.Tensor:
     buf, ev = ent
     if ev is not None:
         ev.synchronize()                        # the previous copy out of this buffer has completed
-    buf.copy_(t)
+    _host_copy(buf, t)
     out = buf.to(dev, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
@@ -340,6 +376,27 @@ class Policy:
         return len(self.Ks) if len(self.Ks) > 1 else 1
 
 
+def coop_tiles(B: int, M: int, n_cu: int) -> int:
+    """Workgroups per instance of the cooperative rollout kernel.  A workgroup (one per CU: the instance's tables fill its LDS) walks
+    its ceil(M / tiles) trajectories in evenly sized groups of <= 32 lockstep trajectories, one whole rollout per group, so a launch
+    takes  rounds x groups x (time of one group)  with rounds = ceil(B tiles / CUs); a group of <= 16 trajectories (one MFMA row
+    tile) costs ~0.9 of a larger one.  Measured (training step, ms; tools/time_b120_geometry.py): B = 64: tiles 4 -> 5.19 (1 x 1),
+    2 -> 6.89 (1 x 2), 7 -> 6.52 (2 x 1 x 0.9); B = 120, the reference's default batch: 3 -> 13.48 (what ceil(CUs / B) gave: 360
+    workgroups of 34 = 2 groups of 17, two rounds), 2 or 4 -> 10.31.  The chip-filling choice ceil(CUs / B) stays whenever the model
+    finds nothing strictly cheaper; among cheaper ones the fewest workgroups win (the tables are staged once per workgroup)."""
+    def cost(t):
+        traj = (M + t - 1) // t
+        groups = (traj + 31) // 32
+        gsize = (traj + groups - 1) // groups
+        return ((B * t + n_cu - 1) // n_cu) * groups * (0.9 if gsize <= 16 else 1.0)
+    best = max(1, min(M, (n_cu + B - 1) // B))
+    best_cost = cost(best)
+    for t in range(1, min(M, 64) + 1):
+        if cost(t) < best_cost - 1e-9:
+            best, best_cost = t, cost(t)
+    return best
+
+
 def launch_geometry(B: int, M: int, N1: int, n_cu: Optional[int] = None):
     """(waves, tiles, lds_stage).  One workgroup per CU (256 on an MI355X) when K/V/PK are staged in LDS:
     aim for ~n_cu workgroups of 8 waves (2 per SIMD, 256-VGPR budget: no spills)."""
@@ -348,6 +405,8 @@ def launch_geometry(B: int, M: int, N1: int, n_cu: Optional[int] = None):
     if n_cu is None:
         n_cu = n_cus() if torch.cuda.is_available() else 256
     tiles = max(1, min(M, (n_cu + B - 1) // B))
+    if lds:
+        tiles = coop_tiles(B, M, n_cu)
     if not lds and N1 <= 128:
         tiles = max(tiles, min(M, (4 * n_cu + B - 1) // B))
     # N1 > 128: the fused rollout picks its own geometry (16 or 32 trajectories per workgroup, launch_fwd_mt)

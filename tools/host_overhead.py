@@ -15,7 +15,7 @@ cfg = yaml.safe_load(open(os.path.join(ROOT, "elg_amd/CVRP/config.yml")))
 seed_everything(924); dev = "cuda:0"
 model = CVRPModel(**cfg["model_params"]); model.decoder.add_local_policy(dev); model.to(dev)
 env = CVRPEnv(100, dev); opt = Adam(model.parameters(), lr=1e-4, weight_decay=1e-6)
-batches = [generate_vrp_data(64, 100, dict(cfg["distribution"], data_type="uniform")) for _ in range(8)]
+batches = [generate_vrp_data(int(os.environ.get("ELG_HOST_B", "64")), 100, dict(cfg["distribution"], data_type="uniform")) for _ in range(8)]
 prec = 1 if os.environ.get("ELG_FWD_MODE") == "bf16" else 0
 eng.FWD_PRECISION = prec
 for i in range(10): T_.train_step(model, env, opt, batches[i % 8], True, check=False)
