@@ -331,6 +331,7 @@ def main():
     args = ap.parse_args()
 
     from elg_amd import parallel
+    parallel.respect_cpu_quota()                # (the CPU baseline sets its own thread counts)
     rank, world, local = parallel.init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")

@@ -182,6 +182,7 @@ def train(model, training, T, start_steps, train_steps, mixed, train_batch_size,
 if __name__ == "__main__":
     with open('config.yml', 'r', encoding='utf-8') as fh:
         config = yaml.load(fh.read(), Loader=yaml.FullLoader)
+    parallel.respect_cpu_quota()
     rank, world, local = parallel.init_distributed()
     if config['training'] not in ('joint', 'only_global', 'only_local'):
         raise ValueError("training: {} (config.yml:9 allows joint, only_local, only_global)".format(config['training']))

@@ -141,6 +141,7 @@ def train(model, training, T, start_steps, train_steps, mixed, train_batch_size,
 if __name__ == "__main__":
     with open('config.yml', 'r', encoding='utf-8') as fh:
         config = yaml.load(fh.read(), Loader=yaml.FullLoader)
+    parallel.respect_cpu_quota()
     rank, world, local = parallel.init_distributed()
     if config['training'] not in ('joint', 'only_global'):
         # the reference's own entry point names a class it never defines for this mode (train.py:199-200)

@@ -17,6 +17,33 @@ import torch
 import torch.distributed as dist
 
 
+def respect_cpu_quota(cgroup_root: str = "/sys/fs/cgroup") -> int:
+    """Cap torch's intra-op thread pool at the container's CPU quota (cgroup v2 `cpu.max`, v1 `cpu.cfs_quota_us`).  torch sizes
+    the pool by the machine's CPU count; in a container limited to fewer CPUs every CPU tensor op above 32 768 elements then wakes
+    far more threads than may run, their spin-waiting exhausts the quota and the kernel stalls the whole process until the next
+    period (measured on the GPU box: 128 threads, quota 16, 40 - 60 ms stalls in a training loop).  Called by the
+    entry points (train.py, the testers, bench.py), not at import.  Returns the thread count in force."""
+    quota = None
+    try:
+        with open(os.path.join(cgroup_root, "cpu.max")) as f:
+            q, period = f.read().split()[:2]
+            if q != "max":
+                quota = int(q) / int(period)
+    except (OSError, ValueError):
+        try:
+            with open(os.path.join(cgroup_root, "cpu", "cpu.cfs_quota_us")) as f, open(os.path.join(cgroup_root, "cpu", "cpu.cfs_period_us")) as g:
+                q, period = int(f.read()), int(g.read())
+                if q > 0:
+                    quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, int(quota) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))      # the node's ranks share the quota
+        if n < torch.get_num_threads():
+            torch.set_num_threads(n)
+    return torch.get_num_threads()
+
+
 def world_info():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 

@@ -145,3 +145,28 @@ def test_sharded_validation_sum_and_error_guard_world2():
     assert bad[0][0] == "RuntimeError" and "rank 1 failed" in bad[0][1] and "boom" in bad[0][1]
     from elg_amd import parallel
     assert parallel.guarded(lambda: 42) == 42 and parallel.sum_over_ranks([1, 2.5]) == [1.0, 2.5]
+
+
+def test_cpu_quota_caps_the_intra_op_pool(tmp_path, monkeypatch):
+    """parallel.respect_cpu_quota: cgroup v2 / v1 quota -> torch's thread count, shared between the node's ranks; no quota, no change."""
+    import torch
+    from elg_amd import parallel
+    before = torch.get_num_threads()
+    try:
+        torch.set_num_threads(6)
+        (tmp_path / "cpu.max").write_text("max 100000\n")
+        assert parallel.respect_cpu_quota(str(tmp_path)) == 6
+        (tmp_path / "cpu.max").write_text("400000 100000\n")
+        assert parallel.respect_cpu_quota(str(tmp_path)) == 4 and torch.get_num_threads() == 4
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
+        assert parallel.respect_cpu_quota(str(tmp_path)) == 2
+        monkeypatch.delenv("LOCAL_WORLD_SIZE")
+        (tmp_path / "cpu.max").unlink()
+        (tmp_path / "cpu").mkdir()
+        (tmp_path / "cpu" / "cpu.cfs_quota_us").write_text("100000\n")
+        (tmp_path / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+        torch.set_num_threads(3)
+        assert parallel.respect_cpu_quota(str(tmp_path)) == 1
+        assert parallel.respect_cpu_quota(str(tmp_path / "nothing_here")) == 1       # no cgroup files: unchanged
+    finally:
+        torch.set_num_threads(before)
