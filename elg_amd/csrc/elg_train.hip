@@ -235,20 +235,8 @@ __global__ __launch_bounds__(1024) void pomo_loss_grad_kernel(const float* __res
     for (int m0 = 0; m0 < M; m0 += MP) {
         const int m = m0 + mc;
         float lp = 0.f;
-        // a thread's first PC steps stay in registers for the gradient pass below, and their loads are all in flight at once (the
-        // launch is 64 workgroups of dependent latency: a rolled loop of load -> log -> add took 19 us for 3 MB)
-        constexpr int PC = 16;
-        float pv[PC];
-        if (m < M) {
-#pragma unroll
-            for (int i = 0; i < PC; ++i) {
-                const int t = g + i * G;
-                pv[i] = t < Te ? pb[(size_t)t * p_tstride + m] + (zsteps && zsteps[t] ? 1e-6f : 0.f) : 1.f;
-            }
-#pragma unroll
-            for (int i = 0; i < PC; ++i) lp += (g + i * G < Te) ? logf(pv[i]) : 0.f;
-            for (int t = g + PC * G; t < Te; t += G) lp += logf(pb[(size_t)t * p_tstride + m] + (zsteps && zsteps[t] ? 1e-6f : 0.f));
-        }
+        if (m < M)
+            for (int t = g; t < Te; t += G) lp += logf(pb[(size_t)t * p_tstride + m] + (zsteps && zsteps[t] ? 1e-6f : 0.f));
         __syncthreads();
         part[tid] = lp;
         __syncthreads();
@@ -263,14 +251,9 @@ __global__ __launch_bounds__(1024) void pomo_loss_grad_kernel(const float* __res
         // the gradient rows of these MP trajectories
         if (m < M) {
             const float cf = coef[mc] * inv_count;
-#pragma unroll
-            for (int i = 0; i < PC; ++i) {
-                const int t = g + i * G;
-                if (t < Te) gprob[((size_t)b * T + t) * M + m] = cf / pv[i];
-            }
-            for (int t = g + PC * G; t < Te; t += G) {
-                const float pq = pb[(size_t)t * p_tstride + m] + (zsteps && zsteps[t] ? 1e-6f : 0.f);
-                gprob[((size_t)b * T + t) * M + m] = cf / pq;
+            for (int t = g; t < Te; t += G) {
+                const float pv = pb[(size_t)t * p_tstride + m] + (zsteps && zsteps[t] ? 1e-6f : 0.f);
+                gprob[((size_t)b * T + t) * M + m] = cf / pv;
             }
             for (int t = Te + g; t < T; t += G) gprob[((size_t)b * T + t) * M + m] = cf;
         }
