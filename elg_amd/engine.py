@@ -580,6 +580,18 @@ def _rows_fit(B, M, N1, Tcap, dev) -> bool:
     return fits
 
 
+_F32_NOTED = set()
+
+
+def _note_f32_fallback(what: str):
+    """The bf16 mode (ELG_FWD_MODE=bf16 / engine.FWD_PRECISION = 1) covers the cooperative kernel (N + 1 <= 112, training and
+    evaluation) and the streaming kernels' evaluation; where a launch runs in f32 although the mode is on, say so -- once per case."""
+    if what not in _F32_NOTED:
+        _F32_NOTED.add(what)
+        import warnings
+        warnings.warn(f"elg_amd: bf16 mode requested, but this launch runs in f32: {what}", RuntimeWarning, stacklevel=3)
+
+
 def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mode: int, *, forced=None, seed: int = 0,
                     uniforms=None, dump_T: int = 0, geometry=None, Tcap: Optional[int] = None,
                     train: bool = False, variant: int = 0, dump: str = "probs", precision: Optional[int] = None,
@@ -607,8 +619,11 @@ def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mo
     a.seed = seed & 0xFFFFFFFFFFFFFFFF
     a.variant = variant
     a.precision = FWD_PRECISION if precision is None else int(precision)
-    if train and N1 > 128:
+    if a.precision == 1 and train and N1 > 128:
         a.precision = 0                  # the saved-rows backward of the streaming kernel differentiates the f32 forward
+        _note_f32_fallback(f"training forward at N + 1 = {N1} > 128 nodes")
+    elif a.precision == 1 and 112 < N1 <= 128:
+        _note_f32_fallback(f"N + 1 = {N1} in 113 .. 128 (the one-wavefront kernel has no bf16 instantiation)")
     a.dump_logits = {"probs": 0, "logits": 1, "scores": 2}[dump]
     # (a pageable host tensor would block the host until the stream has drained: staged through pinned memory instead)
     starts = h2d(starts.to(torch.int32).contiguous(), dev) if not starts.is_cuda else starts.to(torch.int32).contiguous()

@@ -231,3 +231,33 @@ def test_product_train_step_in_the_112_to_128_node_band(problem, N):
     gc.record_parity(f"band_112_128/{problem}_n{N}_decoder_local_grad_over_tensor_max", worst)
     gc.record_parity(f"band_112_128/{problem}_n{N}_chosen_prob_rel", pe)
     print(problem, N, f"decoder/local gradients {worst:.2e} of the tensor maximum, chosen probabilities {pe:.2e}")
+
+
+def test_bf16_mode_says_where_it_runs_in_f32(monkeypatch):
+    """The bf16 mode covers the cooperative kernel (N + 1 <= 112) and the streaming kernels' evaluation.  Where a launch runs in f32
+    although the mode is on (113 <= N + 1 <= 128: one-wavefront kernel; a TRAINING forward above 128 nodes), the engine warns once
+    per case instead of switching silently; the result is the f32 result."""
+    import warnings
+    from elg_amd import engine as eng
+    from elg_amd.TSP.TSPEnv import TSPEnv
+    from elg_amd.TSP.utils import rollout
+    mp = dict(gu.TSP_MODEL_PARAMS)
+    model = gc.load_model("tsp", 31, mp, 1.0).eval()
+    xy = torch.from_numpy(gu.golden_tsp_problem(640, 2, 120))
+    env = TSPEnv(8, gc.DEV)
+    env.load_random_problems(xy)
+    rs, _, _ = env.reset()
+    with torch.no_grad():
+        model.pre_forward(rs)
+        random.seed(5)
+        ref_actions, _, ref_reward = rollout(model, env, "greedy")
+        monkeypatch.setattr(eng, "FWD_PRECISION", 1)
+        eng._F32_NOTED.clear()
+        random.seed(5)
+        with pytest.warns(RuntimeWarning, match="runs in f32"):
+            actions, _, reward = rollout(model, env, "greedy")
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                 # ... and only once
+            random.seed(5)
+            rollout(model, env, "greedy")
+    assert torch.equal(actions, ref_actions) and torch.equal(reward, ref_reward)
