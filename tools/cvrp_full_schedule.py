@@ -12,6 +12,8 @@ from elg_amd.CVRP import train as T_
 from elg_amd.CVRP.CVRPModel import CVRPModel
 from elg_amd.CVRP.utils import seed_everything
 from elg_amd.CVRP.test_vrplib import VRPLib_Tester
+from elg_amd import parallel
+parallel.respect_cpu_quota()            # as train.py's entry point does
 
 cfg = yaml.safe_load(open(os.path.join(ROOT, "elg_amd/CVRP/config.yml")))
 p = cfg["params"]
