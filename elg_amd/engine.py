@@ -688,8 +688,10 @@ class _ChosenProbs(torch.autograd.Function):
         ctx.has = (Q2t is not None, wlt is not None, loct is not None)
         # the consumer of d loc is known to wait for a side-stream launch only when loc came out of _FoldLocal
         ctx.loc_from_fold = bool(loc_from_fold)
-        out = probs_val.contiguous().clone()
-        ctx.probs_out = out.detach()
+        # a NEW tensor over the rollout's own probability buffer (nobody writes that buffer again: every rollout allocates its own);
+        # a clone only where the slice is not contiguous (utils.rollout with T below the capacity)
+        out = probs_val.detach() if probs_val.is_contiguous() else probs_val.contiguous()
+        ctx.probs_out = out.detach()            # (never `out` itself: output -> grad_fn -> ctx -> output is a cycle only the GC frees)
         return out
 
     @staticmethod
