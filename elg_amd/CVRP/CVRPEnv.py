@@ -151,10 +151,10 @@ class CVRPEnv:
             def upload():                  # host data only: on the preparation stream, next to the previous step's backward
                 flat, (xy, dem) = eng.h2d_parts((xy_h, dem_hh), self.device)
                 nbr = eng.nbr_tables(xy)
-                return flat, nbr.idx, nbr.dist, nbr.theta
-            flat, idx, dist, theta = eng.on_prep_stream(self.device, upload)
-            nxy = (B_ * n1 * 2 + 63) // 64 * 64
-            xy, dem = flat[:B_ * n1 * 2].view(B_, n1, 2), flat[nxy:nxy + B_ * n1].view(B_, n1)
+                # (xy / dem are h2d_parts' own views of `flat`: its layout is not recomputed here; `flat` comes first so that
+                # on_prep_stream's record_stream covers the storage the views share)
+                return flat, nbr.idx, nbr.dist, nbr.theta, xy, dem
+            flat, idx, dist, theta, xy, dem = eng.on_prep_stream(self.device, upload)
             self.depot_node_xy = xy
             self._finish_load(xy[:, :1, :], dem, eng.NbrTables(idx, dist, theta))
             return

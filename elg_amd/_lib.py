@@ -12,6 +12,8 @@ LIB_PATH = os.environ.get("ELG_HIP_LIB") or os.path.join(HERE, "libelg_hip.so")
 ELG_OK, ELG_EINVAL, ELG_ELAUNCH, ELG_ENOTIMPL = 0, -1, -2, -3
 PROBLEM_CVRP, PROBLEM_TSP = 0, 1
 MODE_GREEDY, MODE_SAMPLE, MODE_FORCED = 0, 1, 2
+# elg_rollout_last_kernel(): which construction kernel the last elg_rollout_fwd of this thread launched (include/elg_hip.h)
+KERNEL_WAVE, KERNEL_COOP, KERNEL_COOP_SPLIT, KERNEL_STREAM, KERNEL_XL, KERNEL_XM = 1, 2, 3, 4, 5, 6
 
 LOC_ROWS = 64
 LOC_LA, LOC_LT, LOC_LAV, LOC_LCV, LOC_LWC, LOC_LBC, LOC_LWE, LOC_LPE, LOC_SIZE = \
@@ -102,7 +104,7 @@ EXPORTS = ["elg_version", "elg_last_error", "elg_aug8", "elg_dist_matrix", "elg_
            "elg_encoder_ws_floats", "elg_encoder_fwd", "elg_encoder_bwd_ws_floats", "elg_encoder_bwd",
            "elg_local_fold_fwd", "elg_local_fold_bwd", "elg_check_feasible", "elg_rollout_stats", "elg_decoder_bwd",
            "elg_decoder_bwd_ws_floats",
-           "elg_rollout_scratch_floats"]
+           "elg_rollout_scratch_floats", "elg_rollout_last_kernel"]
 
 _lib = None
 
@@ -129,6 +131,8 @@ def lib() -> C.CDLL:
         L.elg_nbr_tables.argtypes = [f, f, f, f, i, i, f]
         L.elg_route_length.argtypes = [f, f, f, i, i, i, i, i, f]
         L.elg_rollout_fwd.argtypes = [C.POINTER(RolloutArgs), f]
+        L.elg_rollout_last_kernel.argtypes = []
+        L.elg_rollout_last_kernel.restype = C.c_int
         L.elg_rollout_bwd.argtypes = [C.POINTER(BwdArgs), f]
         L.elg_glimpse_rows_bwd.argtypes = [f, f, f, f, f, f, f, i, i, i, C.c_int64, C.c_int64, f]
         L.elg_glimpse_bwd_fused.argtypes = [f, f, f, f, f, f, f, f, f, f, i, i, i, C.c_int64, C.c_int64, C.c_int64, i, f]

@@ -12,8 +12,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libelg_hip.so")
-SOURCES = ["elg_fwd.hip", "elg_bwd.hip", "elg_gemm.hip", "elg_train.hip", "elg_local.hip", "elg_encoder.hip", "elg_enc.hip", "elg_enc_fused.hip", "elg_fold.hip", "elg_dbwd.hip"]
-HEADERS = ["elg_common.h", "elg_rollout.h", "elg_bwd_internal.h", "elg_bf16.h", "elg_enc_internal.h", os.path.join("..", "..", "include", "elg_hip.h")]
+SOURCES = ["elg_fwd.hip", "elg_fwd_coop.hip", "elg_bwd.hip", "elg_gemm.hip", "elg_train.hip", "elg_local.hip", "elg_encoder.hip", "elg_enc.hip", "elg_enc_fused.hip", "elg_fold.hip", "elg_dbwd.hip"]
+HEADERS = ["elg_common.h", "elg_rollout.h", "elg_coop.h", "elg_bwd_internal.h", "elg_bf16.h", "elg_enc_internal.h", os.path.join("..", "..", "include", "elg_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math",
          "-Wno-unused-value"]
 

@@ -970,7 +970,10 @@ int DwList::add(const float* dY, int ldy, const float* X, int ldx, float* dW, in
         const int rc = launch();
         if (rc != ELG_OK) return rc;
     }
-    if ((M & 127) || (N & 127) || (ldy & 1) || (ldx & 1)) return fail(ELG_EINVAL, "encoder bwd: dW shapes must be multiples of 128");
+    // (enc_dw_kernel stages both operands with 16-byte loads: leading dimensions in multiples of 4 floats, 16-byte aligned bases)
+    if ((M & 127) || (N & 127)) return fail(ELG_EINVAL, "encoder bwd: dW shapes must be multiples of 128");
+    if ((ldy & 3) || (ldx & 3) || (reinterpret_cast<uintptr_t>(dY) & 15) || (reinterpret_cast<uintptr_t>(X) & 15))
+        return fail(ELG_EINVAL, "encoder bwd: dW operands need leading dimensions in multiples of 4 floats and 16-byte aligned bases");
     DwJob& j = bt.job[bt.njobs++];
     j.dY = dY; j.X = X; j.dW = dW; j.db = db; j.ldy = ldy; j.ldx = ldx; j.ldw = ldw; j.M = M; j.N = N; j.alpha = alpha;
     j.tile0 = bt.ntiles;
@@ -994,7 +997,16 @@ int DwList::launch() {
     rps = (rps + 15) / 16 * 16;
     splits = (int)((rows + rps - 1) / rps);
     bt.rows = (int)rows; bt.rows_per_split = rps;
-    if (!scratch || (long)splits * bt.ntiles * (128 * 128) > scratch_floats) return fail(ELG_EINVAL, "encoder bwd: weight-gradient scratch too small");
+    if (!scratch || (long)bt.ntiles * (128 * 128) > scratch_floats) return fail(ELG_EINVAL, "encoder bwd: weight-gradient scratch too small");
+    // (an ELG_DW_WGS beyond what the scratch holds: fewer, longer row splits instead of a failed backward)
+    const int cap = (int)(scratch_floats / ((long)bt.ntiles * (128 * 128)));
+    if (splits > cap) {
+        splits = cap;
+        rps = (int)((rows + splits - 1) / splits);
+        rps = (rps + 15) / 16 * 16;
+        splits = (int)((rows + rps - 1) / rps);
+        bt.rows_per_split = rps;
+    }
     bt.scratch = scratch;
     (void)hipGetLastError();
     hipLaunchKernelGGL(enc_dw_kernel, dim3(bt.ntiles, splits), dim3(256), 0, s, bt);
@@ -1044,7 +1056,9 @@ EncWs2 enc_ws2(int B, int N1, int n_layers, int ff) {
         w.P1 = o; o += (long)(ff >> 7) * w.R * ELG_E;
         w.WT = o; w.wt_stride = 4L * ELG_E * ELG_E + 2L * ELG_E * ff; o += w.wt_stride * n_layers;
     }
-    // partial tiles of the grouped weight-gradient launch: splits * ntiles <= 1024 + ntiles, ntiles <= 12 per layer + 5 table jobs
+    // partial tiles of the grouped weight-gradient launch: splits * ntiles <= max(3 CUs, ntiles) by default, ntiles = 4 + 2 ff / 128
+    // per layer (12 at ff = 512, 20 at ff = 1024) + 5 table jobs, at most DW_MAX_JOBS jobs per launch; DwList::launch clamps the
+    // row splits to what fits here
     w.DW = o; w.dw_floats = (1024L + 12L * n_layers + 5) * (128 * 128); o += w.dw_floats;
     w.total = o;
     return w;

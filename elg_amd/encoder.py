@@ -4,6 +4,7 @@ elg_encoder_bwd, csrc/elg_enc.hip).  The parameters stay where the reference's s
 collects their device pointers, owns the activation workspace and hands the gradients back to autograd."""
 from __future__ import annotations
 
+import os
 import ctypes as C
 from typing import Dict, List, Optional, Sequence
 
@@ -94,6 +95,15 @@ class _EncodeFold(torch.autograd.Function):
         a = L.EncoderArgs()
         a.problem, a.B, a.N1, a.n_layers, a.ff_hidden, a.save, a.eps = kind, B, N1, n_layers, ff, int(train), eps
         a.precision = precision
+        if precision == 1:
+            # the bf16 mode exists in the fused per-instance kernels only (csrc/elg_enc_fused.hip::enc_fused_ok): say so where the
+            # per-GEMM f32 path runs instead, like the rollout does (engine._note_f32_fallback, once per case)
+            fused = (4 <= N1 <= 128 and 128 <= ff <= 1024 and ff % 128 == 0 and os.environ.get("ELG_ENC_FUSED", "1")[:1] != "0")
+            if not fused:
+                from . import engine as _eng
+                _eng._note_f32_fallback(f"encoder at N + 1 = {N1}, ff_hidden_dim = {ff}"
+                                        + (" with ELG_ENC_FUSED=0" if os.environ.get("ELG_ENC_FUSED", "1")[:1] == "0" else "")
+                                        + " (the per-GEMM encoder path has no bf16 instantiation)")
         a.xy, a.demand = _ptr(xy), _ptr(demand)
         _fill_weights(a.W, kind, n_layers, [p.data_ptr() for p in params])
         enc, K, V, PK, Q1 = (torch.empty(B, N1, E, device=dev) for _ in range(5))

@@ -528,6 +528,7 @@ class RolloutResult:
     tlen: torch.Tensor              # (B,M) int32
     full_probs: Optional[torch.Tensor] = None
     rows: Optional["TrainRows"] = None      # backward rows saved by a training forward
+    kernel_id: int = 0                      # _lib.KERNEL_*: the construction kernel that ran (elg_rollout_last_kernel)
 
 
 # Arithmetic of the glimpse backward's five products (elg_decoder_bwd_args.mfma_mode; include/elg_hip.h): 0 = f32 MFMAs (exact
@@ -649,20 +650,21 @@ def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mo
         rows = TrainRows.get(B, M, N1, Tcap, dev)
         rows.prepare()
         # (only the cooperative kernel has a bf16 mode: every other kernel computes -- and is differentiated -- in f32)
-        rows.precision = int(a.precision) if (a.lds_stage and 4 <= N1 <= 112 and variant == 0) else 0
+        rows.precision = int(a.precision) if (a.lds_stage and 4 <= N1 <= 112 and variant in (0, 4)) else 0
         # the cooperative kernel (what dispatch_fwd picks for this launch shape) saves the rows' 128-bit mask words and the
         # glimpse log2-sum-exp per head instead of the glimpse weights: the backward recomputes the weights from q, K, the
         # mask and the saved normaliser (28 MFMAs + one exp2 per weight).  4.2 GB less workspace and 6.6 GB less HBM traffic
         # per step at the bench shape, and no slower (the forward's 3.3 GB of scattered stores cost what the recompute does)
         # The streaming kernel (128 < N1 <= 1024) saves the same rows with W = 4 / 8 / 16 mask words.
-        rows.use_mask = bool((a.lds_stage and a.waves == 8 and 4 <= N1 <= 112 and variant == 0) or N1 > 128)
+        rows.use_mask = bool((a.lds_stage and a.waves == 8 and 4 <= N1 <= 112 and variant in (0, 4)) or N1 > 128)
         a.trA = None if rows.use_mask else _ptr(rows.A)
         a.trMask = _ptr(rows.Mask) if rows.use_mask else None
         a.trLse = _ptr(rows.Lse) if rows.use_mask else None
         a.trPC, a.trCsel, a.trQ, a.trO = _ptr(rows.PC), _ptr(rows.Csel), _ptr(rows.Q), _ptr(rows.O)
         a.trLoad, a.trSlot, a.trF = _ptr(rows.Load), _ptr(rows.Slot), _ptr(rows.F)
     L.check(L.lib().elg_rollout_fwd(C.byref(a), _stream()), "elg_rollout_fwd")
-    res = RolloutResult(actions, probs, reward, tlen, full)
+    kernel_id = int(L.lib().elg_rollout_last_kernel())
+    res = RolloutResult(actions, probs, reward, tlen, full, kernel_id=kernel_id)
     if rows is not None:
         res.rows = rows
         res.rows_gen = rows.gen

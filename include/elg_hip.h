@@ -92,7 +92,9 @@ typedef struct elg_rollout_args {
                                2: the one-wavefront-per-trajectory N1 > 1024 kernel (runtime node loops, needs `scratch`) for any
                                N1: the tests' reference at Vrp-Set-XXL sizes; 3: the matrix-core N1 > 1024 kernel (what variant 0
                                picks for 1024 < N1 <= 8192: 16 lockstep trajectories per workgroup, K / V / PK streamed in
-                               MFMA-fragment order, score rows in `scratch`) for any N1                                      */
+                               MFMA-fragment order, score rows in `scratch`) for any N1; 4: the split-group form of the
+                               cooperative kernel (N1 <= 112: two independent 4-wave groups per workgroup, LDS-counter barriers;
+                               bit-identical results, measured 9 % slower: DESIGN 4.1)                                      */
     int32_t dump_logits;    /* what full_probs receives: 0 probabilities, 1 the clipped + masked logits
                                clip * tanh(s) (-inf at closed nodes), 2 the scores s before the clip            */
     int32_t euclidean;      /* model_params.euclidean: local-policy slot features (x, y) / norm relative to the current node
@@ -161,6 +163,15 @@ typedef struct elg_rollout_args {
 /* POMO construction: CVRPEnv.reset/step + CVRPModel.one_step_rollout + utils.rollout fused into one
  * persistent launch (CVRP/utils.py:7-29), or single steps of it (use_state / max_steps). */
 int elg_rollout_fwd(const elg_rollout_args* args, void* stream);
+/* Which construction kernel the calling thread's last elg_rollout_fwd launched (0: none yet): the tests assert that a
+   `variant` they name is the kernel that ran. */
+#define ELG_KERNEL_WAVE 1        /* rollout_fwd_kernel: one wavefront per trajectory (step-wise protocol, variant 1, ensembles)  */
+#define ELG_KERNEL_COOP 2        /* rollout_fwd_coop_kernel: N1 <= 112, lockstep trajectories on the matrix cores              */
+#define ELG_KERNEL_COOP_SPLIT 3  /* rollout_fwd_coop2_kernel: the same with two independent 4-wave groups (variant 4)          */
+#define ELG_KERNEL_STREAM 4      /* rollout_fwd_mt_kernel: 128 < N1 <= 1024, operands streamed from L2                         */
+#define ELG_KERNEL_XL 5          /* rollout_fwd_xl_kernel: one wavefront per trajectory, runtime node loops (variant 2)        */
+#define ELG_KERNEL_XM 6          /* rollout_fwd_xm_kernel: N1 > 1024 on the matrix cores (variant 3)                           */
+int elg_rollout_last_kernel(void);
 /* Floats of elg_rollout_args.scratch a fused rollout of this shape needs (0: none): the fragment-major K / V / PK copies the
    128 < N1 <= 1024 kernel streams its matrix-core operands from; for N1 > 1024 (or variant 3) the same copies over
    64 ceil(N1 / 64) padded rows plus one score row per trajectory slot (16 per workgroup); variant 2: B M N1 score rows. */

@@ -175,3 +175,38 @@ def test_lean_production_instantiation_equals_the_generic_one(kind, N, B, M):
     g1 = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY)
     g2 = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, dump_T=1)
     assert torch.equal(g1.actions, g2.actions) and torch.equal(g1.reward, g2.reward)
+
+
+@pytest.mark.parametrize("kind,N,B,M,tiles", [("cvrp", 100, 3, 100, 4), ("cvrp", 100, 2, 100, 2), ("cvrp", 50, 3, 50, 1), ("tsp", 100, 2, 100, 4),
+                                              ("cvrp", 20, 4, 7, 1)])
+def test_split_group_kernel_is_bit_identical(kind, N, B, M, tiles):
+    """rollout_fwd_coop2_kernel (elg_rollout_args.variant = 4; round 6): the cooperative kernel as two independent 4-wave groups per
+    workgroup, each with its own tile of <= 16 trajectories and its own LDS-counter barriers, so that the two waves of a SIMD sit in
+    different phases.  Every product is formed by the same instruction sequence on the same operands: sampled
+    tours, chosen probabilities, rewards and the saved training rows are equal to the lockstep kernel's bit for bit, in both
+    arithmetic modes, with one or several tiles per group and with a group that has no tile (M = 7)."""
+    from elg_amd import _lib as L, engine as eng
+    P, cfg, xy, dem, enc, prob, pol = _setup(kind, N, B, 5100 + N)
+    off = 1 if kind == "cvrp" else 0
+    starts = torch.randperm(N, generator=torch.Generator().manual_seed(M))[:M] + off
+    geom = (8, tiles, 1)
+    for precision in (0, 1):
+        for train in (False, True):
+            ref = eng.rollout_forward(prob, pol, M, starts, L.MODE_SAMPLE, seed=91, train=train, geometry=geom, precision=precision)
+            assert ref.kernel_id == L.KERNEL_COOP
+            rows_ref = None
+            if train:
+                rows_ref = {k: getattr(ref.rows, k).clone() for k in ("PC", "Csel", "Q", "O", "Lse", "Mask", "Slot", "F", "Load")}
+            got = eng.rollout_forward(prob, pol, M, starts, L.MODE_SAMPLE, seed=91, train=train, geometry=geom, precision=precision, variant=4)
+            assert got.kernel_id == L.KERNEL_COOP_SPLIT
+            assert torch.equal(ref.actions, got.actions) and torch.equal(ref.tlen, got.tlen)
+            assert torch.equal(ref.probs, got.probs) and torch.equal(ref.reward, got.reward)
+            if train:
+                live = int(got.tlen.max()) * M
+                for k, v in rows_ref.items():
+                    if k == "Load" and kind == "tsp":
+                        continue
+                    assert torch.equal(v[:, :live], getattr(got.rows, k)[:, :live]), (k, precision)
+        g1 = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, geometry=geom, precision=precision)
+        g2 = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, geometry=geom, precision=precision, variant=4)
+        assert torch.equal(g1.actions, g2.actions) and torch.equal(g1.reward, g2.reward)

@@ -43,7 +43,13 @@ def _check(tag, kernel, lg, scores, logits, clip, steps, t_index, tlen):
     print(tag, kernel, f"scores {worst_s:.2e}  logits/clip {worst_l:.2e}")
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3], ids=["cooperative", "wave_per_trajectory", "xl", "xm"])
+SMALL_VARIANTS = [0, 1, 2, 3, 4]
+SMALL_IDS = ["cooperative", "wave_per_trajectory", "xl", "xm", "cooperative_split"]
+KERNEL_OF = {0: L.KERNEL_COOP, 1: L.KERNEL_WAVE, 2: L.KERNEL_XL, 3: L.KERNEL_XM, 4: L.KERNEL_COOP_SPLIT}
+KNAME = {0: "coop", 1: "wave", 2: "xl", 3: "xm", 4: "coop_split"}
+
+
+@pytest.mark.parametrize("variant", SMALL_VARIANTS, ids=SMALL_IDS)
 @pytest.mark.parametrize("tag", ["n50", "n20k8", "n100"])
 def test_cvrp_logits_through_the_product_path(tag, variant):
     from elg_amd.CVRP.CVRPEnv import CVRPEnv
@@ -65,12 +71,13 @@ def test_cvrp_logits_through_the_product_path(tag, variant):
     dumps = {}
     for what in ("scores", "logits"):
         r = eng.rollout_forward(env.problem, pol, M, acts[0, :, 1], L.MODE_FORCED, forced=acts, dump_T=T, variant=variant, dump=what)
+        assert r.kernel_id == KERNEL_OF[variant], (variant, r.kernel_id)         # the variant named IS the kernel that ran
         dumps[what] = r.full_probs
-    _check(f"cvrp_{tag}", ("coop", "wave", "xl", "xm")[variant], lg, dumps["scores"], dumps["logits"], mp["logit_clipping"],
+    _check(f"cvrp_{tag}", KNAME[variant], lg, dumps["scores"], dumps["logits"], mp["logit_clipping"],
            lg["steps"], lambda t: int(t), r.tlen)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3], ids=["cooperative", "wave_per_trajectory", "xl", "xm"])
+@pytest.mark.parametrize("variant", SMALL_VARIANTS, ids=SMALL_IDS)
 @pytest.mark.parametrize("tag", ["n50", "n20"])
 def test_tsp_logits_through_the_product_path(tag, variant):
     from elg_amd.TSP.TSPEnv import TSPEnv
@@ -90,8 +97,9 @@ def test_tsp_logits_through_the_product_path(tag, variant):
     dumps = {}
     for what in ("scores", "logits"):
         r = eng.rollout_forward(env.problem, pol, M, acts[0, :, 0], L.MODE_FORCED, forced=acts, dump_T=N, variant=variant, dump=what)
+        assert r.kernel_id == KERNEL_OF[variant], (variant, r.kernel_id)
         dumps[what] = r.full_probs
-    _check(f"tsp_{tag}", ("coop", "wave", "xl", "xm")[variant], lg, dumps["scores"], dumps["logits"], mp["logit_clipping"],
+    _check(f"tsp_{tag}", KNAME[variant], lg, dumps["scores"], dumps["logits"], mp["logit_clipping"],
            lg["steps"], lambda t: int(t), r.tlen)
 
 
@@ -115,6 +123,7 @@ def test_large_instance_logits(variant):
     dumps = {}
     for what in ("scores", "logits"):
         r = eng.rollout_forward(env.problem, pol, M, acts[0, :, 1], L.MODE_FORCED, forced=acts, dump_T=T, variant=variant, dump=what)
+        assert r.kernel_id == {0: L.KERNEL_STREAM, 1: L.KERNEL_WAVE, 2: L.KERNEL_XL, 3: L.KERNEL_XM}[variant], (variant, r.kernel_id)
         dumps[what] = r.full_probs
     np.testing.assert_allclose(r.reward.cpu().numpy(), lg["reward"], rtol=2e-6)
     _check("cvrp_n150", ("tiled", "wave", "xl", "xm")[variant], lg, dumps["scores"], dumps["logits"], mp["logit_clipping"],
