@@ -328,7 +328,16 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the TSP-500 / VRPLIB X-n1001 secondary timings")
     ap.add_argument("--no-fast", action="store_true", help="skip the split-bf16 backward leg (value_fast) and the bf16 leg (value_bf16)")
     ap.add_argument("--sustain-s", type=float, default=10.0, help="length of the sustained leg in seconds (0: skip)")
+    ap.add_argument("--host-cpus", type=int, default=0,
+                    help="restrict this process to its first N allowed CPUs and torch to N threads (what a rank gets when 8 ranks "
+                         "share a 16-CPU quota: N = 2), to show that the GPU stays the critical path; 0: leave the host alone")
     args = ap.parse_args()
+    if args.host_cpus > 0:
+        try:
+            os.sched_setaffinity(0, sorted(os.sched_getaffinity(0))[:args.host_cpus])
+        except (AttributeError, OSError):
+            pass
+        torch.set_num_threads(args.host_cpus)
 
     from elg_amd import parallel
     parallel.respect_cpu_quota()                # (the CPU baseline sets its own thread counts)
@@ -397,6 +406,8 @@ def main():
         model.train()
         return train_step(model, env, opt, batch, cfg["params"]["scale_norm"], bucket, world, check=True)
 
+    host_leg = {}                                 # host side of the last timed leg: ms per step busy / blocked on the device
+
     def timed_leg(n_warm, n_steps):
         """W untimed steps, then exactly K steps between barrier + synchronize; -> (max over ranks, this rank's own) seconds"""
         for _ in range(n_warm):
@@ -406,9 +417,13 @@ def main():
         ar_events.clear()
         parallel.barrier()
         torch.cuda.synchronize()
+        eng.HostFetch.waited_s = 0.0
         t0 = time.perf_counter()
         for _ in range(n_steps):
             one_step()
+        t_enq = time.perf_counter() - t0            # the Python thread has enqueued the last step (its own syncs included)
+        host_leg["busy_ms"] = (t_enq - eng.HostFetch.waited_s) / n_steps * 1e3
+        host_leg["wait_ms"] = eng.HostFetch.waited_s / n_steps * 1e3
         parallel.barrier()
         torch.cuda.synchronize()
         own = time.perf_counter() - t0
@@ -434,7 +449,11 @@ def main():
     mean_T = float(torch.stack([t.float().mean() for t in fwd_steps]).mean().item())
     max_T = float(torch.stack([t.float().max() for t in fwd_steps]).mean().item())
     ar_ms = (sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events)) if ar_events else 0.0
-    ranks = per_rank([dt_own / args.steps * 1e3, mean_T, max_T, ar_ms, kern_ms])
+    ranks = per_rank([dt_own / args.steps * 1e3, mean_T, max_T, ar_ms, kern_ms, host_leg["busy_ms"], host_leg["wait_ms"]])
+    try:
+        host_cpus = len(os.sched_getaffinity(0))
+    except AttributeError:
+        host_cpus = os.cpu_count()
     ranks_seen = parallel.ranks_seen()          # world size as the collectives see it (an all-reduce of ones)
 
     # ---- fast leg: the same step with the glimpse backward on split-bf16 MFMAs (engine.BWD_MFMA_MODE = 2)
@@ -443,6 +462,7 @@ def main():
         eng.BWD_MFMA_MODE = 2
         dtf, _ = timed_leg(3, args.steps)
         fast = {"value": round(LOCAL_BATCH * world * args.steps / dtf, 2), "ms_per_step": round(dtf / args.steps * 1e3, 3),
+                "host_ms_per_step": round(host_leg["busy_ms"], 3),
                 "mode": "glimpse backward: " + MODE_NAMES[2] + " on v_mfma_f32_16x16x32_bf16, f32 accumulation; everything else f32"}
         eng.BWD_MFMA_MODE = 0
 
@@ -454,6 +474,7 @@ def main():
         dtb, _ = timed_leg(3, args.steps)
         kb_ms = sum(a.elapsed_time(b) for a, b in fwd_events) / len(fwd_events)
         bf16 = {"value": round(LOCAL_BATCH * world * args.steps / dtb, 2), "ms_per_step": round(dtb / args.steps * 1e3, 3),
+                "host_ms_per_step": round(host_leg["busy_ms"], 3), "host_wait_ms_per_step": round(host_leg["wait_ms"], 3),
                 "rollout_launch_ms": round(kb_ms, 4),
                 "mode": "rollout: glimpse scores / output and pointer scores on bf16 operands (v_mfma_f32_16x16x32_bf16, f32 "
                         "accumulation), softmax / masks / local policy / environment f32; glimpse backward: bf16-forward scores + "
@@ -475,7 +496,7 @@ def main():
         n_sus = max(args.steps, int(args.sustain_s / (dt / args.steps)) + 1)
         dts, _ = timed_leg(0, n_sus)
         sustained = {"value": round(LOCAL_BATCH * world * n_sus / dts, 2), "ms_per_step": round(dts / n_sus * 1e3, 3),
-                     "steps": n_sus, "seconds": round(dts, 2), "dtype": "f32"}
+                     "steps": n_sus, "seconds": round(dts, 2), "dtype": "f32", "host_ms_per_step": round(host_leg["busy_ms"], 3)}
 
     if rank == 0:
         digest = elg_build._digest()
@@ -508,7 +529,14 @@ def main():
                                     "decode_steps_mean": [round(r[1], 2) for r in ranks],
                                     "decode_steps_max": [round(r[2], 2) for r in ranks],
                                     "allreduce_ms": [round(r[3], 4) for r in ranks],
-                                    "rollout_launch_ms": [round(r[4], 4) for r in ranks]}},
+                                    "rollout_launch_ms": [round(r[4], 4) for r in ranks],
+                                    # host side: what the Python thread needs to ENQUEUE a step (wall time of the step loop minus
+                                    # the time blocked in the step's own device syncs) and that blocked time; the GPU is the
+                                    # critical path while host_ms_per_step < ms_per_step (tests/test_gpu_zz_dp.py caps the host
+                                    # at two CPUs / two torch threads and asserts it)
+                                    "host_ms_per_step": [round(r[5], 3) for r in ranks],
+                                    "host_wait_ms_per_step": [round(r[6], 3) for r in ranks],
+                                    "host_threads": torch.get_num_threads(), "host_cpus_allowed": host_cpus}},
             # The decode step is bound by vector-instruction issue + dependent-issue latency, not by HBM (SURVEY 8(d):
             # ~200 FLOP/B, the tables live in registers / LDS / L2): the top-level fraction is against the f32 ceiling by the
             # EXECUTED flop count; the HBM figure north_star asks for is nested.

@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import time
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -77,9 +78,21 @@ class HostFetch:
         self.ev = torch.cuda.Event()
         self.ev.record(torch.cuda.current_stream(t.device))
 
+    # seconds the host has spent BLOCKED on the device in the step's syncs (this fetch and the pinned staging buffers' reuse
+    # events): wall time per step minus this is what the Python thread needs to enqueue a step (bench.py: host_ms_per_step)
+    waited_s = 0.0
+
     def get(self) -> list:
+        t0 = time.perf_counter()
         self.ev.synchronize()
+        HostFetch.waited_s += time.perf_counter() - t0
         return self.buf.tolist()
+
+
+def _wait_event(ev):
+    t0 = time.perf_counter()
+    ev.synchronize()
+    HostFetch.waited_s += time.perf_counter() - t0
 
 
 _PINNED = {}
@@ -110,7 +123,7 @@ def h2d_parts(parts, dev, pad: int = 64):
         ent = _PINNED[key] = [torch.zeros(n, dtype=torch.float32).pin_memory(), None]
     buf, ev = ent
     if ev is not None:
-        ev.synchronize()                        # the previous copy out of this buffer has completed
+        _wait_event(ev)                         # the previous copy out of this buffer has completed
     host = buf.numpy()
     for p, o in zip(parts, offs):
         host[o:o + p.numel()] = p.detach().float().contiguous().numpy().reshape(-1)
@@ -134,7 +147,7 @@ def h2d(t: torch.Tensor, dev) -> torch.Tensor:
         ent = _PINNED[key] = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True), None]
     buf, ev = ent
     if ev is not None:
-        ev.synchronize()                        # the previous copy out of this buffer has completed
+        _wait_event(ev)                         # the previous copy out of this buffer has completed
     _host_copy(buf, t)
     out = buf.to(dev, non_blocking=True)
     ev = torch.cuda.Event()

@@ -168,3 +168,24 @@ def test_bench_under_the_launcher(tmp_path):
     assert 80 < pr["decode_steps_mean"][0] <= pr["decode_steps_max"][0] < 202
     assert out["roofline"]["bound"] != "hbm" and "hbm" in out["roofline"]
     assert cfg["library_is_built_from_these_sources"] and len(cfg["library_sha256"]) == 64
+
+
+def test_gpu_stays_the_critical_path_with_a_two_cpu_host(tmp_path):
+    """Eight ranks under the pool's 16-CPU quota get two CPUs each (parallel.respect_cpu_quota).  bench.py --host-cpus 2 pins the
+    process to two CPUs and torch to two threads: the Python thread must still enqueue a step faster than the GPU executes it, in
+    the f32 step and in the shorter bf16 step -- the host then spends the difference blocked in the step's own read-back
+    (per_rank.host_wait_ms_per_step > 0), i.e. the GPU is the critical path."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "60", "--warmup", "5", "--host-cpus", "2",
+           "--no-cpu-baseline", "--no-secondary", "--sustain-s", "0"]
+    (rc, log), = _run_children([(cmd, _env({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"}))], tmp_path, "bench_2cpu_", limit_s=240,
+                               cwd=ROOT)
+    assert rc == 0, log[-4000:]
+    out = json.loads([ln for ln in log.splitlines() if ln.startswith("{")][-1])
+    pr = out["config"]["per_rank"]
+    assert pr["host_cpus_allowed"] == 2 and pr["host_threads"] == 2
+    step, host, wait = out["ms_per_step"], pr["host_ms_per_step"][0], pr["host_wait_ms_per_step"][0]
+    assert host < 0.9 * step and wait > 0.05 * step, (step, host, wait)
+    b = out["bf16"]
+    assert b["host_ms_per_step"] < 0.95 * b["ms_per_step"] and b["host_wait_ms_per_step"] > 0.0, b
+    print(f"two-CPU host: f32 step {step} ms, host busy {host} ms, blocked {wait} ms; bf16 step {b['ms_per_step']} ms, host busy "
+          f"{b['host_ms_per_step']} ms")
