@@ -403,23 +403,35 @@ __device__ __forceinline__ void co_finish4(const elg_rollout_args& A, int N1, in
             uni = __shfl(ubuf, (lane & 48) | (t & 15), ELG_WAVE);
         }
         const float target = uni * tot;
-        float run = 0.f;
-        int found = 0x7fffffff, lastpos = -1;
+        // Inverse CDF in node order (node lo + 16 k: chunk-major), in two levels (round 6): the 16-node chunk the target falls into
+        // from the chunks' row totals, then ONE row scan inside that chunk -- a scan of every chunk was 7 x (4 + 4) dependent DPP
+        // steps per row.  `run` is the same running sum of row totals as before; where rounding leaves no node of the chunk above
+        // the target (or the target above the last total) the chunk's last open node is taken, as the old scan's `lastpos` did.
+        float run = 0.f, base = 0.f;
+        int kstar = -1, klast = 0;
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
-            float c = e[k];
-            c += dpp<0x111>(c); c += dpp<0x112>(c); c += dpp<0x114>(c); c += dpp<0x118>(c);   // row inclusive scan
-            c += run;
-            run += row16_sum(e[k]);
-            const int n = lo + 16 * k;
-            if (e[k] > 0.f) {
-                lastpos = n;                                          // k ascending: the lane's largest open node
-                if (c > target && found == 0x7fffffff) found = n;
-            }
+            const float tk = row16_sum(e[k]);
+            const float nr = run + tk;
+            klast = tk > 0.f ? k : klast;
+            const bool here = kstar < 0 && nr > target;
+            base = here ? run : base;
+            kstar = here ? k : kstar;
+            run = nr;
         }
-        found = row16_min_i(found);
-        lastpos = row16_max_i(lastpos);
-        sel = (found != 0x7fffffff) ? found : max(lastpos, 0);
+        const bool fb = kstar < 0;                                   // target beyond the last total: last open node overall
+        const int kc = fb ? klast : kstar;
+        float ek = e[0];
+#pragma unroll
+        for (int k = 1; k < NK; ++k) ek = (kc == k) ? e[k] : ek;
+        float c = ek;
+        c += dpp<0x111>(c); c += dpp<0x112>(c); c += dpp<0x114>(c); c += dpp<0x118>(c);       // row inclusive scan
+        c += base;
+        const bool open = ek > 0.f;
+        const unsigned long long bh = __ballot(open && !fb && c > target), bo = __ballot(open);
+        const unsigned hit = (unsigned)(bh >> (lane & 48)) & 0xffffu, opn = (unsigned)(bo >> (lane & 48)) & 0xffffu;
+        const int pos = hit ? __builtin_ctz(hit) : (opn ? 31 - __builtin_clz(opn) : 0);
+        sel = 16 * kc + pos;
     }
     ELG_STAMP(sc, 6);
     // probability (and clip Jacobian) of the chosen node: held by lane (sel & 15), register sel >> 4

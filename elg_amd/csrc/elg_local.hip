@@ -53,7 +53,7 @@ constexpr int S_LWE = S_LAV + 32 * 4;        // [32][4]          lWe[d][k], k < 
 constexpr int S_LBC = S_LWE + 32 * 4;        // [32]
 constexpr int S_TABLES = S_LBC + 32;         // = 7840 floats
 constexpr int S_TR = 16 * TP;                // one transpose tile (320 floats)
-constexpr int NTRB = 4;                      // transpose buffers per wave
+constexpr int NTRB = 8;                      // transpose buffers per wave (a batch of transposes = ONE LDS round trip)
 
 // X (L1 or L2 tile in registers) -> X^T in the same register layout, through the per-wave buffer `buf`.
 __device__ __forceinline__ f32x4 transpose16(f32x4 x, float* buf, int lo, int hi) {
@@ -64,6 +64,21 @@ __device__ __forceinline__ f32x4 transpose16(f32x4 x, float* buf, int lo, int hi
     for (int v = 0; v < 4; ++v) y[v] = buf[(4 * hi + v) * TP + lo];
     wave_lds_fence();
     return y;
+}
+
+// N tiles at once: all stores, one fence, all loads, one fence.  (At one wave per SIMD every LDS round trip is exposed: the 34
+// transposes of a row tile, one round trip each, were a fifth of the tile's cycles; batched they are six.)
+template <int N>
+__device__ __forceinline__ void transpose16_batch(const f32x4 (&x)[N], f32x4 (&y)[N], float* bufs, int lo, int hi) {
+    static_assert(N <= NTRB, "transpose buffers");
+#pragma unroll
+    for (int i = 0; i < N; ++i) *reinterpret_cast<float4*>(bufs + i * S_TR + lo * TP + 4 * hi) = make_float4(x[i][0], x[i][1], x[i][2], x[i][3]);
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) y[i][v] = bufs[i * S_TR + (4 * hi + v) * TP + lo];
+    wave_lds_fence();
 }
 
 template <int JT>
@@ -325,12 +340,12 @@ __global__ __launch_bounds__(256) void local_bwd_rows_kernel(const float* __rest
         }
         // per head: dalpha, dsc; d la in place; dsc / alpha transposed for d lt / d lcv
         f32x4 o2[2], g2[2], dg2[2], do2[2];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            o2[dt] = transpose16(o1[dt], trb + 0 * S_TR, lo, hi);
-            g2[dt] = transpose16(g1[dt], trb + 1 * S_TR, lo, hi);
-            dg2[dt] = transpose16(dg1[dt], trb + 2 * S_TR, lo, hi);
-            do2[dt] = transpose16(do1[dt], trb + 3 * S_TR, lo, hi);
+        {
+            const f32x4 tin[8] = {o1[0], o1[1], g1[0], g1[1], dg1[0], dg1[1], do1[0], do1[1]};
+            f32x4 tout[8];
+            transpose16_batch<8>(tin, tout, trb, lo, hi);
+            o2[0] = tout[0]; o2[1] = tout[1]; g2[0] = tout[2]; g2[1] = tout[3];
+            dg2[0] = tout[4]; dg2[1] = tout[5]; do2[0] = tout[6]; do2[1] = tout[7];
         }
 #pragma unroll
         for (int h = 0; h < ELG_LH; ++h) {
@@ -361,6 +376,7 @@ __global__ __launch_bounds__(256) void local_bwd_rows_kernel(const float* __rest
             }
             ts = quarters_sum(ts);
             const bool lane_lo_half = lo < 8;
+            f32x4 tin[2 * JT], tout[2 * JT];                    // dsc | alpha of the head, every slot tile: one round trip
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt) {
                 f32x4 dsc;
@@ -370,9 +386,15 @@ __global__ __launch_bounds__(256) void local_bwd_rows_kernel(const float* __rest
 #pragma unroll
                     for (int k = 0; k < 3; ++k) aLa[h][k] = fmaf(dsc[v], f1[k][jt][v], aLa[h][k]);
                 }
-                const f32x4 dsc2 = transpose16(dsc, trb + 0 * S_TR, lo, hi);      // [row 4 hi + v][slot 16 jt + lo]
+                tin[jt] = dsc;
+                tin[JT + jt] = al[h][jt];
+            }
+            transpose16_batch<2 * JT>(tin, tout, trb, lo, hi);
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                const f32x4 dsc2 = tout[jt];                                       // [row 4 hi + v][slot 16 jt + lo]
                 aLt[h][jt] += (dsc2[0] + dsc2[1]) + (dsc2[2] + dsc2[3]);
-                const f32x4 al2 = transpose16(al[h][jt], trb + 1 * S_TR, lo, hi);
+                const f32x4 al2 = tout[JT + jt];
                 // d lcv[j][d] += alpha_h[r][j] do'[r][d] for the 8 channels d of head h (columns lo of tile dt)
                 const bool col = lane_lo_half == !(h & 1);
 #pragma unroll
@@ -380,17 +402,27 @@ __global__ __launch_bounds__(256) void local_bwd_rows_kernel(const float* __rest
             }
         }
         // ---- remaining table gradients: contractions over the 16 rows (L2 operands)
-        const int rr = min(4 * hi, rleft);
-        (void)rr;
+        (void)b; (void)rleft;
+        // F and dw as feature-major tiles (column c = 3 h + k of F, c = k of dw), the cotangents du1 (rows past R carry zeros):
+        // their row-major forms in one batch -- du2[v] = du[row 4 hi + v][slot 16 jt + lo] used to be a second, dependent global read
+        f32x4 Ft, dwt;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            float x0 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 12; ++c) x0 = (4 * hi + v == c) ? F[c / 3][c % 3] : x0;
+            Ft[v] = x0;
+            dwt[v] = (hi == 0 && v < 3) ? dw[v] : 0.f;
+        }
+        f32x4 tin2[2 + JT], tout2[2 + JT];
+        tin2[0] = Ft; tin2[1] = dwt;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) tin2[2 + jt] = du1[jt];
+        transpose16_batch<2 + JT>(tin2, tout2, trb, lo, hi);
+        const f32x4 F2 = tout2[0], dw2 = tout2[1];
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
-            f32x4 du2;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int r = 4 * hi + v;
-                const float x = rowDU[((size_t)b * R + row0 + min(r, rleft)) * ELG_SLOT_STRIDE + 16 * jt + lo];
-                du2[v] = x * ((r <= rleft) ? 1.f : 0.f);
-            }
+            const f32x4 du2 = tout2[2 + jt];
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -402,19 +434,6 @@ __global__ __launch_bounds__(256) void local_bwd_rows_kernel(const float* __rest
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) aLwc[dq][dt] = ELG_MFMA(dg2[dq][v], o2[dt][v], aLwc[dq][dt]);
-        // F and dw as row-major tiles: feature column c = 3 h + k (12 of 16) / c = k (3 of 16)
-        f32x4 Ft, dwt;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            // element c = 4 hi + v of this row (row = lo): F flattened as c = 3 h + k
-            float x0 = 0.f;
-#pragma unroll
-            for (int c = 0; c < 12; ++c) x0 = (4 * hi + v == c) ? F[c / 3][c % 3] : x0;
-            Ft[v] = x0;
-            dwt[v] = (hi == 0 && v < 3) ? dw[v] : 0.f;
-        }
-        const f32x4 F2 = transpose16(Ft, trb + 2 * S_TR, lo, hi);               // [row 4 hi + v][c = lo]
-        const f32x4 dw2 = transpose16(dwt, trb + 3 * S_TR, lo, hi);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
 #pragma unroll
