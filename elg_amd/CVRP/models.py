@@ -41,7 +41,8 @@ class local_policy_att(nn.Module):
                              f"libelg_hip.so is built for {(eng.LE, eng.LH, eng.LDK)} only (the reference's config.yml:47-49)")
         if not 1 <= int(self.local_size) <= L.MAX_LOCAL_SIZE:
             raise ValueError(f"local_size {self.local_size}: the kernels hold the k nearest neighbours (+ the depot) in "
-                             f"{L.MAX_LOCAL_SIZE + 1} slots -- supported 1 .. {L.MAX_LOCAL_SIZE} (the reference's default: 40 / 30)")
+                             f"{L.MAX_LOCAL_SIZE + 1} slots, one per lane -- supported 1 .. {L.MAX_LOCAL_SIZE} (the reference's default: 40 / 30; "
+                             f"above {L.ROWS_LOCAL_SIZE} the one-wavefront kernels and the replay backward run)")
 
     def folded_tables(self, n_slots: int) -> torch.Tensor:
         lp = {k: v for k, v in self.named_parameters()}

@@ -41,16 +41,17 @@ def pomo_loss(probs, rewards, scale_norm=True, zero_steps=None, T_dev=None):
 _NOTED = set()
 
 
-def _note_host_sync_path(N1, vrplib, ens):
+def _note_host_sync_path(N1, vrplib, ens, wide=False):
     """Say ONCE per configuration that a training step runs the reference's own sequence (rollout's length read back on the host
     before the loss is built: ~0.4 ms of idle GPU per step at the bench scale) instead of the deferred-sync path."""
-    key = (N1 > 128, bool(vrplib), ens > 1)
+    key = (N1 > 128, bool(vrplib), ens > 1, bool(wide))
     if key in _NOTED:
         return
     _NOTED.add(key)
-    why = [w for w, c in (("N + 1 > 128 nodes", N1 > 128), ("VRPLIB instance", vrplib), ("ensemble_size > 1", ens > 1)) if c]
+    why = [w for w, c in (("N + 1 > 128 nodes", N1 > 128), ("VRPLIB instance", vrplib), ("ensemble_size > 1", ens > 1),
+                               ("local_size > 47", wide)) if c]
     print(f"[elg_amd] train_step: host-synchronised rollout path ({', '.join(why)}); the deferred-sync path covers N + 1 <= 128, "
-          "one local policy", file=sys.stderr, flush=True)
+          "one local policy, local_size <= 47", file=sys.stderr, flush=True)
 
 
 def train_step(model, env, optimizer, batch, scale_norm=True, bucket=None, world=1, check=True):
@@ -60,9 +61,9 @@ def train_step(model, env, optimizer, batch, scale_norm=True, bucket=None, world
     reset_state, _, _ = env.reset()
     model.pre_forward(reset_state)
     pol = model.policy if hasattr(model, 'policy') else model.decoder.policy
-    if env.problem.N1 > 128 or env.vrplib or pol.ens > 1:
+    if env.problem.N1 > 128 or env.vrplib or pol.ens > 1 or pol.wide_slots:
         # sizes / variants whose training forward saves no rows: the reference's sequence with the host sync inside rollout()
-        _note_host_sync_path(env.problem.N1, env.vrplib, pol.ens)
+        _note_host_sync_path(env.problem.N1, env.vrplib, pol.ens, pol.wide_slots)
         solutions, probs, rewards = rollout(model=model, env=env, eval_type='sample')
         if check:
             check_feasible(solutions[0:1], reset_state.node_demand[0:1])

@@ -20,7 +20,8 @@ LOC_LA, LOC_LT, LOC_LAV, LOC_LCV, LOC_LWC, LOC_LBC, LOC_LWE, LOC_LPE, LOC_SIZE =
     0, 16, 272, 368, 2416, 3440, 3472, 3568, 5616
 
 MAX_ENS = 4
-MAX_LOCAL_SIZE = 47             # ELG_SLOT_STRIDE - 1 (csrc/elg_rollout.h): k nearest neighbours + the depot slot
+MAX_LOCAL_SIZE = 63             # ELG_SLOT_MAX - 1 (csrc/elg_rollout.h): k nearest neighbours + the depot slot, one slot per lane
+ROWS_LOCAL_SIZE = 47            # ELG_SLOT_STRIDE - 1: what the matrix-core kernels and the saved training rows are built for
 _vp = C.c_void_p
 
 

@@ -166,10 +166,11 @@ __device__ __forceinline__ void bwd_step(const elg_bwd_args& BA, const Inst& I, 
     }
     wave_lds_fence();
     // d u_slot (local policy output), consumed by local_bwd_kernel
-    if (BA.rowDU && lane < ELG_SLOT_STRIDE) {
+    const int dus = slot_stride_of(kmax_of(A));                  // rowDU of the replay: 48 floats per row up to local_size 47, 64 above
+    if (BA.rowDU && lane < dus) {
         float du = 0.f;
         if (snid >= 0) du = sb[snid] * A.inv_ens;
-        BA.rowDU[(b * R + r) * ELG_SLOT_STRIDE + lane] = du;
+        BA.rowDU[(b * R + r) * dus + lane] = du;
     }
     // rows consumed by the dense part of the backward (host: batched GEMMs, see engine.py):
     // a_h[n] (glimpse attention), q and o of this step, the load seen by the query
@@ -201,7 +202,8 @@ __device__ __forceinline__ void zero_rows(const elg_bwd_args& BA, int lane, size
     for (int n = lane; n < N1; n += 64) rDL[n] = 0.f;
     const size_t off = (b * R + r) * ELG_E;
     for (int c = lane; c < ELG_E; c += 64) { BA.rowQ[off + c] = 0.f; BA.rowO[off + c] = 0.f; }
-    if (BA.rowDU && lane < ELG_SLOT_STRIDE) BA.rowDU[(b * R + r) * ELG_SLOT_STRIDE + lane] = 0.f;
+    const int dus = slot_stride_of(kmax_of(BA.fwd));
+    if (BA.rowDU && lane < dus) BA.rowDU[(b * R + r) * dus + lane] = 0.f;
     if (lane == 0 && BA.rowLoad) BA.rowLoad[b * R + r] = 0.f;
 }
 
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(WAVES * 64) void rollout_bwd_kernel(const elg_bwd_a
     unit_of_block(A, bi, m_lo, m_hi);
     Inst I;
     float* p = stage_instance<TSP, LDSK, WAVES * 64>(A, bi, lds, I);
-    float* sb = p + wave * SbSize<NCH>::value;
+    float* sb = p + wave * sb_floats_of(NCH, kmax_of(A));
     __syncthreads();
     const size_t b = bi, R = (size_t)A.M * T;
 
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(WAVES * 64) void local_bwd_kernel(const elg_bwd_arg
     Inst I;
     float* p = stage_instance<TSP, false, WAVES * 64>(A, bi, lds, I);
     float* acc = p; p += ELG_LOC_SIZE;
-    float* sb = p + wave * SbSize<NCH>::value;
+    float* sb = p + wave * sb_floats_of(NCH, kmax_of(A));
     for (int i = threadIdx.x; i < ELG_LOC_SIZE; i += WAVES * 64) acc[i] = 0.f;
     __syncthreads();
     const size_t b = bi, R = BA.row_stride > 0 ? (size_t)BA.row_stride : (size_t)A.M * T;
@@ -371,6 +373,8 @@ __global__ __launch_bounds__(WAVES * 64) void local_bwd_kernel(const elg_bwd_arg
 #pragma unroll
     for (int k = 0; k < 3; ++k) { LA.lwe[k] = 0.f; LA.lav[k] = 0.f; }
     LA.lbc = 0.f; LA.la = 0.f;
+    // rowDU rows: the replay's own (slot stride by local_size) or the saved-rows path's (row_stride > 0: always ELG_SLOT_STRIDE)
+    const int dus = BA.row_stride > 0 ? ELG_SLOT_STRIDE : slot_stride_of(kmax_of(A));
 
     for (int m = m_lo + wave; m < m_hi; m += WAVES) {
         const size_t bm = b * A.M + m;
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(WAVES * 64) void local_bwd_kernel(const elg_bwd_arg
             const int sel = __builtin_amdgcn_readfirstlane(A.forced[bm * A.Tforced + t]);
             const bool first_move = (!TSP && t <= 1) || (TSP && t == 0);
             if (!st.fin && !first_move) {
-                const float du = (lane < ELG_SLOT_STRIDE) ? BA.rowDU[(b * R + r) * ELG_SLOT_STRIDE + lane] : 0.f;
+                const float du = (lane < dus) ? BA.rowDU[(b * R + r) * dus + lane] : 0.f;
                 if (__ballot(du != 0.f)) {
                     unsigned long long mk[NCH];
                     build_mask<NCH, TSP>(st, I, N1, lane, mk);
@@ -527,7 +531,7 @@ static int launch_bwd_impl(const elg_bwd_args& BA, hipStream_t stream) {
     const elg_rollout_args& A = BA.fwd;
     size_t lds = 0;
     if (LDSK) lds += (size_t)3 * A.N1 * ELG_E * 4;
-    lds += (size_t)((A.N1 + 3) & ~3) * 4 + 16 + (size_t)WAVES * SbSize<NCH>::value * 4;
+    lds += (size_t)((A.N1 + 3) & ~3) * 4 + 16 + (size_t)WAVES * sb_floats_of(NCH, kmax_of(A)) * 4;
     if (LDSK) lds += (size_t)((2 * A.N1 + 3) & ~3) * 4;
     if (lds > 163840) return fail(ELG_EINVAL, "rollout_bwd: LDS budget exceeded");
     auto kern = rollout_bwd_kernel<NCH, TSP, LDSK, WAVES, SMALL>;
@@ -540,7 +544,7 @@ static int launch_bwd_impl(const elg_bwd_args& BA, hipStream_t stream) {
     }
     if (A.has_local) {
         constexpr int LW = 8;
-        size_t l2 = (size_t)((A.N1 + 3) & ~3) * 4 + 16 + (size_t)ELG_LOC_SIZE * 4 + (size_t)LW * SbSize<NCH>::value * 4;
+        size_t l2 = (size_t)((A.N1 + 3) & ~3) * 4 + 16 + (size_t)ELG_LOC_SIZE * 4 + (size_t)LW * sb_floats_of(NCH, kmax_of(A)) * 4;
         auto k2 = local_bwd_kernel<NCH, TSP, LW>;
         static DynLds optin2;
         if (!optin2.opt_in(reinterpret_cast<const void*>(k2), 163840)) return fail(ELG_ELAUNCH, "hipFuncSetAttribute failed");
@@ -1726,11 +1730,11 @@ extern "C" int elg_rollout_bwd(const elg_bwd_args* a, void* stream) {
     if (!BA.local_only && (!BA.gprob || !BA.rowA || !BA.rowDL || !BA.rowQ || !BA.rowO))
         return fail(ELG_EINVAL, "rollout_bwd: missing row buffers");
     if (A.has_local && (!A.loc || !BA.rowDU || !BA.gloc)) return fail(ELG_EINVAL, "rollout_bwd: local buffers missing");
-    if (A.K + 1 > ELG_SLOT_STRIDE) return fail(ELG_EINVAL, "rollout_bwd: local_size must be <= 47");
+    if (A.K + 1 > ELG_SLOT_MAX) return fail(ELG_EINVAL, "rollout_bwd: local_size must be <= 63");
     if (A.ens > 1) {
         if (A.ens > ELG_MAX_ENS || A.problem != ELG_PROBLEM_CVRP || A.Kens[0] != A.K) return fail(ELG_EINVAL, "rollout_bwd: bad ensemble");
         for (int i = 0; i < A.ens; ++i)
-            if (A.Kens[i] < 0 || A.Kens[i] + 1 > ELG_SLOT_STRIDE) return fail(ELG_EINVAL, "rollout_bwd: local_size must be <= 47");
+            if (A.Kens[i] < 0 || A.Kens[i] + 1 > ELG_SLOT_MAX) return fail(ELG_EINVAL, "rollout_bwd: local_size must be <= 63");
     }
     if (A.problem == ELG_PROBLEM_CVRP) return dispatch_bwd<false>(BA, (hipStream_t)stream);
     if (A.problem == ELG_PROBLEM_TSP) return dispatch_bwd<true>(BA, (hipStream_t)stream);

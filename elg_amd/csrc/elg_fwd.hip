@@ -355,7 +355,7 @@ __global__ __launch_bounds__(WAVES * 64) void rollout_fwd_kernel(const elg_rollo
     float* sdem = p; p += (N1 + 3) & ~3;
     float* sxy = p; if (LDSK) p += (2 * N1 + 3) & ~3;
     p += 4;
-    float* sb = p + wave * SbSize<NCH>::value;
+    float* sb = p + wave * sb_floats_of(NCH, kmax_of(A));
 
     const float* gK = A.Kmat + (size_t)b * NE;
     const float* gV = A.Vmat + (size_t)b * NE;
@@ -476,7 +476,7 @@ template <int NCH, bool TSP, bool LDSK, int WAVES, bool TRAIN, bool SMALL>
 static int launch_fwd_impl(const elg_rollout_args& A, hipStream_t stream) {
     size_t lds = 0;
     if (LDSK) lds += (size_t)3 * A.N1 * ELG_E * 4;
-    lds += (size_t)((A.N1 + 3) & ~3) * 4 + 16 + (size_t)WAVES * SbSize<NCH>::value * 4;
+    lds += (size_t)((A.N1 + 3) & ~3) * 4 + 16 + (size_t)WAVES * sb_floats_of(NCH, kmax_of(A)) * 4;
     if (LDSK) lds += (size_t)((2 * A.N1 + 3) & ~3) * 4;
     if (lds > 163840) return fail(ELG_EINVAL, "rollout: LDS budget exceeded");
     auto kern = rollout_fwd_kernel<NCH, TSP, LDSK, WAVES, TRAIN, SMALL>;
@@ -1634,8 +1634,9 @@ __global__ __launch_bounds__(512) void rollout_fwd_xl_kernel(const elg_rollout_a
     unsigned long long* svis = reinterpret_cast<unsigned long long*>(p) + (size_t)wave * 2 * NW;
     unsigned long long* smk = svis + NW;
     p += (size_t)WAVES * 4 * NW;
-    float* sb = p + wave * (ELG_SB_MIN + ELG_E);
-    float* so = sb + ELG_SB_MIN;
+    const int ss = slot_stride_of(A.K), sbf = 3 * ss;              // slot scratch: 144 floats up to local_size 47, 192 above
+    float* sb = p + wave * (sbf + ELG_E);
+    float* so = sb + sbf;
     if (!TSP)
         for (int i = tid; i < N1; i += NT) sdem[i] = A.demand[(size_t)b * N1 + i];
     __syncthreads();
@@ -1720,8 +1721,8 @@ __global__ __launch_bounds__(512) void rollout_fwd_xl_kernel(const elg_rollout_a
                             const int rank = found + lanes_below(bal);
                             if (cand && rank < A.K) {
                                 sb[S0 + rank] = nd;
-                                sb[ELG_SLOT_STRIDE + S0 + rank] = nth;
-                                sb[2 * ELG_SLOT_STRIDE + S0 + rank] = i2f(nid);
+                                sb[ss + S0 + rank] = nth;
+                                sb[2 * ss + S0 + rank] = i2f(nid);
                             }
                             found += __popcll(bal);
                         }
@@ -1730,7 +1731,7 @@ __global__ __launch_bounds__(512) void rollout_fwd_xl_kernel(const elg_rollout_a
                         const int j = lane;
                         const bool cust = (j >= S0) && (j < S0 + k);
                         float sd = 0.f, sth = 0.f;
-                        if (cust) { sd = sb[j]; sth = sb[ELG_SLOT_STRIDE + j]; snid = f2i(sb[2 * ELG_SLOT_STRIDE + j]); }
+                        if (cust) { sd = sb[j]; sth = sb[ss + j]; snid = f2i(sb[2 * ss + j]); }
                         const float dmax = (k > 0) ? sb[S0 + k - 1] : 0.f;
                         wave_lds_fence();
                         if (!TSP && j == 0) snid = 0;
@@ -1926,7 +1927,7 @@ static int launch_fwd_xl(const elg_rollout_args& A, hipStream_t stream) {
     if (!A.scratch) return fail(ELG_EINVAL, "rollout: N1 > 1024 needs the (B,M,N1) scratch rows");
     if (A.N1 > 8192) return fail(ELG_ENOTIMPL, "rollout: N1 > 8192 not built");
     const int NW = (A.N1 + 63) / 64;
-    const size_t lds = ((size_t)2 * 64 * ELG_E + ((A.N1 + 3) & ~3) + (size_t)8 * 4 * NW + (size_t)8 * (ELG_SB_MIN + ELG_E)) * 4;
+    const size_t lds = ((size_t)2 * 64 * ELG_E + ((A.N1 + 3) & ~3) + (size_t)8 * 4 * NW + (size_t)8 * (3 * slot_stride_of(A.K) + ELG_E)) * 4;
     if (lds > 163840 - 256) return fail(ELG_EINVAL, "xl rollout: LDS budget exceeded");
     auto kern = rollout_fwd_xl_kernel<TSP>;
     static DynLds optin;
@@ -2519,7 +2520,16 @@ static int dispatch_fwd(const elg_rollout_args& A, hipStream_t stream) {
     if (A.waves != 8) return fail(ELG_EINVAL, "waves must be 8");
     // lds_stage = "keep the instance's tables on chip": MFMA operand images (cooperative kernel, N1 <= 112) or the
     // LDS copies of the one-wavefront-per-trajectory kernel (N1 <= 104; 105..112 fall back to its L2 variant)
-    const bool lds = A.lds_stage != 0 && A.N1 <= 104;
+    // local_size > 47 (K + 1 > ELG_SLOT_STRIDE slots): the one-wavefront kernels only -- one slot per lane, up to 64; the
+    // cooperative / streaming / N1 > 1024 matrix kernels and the saved training rows are built on 48-wide slot blocks.  Their
+    // LDS-staged form leaves no room for the wider slot scratch at the largest sizes: its tables then stay in L2.
+    const bool wide = kmax_of(A) + 1 > ELG_SLOT_STRIDE;
+    if (wide && (A.trA || A.trMask)) return fail(ELG_ENOTIMPL, "rollout: training rows are built for local_size <= 47 (replay backward above)");
+    if (wide && A.variant != 0 && A.variant != 1 && A.variant != 2) return fail(ELG_ENOTIMPL, "rollout: local_size > 47 runs the one-wavefront kernels (variant 0, 1 or 2)");
+    // (LDS-staged one-wavefront kernel: K | V | PK + demands + coordinates + the per-wave scratch must fit the CU's 160 KB: launch_fwd_impl)
+    const size_t ldsk_bytes = (size_t)3 * A.N1 * ELG_E * 4 + (size_t)((A.N1 + 3) & ~3) * 4 + 16 + (size_t)8 * sb_floats_of(nch, kmax_of(A)) * 4 +
+                              (size_t)((2 * A.N1 + 3) & ~3) * 4;
+    const bool lds = A.lds_stage != 0 && A.N1 <= 104 && ldsk_bytes <= 163840;
 #define ELG_GO(NCHV, L, W) return launch_fwd<NCHV, TSP, L, W>(A, stream)
     if (A.ens > 1) {        // ensemble_size > 1: the one-wavefront-per-trajectory kernel walks the members
         if (A.trA || A.trMask) return fail(ELG_ENOTIMPL, "rollout: training rows are not built for ensemble_size > 1 (replay backward)");
@@ -2531,7 +2541,7 @@ static int dispatch_fwd(const elg_rollout_args& A, hipStream_t stream) {
         ELG_GO(16, false, 8);
     }
     if (A.lds_stage && A.waves == 8 && A.N1 >= 4 && A.N1 <= 16 * CO_NT && !A.use_state && A.do_decode && A.do_update &&
-        A.max_steps <= 0 && (A.variant == 0 || A.variant == 4)) {
+        A.max_steps <= 0 && (A.variant == 0 || A.variant == 4) && !wide) {
         // fused rollout at the training scale: lockstep trajectories, tables as MFMA operands in registers (variant 4: the
         // split-group form of the same kernel, two independent 4-wave groups per workgroup -- same results bit for bit)
         const bool train = A.trA || A.trMask;      // training forward (glimpse weights saved, or recomputed from the mask rows)
@@ -2545,7 +2555,7 @@ static int dispatch_fwd(const elg_rollout_args& A, hipStream_t stream) {
         if (A.variant == 3) return A.precision == 1 ? launch_fwd_xm<TSP, true>(A, stream) : launch_fwd_xm<TSP, false>(A, stream);
         return launch_fwd_xl<TSP>(A, stream);
     }
-    const bool mt_shape = !lds && nch > 2 && nch <= 16 && !A.use_state && A.do_decode && A.do_update && A.max_steps <= 0 && A.variant == 0;
+    const bool mt_shape = !lds && nch > 2 && nch <= 16 && !A.use_state && A.do_decode && A.do_update && A.max_steps <= 0 && A.variant == 0 && !wide;
     if (A.trMask && !A.trA && !mt_shape) return fail(ELG_EINVAL, "rollout: this kernel needs trA (mask-only rows: cooperative / streaming kernels)");
     if (A.trA) {        // training forward: saves the backward rows; built for N1 <= 128, 8 waves
         if (!A.trPC || !A.trCsel || !A.trQ || !A.trO) return fail(ELG_EINVAL, "rollout: incomplete training rows");
@@ -2563,14 +2573,14 @@ static int dispatch_fwd(const elg_rollout_args& A, hipStream_t stream) {
         else ELG_GO(2, false, 8);
     }
     if (lds) return fail(ELG_EINVAL, "lds_stage needs N1 <= 104");
-    if (!A.use_state && A.do_decode && A.do_update && A.max_steps <= 0 && A.variant == 0) {
+    if (!A.use_state && A.do_decode && A.do_update && A.max_steps <= 0 && A.variant == 0 && !wide) {
         // fused rollout of a large instance: node-tiled kernel (tables shared through LDS tiles)
         if (nch <= 4) return launch_fwd_mt<4, TSP>(A, stream);
         if (nch <= 8) return launch_fwd_mt<8, TSP>(A, stream);
         if (nch <= 16) return launch_fwd_mt<16, TSP>(A, stream);
     }
     const bool fused = !A.use_state && A.do_decode && A.do_update && A.max_steps <= 0;
-    if (fused && (A.variant == 3 || (A.variant == 0 && nch > 16))) {
+    if (fused && !wide && (A.variant == 3 || (A.variant == 0 && nch > 16))) {
         // Vrp-Set-XXL scale (or variant 3: the same kernel at any size, for the tests): matrix phases of the streaming kernel,
         // runtime chunk loops in the owners, score rows in the scratch
         if (A.trA || A.trMask) return fail(ELG_ENOTIMPL, "rollout: training rows for N1 > 1024 not built");
@@ -2654,14 +2664,14 @@ int elg_rollout_fwd(const elg_rollout_args* a, void* stream) {
     if (!a) return fail(ELG_EINVAL, "null args");
     const elg_rollout_args& A = *a;
     if (A.B <= 0 || A.M <= 0 || A.N1 <= 1 || A.tiles <= 0) return fail(ELG_EINVAL, "rollout: bad sizes");
-    if (A.K < 0 || A.K + 1 > ELG_SLOT_STRIDE) return fail(ELG_EINVAL, "rollout: local_size must be <= 47");
+    if (A.K < 0 || A.K + 1 > ELG_SLOT_MAX) return fail(ELG_EINVAL, "rollout: local_size must be <= 63");
     if (A.has_local && !A.loc) return fail(ELG_EINVAL, "rollout: has_local without tables");
     if (A.ens > 1) {
         if (A.ens > ELG_MAX_ENS) return fail(ELG_ENOTIMPL, "rollout: ensemble_size > 4 not built");
         if (A.problem != ELG_PROBLEM_CVRP) return fail(ELG_EINVAL, "rollout: the TSP decoder has one local policy (TSP/models.py:223-225)");
         if (A.Kens[0] != A.K) return fail(ELG_EINVAL, "rollout: Kens[0] must equal K (local_size[0])");
         for (int i = 0; i < A.ens; ++i)
-            if (A.Kens[i] < 0 || A.Kens[i] + 1 > ELG_SLOT_STRIDE) return fail(ELG_EINVAL, "rollout: local_size must be <= 47");
+            if (A.Kens[i] < 0 || A.Kens[i] + 1 > ELG_SLOT_MAX) return fail(ELG_EINVAL, "rollout: local_size must be <= 63");
     }
     if (A.mode == ELG_MODE_FORCED && !A.forced) return fail(ELG_EINVAL, "rollout: forced mode without actions");
     if (A.precision != 0 && A.precision != 1) return fail(ELG_EINVAL, "rollout: precision 0 (f32) or 1 (bf16 table products)");

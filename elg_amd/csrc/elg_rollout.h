@@ -13,7 +13,9 @@
 #include "elg_common.h"
 #include "../../include/elg_hip.h"
 
-#define ELG_SLOT_STRIDE 48      // max slots (K + 1 <= 48)
+#define ELG_SLOT_STRIDE 48      // slot stride of the saved training rows, of the cooperative / streaming kernels' slot blocks and of the
+                                // row backward (K + 1 <= 48: the reference's defaults are 40 / 30)
+#define ELG_SLOT_MAX 64         // one slot per lane: what the one-wavefront kernels (forward, replay backward) take (K + 1 <= 64)
 #define ELG_SB_MIN 144          // per-wave LDS scratch floats (>= 3*ELG_SLOT_STRIDE, >= 128)
 
 namespace elg {
@@ -21,6 +23,19 @@ namespace elg {
 // per-wave LDS scratch: slot compaction (3*48), o broadcast (128), node-indexed terms (64*NCH)
 template <int NCH>
 struct SbSize { static constexpr int value = (64 * NCH > ELG_SB_MIN) ? 64 * NCH : ELG_SB_MIN; };
+// One-wavefront kernels: slot stride of the per-wave scratch and of the replay backward's rowDU rows (48 up to local_size 47,
+// so that nothing changes there; 64 above), and the scratch floats per wave (d | theta | node id of the slots; >= 128, >= 64 NCH)
+__host__ __device__ inline int slot_stride_of(int K) { return (K + 1 > ELG_SLOT_STRIDE) ? ELG_SLOT_MAX : ELG_SLOT_STRIDE; }
+__host__ __device__ inline int kmax_of(const elg_rollout_args& A) {      // the widest neighbourhood of the launch (ensembles: max_i Kens[i])
+    int k = A.K;
+    if (A.ens > 1)
+        for (int i = 0; i < ELG_MAX_ENS; ++i) if (i < A.ens && A.Kens[i] > k) k = A.Kens[i];
+    return k;
+}
+__host__ __device__ inline int sb_floats_of(int nch, int K) {
+    const int a = 64 * nch, b = 3 * slot_stride_of(K);
+    return a > b ? a : b;
+}
 
 struct Inst {                 // per-instance table pointers (global or LDS)
     const float* K;           // [N1][128]
@@ -136,7 +151,7 @@ __device__ __forceinline__ void env_update(Traj<NCH>& st, const Inst& I, int N1,
 template <int NCH, bool TSP>
 __device__ __forceinline__ int knn_slots(const Inst& I, int N1, int K, int cur, int lane,
                                          const unsigned long long (&mk)[NCH], float* sb,
-                                         const unsigned long long* lds_mk = nullptr) {
+                                         const unsigned long long* lds_mk = nullptr, int ss = ELG_SLOT_STRIDE) {
     constexpr int S0 = TSP ? 0 : 1;
     int found = 0;
     const size_t row = (size_t)cur * N1;
@@ -155,8 +170,8 @@ __device__ __forceinline__ int knn_slots(const Inst& I, int N1, int K, int cur, 
             const int rank = found + lanes_below(bal);
             if (cand && rank < K) {
                 sb[S0 + rank] = nd;
-                sb[ELG_SLOT_STRIDE + S0 + rank] = nth;
-                sb[2 * ELG_SLOT_STRIDE + S0 + rank] = i2f(nid);
+                sb[ss + S0 + rank] = nth;
+                sb[2 * ss + S0 + rank] = i2f(nid);
             }
             found += __popcll(bal);
         }
@@ -194,7 +209,8 @@ __device__ __forceinline__ Slots slot_setup(const Inst& I, int N1, int K, bool h
 #pragma unroll
         for (int i = 0; i < ELG_MAX_ENS; ++i) if (i < ens) Kw = max(Kw, Kens[i]);
     }
-    S.k = knn_slots<NCH, TSP>(I, N1, Kw, st.cur, lane, mk, sb, lds_mk);
+    const int ss = slot_stride_of(Kw);                                // (the scratch is sized by the same rule: sb_floats_of)
+    S.k = knn_slots<NCH, TSP>(I, N1, Kw, st.cur, lane, mk, sb, lds_mk, ss);
     wave_lds_fence();
     const int j = lane;
     const int kp = min(S.k, K);
@@ -204,8 +220,8 @@ __device__ __forceinline__ Slots slot_setup(const Inst& I, int N1, int K, bool h
     S.snid = -1;
     if (S.cust) {
         sd = sb[j];
-        sth = sb[ELG_SLOT_STRIDE + j];
-        S.snid = f2i(sb[2 * ELG_SLOT_STRIDE + j]);
+        sth = sb[ss + j];
+        S.snid = f2i(sb[2 * ss + j]);
     }
     S.dmax = (kp > 0) ? sb[S0 + kp - 1] : 0.f;
 #pragma unroll

@@ -388,6 +388,12 @@ class Policy:
     def ens(self) -> int:
         return len(self.Ks) if len(self.Ks) > 1 else 1
 
+    @property
+    def wide_slots(self) -> bool:
+        """local_size > 47: more than the 48 slots the matrix-core kernels and the saved training rows are built on -- the
+        one-wavefront kernels run (one slot per lane, up to 64) and training goes through the replay backward."""
+        return max((self.K,) + tuple(self.Ks)) > L.ROWS_LOCAL_SIZE
+
 
 def coop_tiles(B: int, M: int, n_cu: int) -> int:
     """Workgroups per instance of the cooperative rollout kernel.  A workgroup (one per CU: the instance's tables fill its LDS) walks
@@ -658,7 +664,8 @@ def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mo
         a.scratch = _ptr(scratch)
     rows = None
     # an ensemble trains through the replay backward; so do shapes whose rows would not fit next to the backward's scratch
-    save_rows = train and pol.ens == 1 and (N1 <= 128 or (N1 <= 1024 and variant == 0 and _rows_fit(B, M, N1, Tcap, dev)))
+    save_rows = (train and pol.ens == 1 and not pol.wide_slots
+                 and (N1 <= 128 or (N1 <= 1024 and variant == 0 and _rows_fit(B, M, N1, Tcap, dev))))
     if save_rows:
         rows = TrainRows.get(B, M, N1, Tcap, dev)
         rows.prepare()
@@ -744,7 +751,7 @@ class _ChosenProbs(torch.autograd.Function):
         rowQ = torch.empty(B, R, E, device=dev)
         rowO = torch.empty(B, R, E, device=dev)
         rowLoad = torch.empty(B, R, device=dev) if haswl else None
-        rowDU = torch.empty(B, R, 48, device=dev) if meta.has_local else None
+        rowDU = torch.empty(B, R, 64 if pol.wide_slots else 48, device=dev) if meta.has_local else None    # csrc slot_stride_of()
         ba.gprob = _ptr(g)
         ba.rowA, ba.rowDL, ba.rowQ, ba.rowO = _ptr(rowA), _ptr(rowDL), _ptr(rowQ), _ptr(rowO)
         ba.rowLoad, ba.rowDU = _ptr(rowLoad), _ptr(rowDU)

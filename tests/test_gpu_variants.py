@@ -142,3 +142,109 @@ def test_euclidean_local_features(problem, variant):
             worst[key] = max(worst.get(key, 0.0), e)
     assert max(worst.values()) <= LOGIT_RTOL, worst
     gc.record_parity(f"euclidean_{problem}_v{variant}", max(worst.values()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# local_size above 47 (round 6): the reference takes any K (models.py:8-36); here the one-wavefront kernels (one slot per lane,
+# up to 64) run the rollout and the replay backward trains -- fixtures of the real reference at local_size 50 and 63
+# ---------------------------------------------------------------------------------------------------------------------
+def _wide_model(mp, P):
+    from elg_amd.CVRP.CVRPModel import CVRPModel
+    model = CVRPModel(**mp)
+    model.decoder.add_local_policy(DEV)
+    model.load_state_dict({k: v.clone() for k, v in P.items()}, strict=True)
+    return model.to(DEV)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2], ids=["by_shape", "wave_per_trajectory", "xl"])
+@pytest.mark.parametrize("tag", ["k50", "k63"])
+def test_local_size_above_47_logits_and_tours(tag, variant):
+    from test_oracle_golden import wide_slots_setup
+    fx, mp, cfg, P, xy, dem, B, N, M = wide_slots_setup(tag)
+    model = _wide_model(mp, P).eval()
+    env = _env(mp, xy, dem, M)
+    acts = torch.from_numpy(fx[f"{tag}_greedy_actions"].astype(np.int64))
+    T = acts.shape[2]
+    with torch.no_grad():
+        rs, _, _ = env.reset()
+        model.pre_forward(rs)
+        pol = model.decoder.policy
+        assert pol.wide_slots and pol.K == int(tag[1:])
+        worst = {}
+        for dump, key, scale in (("scores", "pre_clip", None), ("logits", "logits", cfg.logit_clipping)):
+            res = eng.rollout_forward(env.problem, pol, M, acts[0, :, 1], L.MODE_FORCED, forced=acts, dump_T=T, dump=dump, variant=variant)
+            assert res.kernel_id == (L.KERNEL_XL if variant == 2 else L.KERNEL_WAVE)       # never a 48-slot matrix kernel
+            got = res.full_probs.cpu().numpy()
+            tl = res.tlen.cpu().numpy()
+            for i, t in enumerate(fx[f"{tag}_steps"]):
+                live = (int(t) < tl)[:, :, None]                     # (a finished trajectory decodes nothing: its dump rows stay zero)
+                ref = fx[f"{tag}_{key}"][i]
+                open_ = np.isfinite(fx[f"{tag}_logits"][i]) & live
+                assert open_.any()
+                if key == "logits":
+                    assert np.array_equal(np.isfinite(got[:, :, int(t), :]) & live, open_), int(t)
+                worst[key] = max(worst.get(key, 0.0), logit_errors(got[:, :, int(t), :], ref, open_, scale))
+        assert max(worst.values()) <= LOGIT_RTOL, worst
+        gc.record_parity(f"local_size_{tag}_variant{variant}_logits", max(worst.values()))
+        g = eng.rollout_forward(env.problem, pol, M, acts[0, :, 1], L.MODE_GREEDY, variant=variant)
+        assert int(g.tlen.max()) == T and torch.equal(g.actions[:, :, :T].cpu(), acts.int())
+        np.testing.assert_allclose(g.reward.cpu().numpy(), fx[f"{tag}_greedy_reward"], rtol=1e-5)
+        if variant == 0:                                             # the step-wise protocol (CVRPEnv.step + one_step_rollout)
+            env.reset()
+            state, _, done = env.pre_step()
+            t = 0
+            starts = [int(a) for a in acts[0, :, 1]]
+            model.draw_starts = staticmethod(lambda n, m: starts)
+            while not done and t < 12:
+                sel, _ = model.one_step_rollout(state, *env.get_cur_feature(), eval_type='greedy')
+                assert np.array_equal(sel.cpu().numpy(), acts[:, :, t].numpy()), t
+                state, rew, done = env.step(sel)
+                t += 1
+
+
+@pytest.mark.parametrize("tag", ["k50", "k63"])
+def test_local_size_above_47_training_gradients(tag):
+    """The reference's REINFORCE step on its own sampled tours through the engine's replay backward (no saved rows above 47)."""
+    from elg_amd.CVRP.train import pomo_loss
+    from test_oracle_golden import wide_slots_setup
+    fx, mp, cfg, P, xy, dem, B, N, M = wide_slots_setup(tag)
+    model = _wide_model(mp, P).train()
+    env = _env(mp, xy, dem, M)
+    rs, _, _ = env.reset()
+    model.pre_forward(rs)
+    pol = model.decoder.policy
+    sacts = torch.from_numpy(fx[f"{tag}_sample_actions"].astype(np.int64))
+    T = sacts.shape[2]
+    res = eng.rollout_forward(env.problem, pol, M, sacts[0, :, 1], L.MODE_FORCED, forced=sacts, train=True)
+    assert res.rows is None and res.kernel_id == L.KERNEL_WAVE
+    probs = eng.chosen_probs(env.problem, pol, M, res, T)
+    np.testing.assert_allclose(probs.detach().cpu().numpy(), fx[f"{tag}_sample_probs"], rtol=5e-4, atol=1e-9)
+    J = pomo_loss(probs, torch.from_numpy(fx[f"{tag}_sample_reward"]).to(DEV), True)
+    assert abs(float(J.detach()) - float(fx[f"{tag}_loss"])) <= 2e-4 * max(1.0, abs(float(fx[f"{tag}_loss"])))
+    J.backward()
+    got = dict(model.named_parameters())
+    worst = 0.0
+    for n in [k[len(f"{tag}_grad_"):] for k in fx.files if k.startswith(f"{tag}_grad_")]:
+        ref = fx[f"{tag}_grad_{n}"]
+        err = float(np.abs(got[n].grad.cpu().numpy() - ref).max()) / max(float(np.abs(ref).max()), 1e-6)
+        worst = max(worst, err)
+        assert err <= 2e-3, (n, err)
+    gc.record_parity(f"local_size_{tag}_grad_over_max", worst)
+
+
+def test_local_size_63_train_step_runs():
+    """The product train_step at local_size 63 (host-synchronised path + replay backward) moves the local policy's parameters."""
+    from elg_amd.CVRP.CVRPEnv import CVRPEnv
+    from elg_amd.CVRP.generate_data import generate_vrp_data
+    from elg_amd.CVRP.train import train_step
+    from elg_amd.optim import Adam
+    from test_oracle_golden import wide_slots_setup
+    fx, mp, cfg, P, xy, dem, B, N, M = wide_slots_setup("k63")
+    model = _wide_model(mp, P).train()
+    env = CVRPEnv(multi_width=M, device=DEV)
+    opt = Adam(model.parameters(), lr=1e-3, weight_decay=1e-6)
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    torch.manual_seed(0)
+    J, rew = train_step(model, env, opt, generate_vrp_data(3, N, {"data_type": "uniform"}))
+    assert torch.isfinite(J).item()
+    assert all(float((v.detach() - before[k]).abs().max()) > 0 for k, v in model.named_parameters() if k.startswith("decoder.local_policies."))

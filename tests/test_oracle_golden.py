@@ -434,6 +434,53 @@ def test_oracle_ensemble_of_local_policies(tag):
         assert np.abs(got - ref).max() <= 1e-3 * max(np.abs(ref).max(), 1e-6), n
 
 
+def wide_slots_setup(tag, dtype=torch.float32, requires_grad=False):
+    """The r06_cvrp_wide_slots.npz configuration `tag` (tools/make_golden_r06.py): local_size 50 (k50) / 63 (k63) on CVRP-100."""
+    fx = gu.load_golden("r06_cvrp_wide_slots.npz")
+    B, N, M, wseed, pseed = [int(x) for x in fx["meta"]]
+    mp = dict(gu.CVRP_MODEL_PARAMS)
+    mp["local_size"] = [int(tag[1:])]
+    cfg = orc.ModelCfg.from_model_params(mp, "cvrp")
+    P = _weights("cvrp", wseed, mp, float(fx["gain"]), dtype)
+    if requires_grad:
+        P = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    depot, loc, demand = gu.golden_cvrp_problem(pseed, B, N, 50.0)
+    xy = torch.from_numpy(np.concatenate([depot, loc], 1)).to(dtype)
+    dem = torch.from_numpy(np.concatenate([np.zeros((B, 1), np.float32), demand], 1)).to(dtype)
+    return fx, mp, cfg, P, xy, dem, B, N, M
+
+
+@pytest.mark.parametrize("tag", ["k50", "k63"])
+def test_oracle_local_size_above_47(tag):
+    """local_size 50 / 63 (the reference takes any K: models.py:8-36, 55-120): local-policy output, score before the clip and logits
+    at teacher-forced steps of the reference's own greedy tours (early steps with all K neighbours, late ones with K_eff < K), the
+    greedy choices, then the gradients of one REINFORCE step on the reference's sampled tours."""
+    fx, mp, cfg, P, xy, dem, B, N, M = wide_slots_setup(tag)
+    acts = torch.from_numpy(fx[f"{tag}_greedy_actions"].astype(np.int64))
+    out = orc.rollout_cvrp(P, cfg, xy, dem, M, starts=acts[0, :, 1], forced=acts, keep_parts=True, keep_probs=True)
+    for i, t in enumerate(fx[f"{tag}_steps"]):
+        parts = out["parts"][int(t) - 2]
+        open_ = np.isfinite(fx[f"{tag}_logits"][i])
+        s = parts["s"].numpy()
+        for k, g in {"pre_clip": s, "local": parts["u"].numpy(), "logits": cfg.logit_clipping * np.tanh(s)}.items():
+            e = logit_errors(g, fx[f"{tag}_{k}"][i], open_, cfg.logit_clipping if k == "logits" else None)
+            assert e <= LOGIT_RTOL, (k, int(t), e)
+    agree = np.mean([(p.argmax(-1) == acts[:, :, i + 2]).float().mean().item() for i, p in enumerate(out["full_probs"])])
+    assert agree == 1.0
+    np.testing.assert_allclose(out["reward"].numpy(), fx[f"{tag}_greedy_reward"], rtol=1e-5)
+    fx, mp, cfg, P, xy, dem, B, N, M = wide_slots_setup(tag, torch.float64, requires_grad=True)
+    sacts = torch.from_numpy(fx[f"{tag}_sample_actions"].astype(np.int64))
+    out = orc.rollout_cvrp(P, cfg, xy, dem, M, starts=sacts[0, :, 1], forced=sacts)
+    np.testing.assert_allclose(out["probs"].detach().numpy(), fx[f"{tag}_sample_probs"], rtol=2e-4, atol=1e-7)
+    J = orc.pomo_loss(out["probs"], torch.from_numpy(fx[f"{tag}_sample_reward"]).double())
+    assert abs(J.item() - float(fx[f"{tag}_loss"])) <= 1e-4 * max(1.0, abs(float(fx[f"{tag}_loss"])))
+    J.backward()
+    for n in [k[len(f"{tag}_grad_"):] for k in fx.files if k.startswith(f"{tag}_grad_")]:
+        ref = fx[f"{tag}_grad_{n}"]
+        got = P[n].grad.numpy()
+        assert np.abs(got - ref).max() <= 1e-3 * max(np.abs(ref).max(), 1e-6), n
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # the folded decode and the bf16 restatement (round 5): the oracle of the engine's bf16 throughput mode
 # ---------------------------------------------------------------------------------------------------------------------
