@@ -143,8 +143,13 @@ def cpu_baseline(cfg, mean_T, state0, replay, budget_s=150.0):
                 times.append(time.perf_counter() - t0)
                 T_seen.append(int(out["actions"].shape[2]))      # the longest trajectory of the batch (the loop's length)
         dt = sum(times) / len(times)
+        # a whole step's time follows the longest trajectory of its batch (random-init tours: 120 ... 180 decode steps), so the
+        # three steps differ by tens of per cent; per decode step of the loop they agree -- reported beside the step rate
+        per_dec = [t / max(T, 1) for t, T in zip(times, T_seen)]
         full = {"inst_per_s": round(LOCAL_BATCH / dt, 4), "seconds_per_step": [round(t, 2) for t in times], "batch": LOCAL_BATCH,
-                "warmup_steps": 1, "timed_steps": n_timed, "decode_steps_longest_trajectory": T_seen, "threads": best}
+                "warmup_steps": 1, "timed_steps": n_timed, "decode_steps_longest_trajectory": T_seen, "threads": best,
+                "seconds_per_decode_step": [round(x, 4) for x in per_dec],
+                "trajectory_steps_per_s": round(LOCAL_BATCH * POMO * sum(T_seen) / sum(times), 1)}
     value = full["inst_per_s"] if full else sweep[best]["inst_per_s"]
     what = (f"value = mean of {n_timed} whole training steps (after 1 warm-up) at batch={LOCAL_BATCH} pomo={POMO}, {best} threads"
             if full else "value = the sampled estimate (whole steps did not fit the time budget)")
@@ -152,6 +157,9 @@ def cpu_baseline(cfg, mean_T, state0, replay, budget_s=150.0):
             "sampled_estimate": sweep[best]["inst_per_s"],
             "value_1thread": sweep.get(1, {}).get("inst_per_s"), "cpu_model": _cpu_model(), "host_cpus": ncpu,
             "thread_sweep": sweep,
+            # per decode step (forward + backward through the tape, encoder excluded), at the best thread count of the sweep
+            "per_decode_step": {"batch": Bc, "seconds": sweep[best]["decode_step_s"],
+                                "trajectory_steps_per_s": round(Bc * POMO / max(sweep[best]["decode_step_s"], 1e-9), 1)},
             "weights": "the GPU leg's initial state_dict", "inputs": f"the GPU leg's first {len(replay)} batches (same generator seed)",
             "sample": f"oracle/elg_oracle.py, CVRP-100 fp32. {what}; thread sweep at batch={Bc}: encoder+set_kv fwd+bwd and {S} "
                       f"teacher-forced decode steps fwd+bwd per thread count (1 warm-up), estimate = {Bc} / (t_encoder + "

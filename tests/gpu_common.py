@@ -155,10 +155,10 @@ def assert_same_mask(got, ref, what=""):
 
 
 def record_parity(name: str, value: float):
-    """Keep the worst observed error of a parity test: merged into gpurun_out/parity_r05.json (copied to profiles/)."""
+    """Keep the worst observed error of a parity test: merged into gpurun_out/parity_r06.json (copied to profiles/)."""
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r05.json")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r06.json")
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         cur = json.load(open(path)) if os.path.exists(path) else {}

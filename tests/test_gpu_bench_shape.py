@@ -7,7 +7,7 @@
 * the bench launch geometry (64 instances x pomo 100 -> tiles = 4, 256 workgroups of 25 lockstep trajectories) diffed against
   the oracle's probabilities on two of its instances.
 
-Worst observed values go to gpurun_out/parity_r05.json (copied to profiles/)."""
+Worst observed values go to gpurun_out/parity_r06.json (copied to profiles/)."""
 import random
 
 import numpy as np
