@@ -13,7 +13,7 @@ ELG_OK, ELG_EINVAL, ELG_ELAUNCH, ELG_ENOTIMPL = 0, -1, -2, -3
 PROBLEM_CVRP, PROBLEM_TSP = 0, 1
 MODE_GREEDY, MODE_SAMPLE, MODE_FORCED = 0, 1, 2
 # elg_rollout_last_kernel(): which construction kernel the last elg_rollout_fwd of this thread launched (include/elg_hip.h)
-KERNEL_WAVE, KERNEL_COOP, KERNEL_COOP_SPLIT, KERNEL_STREAM, KERNEL_XL, KERNEL_XM = 1, 2, 3, 4, 5, 6
+KERNEL_WAVE, KERNEL_COOP, KERNEL_COOP_SPLIT, KERNEL_STREAM, KERNEL_XL, KERNEL_XM, KERNEL_COOP_WIDE = 1, 2, 3, 4, 5, 6, 7
 
 LOC_ROWS = 64
 LOC_LA, LOC_LT, LOC_LAV, LOC_LCV, LOC_LWC, LOC_LBC, LOC_LWE, LOC_LPE, LOC_SIZE = \

@@ -16,7 +16,7 @@ int fail(int code, const std::string& msg);
 int launch_status(const char* what);
 void note_kernel(int id);        // which construction kernel the calling thread launched last (elg_rollout_last_kernel)
 // the cooperative rollout (csrc/elg_fwd_coop.hip): tsp / train select the instantiation, A.precision the arithmetic
-int launch_fwd_coop_any(const elg_rollout_args& A, hipStream_t stream, bool tsp, bool train, bool split);
+int launch_fwd_coop_any(const elg_rollout_args& A, hipStream_t stream, bool tsp, bool train, int split);
 
 // In-kernel phase clock of the cooperative kernel: only in the diagnostic build (-DELG_STAMPS, tools/stamp_coop.py); the
 // shipped library executes no stamp.  Segment sums leave through elg_rollout_args.scratch (unused at this size).

@@ -2541,14 +2541,14 @@ static int dispatch_fwd(const elg_rollout_args& A, hipStream_t stream) {
         ELG_GO(16, false, 8);
     }
     if (A.lds_stage && A.waves == 8 && A.N1 >= 4 && A.N1 <= 16 * CO_NT && !A.use_state && A.do_decode && A.do_update &&
-        A.max_steps <= 0 && (A.variant == 0 || A.variant == 4) && !wide) {
+        A.max_steps <= 0 && (A.variant == 0 || A.variant == 4 || A.variant == 5) && !wide) {
         // fused rollout at the training scale: lockstep trajectories, tables as MFMA operands in registers (variant 4: the
         // split-group form of the same kernel, two independent 4-wave groups per workgroup -- same results bit for bit)
         const bool train = A.trA || A.trMask;      // training forward (glimpse weights saved, or recomputed from the mask rows)
         if (train && (!A.trPC || !A.trCsel || !A.trQ || !A.trO)) return fail(ELG_EINVAL, "rollout: incomplete training rows");
-        return launch_fwd_coop_any(A, stream, TSP, train, A.variant == 4);
+        return launch_fwd_coop_any(A, stream, TSP, train, A.variant == 4 ? 1 : A.variant == 5 ? 2 : 0);
     }
-    if (A.variant == 4) return fail(ELG_EINVAL, "rollout: variant 4 (split-group cooperative kernel) needs lds_stage, 4 <= N1 <= 112, a fused rollout");
+    if (A.variant == 4 || A.variant == 5) return fail(ELG_EINVAL, "rollout: variants 4 / 5 (split-group cooperative kernels) need lds_stage, 4 <= N1 <= 112, a fused rollout");
     // variants 2 / 3 name a kernel, whatever the size (the tests' A/B references): checked before the shape dispatch
     if ((A.variant == 2 || A.variant == 3) && !A.use_state && A.do_decode && A.do_update && A.max_steps <= 0) {
         if (A.trA || A.trMask) return fail(ELG_ENOTIMPL, "rollout: training rows for N1 > 1024 not built");

@@ -964,12 +964,363 @@ static int launch_fwd_coop2(const elg_rollout_args& A, hipStream_t stream, int s
     return lean ? launch_fwd_coop2_l<TSP, TRAIN, BF, true>(A, stream, stagger) : launch_fwd_coop2_l<TSP, TRAIN, BF, false>(A, stream, stagger);
 }
 
-int launch_fwd_coop_any(const elg_rollout_args& A, hipStream_t stream, bool tsp, bool train, bool split) {
+// =============================================================================================
+// Split-group kernel at FOUR waves per SIMD (round 6, `variant = 5`): 16 waves per workgroup = two independent groups of EIGHT.
+// The owners' phase needs 81 VGPRs, so once the matrix phases fit 128 registers the whole kernel runs at four waves per SIMD:
+// in a group, wave wg = head wg for the group's ONE tile of <= 16 trajectories (62 f32 MFMAs per wave and step -- one
+// 28-register K image, V streamed in while the scores form), waves 0-6 one node tile of the pointer each, wave 7 the local tail,
+// waves 4-7 the four local head units (after their glimpse unit: registers reused), waves 0-3 the owners' phase of four
+// trajectories each.  Group barriers through LDS arrival counters as in rollout_fwd_coop2_kernel; same arithmetic, same results.
+// =============================================================================================
+__device__ __forceinline__ void grp8_barrier(unsigned* cnt, unsigned& target, int lane) {
+    target += 8u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (;;) {
+        const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if ((int)(v - target) >= 0) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <bool TSP, bool TRAIN, bool BF, bool LEAN>
+__global__ __launch_bounds__(1024) void rollout_fwd_coop3_kernel(const elg_rollout_args A, const int stagger) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 3, wg = wave & 7;
+    const int lo = lane & 15, hi = lane >> 4;
+    const int N1 = A.N1;
+    const int G = gridDim.x;
+    int u = blockIdx.x;
+    if ((G & 7) == 0) u = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int b = u / A.tiles, tile = u % A.tiles;
+    const int tile_m = (A.M + A.tiles - 1) / A.tiles;
+    const int m_lo = tile * tile_m, m_hi = min(A.M, m_lo + tile_m);
+    const size_t NE = (size_t)N1 * ELG_E;
+    const size_t Rcap = (size_t)A.Tmax * A.M;
+
+    float* sQ = lds;
+    float* sSc = sQ + CO_MAXTR * CO_QP;
+    unsigned long long* sMask = reinterpret_cast<unsigned long long*>(sSc + CO_MAXTR * CO_SP);
+    int* sState = reinterpret_cast<int*>(sMask + 2 * CO_MAXTR);
+    float* sdem = reinterpret_cast<float*>(sState + 16 * CO_MAXTR);
+    float* sxy = sdem + ((N1 + 3) & ~3);
+    float* sX = sxy + ((2 * N1 + 3) & ~3);
+    float* sT = sX + CO_MAXTR * CO_XP;
+    float* sP = sT + CL_SIZE;
+    float* sPb = sP + CO_NT * 32 * 64;
+    float* sO1 = sPb + 16 * CO_NT;                                     // [2 groups][2][64][4]
+    unsigned* sSync = reinterpret_cast<unsigned*>(sO1 + 2 * 512);      // [2 groups][32]: arrival counter | 2 x 8 "any left" words
+    if (!TSP)
+        for (int i = tid; i < N1; i += 1024) sdem[i] = A.demand[(size_t)b * N1 + i];
+    for (int i = tid; i < 2 * N1; i += 1024) sxy[i] = A.xy[(size_t)b * N1 * 2 + i];
+    if (LEAN || A.has_local) co_stage_local(A.loc, sT, tid, 1024);
+    if (tid < 64) sSync[tid] = 0u;
+
+    Inst I;
+    I.K = nullptr; I.V = nullptr; I.PK = nullptr;
+    I.pb = A.pb + (size_t)b * N1;
+    I.Q1 = A.Q1 + b * NE;
+    I.Q2 = TSP ? A.Q2 + b * NE : nullptr;
+    I.wl = A.wl;
+    I.xy = sxy;
+    I.dem = sdem;
+    I.nidx = A.nbr_idx + (size_t)b * N1 * N1;
+    I.ndist = A.nbr_dist + (size_t)b * N1 * N1;
+    I.ntheta = A.nbr_theta + (size_t)b * N1 * N1;
+    I.loc = A.loc;
+
+    const float* gK = A.Kmat + b * NE;
+    const float* gV = A.Vmat + b * NE;
+    {
+        // PK operand image in LDS, shared by both groups (rollout_fwd_coop_kernel's layout); waves 0-6 of group 0 write it
+        const int np = 16 * wave + lo;
+        const float* gP = A.PK + b * NE + (size_t)min(np, N1 - 1) * ELG_E;
+        if (!BF && wave < CO_NT)
+            for (int g = 0; g < 8; ++g) {
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (np < N1) x = *reinterpret_cast<const float4*>(gP + 16 * g + 4 * hi);
+                *reinterpret_cast<float4*>(sP + ((wave * 8 + g) * 64 + lane) * 4) = x;
+            }
+        if (BF && wave < CO_NT)
+            for (int g = 0; g < 4; ++g) {
+                uint4 x = make_uint4(0u, 0u, 0u, 0u);
+                if (np < N1) {
+                    const float4 a = *reinterpret_cast<const float4*>(gP + 32 * g + 8 * hi);
+                    const float4 c = *reinterpret_cast<const float4*>(gP + 32 * g + 8 * hi + 4);
+                    x = make_uint4(pk_bf16(a.x, a.y), pk_bf16(a.z, a.w), pk_bf16(c.x, c.y), pk_bf16(c.z, c.w));
+                }
+                *reinterpret_cast<uint4*>(sP + ((wave * 4 + g) * 64 + lane) * 4) = x;
+            }
+    }
+    for (int i = tid; i < 16 * CO_NT; i += 1024) sPb[i] = (i < N1) ? I.pb[i] : 0.f;
+    __syncthreads();                                                   // the only workgroup barrier of the launch
+
+    unsigned* gcnt = sSync + 32 * grp;
+    unsigned* gany = sSync + 32 * grp + 8;                             // [2 parities][8 waves]
+    unsigned bar_target = 0u, or_epoch = 0u;
+    if (grp == 1)
+        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(64);
+
+    const int n_my = m_hi - m_lo;
+    const int n_tiles = (n_my + 15) / 16;
+    const int t_size = n_tiles > 0 ? (n_my + n_tiles - 1) / n_tiles : 16;
+    const bool owner = wg < 4;                                          // waves 0-3 of a group own four trajectories each
+    const int ow = 4 * grp + wg;                                        // the owners' "wave" index: slots 4 ow .. 4 ow + 3
+    for (int ti = grp; ti < n_tiles; ti += 2) {
+        const int g_lo_real = m_lo + ti * t_size;
+        const int nreal = min(t_size, m_hi - g_lo_real);
+        const int ntraj = 16 * grp + nreal;
+        const int g_lo = g_lo_real - 16 * grp;
+        for (int q = 16 * grp + wg; q < 16 * grp + 16; q += 8) {
+            Traj<2> st;
+            st.cur = 0; st.first = 0; st.cnt = 0; st.fin = (q < ntraj) ? 0 : 1; st.load = 1.0f; st.len = 0.f;
+            st.cx = 0.f; st.cy = 0.f; st.vis[0] = 0ull; st.vis[1] = 0ull;
+            co_store_state<TSP>(sState + 16 * q, st, lane);
+            if (lane == 0) { sMask[2 * q] = ~0ull; sMask[2 * q + 1] = ~0ull; }
+            if (lane < 33) *reinterpret_cast<float4*>(sQ + q * CO_QP + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = lane; i < CO_XP; i += 64) sX[q * CO_XP + i] = (i >= CO_XS && i < CO_XPEN) ? i2f(-1) : 0.f;
+        }
+        grp8_barrier(gcnt, bar_target, lane);
+        const int step_cap = TSP ? N1 : 2 * N1 + 2;
+        CoRow row;
+        float ubuf = 0.f;
+        row.cur = 0; row.first = 0; row.cnt = 0; row.fin = (owner && 4 * ow + (lane >> 4) < ntraj) ? 0 : 1;
+        row.load = 1.0f; row.len = 0.f; row.cx = 0.f; row.cy = 0.f; row.v0 = 0ull; row.v1 = 0ull;
+        StampCtx sc;
+#ifdef ELG_STAMPS
+        for (int i = 0; i < 16; ++i) sc.acc[i] = 0.f;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sc.last) :: "memory");
+#endif
+        float kA[CO_NT][4];                                          // K image of head wg, (re)loaded at the end of the step
+        u32x4 kAb[CO_NT];
+#pragma unroll
+        for (int nt = 0; nt < CO_NT; ++nt) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) kA[nt][v] = 0.f;
+            kAb[nt] = u32x4{0u, 0u, 0u, 0u};
+        }
+        for (int t = 0; t < step_cap && t < A.Tmax; ++t) {
+            int lane_t = lane;
+            asm volatile("" : "+v"(lane_t));
+            const int lo_t = lane_t & 15, hi_t = lane_t >> 4;
+            const bool decode_step = TSP ? (t >= 1) : (t >= 2);
+            ELG_STAMP(sc, 15);
+            if (decode_step) {
+                // =============== glimpse: wave wg = head wg of the group's tile ===============
+                {
+                    const float cs = 0.25f * 1.4426950408889634f;
+                    const int traj = 16 * grp + lo_t;
+                    const float4 q4 = *reinterpret_cast<const float4*>(sQ + traj * CO_QP + 16 * wg + 4 * hi_t);
+                    const float qb[4] = {q4.x, q4.y, q4.z, q4.w};
+                    const u32x4 qbb = {pk_bf16(q4.x, q4.y), pk_bf16(q4.z, q4.w), 0u, 0u};
+                    float vA[CO_NT][4];
+                    u32x4 vAb[4];
+                    if (BF) { ELG_C2_LOAD_V_BF(vAb, wg) } else { ELG_C2_LOAD_V(vA, wg) }
+                    f32x4c scr[CO_NT];
+                    float mx = -1e30f, den = 0.f;
+#pragma unroll
+                    for (int nt = 0; nt < CO_NT; ++nt) {
+                        const float4 m4 = *reinterpret_cast<const float4*>(sSc + traj * CO_SP + 16 * nt + 4 * hi_t);
+                        f32x4c acc = {m4.x, m4.y, m4.z, m4.w};
+                        if (BF) acc = mfma_bf(kAb[nt], qbb, acc);
+                        else {
+#pragma unroll
+                            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kA[nt][kk], qb[kk], acc, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) mx = fmaxf(mx, acc[v]);
+                        scr[nt] = acc;
+                    }
+                    mx = quarters_max(mx);
+                    const float cm = -mx * cs;
+#pragma unroll
+                    for (int nt = 0; nt < CO_NT; ++nt)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const float e = __builtin_amdgcn_exp2f(fmaf(scr[nt][v], cs, cm));
+                            scr[nt][v] = e;
+                            den += e;
+                        }
+                    f32x4c o = {0.f, 0.f, 0.f, 0.f}, o2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int nt = 0; nt < CO_NT; ++nt) {
+                        if (BF) {
+                            if (nt & 1) {
+                                const u32x4 pb_ = {pk_bf16(scr[nt - 1][0], scr[nt - 1][1]), pk_bf16(scr[nt - 1][2], scr[nt - 1][3]),
+                                                   pk_bf16(scr[nt][0], scr[nt][1]), pk_bf16(scr[nt][2], scr[nt][3])};
+                                if (nt & 2) o2 = mfma_bf(vAb[nt >> 1], pb_, o2);
+                                else o = mfma_bf(vAb[nt >> 1], pb_, o);
+                            } else if (nt == CO_NT - 1) {
+                                const u32x4 pb_ = {pk_bf16(scr[nt][0], scr[nt][1]), pk_bf16(scr[nt][2], scr[nt][3]), 0u, 0u};
+                                o2 = mfma_bf(vAb[nt >> 1], pb_, o2);
+                            }
+                        } else {
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                if (v & 1) o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vA[nt][v], scr[nt][v], o2, 0, 0, 0);
+                                else o = __builtin_amdgcn_mfma_f32_16x16x4f32(vA[nt][v], scr[nt][v], o, 0, 0, 0);
+                            }
+                        }
+                    }
+                    const size_t r = (size_t)t * A.M + g_lo + traj;
+                    const float dn = quarters_sum(den);
+                    const bool live = dn > 0.f;
+                    if (TRAIN && (LEAN || A.trLse) && hi_t == 0 && live)
+                        A.trLse[((size_t)b * Rcap + r) * ELG_H + wg] = __log2f(dn) - cm;
+                    const float inv = live ? 1.0f / dn : 0.f;
+                    if (TRAIN && live && !LEAN && A.trA) {
+#pragma unroll
+                        for (int nt = 0; nt < CO_NT; ++nt) {
+                            float* rA = A.trA + (((size_t)b * ELG_H + wg) * Rcap + r) * N1 + 16 * nt + 4 * hi_t;
+#pragma unroll
+                            for (int v = 0; v < 4; ++v)
+                                if (16 * nt + 4 * hi_t + v < N1) rA[v] = scr[nt][v] * inv;
+                        }
+                    }
+                    const float4 ov = make_float4((o[0] + o2[0]) * inv, (o[1] + o2[1]) * inv, (o[2] + o2[2]) * inv, (o[3] + o2[3]) * inv);
+                    *reinterpret_cast<float4*>(sQ + traj * CO_QP + 16 * wg + 4 * hi_t) = ov;
+                    if (TRAIN && live && !(ELG_EXP_SKIP & 4)) *reinterpret_cast<float4*>(A.trO + ((size_t)b * Rcap + r) * ELG_E + 16 * wg + 4 * hi_t) = ov;
+                }
+                // local policy, stage 1: the group's four head units on waves 4-7 (which carry no trajectories), after their glimpse unit
+                if ((LEAN || A.has_local) && wg >= 4) co_local_head_call(sT, sX + grp * 16 * CO_XP, sO1 + grp * 512, wg - 4, lo_t, hi_t);
+                ELG_STAMP(sc, 0);
+                grp8_barrier(gcnt, bar_target, lane);
+                ELG_STAMP(sc, 1);
+                // =============== pointer (waves 0-6: node tile wg) || local tail (wave 7) ===============
+                if (wg < CO_NT) {
+                    const int nt = wg;
+                    const int traj = 16 * grp + lo_t;
+                    if (BF) {
+                        const float* orow8 = sQ + traj * CO_QP + 8 * hi_t;
+                        const unsigned* popb = reinterpret_cast<const unsigned*>(sP) + (nt * 4 * 64 + lane_t) * 4;
+                        const float4 pb4b = *reinterpret_cast<const float4*>(sPb + 16 * nt + 4 * hi_t);
+                        f32x4c b0 = {pb4b.x, pb4b.y, pb4b.z, pb4b.w}, b1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const uint4 pk8 = *reinterpret_cast<const uint4*>(popb + g * 256);
+                            const float4 oa = *reinterpret_cast<const float4*>(orow8 + 32 * g);
+                            const float4 oc = *reinterpret_cast<const float4*>(orow8 + 32 * g + 4);
+                            const u32x4 ob_ = {pk_bf16(oa.x, oa.y), pk_bf16(oa.z, oa.w), pk_bf16(oc.x, oc.y), pk_bf16(oc.z, oc.w)};
+                            if (g & 1) b1 = mfma_bf(u32x4{pk8.x, pk8.y, pk8.z, pk8.w}, ob_, b1);
+                            else b0 = mfma_bf(u32x4{pk8.x, pk8.y, pk8.z, pk8.w}, ob_, b0);
+                        }
+                        *reinterpret_cast<float4*>(sSc + traj * CO_SP + 16 * nt + 4 * hi_t) =
+                            make_float4(b0[0] + b1[0], b0[1] + b1[1], b0[2] + b1[2], b0[3] + b1[3]);
+                    } else {
+                        const float* orow = sQ + traj * CO_QP + 4 * hi_t;
+                        const float* pop = sP + (nt * 8 * 64 + lane_t) * 4;
+                        const float4 pb4 = *reinterpret_cast<const float4*>(sPb + 16 * nt + 4 * hi_t);
+                        f32x4c a0 = {pb4.x, pb4.y, pb4.z, pb4.w}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int g = 0; g < 8; ++g) {
+                            const float4 pk4 = *reinterpret_cast<const float4*>(pop + g * 256);
+                            const float4 ov = *reinterpret_cast<const float4*>(orow + 16 * g);
+                            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pk4.x, ov.x, a0, 0, 0, 0);
+                            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pk4.y, ov.y, a1, 0, 0, 0);
+                            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pk4.z, ov.z, a0, 0, 0, 0);
+                            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pk4.w, ov.w, a1, 0, 0, 0);
+                        }
+                        *reinterpret_cast<float4*>(sSc + traj * CO_SP + 16 * nt + 4 * hi_t) =
+                            make_float4(a0[0] + a1[0], a0[1] + a1[1], a0[2] + a1[2], a0[3] + a1[3]);
+                    }
+                } else if (LEAN || A.has_local) {
+                    co_local_tail_call(sT, sX + grp * 16 * CO_XP, sO1 + grp * 512, lo_t, hi_t);
+                }
+                ELG_STAMP(sc, 2);
+                grp8_barrier(gcnt, bar_target, lane);
+                ELG_STAMP(sc, 3);
+            }
+            // =============== owners (waves 0-3 of the group): rollout_fwd_coop_kernel's, unchanged ===============
+            int any_left = 0;
+            if (owner) {
+                const int q4 = 4 * ow + (lane_t >> 4);
+                const int m4 = g_lo + min(q4, ntraj - 1);
+                const size_t bm4 = (size_t)b * A.M + m4;
+                const bool active = q4 < ntraj && !row.fin;
+                int sel = 0;
+                float pr = 1.0f;
+                if (decode_step) {
+                    co_finish4<TSP, TRAIN, LEAN>(A, N1, lane_t, ow, ntraj, t, g_lo, (size_t)b, Rcap, sSc, sMask, sX, sState,
+                                           q4 < ntraj ? row.fin : 1, sel, pr, ubuf, sc);
+                } else if (!LEAN && A.mode == ELG_MODE_FORCED) {
+                    sel = (A.forced && t < A.Tforced) ? A.forced[bm4 * A.Tforced + t] : 0;
+                } else {
+                    sel = (!TSP && t == 0) ? 0 : A.starts[m4];
+                }
+                if (active && (lane_t & 15) == 0) {
+                    if (LEAN || A.actions) A.actions[bm4 * A.Tmax + t] = sel;
+                    if (LEAN || A.probs) A.probs[((size_t)b * A.Tmax + t) * A.M + m4] = pr;
+                }
+                co_advance4<TSP, TRAIN, LEAN>(A, I, N1, lane_t, ow, ntraj, t, g_lo, (size_t)b, Rcap, row, sel, active, sMask, sQ, sX, sSc, sc);
+                any_left = (q4 < ntraj && !row.fin) ? 1 : 0;
+            }
+            ELG_STAMP(sc, 11);
+            if (BF) { ELG_C2_LOAD_K_BF(kAb, wg) } else { ELG_C2_LOAD_K(kA, wg) }
+            ELG_STAMP(sc, 12);
+            const unsigned wany = __ballot(any_left) != 0ull ? 1u : 0u;
+            unsigned* slot = gany + 8 * (or_epoch & 1u);
+            if (lane == 0) __hip_atomic_store(slot + wg, wany, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            grp8_barrier(gcnt, bar_target, lane);
+            const uint4 a4 = *reinterpret_cast<const uint4*>(slot);          // (only the owner waves 0-3 can have anything left)
+            or_epoch += 1u;
+            ELG_STAMP(sc, 13);
+            if (!__builtin_amdgcn_readfirstlane((int)(a4.x | a4.y | a4.z | a4.w))) break;
+        }
+#ifdef ELG_STAMPS
+        if (A.scratch && lane == 0 && wg < 4)
+            for (int i = 0; i < 16; ++i) A.scratch[((size_t)blockIdx.x * 8 + ow) * 16 + i] = sc.acc[i];
+#endif
+        if (owner) {
+            const int q4 = 4 * ow + (lane >> 4);
+            if (q4 < ntraj && (lane & 15) == 0) {
+                const size_t bm = (size_t)b * A.M + g_lo + q4;
+                if (A.reward) A.reward[bm] = -row.len;
+                if (A.tlen) A.tlen[bm] = row.cnt;
+            }
+        }
+        grp8_barrier(gcnt, bar_target, lane);
+    }
+}
+
+template <bool TSP, bool TRAIN, bool BF, bool LEAN>
+static int launch_fwd_coop3_l(const elg_rollout_args& A, hipStream_t stream, int stagger) {
+    const size_t lds = ((size_t)CO_MAXTR * CO_QP + (size_t)CO_MAXTR * CO_SP + 4 * CO_MAXTR + 16 * CO_MAXTR +
+                        ((A.N1 + 3) & ~3) + ((2 * A.N1 + 3) & ~3) + (size_t)CO_MAXTR * CO_XP + CL_SIZE + CO_NT * 32 * 64 + 16 * CO_NT +
+                        2 * 512 + 64) * 4 + 64;
+    auto kern = rollout_fwd_coop3_kernel<TSP, TRAIN, BF, LEAN>;
+    static DynLds optin;
+    if (!optin.opt_in(reinterpret_cast<const void*>(kern), lds)) return fail(ELG_ELAUNCH, "coop rollout: hipFuncSetAttribute failed");
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3(A.B * A.tiles), dim3(1024), lds, stream, A, stagger);
+    return launch_status("rollout_fwd_coop3");
+}
+template <bool TSP, bool TRAIN, bool BF>
+static int launch_fwd_coop3(const elg_rollout_args& A, hipStream_t stream, int stagger) {
+    const bool lean = A.mode != ELG_MODE_FORCED && !A.forced && !A.uniforms && !A.full_probs && A.has_local && A.has_penalty &&
+                      !A.euclidean && A.actions && A.probs &&
+                      (!TRAIN || (!A.trA && A.trMask && A.trLse && A.trSlot && A.trF && (TSP || A.trLoad)));
+    return lean ? launch_fwd_coop3_l<TSP, TRAIN, BF, true>(A, stream, stagger) : launch_fwd_coop3_l<TSP, TRAIN, BF, false>(A, stream, stagger);
+}
+
+int launch_fwd_coop_any(const elg_rollout_args& A, hipStream_t stream, bool tsp, bool train, int split) {
     // split: the split-group kernel (elg_rollout_args.variant = 4; ELG_COOP_KERNEL=split makes it what variant 0 runs, for A/B
     // timing of whole steps; ELG_COOP_STAGGER = group 1's start delay in units of s_sleep 64).  Same results bit for bit.
-    static const bool env_split = [] { const char* e = getenv("ELG_COOP_KERNEL"); return e && e[0] == 's'; }();
+    static const int env_split = [] { const char* e = getenv("ELG_COOP_KERNEL"); return (e && e[0] == 's') ? 1 : (e && e[0] == 'w') ? 2 : 0; }();
     static const int stagger = [] { const char* e = getenv("ELG_COOP_STAGGER"); return e ? atoi(e) : 3; }();
-    if (split || env_split) {
+    if (split == 0) split = env_split;
+    if (split == 2) {                           // ELG_COOP_KERNEL=wide / variant 5: two groups of eight waves, four waves per SIMD
+        note_kernel(ELG_KERNEL_COOP_WIDE);
+        if (A.precision == 1) {
+            if (tsp) return train ? launch_fwd_coop3<true, true, true>(A, stream, stagger) : launch_fwd_coop3<true, false, true>(A, stream, stagger);
+            return train ? launch_fwd_coop3<false, true, true>(A, stream, stagger) : launch_fwd_coop3<false, false, true>(A, stream, stagger);
+        }
+        if (tsp) return train ? launch_fwd_coop3<true, true, false>(A, stream, stagger) : launch_fwd_coop3<true, false, false>(A, stream, stagger);
+        return train ? launch_fwd_coop3<false, true, false>(A, stream, stagger) : launch_fwd_coop3<false, false, false>(A, stream, stagger);
+    }
+    if (split == 1) {
         note_kernel(ELG_KERNEL_COOP_SPLIT);
         if (A.precision == 1) {
             if (tsp) return train ? launch_fwd_coop2<true, true, true>(A, stream, stagger) : launch_fwd_coop2<true, false, true>(A, stream, stagger);

@@ -670,13 +670,13 @@ def rollout_forward(prob: Problem, pol: Policy, M: int, starts: torch.Tensor, mo
         rows = TrainRows.get(B, M, N1, Tcap, dev)
         rows.prepare()
         # (only the cooperative kernel has a bf16 mode: every other kernel computes -- and is differentiated -- in f32)
-        rows.precision = int(a.precision) if (a.lds_stage and 4 <= N1 <= 112 and variant in (0, 4)) else 0
+        rows.precision = int(a.precision) if (a.lds_stage and 4 <= N1 <= 112 and variant in (0, 4, 5)) else 0
         # the cooperative kernel (what dispatch_fwd picks for this launch shape) saves the rows' 128-bit mask words and the
         # glimpse log2-sum-exp per head instead of the glimpse weights: the backward recomputes the weights from q, K, the
         # mask and the saved normaliser (28 MFMAs + one exp2 per weight).  4.2 GB less workspace and 6.6 GB less HBM traffic
         # per step at the bench shape, and no slower (the forward's 3.3 GB of scattered stores cost what the recompute does)
         # The streaming kernel (128 < N1 <= 1024) saves the same rows with W = 4 / 8 / 16 mask words.
-        rows.use_mask = bool((a.lds_stage and a.waves == 8 and 4 <= N1 <= 112 and variant in (0, 4)) or N1 > 128)
+        rows.use_mask = bool((a.lds_stage and a.waves == 8 and 4 <= N1 <= 112 and variant in (0, 4, 5)) or N1 > 128)
         a.trA = None if rows.use_mask else _ptr(rows.A)
         a.trMask = _ptr(rows.Mask) if rows.use_mask else None
         a.trLse = _ptr(rows.Lse) if rows.use_mask else None

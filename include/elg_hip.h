@@ -94,7 +94,8 @@ typedef struct elg_rollout_args {
                                picks for 1024 < N1 <= 8192: 16 lockstep trajectories per workgroup, K / V / PK streamed in
                                MFMA-fragment order, score rows in `scratch`) for any N1; 4: the split-group form of the
                                cooperative kernel (N1 <= 112: two independent 4-wave groups per workgroup, LDS-counter barriers;
-                               bit-identical results, measured 9 % slower: DESIGN 4.1)                                      */
+                               bit-identical results, measured 9 % slower: DESIGN 4.1); 5: the split-group form at four waves per
+                               SIMD (two groups of eight waves, 128 registers; bit-identical, 14 % slower: DESIGN 7)      */
     int32_t dump_logits;    /* what full_probs receives: 0 probabilities, 1 the clipped + masked logits
                                clip * tanh(s) (-inf at closed nodes), 2 the scores s before the clip            */
     int32_t euclidean;      /* model_params.euclidean: local-policy slot features (x, y) / norm relative to the current node
@@ -171,6 +172,7 @@ int elg_rollout_fwd(const elg_rollout_args* args, void* stream);
 #define ELG_KERNEL_STREAM 4      /* rollout_fwd_mt_kernel: 128 < N1 <= 1024, operands streamed from L2                         */
 #define ELG_KERNEL_XL 5          /* rollout_fwd_xl_kernel: one wavefront per trajectory, runtime node loops (variant 2)        */
 #define ELG_KERNEL_XM 6          /* rollout_fwd_xm_kernel: N1 > 1024 on the matrix cores (variant 3)                           */
+#define ELG_KERNEL_COOP_WIDE 7   /* rollout_fwd_coop3_kernel: two groups of eight waves, four waves per SIMD (variant 5)        */
 int elg_rollout_last_kernel(void);
 /* Floats of elg_rollout_args.scratch a fused rollout of this shape needs (0: none): the fragment-major K / V / PK copies the
    128 < N1 <= 1024 kernel streams its matrix-core operands from; for N1 > 1024 (or variant 3) the same copies over

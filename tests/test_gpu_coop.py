@@ -197,16 +197,19 @@ def test_split_group_kernel_is_bit_identical(kind, N, B, M, tiles):
             rows_ref = None
             if train:
                 rows_ref = {k: getattr(ref.rows, k).clone() for k in ("PC", "Csel", "Q", "O", "Lse", "Mask", "Slot", "F", "Load")}
-            got = eng.rollout_forward(prob, pol, M, starts, L.MODE_SAMPLE, seed=91, train=train, geometry=geom, precision=precision, variant=4)
-            assert got.kernel_id == L.KERNEL_COOP_SPLIT
-            assert torch.equal(ref.actions, got.actions) and torch.equal(ref.tlen, got.tlen)
-            assert torch.equal(ref.probs, got.probs) and torch.equal(ref.reward, got.reward)
-            if train:
-                live = int(got.tlen.max()) * M
-                for k, v in rows_ref.items():
-                    if k == "Load" and kind == "tsp":
-                        continue
-                    assert torch.equal(v[:, :live], getattr(got.rows, k)[:, :live]), (k, precision)
+            for variant, kid in ((4, L.KERNEL_COOP_SPLIT), (5, L.KERNEL_COOP_WIDE)):
+                got = eng.rollout_forward(prob, pol, M, starts, L.MODE_SAMPLE, seed=91, train=train, geometry=geom, precision=precision,
+                                          variant=variant)
+                assert got.kernel_id == kid
+                assert torch.equal(ref.actions, got.actions) and torch.equal(ref.tlen, got.tlen), variant
+                assert torch.equal(ref.probs, got.probs) and torch.equal(ref.reward, got.reward), variant
+                if train:
+                    live = int(got.tlen.max()) * M
+                    for k, v in rows_ref.items():
+                        if k == "Load" and kind == "tsp":
+                            continue
+                        assert torch.equal(v[:, :live], getattr(got.rows, k)[:, :live]), (k, precision, variant)
         g1 = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, geometry=geom, precision=precision)
-        g2 = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, geometry=geom, precision=precision, variant=4)
-        assert torch.equal(g1.actions, g2.actions) and torch.equal(g1.reward, g2.reward)
+        for variant in (4, 5):
+            g2 = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, geometry=geom, precision=precision, variant=variant)
+            assert torch.equal(g1.actions, g2.actions) and torch.equal(g1.reward, g2.reward), variant

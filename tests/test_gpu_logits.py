@@ -43,10 +43,10 @@ def _check(tag, kernel, lg, scores, logits, clip, steps, t_index, tlen):
     print(tag, kernel, f"scores {worst_s:.2e}  logits/clip {worst_l:.2e}")
 
 
-SMALL_VARIANTS = [0, 1, 2, 3, 4]
-SMALL_IDS = ["cooperative", "wave_per_trajectory", "xl", "xm", "cooperative_split"]
-KERNEL_OF = {0: L.KERNEL_COOP, 1: L.KERNEL_WAVE, 2: L.KERNEL_XL, 3: L.KERNEL_XM, 4: L.KERNEL_COOP_SPLIT}
-KNAME = {0: "coop", 1: "wave", 2: "xl", 3: "xm", 4: "coop_split"}
+SMALL_VARIANTS = [0, 1, 2, 3, 4, 5]
+SMALL_IDS = ["cooperative", "wave_per_trajectory", "xl", "xm", "cooperative_split", "cooperative_wide"]
+KERNEL_OF = {0: L.KERNEL_COOP, 1: L.KERNEL_WAVE, 2: L.KERNEL_XL, 3: L.KERNEL_XM, 4: L.KERNEL_COOP_SPLIT, 5: L.KERNEL_COOP_WIDE}
+KNAME = {0: "coop", 1: "wave", 2: "xl", 3: "xm", 4: "coop_split", 5: "coop_wide"}
 
 
 @pytest.mark.parametrize("variant", SMALL_VARIANTS, ids=SMALL_IDS)
