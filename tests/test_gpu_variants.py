@@ -248,3 +248,34 @@ def test_local_size_63_train_step_runs():
     J, rew = train_step(model, env, opt, generate_vrp_data(3, N, {"data_type": "uniform"}))
     assert torch.isfinite(J).item()
     assert all(float((v.detach() - before[k]).abs().max()) > 0 for k, v in model.named_parameters() if k.startswith("decoder.local_policies."))
+
+
+@pytest.mark.parametrize("K", [48, 63])
+def test_tsp_local_size_above_47_against_the_oracle(K):
+    """TSP with local_size 48 / 63 (no depot slot: K slots, the 64-lane limit is K <= 64; kept <= 63 like CVRP): the oracle's own
+    greedy tours teacher-forced through the one-wavefront kernels -- chosen probabilities, rewards; the engine's free-running
+    greedy rollout reproduces the tours; sampled rollout = its forced replay."""
+    mp = dict(gu.TSP_MODEL_PARAMS)
+    mp["local_size"] = [K]
+    cfg = orc.ModelCfg.from_model_params(mp, "tsp")
+    P = gc.weights("tsp", 17, mp, 1.0)
+    B, N, M = 2, 100, 16
+    xy = torch.from_numpy(gu.golden_tsp_problem(33, B, N))
+    enc = orc.encoder_forward(P, cfg, xy)
+    prob = gc.make_problem(xy, None, L.PROBLEM_TSP)
+    pol = gc.make_policy(P, cfg, enc.to(DEV), L.PROBLEM_TSP)
+    assert pol.wide_slots
+    starts = torch.arange(M)
+    out = orc.rollout_tsp(P, cfg, xy, M, starts=starts, mode="greedy", enc=enc)
+    acts = out["actions"].int()
+    res = eng.rollout_forward(prob, pol, M, starts, L.MODE_FORCED, forced=acts)
+    assert res.kernel_id == L.KERNEL_WAVE
+    T = acts.shape[2]
+    np.testing.assert_allclose(res.probs[:, :T].cpu().numpy(), out["probs"].numpy(), rtol=5e-4, atol=1e-9)
+    np.testing.assert_allclose(res.reward.cpu().numpy(), out["reward"].numpy(), rtol=1e-5)
+    g = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY)
+    agree = float((g.actions[:, :, :T].cpu() == acts).float().mean())
+    assert agree > 0.995, agree                                   # (free-running arg-max: a near-tie may flip a step)
+    s1 = eng.rollout_forward(prob, pol, M, starts, L.MODE_SAMPLE, seed=5)
+    s2 = eng.rollout_forward(prob, pol, M, starts, L.MODE_FORCED, forced=s1.actions)
+    np.testing.assert_allclose(s1.probs.cpu().numpy(), s2.probs.cpu().numpy(), rtol=1e-6, atol=0)
