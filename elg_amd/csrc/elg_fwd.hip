@@ -1078,6 +1078,10 @@ __global__ __launch_bounds__(512) void rollout_fwd_mt_kernel(const elg_rollout_a
             __syncthreads();
             ELG_STAMP(sc_, 1);
             // ================= glimpse: wave = head; every K / V fragment serves the NG groups of 16 trajectories =================
+            // (waves 4-7 are the younger wave of their SIMD and lose the issue arbitration for the whole phase -- phase clock: 51 % of a
+            // step against 35 % for waves 0-3, which then idle at the barrier.  A static s_setprio 1 / 2 for the younger half through
+            // this phase was measured in round 6: TSP-500 19.80 -> 19.84 / 19.86 ms, X-n1001-sized CVRP 163.1 -> 165.4 / 165.7 ms:
+            // the phase is bound by the SIMD's matrix pipe, priority only moves the wait from one wave to the other.)
             {
                 const float cs = 0.25f * 1.4426950408889634f;
                 u32x4 q11[NG], q22[NG], q31[NG];            // the query's bf16 terms as the B operand: [q1 | q1], [q2 | q2], [q3 | q1]
