@@ -213,3 +213,34 @@ def test_split_group_kernel_is_bit_identical(kind, N, B, M, tiles):
         for variant in (4, 5):
             g2 = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, geometry=geom, precision=precision, variant=variant)
             assert torch.equal(g1.actions, g2.actions) and torch.equal(g1.reward, g2.reward), variant
+
+
+@pytest.mark.parametrize("kind,N,B,M", [("cvrp", 4, 1, 1), ("cvrp", 5, 3, 4), ("tsp", 4, 1, 4), ("tsp", 6, 2, 1), ("cvrp", 10, 1, 10)])
+def test_smallest_shapes_all_cooperative_forms(kind, N, B, M):
+    """Edge shapes: the smallest instances the cooperative kernels take (N1 >= 4), one trajectory, one instance -- the lockstep
+    kernel, both split-group forms and the one-wavefront kernel make the same greedy tours with the same rewards, a sampled rollout
+    equals its forced replay, and every tour is feasible (each customer once; TSP: a permutation)."""
+    from elg_amd import _lib as L, engine as eng
+    P, cfg, xy, dem, enc, prob, pol = _setup(kind, N, B, 7700 + 10 * N + M)
+    if pol.K > N - 1:
+        pol.K = N - 1                                           # (local_size cannot exceed the customers there are)
+    off = 1 if kind == "cvrp" else 0
+    starts = torch.randperm(N, generator=torch.Generator().manual_seed(M))[:M] + off
+    ref = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, variant=1)
+    assert ref.kernel_id == L.KERNEL_WAVE
+    for variant, kid in ((0, L.KERNEL_COOP), (4, L.KERNEL_COOP_SPLIT), (5, L.KERNEL_COOP_WIDE)):
+        g = eng.rollout_forward(prob, pol, M, starts, L.MODE_GREEDY, variant=variant)
+        assert g.kernel_id == kid
+        assert torch.equal(g.tlen, ref.tlen), variant
+        T = int(ref.tlen.max())
+        assert torch.equal(g.actions[:, :, :T], ref.actions[:, :, :T]), variant
+        np.testing.assert_allclose(g.reward.cpu().numpy(), ref.reward.cpu().numpy(), rtol=1e-6)
+        s = eng.rollout_forward(prob, pol, M, starts, L.MODE_SAMPLE, seed=3, variant=variant)
+        f = eng.rollout_forward(prob, pol, M, starts, L.MODE_FORCED, forced=s.actions, variant=variant)
+        np.testing.assert_allclose(s.probs.cpu().numpy(), f.probs.cpu().numpy(), rtol=1e-6, atol=0)
+        acts = s.actions.cpu().numpy()
+        for b in range(B):
+            for m in range(M):
+                tour = acts[b, m, :int(s.tlen[b, m])]
+                cust = tour[tour > 0] if kind == "cvrp" else tour
+                assert sorted(cust.tolist()) == list(range(off, N + off)), (variant, b, m, tour)
